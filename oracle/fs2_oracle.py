@@ -1,0 +1,365 @@
+"""ORACLE — test infrastructure, not product code.
+
+CPU restatement (torch fp32, functional, autograd for the derivatives) of the Meta-TTS hot
+path: FastSpeech2 forward, its 5-term loss, the MAML inner/outer loop and the outer
+Adam/Noam/clip update.  Every function cites the reference file:line it follows
+(paths relative to /root/reference).  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import this file; the product path
+(``meta_tts_amd``) never does and fails loudly without its HIP library.
+
+Pinning: ``tests/golden/make_golden.py`` imports the reference's own ``FastSpeech2`` /
+``FastSpeech2Loss`` in the build container and stores inputs + outputs as fixtures;
+``tests/test_oracle_golden.py`` checks this file against them.  The MAML update rule lives in
+un-vendored learn2learn (requirements.txt:2, absent here) => that single rule is restated from
+its published definition (theta' = theta - lr * grad, create_graph = second order) and is
+"parity unpinned" against learn2learn itself; the model arithmetic underneath it is pinned.
+
+Parameters are a dict {reference state_dict name (without the ``model.`` prefix): tensor}.
+Dropout is the identity here (parity runs patch it out).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+
+# --------------------------------------------------------------------------------------
+# masks / tables
+# --------------------------------------------------------------------------------------
+def mask_from_lengths(lengths: torch.Tensor, max_len: Optional[int] = None) -> torch.Tensor:
+    """utils/tools.py:91-99 — True marks padding: arange(max_len) >= len[:, None]."""
+    if max_len is None:
+        max_len = int(lengths.max().item())
+    ids = torch.arange(0, max_len, device=lengths.device).unsqueeze(0)
+    return ids >= lengths.unsqueeze(1)
+
+
+def sinusoid_table(n_position: int, d_hid: int) -> torch.Tensor:
+    """transformer/Models.py:10-30 (float64 numpy arithmetic, cast to fp32)."""
+    pos = torch.arange(n_position, dtype=torch.float64).unsqueeze(1)
+    j = torch.arange(d_hid, dtype=torch.float64).unsqueeze(0)
+    table = pos / torch.pow(torch.tensor(10000.0, dtype=torch.float64), 2.0 * torch.floor(j / 2.0) / d_hid)
+    table[:, 0::2] = torch.sin(table[:, 0::2])
+    table[:, 1::2] = torch.cos(table[:, 1::2])
+    return table.to(torch.float32)
+
+
+# --------------------------------------------------------------------------------------
+# transformer blocks
+# --------------------------------------------------------------------------------------
+def scaled_dot_product_attention(q, k, v, mask, temperature):
+    """transformer/Modules.py:14-25 — softmax(masked_fill(q k^T / temperature, mask, -inf), dim=2) v."""
+    attn = torch.bmm(q, k.transpose(1, 2)) / temperature
+    attn = attn.masked_fill(mask, float("-inf"))
+    attn = torch.softmax(attn, dim=2)
+    return torch.bmm(attn, v), attn
+
+
+def multi_head_attention(x, p: Params, pre: str, slf_attn_mask, n_head: int):
+    """transformer/SubLayers.py:29-57 — head-major split (permute(2,0,1,3)), mask repeated per
+    head, fc, (dropout = identity), post-LayerNorm over (out + residual), eps 1e-5."""
+    B, L, d = x.shape
+    d_k = d // n_head
+    q = F.linear(x, p[f"{pre}.w_qs.weight"], p[f"{pre}.w_qs.bias"]).view(B, L, n_head, d_k)
+    k = F.linear(x, p[f"{pre}.w_ks.weight"], p[f"{pre}.w_ks.bias"]).view(B, L, n_head, d_k)
+    v = F.linear(x, p[f"{pre}.w_vs.weight"], p[f"{pre}.w_vs.bias"]).view(B, L, n_head, d_k)
+    q = q.permute(2, 0, 1, 3).contiguous().view(-1, L, d_k)
+    k = k.permute(2, 0, 1, 3).contiguous().view(-1, L, d_k)
+    v = v.permute(2, 0, 1, 3).contiguous().view(-1, L, d_k)
+    mask = slf_attn_mask.repeat(n_head, 1, 1)
+    out, attn = scaled_dot_product_attention(q, k, v, mask, math.sqrt(d_k))
+    out = out.view(n_head, B, L, d_k).permute(1, 2, 0, 3).contiguous().view(B, L, -1)
+    out = F.linear(out, p[f"{pre}.fc.weight"], p[f"{pre}.fc.bias"])
+    out = F.layer_norm(out + x, (d,), p[f"{pre}.layer_norm.weight"], p[f"{pre}.layer_norm.bias"], 1e-5)
+    return out, attn
+
+
+def positionwise_ffn(x, p: Params, pre: str):
+    """transformer/SubLayers.py:85-93 — LN(W2 * relu(W1 * x) + x) with Conv1d W1 (k=9,pad=4), W2 (k=1)."""
+    w1, w2 = p[f"{pre}.w_1.weight"], p[f"{pre}.w_2.weight"]
+    h = F.conv1d(x.transpose(1, 2), w1, p[f"{pre}.w_1.bias"], padding=(w1.shape[2] - 1) // 2)
+    h = F.conv1d(F.relu(h), w2, p[f"{pre}.w_2.bias"], padding=(w2.shape[2] - 1) // 2)
+    h = h.transpose(1, 2)
+    d = x.shape[-1]
+    return F.layer_norm(h + x, (d,), p[f"{pre}.layer_norm.weight"], p[f"{pre}.layer_norm.bias"], 1e-5)
+
+
+def fft_block(x, p: Params, pre: str, mask, slf_attn_mask, n_head: int):
+    """transformer/Layers.py:21-30 — MHA, zero padded rows, FFN, zero padded rows."""
+    x, attn = multi_head_attention(x, p, f"{pre}.slf_attn", slf_attn_mask, n_head)
+    x = x.masked_fill(mask.unsqueeze(-1), 0)
+    x = positionwise_ffn(x, p, f"{pre}.pos_ffn")
+    x = x.masked_fill(mask.unsqueeze(-1), 0)
+    return x, attn
+
+
+def _n_layers(p: Params, prefix: str) -> int:
+    n = 0
+    while f"{prefix}.layer_stack.{n}.slf_attn.w_qs.weight" in p:
+        n += 1
+    return n
+
+
+def encoder(texts, mask, p: Params, n_head: int, training: bool, max_seq_len: int):
+    """transformer/Models.py:73-100 — word embedding (pad row 0) + sinusoid positions, 4 FFT blocks."""
+    B, L = texts.shape
+    slf_attn_mask = mask.unsqueeze(1).expand(-1, L, -1)
+    emb = F.embedding(texts, p["encoder.src_word_emb.weight"], padding_idx=0)
+    d = emb.shape[-1]
+    if (not training) and L > max_seq_len:
+        pos = sinusoid_table(L, d)[:L].unsqueeze(0)
+    else:
+        pos = p["encoder.position_enc"][:, :L, :]
+    x = emb + pos.expand(B, -1, -1)
+    for i in range(_n_layers(p, "encoder")):
+        x, _ = fft_block(x, p, f"encoder.layer_stack.{i}", mask, slf_attn_mask, n_head)
+    return x
+
+
+def decoder(x, mask, p: Params, n_head: int, training: bool, max_seq_len: int):
+    """transformer/Models.py:139-171 — training truncates to max_seq_len, eval extends the table."""
+    B, L, d = x.shape
+    if (not training) and L > max_seq_len:
+        slf_attn_mask = mask.unsqueeze(1).expand(-1, L, -1)
+        x = x + sinusoid_table(L, d)[:L].unsqueeze(0).expand(B, -1, -1)
+    else:
+        L = min(L, max_seq_len)
+        slf_attn_mask = mask.unsqueeze(1).expand(-1, L, -1)
+        x = x[:, :L, :] + p["decoder.position_enc"][:, :L, :].expand(B, -1, -1)
+        mask = mask[:, :L]
+        slf_attn_mask = slf_attn_mask[:, :, :L]
+    for i in range(_n_layers(p, "decoder")):
+        x, _ = fft_block(x, p, f"decoder.layer_stack.{i}", mask, slf_attn_mask, n_head)
+    return x, mask
+
+
+# --------------------------------------------------------------------------------------
+# variance adaptor
+# --------------------------------------------------------------------------------------
+def variance_predictor(x, mask, p: Params, pre: str):
+    """lightning/model/modules.py:242-250 (+ Conv :253-296) — [Conv1d k=3 -> ReLU -> LN]x2 -> Linear(->1)
+    -> masked_fill(mask, 0); dropout = identity."""
+    for i in (1, 2):
+        w = p[f"{pre}.conv_layer.conv1d_{i}.conv.weight"]
+        pad = (w.shape[2] - 1) // 2 if i == 1 else 1
+        x = F.conv1d(x.transpose(1, 2), w, p[f"{pre}.conv_layer.conv1d_{i}.conv.bias"], padding=pad).transpose(1, 2)
+        x = F.relu(x)
+        x = F.layer_norm(x, (x.shape[-1],), p[f"{pre}.conv_layer.layer_norm_{i}.weight"],
+                         p[f"{pre}.conv_layer.layer_norm_{i}.bias"], 1e-5)
+    out = F.linear(x, p[f"{pre}.linear_layer.weight"], p[f"{pre}.linear_layer.bias"]).squeeze(-1)
+    if mask is not None:
+        out = out.masked_fill(mask, 0.0)
+    return out
+
+
+def length_regulate(x, durations, max_len: Optional[int]):
+    """lightning/model/modules.py:167-190 + utils/tools.py:304-322 — repeat row i max(int(dur[i]),0)
+    times, concatenate, zero-pad to max_len (or the batch max).  Returns (out, mel_len[int64])."""
+    B = x.shape[0]
+    reps = durations.to(torch.int64).clamp(min=0)
+    outs, lens = [], []
+    for b in range(B):
+        e = torch.repeat_interleave(x[b], reps[b], dim=0)
+        outs.append(e)
+        lens.append(e.shape[0])
+    T = max_len if max_len else max(lens)
+    out = torch.stack([F.pad(e, (0, 0, 0, T - e.shape[0])) for e in outs])
+    return out, torch.tensor(lens, dtype=torch.int64)
+
+
+def variance_adaptor(x, src_mask, mel_mask, max_len, p_t, e_t, d_t, p: Params,
+                     p_control=1.0, e_control=1.0, d_control=1.0):
+    """lightning/model/modules.py:102-158, phoneme-level features: duration predictor on x;
+    pitch predictor on x, x += pitch_emb[bucketize(target or pred*ctl)]; energy predictor on the
+    updated x, x += energy_emb[...]; length regulation with the targets or
+    clamp(round(exp(logd) - 1) * ctl, 0)."""
+    va = "variance_adaptor"
+    logd = variance_predictor(x, src_mask, p, f"{va}.duration_predictor")
+    pp = variance_predictor(x, src_mask, p, f"{va}.pitch_predictor")
+    if p_t is not None:
+        idx = torch.bucketize(p_t, p[f"{va}.pitch_bins"])
+    else:
+        pp = pp * p_control
+        idx = torch.bucketize(pp, p[f"{va}.pitch_bins"])
+    x = x + F.embedding(idx, p[f"{va}.pitch_embedding.weight"])
+    ep = variance_predictor(x, src_mask, p, f"{va}.energy_predictor")
+    if e_t is not None:
+        idx = torch.bucketize(e_t, p[f"{va}.energy_bins"])
+    else:
+        ep = ep * e_control
+        idx = torch.bucketize(ep, p[f"{va}.energy_bins"])
+    x = x + F.embedding(idx, p[f"{va}.energy_embedding.weight"])
+    if d_t is not None:
+        x, mel_len = length_regulate(x, d_t, max_len)
+        d_rounded = d_t
+    else:
+        d_rounded = torch.clamp(torch.round(torch.exp(logd) - 1) * d_control, min=0)
+        x, mel_len = length_regulate(x, d_rounded, max_len)
+        mel_mask = mask_from_lengths(mel_len)
+    return x, pp, ep, logd, d_rounded, mel_len, mel_mask
+
+
+# --------------------------------------------------------------------------------------
+# PostNet
+# --------------------------------------------------------------------------------------
+def postnet(x, p: Params, buffers: Optional[Dict[str, torch.Tensor]], training: bool):
+    """transformer/Layers.py:129-137 — NCL: 4x[Conv1d k=5 -> BatchNorm1d -> tanh] + [Conv -> BN];
+    dropout = identity.  BatchNorm in training mode uses batch statistics over all B*T_max
+    positions (padding included) and updates running stats with momentum 0.1 (unbiased var)."""
+    h = x.transpose(1, 2)
+    n = 0
+    while f"postnet.convolutions.{n}.0.conv.weight" in p:
+        n += 1
+    for i in range(n):
+        pre = f"postnet.convolutions.{i}"
+        w = p[f"{pre}.0.conv.weight"]
+        h = F.conv1d(h, w, p[f"{pre}.0.conv.bias"], padding=(w.shape[2] - 1) // 2)
+        rm = rv = None
+        if buffers is not None:
+            rm, rv = buffers[f"{pre}.1.running_mean"], buffers[f"{pre}.1.running_var"]
+        if training or rm is None:
+            h = F.batch_norm(h, rm, rv, p[f"{pre}.1.weight"], p[f"{pre}.1.bias"], True, 0.1, 1e-5)
+            if buffers is not None and f"{pre}.1.num_batches_tracked" in buffers:
+                buffers[f"{pre}.1.num_batches_tracked"] += 1
+        else:
+            h = F.batch_norm(h, rm, rv, p[f"{pre}.1.weight"], p[f"{pre}.1.bias"], False, 0.1, 1e-5)
+        if i < n - 1:
+            h = torch.tanh(h)
+    return h.transpose(1, 2)
+
+
+# --------------------------------------------------------------------------------------
+# full model + loss
+# --------------------------------------------------------------------------------------
+def fs2_forward(p: Params, buffers, speakers, texts, src_lens, max_src_len, mels=None, mel_lens=None,
+                max_mel_len=None, p_targets=None, e_targets=None, d_targets=None,
+                p_control=1.0, e_control=1.0, d_control=1.0, *, n_head=(2, 2), max_seq_len=1000,
+                training=False, average_spk_emb=False):
+    """lightning/model/fastspeech2.py:40-112 and, with ``average_spk_emb``, the learner variant
+    lightning/systems/base_adaptor.py:41-95 (mean of the support speakers' rows, expanded)."""
+    src_masks = mask_from_lengths(src_lens, max_src_len)
+    mel_masks = mask_from_lengths(mel_lens, max_mel_len) if mel_lens is not None else None
+    out = encoder(texts, src_masks, p, n_head[0], training, max_seq_len)
+    spk = F.embedding(speakers, p["speaker_emb.model.weight"])
+    if average_spk_emb:
+        spk = spk.mean(dim=0, keepdim=True).expand(out.shape[0], -1)
+    out = out + spk.unsqueeze(1).expand(-1, max_src_len, -1)
+    out, pp, ep, logd, d_rounded, mel_lens, mel_masks = variance_adaptor(
+        out, src_masks, mel_masks, max_mel_len, p_targets, e_targets, d_targets, p,
+        p_control, e_control, d_control)
+    out = out + spk.unsqueeze(1).expand(-1, out.shape[1], -1)
+    out, mel_masks = decoder(out, mel_masks, p, n_head[1], training, max_seq_len)
+    mel = F.linear(out, p["mel_linear.weight"], p["mel_linear.bias"])
+    mel_post = postnet(mel, p, buffers, training) + mel
+    return (mel, mel_post, pp, ep, logd, d_rounded, src_masks, mel_masks, src_lens, mel_lens)
+
+
+def fs2_loss(batch, preds):
+    """lightning/model/loss.py:19-92 — L1 over valid frames x n_mel for mel / postnet mel, MSE over
+    valid phonemes for pitch, energy, log-duration (target log(d + 1)); total = plain sum."""
+    mel_t, _, _, p_t, e_t, d_t = batch[6:]
+    mel, mel_post, pp, ep, logd, _, src_masks, mel_masks, _, _ = preds
+    sm, mm = ~src_masks, ~mel_masks
+    logd_t = torch.log(d_t.float() + 1)
+    mel_t = mel_t[:, : mm.shape[1], :]
+    mel_l = F.l1_loss(mel.masked_select(mm.unsqueeze(-1)), mel_t.masked_select(mm.unsqueeze(-1)))
+    post_l = F.l1_loss(mel_post.masked_select(mm.unsqueeze(-1)), mel_t.masked_select(mm.unsqueeze(-1)))
+    p_l = F.mse_loss(pp.masked_select(sm), p_t.masked_select(sm))
+    e_l = F.mse_loss(ep.masked_select(sm), e_t.masked_select(sm))
+    d_l = F.mse_loss(logd.masked_select(sm), logd_t.masked_select(sm))
+    total = mel_l + post_l + d_l + p_l + e_l
+    return (total, mel_l, post_l, p_l, e_l, d_l)
+
+
+def to_torch_batch(batch):
+    """numpy 12-tuple (meta_tts_amd.synth.make_batch) -> torch 12-tuple (lightning/collate.py:47-60)."""
+    out = []
+    for i, x in enumerate(batch):
+        if hasattr(x, "dtype") and hasattr(x, "shape") and not isinstance(x, torch.Tensor):
+            out.append(torch.from_numpy(x))
+        else:
+            out.append(int(x) if i in (5, 8) else x)
+    return tuple(out)
+
+
+# --------------------------------------------------------------------------------------
+# MAML (learn2learn.algorithms.MAML restated; call sites lightning/systems/utils.py:17-77,
+# lightning/systems/base_adaptor.py:98-124)
+# --------------------------------------------------------------------------------------
+def adapted_names(p: Params, modules: Sequence[str]) -> List[str]:
+    """Tensors the inner loop updates: requires_grad parameters of the adapted sub-modules
+    (base_adaptor.py:31-35; position_enc / *_bins are frozen so l2l skips them)."""
+    frozen = ("position_enc", "pitch_bins", "energy_bins")
+    return [k for k in p if k.split(".")[0] in modules and not k.endswith(frozen)]
+
+
+def maml_task(p: Params, buffers, sup, qry, *, steps: int, lr: float, second_order: bool,
+              modules: Sequence[str], n_head=(2, 2), max_seq_len=1000, training=True):
+    """One task of a meta-step: ``steps`` inner SGD updates on the support batch
+    (base_adaptor.py:100-112, ``first_order = not train``), then the query pass with the support
+    speaker ids and ``average_spk_emb=True`` (base_adaptor.py:114-124).  ``p`` tensors that should
+    receive outer gradients must have requires_grad=True.  Returns
+    (query 6-tuple, [support loss per step], fast weights, query predictions)."""
+    names = adapted_names(p, modules)
+    fast = {k: p[k] for k in names}
+    sup_losses = []
+    for _ in range(steps):
+        cur = dict(p)
+        cur.update(fast)
+        preds = fs2_forward(cur, buffers, *sup[2:], n_head=n_head, max_seq_len=max_seq_len, training=training)
+        loss = fs2_loss(sup, preds)
+        sup_losses.append(loss)
+        grads = torch.autograd.grad(loss[0], [fast[k] for k in names], create_graph=second_order,
+                                    allow_unused=False)
+        fast = {k: fast[k] - lr * g for k, g in zip(names, grads)}
+        if not second_order:
+            # first-order MAML: l2l detaches nothing but the graph of g is not kept; the update
+            # theta' = theta - lr*g stays differentiable wrt theta with d theta'/d theta = I.
+            pass
+    cur = dict(p)
+    cur.update(fast)
+    preds = fs2_forward(cur, buffers, sup[2], *qry[3:], n_head=n_head, max_seq_len=max_seq_len,
+                        training=training, average_spk_emb=True)
+    qloss = fs2_loss(qry, preds)
+    return qloss, sup_losses, fast, preds
+
+
+# --------------------------------------------------------------------------------------
+# outer update (lightning/optimizer.py:6-16, lightning/scheduler.py:6-29, main.py:61)
+# --------------------------------------------------------------------------------------
+def noam_lr(step: int, d_model: int = 256, warm_up_step: int = 4000,
+            anneal_steps: Sequence[int] = (300000, 400000, 500000), anneal_rate: float = 0.3) -> float:
+    """LambdaLR factor times init_lr = d_model^-0.5; ``step`` is the 0-based scheduler step."""
+    cur = step + 1
+    lr = min(cur ** -0.5, warm_up_step ** -1.5 * cur)
+    for s in anneal_steps:
+        if cur > s:
+            lr *= anneal_rate
+    return float(d_model ** -0.5 * lr)
+
+
+def clip_grad_norm_(grads: Sequence[torch.Tensor], max_norm: float) -> float:
+    """torch.nn.utils.clip_grad_norm_ semantics (PL gradient_clip_val, main.py:61): global L2
+    norm, scale by max_norm / (norm + 1e-6) clamped to 1."""
+    total = torch.sqrt(sum((g.detach().double() ** 2).sum() for g in grads)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return float(total)
+
+
+def adam_step(param, grad, m, v, step: int, lr: float, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.0):
+    """torch.optim.Adam single-tensor update (optimizer.py:9-15); ``step`` is 1-based."""
+    if weight_decay != 0.0:
+        grad = grad + weight_decay * param
+    m.mul_(betas[0]).add_(grad, alpha=1 - betas[0])
+    v.mul_(betas[1]).addcmul_(grad, grad, value=1 - betas[1])
+    bc1 = 1 - betas[0] ** step
+    bc2 = 1 - betas[1] ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    param.addcdiv_(m, denom, value=-lr / bc1)

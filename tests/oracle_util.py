@@ -1,0 +1,50 @@
+"""Shared helpers for tests that drive the oracle (tests/ may import oracle/, the product may not)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from meta_tts_amd import synth  # noqa: E402
+from meta_tts_amd.config import ModelDims  # noqa: E402
+from oracle import fs2_oracle as O  # noqa: E402
+
+SMALL = dict(s_range=(6, 13), d_range=(1, 7), first_len=12)
+
+
+def torch_params(dims, seed=0, requires_grad=False):
+    p = {k: torch.from_numpy(v.copy()) for k, v in synth.make_params(dims, seed).items()}
+    if requires_grad:
+        frozen = ("position_enc", "pitch_bins", "energy_bins")
+        for k, v in p.items():
+            if not k.endswith(frozen):
+                v.requires_grad_(True)
+    return p
+
+
+def torch_buffers(dims):
+    return {k: torch.from_numpy(v.copy()) for k, v in synth.make_buffers(dims).items()}
+
+
+def heads(dims):
+    return (dims.enc_heads, dims.dec_heads)
+
+
+def tiny_dims(**over):
+    """A small architecture for kernel-logic tests (same code paths, tiny GEMMs)."""
+    from meta_tts_amd.config import default_model_config, default_preprocess_config
+    mc = default_model_config()
+    mc["transformer"].update(dict(encoder_layer=1, decoder_layer=2, encoder_hidden=32, decoder_hidden=32,
+                                  conv_filter_size=64, encoder_head=2, decoder_head=2))
+    mc["variance_predictor"].update(dict(filter_size=32))
+    mc["variance_embedding"]["n_bins"] = 16
+    mc["max_seq_len"] = 64
+    mc["_postnet_dim"] = 48
+    pc = default_preprocess_config()
+    pc["preprocessing"]["mel"]["n_mel_channels"] = 20
+    mc.update(over.pop("model", {}))
+    return ModelDims(mc, pc, n_speaker=over.pop("n_speaker", 12), vocab=over.pop("vocab", 40))

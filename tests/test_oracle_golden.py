@@ -1,0 +1,138 @@
+"""Pin the oracle (oracle/fs2_oracle.py) against fixtures produced by the reference's own code
+(tests/golden/make_golden.py, run in the build container).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle_util import O, SMALL, heads, synth, torch_buffers, torch_params
+from meta_tts_amd.config import ModelDims, default_algorithm_config
+
+DIMS = ModelDims()
+TOL = 2e-5  # fp32 noise floor of the reference itself is ~1.5e-6 max-abs
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def params():
+    return torch_params(DIMS)
+
+
+def test_c1_forward_eval_and_free_running(golden_dir, params):
+    g = _load(golden_dir, "c1_forward.npz")
+    b = O.to_torch_batch(synth.make_batch(0, 1))
+    assert (b[5], b[8]) == (80, 555)
+    with torch.no_grad():
+        o = O.fs2_forward(params, torch_buffers(DIMS), *b[2:], n_head=heads(DIMS), training=False)
+        lo = O.fs2_loss(b, o)
+        fr = O.fs2_forward(params, torch_buffers(DIMS), *b[2:6], n_head=heads(DIMS), training=False)
+    for key, val in (("mel", o[0]), ("mel_post", o[1]), ("p", o[2]), ("e", o[3]), ("logd", o[4])):
+        assert np.abs(val.numpy() - g[key]).max() < TOL, key
+    # the headline parity metric: mel L1 vs the reference CPU path
+    assert np.abs(o[1].numpy() - g["mel_post"]).mean() < 1e-6
+    np.testing.assert_allclose([float(x) for x in lo], g["losses"], rtol=1e-5)
+    np.testing.assert_array_equal(fr[5].numpy(), g["fr_d_rounded"])
+    np.testing.assert_array_equal(fr[9].numpy(), g["fr_mel_len"])
+    assert np.abs(fr[1].numpy() - g["fr_mel_post"]).max() < TOL
+
+
+def test_c1_forward_train_mode_batchnorm(golden_dir, params):
+    g = _load(golden_dir, "c1_forward.npz")
+    b = O.to_torch_batch(synth.make_batch(0, 1))
+    with torch.no_grad():
+        o = O.fs2_forward(params, torch_buffers(DIMS), *b[2:], n_head=heads(DIMS), training=True)
+        lo = O.fs2_loss(b, o)
+    assert np.abs(o[1].numpy() - g["train_mel_post"]).max() < TOL
+    np.testing.assert_allclose([float(x) for x in lo], g["train_losses"], rtol=1e-5)
+
+
+def _small_batch():
+    batch = synth.make_batch(11, 3, speaker=5, **SMALL)
+    batch[9][0, :4] = np.array([DIMS.pitch_min, DIMS.pitch_min - 1.0, DIMS.pitch_max, DIMS.pitch_max + 1.0], np.float32)
+    batch[10][0, :4] = np.array([DIMS.energy_min, DIMS.energy_min - 1.0, DIMS.energy_max, DIMS.energy_max + 1.0], np.float32)
+    return batch
+
+
+def test_small_batch_losses_grads_and_bn_buffers(golden_dir):
+    g = _load(golden_dir, "small_grad.npz")
+    p = torch_params(DIMS, requires_grad=True)
+    buf = torch_buffers(DIMS)
+    batch = _small_batch()
+    np.testing.assert_array_equal(batch[9], g["p_targets"])
+    b = O.to_torch_batch(batch)
+    o = O.fs2_forward(p, buf, *b[2:], n_head=heads(DIMS), training=True)
+    lo = O.fs2_loss(b, o)
+    np.testing.assert_allclose([float(x) for x in lo], g["losses"], rtol=1e-5)
+    assert np.abs(o[1].detach().numpy() - g["mel_post"]).max() < TOL
+    names = [str(n) for n in g["grad_names"]]
+    grads = torch.autograd.grad(lo[0], [p[n] for n in names], allow_unused=True)
+    gd = {n: (x if x is not None else torch.zeros_like(p[n])) for n, x in zip(names, grads)}
+    norms = np.array([float(gd[n].double().norm()) for n in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-7)
+    for key in g.files:
+        if not key.startswith("grad::"):
+            continue
+        n = key[len("grad::"):]
+        if n == "speaker_row":
+            got = gd["speaker_emb.model.weight"][5].numpy()
+        elif n == "src_word_emb_rows":
+            got = gd["encoder.src_word_emb.weight"][:8].numpy()
+            assert np.all(got[0] == 0)  # padding_idx row never receives gradient
+        else:
+            got = gd[n].numpy()
+            got = got[:4] if got.ndim >= 2 else got
+        ref = g[key]
+        assert np.abs(got - ref).max() <= 1e-4 * max(1e-3, np.abs(ref).max()), key
+    for i in range(5):
+        np.testing.assert_allclose(buf[f"postnet.convolutions.{i}.1.running_mean"].numpy(), g[f"bn{i}_running_mean"], atol=1e-6)
+        np.testing.assert_allclose(buf[f"postnet.convolutions.{i}.1.running_var"].numpy(), g[f"bn{i}_running_var"], rtol=1e-5)
+    with torch.no_grad():
+        oe = O.fs2_forward(p, buf, *b[2:], n_head=heads(DIMS), training=False)
+    assert np.abs(oe[1].numpy() - g["eval_mel_post"]).max() < TOL
+
+
+@pytest.mark.parametrize("tag,lr", [("lr1e-3", 0.001), ("lr2e-3", 0.002)])
+@pytest.mark.parametrize("order", ["fo", "so"])
+def test_maml_task(golden_dir, tag, lr, order):
+    g = _load(golden_dir, f"maml_small_{tag}.npz")
+    p = torch_params(DIMS, requires_grad=True)
+    sup = O.to_torch_batch(synth.make_batch(21, 3, speaker=9, **SMALL))
+    qry = O.to_torch_batch(synth.make_batch(22, 3, speaker=9, **SMALL))
+    modules = default_algorithm_config()["adapt"]["modules"]
+    ql, sup_losses, fast, preds = O.maml_task(p, torch_buffers(DIMS), sup, qry, steps=5, lr=lr,
+                                              second_order=(order == "so"), modules=modules, n_head=heads(DIMS))
+    assert [str(n) for n in g["adapted_names"]] == O.adapted_names(p, modules)
+    np.testing.assert_allclose(np.array([[float(x) for x in l] for l in sup_losses]), g[f"{order}_sup_losses"], rtol=2e-5)
+    np.testing.assert_allclose([float(x) for x in ql], g[f"{order}_qry_losses"], rtol=2e-5)
+    # lr=2e-3 is past the stability edge for these random weights (support loss 15.9 -> 85.7 ->
+    # 5.0): fp32 summation-order noise is amplified ~1e3x, so that case carries a looser bound.
+    rtol = 5e-4 if lr <= 0.001 else 5e-3
+    names = [str(n) for n in g[f"{order}_outer_names"]]
+    og = torch.autograd.grad(ql[0], [p[n] for n in names], allow_unused=True)
+    og = {n: (x if x is not None else torch.zeros_like(p[n])) for n, x in zip(names, og)}
+    norms = np.array([float(og[n].double().norm()) for n in names])
+    np.testing.assert_allclose(norms, g[f"{order}_outer_norms"], rtol=rtol, atol=1e-7)
+    deltas = np.array([float((fast[k] - p[k]).detach().double().norm()) for k in O.adapted_names(p, modules)])
+    np.testing.assert_allclose(deltas, g[f"{order}_delta_norms"], rtol=rtol, atol=1e-9)
+    if order == "so":  # second order reaches the (non-adapted) encoder through the inner steps too
+        fo = _load(golden_dir, f"maml_small_{tag}.npz")["fo_outer_norms"]
+        assert np.abs(norms - fo).max() > 0
+
+
+def test_noam_schedule_clip_and_adam(golden_dir):
+    g = _load(golden_dir, "optimizer.npz")
+    lrs = [O.noam_lr(int(s)) for s in g["steps"]]
+    np.testing.assert_allclose(lrs, g["lrs"], rtol=1e-12)
+    x = torch.from_numpy(g["init"].astype(np.float32)).clone()
+    m, v = torch.zeros_like(x), torch.zeros_like(x)
+    for it in range(3):
+        grad = torch.from_numpy(g["grads"][it].astype(np.float32)).clone()
+        norm = O.clip_grad_norm_([grad], 1.0)
+        O.adam_step(x, grad, m, v, it + 1, O.noam_lr(it))
+        np.testing.assert_allclose(norm, g["traj"][it][-2], rtol=1e-6)
+        np.testing.assert_allclose(O.noam_lr(it + 1), g["traj"][it][-1], rtol=1e-9)
+        np.testing.assert_allclose(x.numpy(), g["traj"][it][:-2], rtol=1e-5, atol=1e-7)
