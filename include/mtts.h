@@ -1,0 +1,122 @@
+/* libmtts — C ABI of the MI355X-native Meta-TTS hot path (FastSpeech2 forward/backward inside the
+ * MAML inner/outer loop).  Plain C, raw pointers and sizes only; no torch / C++ types cross this
+ * boundary.  The reference (SungFeng-Huang/Meta-TTS) is pure Python with no FFI layer, so every
+ * entry point below names the Python interface it sits beneath (file:line under /root/reference);
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions: every function returns 0 on success, non-zero on error (mtts_last_error() gives the
+ * message); nothing throws across the ABI.  A handle owns all device memory it needs (allocated in
+ * mtts_create for the stated capacities; no allocation afterwards).  All work is enqueued on the
+ * handle's HIP stream (mtts_set_stream) and is asynchronous w.r.t. the host unless a function
+ * copies results to a host pointer, in which case it synchronises that stream.  A handle must not
+ * be used from two host threads at once.  "host" pointers are host memory, "dev" pointers device.
+ */
+#ifndef MTTS_H
+#define MTTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mtts_handle mtts_handle;
+
+/* Sizes of config/model/base.yaml:1-30 plus what the reference reads from disk:
+ * vocab = len(text.symbols)+1 (transformer/Models.py:40), n_speaker = len(speakers.json)
+ * (lightning/model/speaker_encoder.py:49-50), pitch/energy min/max = stats.json
+ * (lightning/model/modules.py:41-46), PostNet sizes (transformer/Layers.py:72-78). */
+typedef struct mtts_model_cfg {
+    int d_model, enc_layers, dec_layers, enc_heads, dec_heads, d_ff, k1, k2;
+    int vp_filter, vp_kernel, n_bins, max_seq_len, n_mel, vocab, n_speaker;
+    int postnet_dim, postnet_kernel, postnet_layers;
+    float pitch_min, pitch_max, energy_min, energy_max;
+    /* adapt.modules of config/algorithm/<name>.yaml as a bit mask over
+     * {0 encoder, 1 variance_adaptor, 2 decoder, 3 mel_linear, 4 postnet, 5 speaker_emb}
+     * (lightning/systems/base_adaptor.py:31-35) */
+    int adapt_mask;
+} mtts_model_cfg;
+
+/* One padded batch: elements [2:] of the reference 12-tuple (lightning/collate.py:47-60), host memory,
+ * int64 where the reference uses LongTensor. */
+typedef struct mtts_batch {
+    int B, S_max, T_max;
+    const int64_t* speakers;  /* [B]                 batch[2]  */
+    const int64_t* texts;     /* [B][S_max]          batch[3]  */
+    const int64_t* src_lens;  /* [B]                 batch[4]  */
+    const float* mels;        /* [B][T_max][n_mel]   batch[6]  */
+    const int64_t* mel_lens;  /* [B]                 batch[7]  */
+    const float* pitches;     /* [B][S_max]          batch[9]  */
+    const float* energies;    /* [B][S_max]          batch[10] */
+    const int64_t* durations; /* [B][S_max]          batch[11] */
+} mtts_batch;
+
+/* ---- lifecycle (System.__init__, lightning/systems/system.py:30-48) ---------------------------- */
+int mtts_create(const mtts_model_cfg* cfg, int device, int max_tasks, int max_B, int max_S, int max_T,
+                mtts_handle** out);
+void mtts_destroy(mtts_handle* h);
+const char* mtts_last_error(mtts_handle* h); /* h may be NULL: error of the last failed mtts_create */
+int mtts_set_stream(mtts_handle* h, void* hip_stream);
+int mtts_synchronize(mtts_handle* h);
+
+/* ---- parameters: reference state_dict names without the "model." prefix,
+ * torch layouts on the host side ((out,in) Linear, (Cout,Cin,k) Conv1d) -------------------------- */
+int mtts_param_count(mtts_handle* h);
+int mtts_param_info(mtts_handle* h, int index, const char** name, int* ndim, int shape[4], int64_t* flat_offset,
+                    int* adapted);
+int64_t mtts_param_total(mtts_handle* h);  /* floats in the flat parameter / gradient space */
+int64_t mtts_adapt_start(mtts_handle* h);  /* first float of the adapted (fast-weight) slice */
+int mtts_load_param(mtts_handle* h, const char* name, const float* host, int64_t numel);
+/* which: 0 parameter, 1 outer gradient, 2 per-task gradient, 3 fast weight of `task`, 4 Adam m, 5 Adam v */
+int mtts_export_param(mtts_handle* h, const char* name, int which, int task, float* host, int64_t numel);
+/* BatchNorm1d buffers of PostNet layer `layer` (running_mean, running_var, num_batches_tracked) */
+int mtts_set_bn_buffers(mtts_handle* h, int layer, const float* mean_host, const float* var_host, int64_t tracked);
+int mtts_get_bn_buffers(mtts_handle* h, int layer, float* mean_host, float* var_host, int64_t* tracked);
+
+/* ---- batches: slot 0 = support (or a plain batch), slot 1 = query.  `spk_from`/`average_spk`
+ * reproduce forward_learner(..., sup_batch[2], *qry_batch[3:], average_spk_emb=True)
+ * (lightning/systems/base_adaptor.py:64-70,122) --------------------------------------------------- */
+int mtts_set_batches(mtts_handle* h, int slot, int n_tasks, const mtts_batch* batches, const mtts_batch* spk_from,
+                     int average_spk);
+
+/* ---- FastSpeech2.forward, teacher-forced (lightning/model/fastspeech2.py:40-112) and
+ * FastSpeech2Loss.forward (lightning/model/loss.py:19-92) ---------------------------------------- */
+int mtts_forward(mtts_handle* h, int slot, int use_fast_weights, int train_mode);
+/* copy the outputs of task `task` to host: mel, mel_post [B][T_cap][n_mel] (T_cap = min(T_max, max_seq_len));
+ * p, e, logd [B][S_max].  Any pointer may be NULL. */
+int mtts_get_outputs(mtts_handle* h, int slot, int task, float* mel, float* mel_post, float* p, float* e, float* logd);
+int mtts_loss(mtts_handle* h, int slot, float* losses_host /* [n_tasks][6]: total, mel, postnet, pitch, energy, duration */);
+/* gradient of scale * total loss w.r.t. every parameter of the touched modules -> per-task gradient */
+int mtts_backward(mtts_handle* h, int slot, int use_fast_weights, float scale, int need_encoder);
+
+/* ---- MAML: BaseAdaptorSystem.adapt + meta_learn (lightning/systems/base_adaptor.py:98-124),
+ * learn2learn MAML.clone/adapt (lightning/systems/utils.py:17-77).  Produces the outer gradient
+ * sum_t grad_scale * dL_query,t/dtheta in the handle's outer-gradient buffer.  Host loss pointers may
+ * be NULL (then nothing synchronises). ------------------------------------------------------------ */
+int mtts_meta_grad(mtts_handle* h, int steps, float inner_lr, float grad_scale, int second_order,
+                   float* qry_losses_host /* [n_tasks][6] */, float* sup_losses_host /* [steps][n_tasks][6] */);
+/* BaselineSystem.training_step (lightning/systems/baseline.py:25-36): plain gradient of slot's batches */
+int mtts_plain_grad(mtts_handle* h, int slot, float grad_scale, float* losses_host);
+/* device pointer of the outer gradient (mtts_param_total floats) — the buffer the host all-reduces
+ * over RCCL between ranks (PL strategy="ddp", main.py:32) */
+float* mtts_outer_grad_ptr(mtts_handle* h);
+/* clip_grad_norm_(max_norm) (main.py:61) + Adam (lightning/optimizer.py:9-15) with the learning rate of
+ * lightning/scheduler.py:11-23 supplied by the caller.  grad_dev NULL = the internal outer gradient. */
+int mtts_outer_update(mtts_handle* h, const float* grad_dev, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, float max_norm, float* grad_norm_host);
+int mtts_reset_optimizer(mtts_handle* h);
+
+/* ---- kernel-level entry points (parity tests; dev pointers; stream may be NULL) ----------------
+ * form 0: C[M,N] = alpha*A[M,K]*B[N,K]^T + bias   1: C = A[M,K]*B[K,N]   2: C[M,N] = A[K,M]^T*B[K,N]
+ * flags bit0 ReLU, bit1 accumulate; tile 0 (auto) / 64 / 128 */
+int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                  const float* bias, float alpha, int flags, int tile, void* hip_stream);
+/* Conv1d over one zero-guarded sequence, channels-last: x [L][Cin] with >= k/2 zero rows before and
+ * after, w [Cout][k][Cin].  mode 0: y = conv(x) + bias; 1: dx = dgrad(dy); 2: dw = wgrad(dy, x) */
+int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* x_or_dy, const float* w_or_x, float* out,
+                    const float* bias, int tile, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTTS_H */

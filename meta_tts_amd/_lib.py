@@ -1,0 +1,85 @@
+"""ctypes binding of libmtts.so (include/mtts.h).
+
+The product path loads exactly one thing: the HIP library built for gfx950 that sits next to this
+file.  If it is missing this module raises — there is no CPU fallback.  (The test-suite's SIMT
+emulator build of the same sources, tests/emu/libmtts_emu.so, can only be reached by passing its
+path explicitly to :func:`load`, which nothing in this package does.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "libmtts.so")
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "d_model", "enc_layers", "dec_layers", "enc_heads", "dec_heads", "d_ff", "k1", "k2",
+        "vp_filter", "vp_kernel", "n_bins", "max_seq_len", "n_mel", "vocab", "n_speaker",
+        "postnet_dim", "postnet_kernel", "postnet_layers")] + [
+        ("pitch_min", C.c_float), ("pitch_max", C.c_float), ("energy_min", C.c_float), ("energy_max", C.c_float),
+        ("adapt_mask", C.c_int)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("B", C.c_int), ("S_max", C.c_int), ("T_max", C.c_int),
+                ("speakers", C.c_void_p), ("texts", C.c_void_p), ("src_lens", C.c_void_p),
+                ("mels", C.c_void_p), ("mel_lens", C.c_void_p), ("pitches", C.c_void_p),
+                ("energies", C.c_void_p), ("durations", C.c_void_p)]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "mtts_create": (C.c_int, [C.POINTER(ModelCfg), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mtts_destroy": (None, [C.c_void_p]),
+    "mtts_last_error": (C.c_char_p, [C.c_void_p]),
+    "mtts_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mtts_synchronize": (C.c_int, [C.c_void_p]),
+    "mtts_param_count": (C.c_int, [C.c_void_p]),
+    "mtts_param_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int * 4),
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "mtts_param_total": (C.c_int64, [C.c_void_p]),
+    "mtts_adapt_start": (C.c_int64, [C.c_void_p]),
+    "mtts_load_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "mtts_export_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
+    "mtts_set_bn_buffers": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
+    "mtts_get_bn_buffers": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "mtts_set_batches": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Batch), C.POINTER(Batch), C.c_int]),
+    "mtts_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mtts_get_outputs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtts_loss": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mtts_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]),
+    "mtts_meta_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "mtts_plain_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "mtts_outer_grad_ptr": (C.c_void_p, [C.c_void_p]),
+    "mtts_outer_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_float, C.c_void_p]),
+    "mtts_reset_optimizer": (C.c_int, [C.c_void_p]),
+    "mtts_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "mtts_conv1d_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_void_p]),
+}
+
+_cache = {}
+
+
+def load(path: str | None = None) -> C.CDLL:
+    """Load libmtts and type every entry point of include/mtts.h.  Raises if the library (or a
+    symbol) is missing."""
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if path in _cache:
+        return _cache[path]
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "meta_tts_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _cache[path] = lib
+    return lib

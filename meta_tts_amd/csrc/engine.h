@@ -1,0 +1,1153 @@
+// Host-side engine of libmtts: parameter space, batch plans (row spaces), FastSpeech2 forward and
+// hand-derived backward as sequences of grouped launches (gemm.h / rowops.h), the MAML inner/outer
+// loop with per-task fast weights resident in HBM, and the fused clip + Adam outer update.
+//
+// Reference path restated here: lightning/model/fastspeech2.py:40-112 (+ base_adaptor.py:41-95
+// learner variant), lightning/model/modules.py:102-158 (variance adaptor), :167-190 (length
+// regulator), transformer/{Models,Layers,SubLayers,Modules}.py, lightning/model/loss.py:19-92,
+// lightning/systems/base_adaptor.py:98-124 (adapt / meta_learn), lightning/optimizer.py,
+// lightning/scheduler.py, main.py:61 (clip).
+//
+// Row spaces (per task; every activation is a [rows][C] matrix):
+//   P  phoneme rectangle   row(b,s) = G + b*(Smax+G) + s          encoder, variance adaptor
+//   F  frames, packed      row(b,t) = foff[b] + t, t < len_b      decoder (no padded frames)
+//   R  mel rectangle       row(b,t) = G + b*(Tcap+G) + t          mel_linear output, PostNet, loss
+// G = 4 zero guard rows separate sequences so a Conv1d is a GEMM over overlapping rows.  The
+// rectangle spaces keep padded positions because the reference computes on them (variance
+// predictor convs see speaker-embedding rows beyond src_len; PostNet BatchNorm statistics include
+// padded frames).  The decoder only ever exposes valid frames to anything downstream, so it runs
+// on the packed space (35 % fewer rows on LibriTTS-shaped batches).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "gemm.h"
+#include "rowops.h"
+
+namespace mtts {
+
+constexpr int G = 4;  // guard rows between sequences (>= max conv half-width)
+
+struct ModelCfg {
+    int d_model, enc_layers, dec_layers, enc_heads, dec_heads, d_ff, k1, k2;
+    int vp_filter, vp_kernel, n_bins, max_seq_len, n_mel, vocab, n_speaker;
+    int postnet_dim, postnet_kernel, postnet_layers;
+    float pitch_min, pitch_max, energy_min, energy_max;
+    // which top-level modules are adapted in the inner loop (bit i of: encoder,
+    // variance_adaptor, decoder, mel_linear, postnet, speaker_emb)
+    int adapt_mask;
+};
+enum { MOD_ENCODER = 0, MOD_VA, MOD_DECODER, MOD_MEL, MOD_POSTNET, MOD_SPK, MOD_COUNT };
+static const char* kModNames[MOD_COUNT] = {"encoder", "variance_adaptor", "decoder", "mel_linear", "postnet", "speaker_emb"};
+
+struct HostBatch {  // one padded batch in the reference 12-tuple layout (collate.py:47-60), host memory
+    int B, S_max, T_max;
+    const long long* speakers;   // [B]
+    const long long* texts;      // [B][S_max]
+    const long long* src_lens;   // [B]
+    const float* mels;           // [B][T_max][n_mel] or null
+    const long long* mel_lens;   // [B] or null
+    const float* pitches;        // [B][S_max] or null
+    const float* energies;       // [B][S_max] or null
+    const long long* durations;  // [B][S_max] or null
+};
+
+struct ParamEntry {
+    std::string name;
+    std::vector<int> shape;  // torch shape
+    long long off = 0, numel = 0;
+    int conv = 0;  // 1: torch (Cout, Cin, k) stored as [Cout][k][Cin]
+    int module = 0;
+};
+
+struct TS { float* p; long long ts; };
+
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return -1; } } while (0)
+
+class Engine {
+public:
+    ModelCfg cfg;
+    int cap_tasks, cap_B, cap_S, cap_T, cap_Tc;
+    int capMp, capMf, capMr;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+
+    // ---------------- parameter space -------------------------------------------------
+    std::vector<ParamEntry> entries;
+    std::map<std::string, int> by_name;
+    long long n_total = 0, adapt_start = 0, n_adapt = 0;
+    float *theta = nullptr, *adam_m = nullptr, *adam_v = nullptr, *fast = nullptr, *grad = nullptr, *outer = nullptr;
+    float *pos_table = nullptr, *pitch_bins = nullptr, *energy_bins = nullptr;
+    int pos_rows = 0;
+    std::vector<float*> bn_rm, bn_rv;
+    std::vector<long long> bn_tracked;
+    float *norm_partial = nullptr, *norm_out = nullptr;
+    long long adam_step_count = 0;
+
+    struct FFTP { long long wqkv, bqkv, ln1g, ln1b, wfc, bfc, w1, b1, w2, b2, ln2g, ln2b; };
+    struct PredP { long long c1w, c1b, l1g, l1b, c2w, c2b, l2g, l2b, lw, lb; };
+    struct PostP { long long w, b, g, beta; int cin, cout; };
+    std::vector<FFTP> encP, decP;
+    PredP durP, pitP, eneP;
+    std::vector<PostP> postP;
+    long long word_emb, pitch_emb, energy_emb, mel_w, mel_b, spk_table;
+
+    // ---------------- plans -----------------------------------------------------------
+    struct Plan {
+        int tasks = 0;
+        std::vector<int> hB, hSmax, hTcap, hMp, hMf, hMr;
+        int maxMp = 0, maxMf = 0, maxMr = 0, maxB = 0, enc_maxL = 0, dec_maxL = 0, n_enc_groups = 0, n_dec_groups = 0;
+        int average_spk = 0;
+        bool has_targets = false;
+        int* meta = nullptr;
+        // P space
+        int *p_row_b, *p_row_t, *p_tok, *p_first, *p_count, *p_dur, *p_seg_start, *p_seg_len;
+        unsigned char *p_valid, *p_inrect;
+        float *p_pitch_t, *p_energy_t;
+        // F space
+        int *f_row_b, *f_row_t, *f_src, *f_seg_start, *f_seg_len, *f2r;
+        unsigned char* f_valid;
+        // R space
+        int* r2f;
+        unsigned char *r_valid, *r_inrect;
+        float* mel_tgt;
+        int* spk_ids;
+        AttnSeq *enc_seqs, *dec_seqs;
+        GemmGroupDesc *enc_tab[6], *dec_tab[6];
+    };
+    enum { TAB_QK = 0, TAB_PV, TAB_DP, TAB_DV, TAB_DQ, TAB_DK };
+    Plan plans[2];
+    long long row_ts_p, row_ts_f, row_ts_r;  // strides of per-row index arrays
+
+    // ---------------- workspace -------------------------------------------------------
+    struct LayerBuf { TS qkv, P, O, z1, st1, y1, h, z2, st2, y2; };
+    struct PredBuf { TS r1, st1, n1, r2, st2, n2, out; };
+    struct PostBuf { TS c, a, stats, dgamma_tmp; };
+    std::vector<LayerBuf> encB, decB;
+    PredBuf durB, pitB, eneB;
+    std::vector<PostBuf> postB;
+    TS emb_out, spk, x0, x1, x2, dec_in, mel, mel_post;
+    int *pidx = nullptr, *eidx = nullptr;
+    TS d_rounded;
+    // backward scratch
+    TS gP0, gP1, gPqkv, gPh, gPf1, gPf2, gF0, gF1, gFqkv, gFh, dSp, dSf, gR0, gR1, gRm, gRp, gMelF, dspk, dpred[3];
+    float *loss_partial = nullptr, *losses = nullptr;
+    long long S_ts_p = 0, S_ts_f = 0;
+
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+
+    void set_error(const std::string& s) { last_error = s; }
+
+    // =================================================================================
+    // construction
+    // =================================================================================
+    void add_param(const std::string& name, std::vector<int> shape, int module, int conv = 0) {
+        ParamEntry e;
+        e.name = name; e.shape = shape; e.module = module; e.conv = conv;
+        e.numel = 1;
+        for (int s : shape) e.numel *= s;
+        entries.push_back(e);
+    }
+
+    void build_param_table() {
+        const int d = cfg.d_model;
+        std::vector<ParamEntry> all;
+        auto fft = [&](const std::string& pre, int layers, int module) {
+            for (int i = 0; i < layers; ++i) {
+                const std::string p = pre + ".layer_stack." + std::to_string(i);
+                // q, k, v weights then biases stay adjacent: one fused [3d][d] projection
+                add_param(p + ".slf_attn.w_qs.weight", {d, d}, module);
+                add_param(p + ".slf_attn.w_ks.weight", {d, d}, module);
+                add_param(p + ".slf_attn.w_vs.weight", {d, d}, module);
+                add_param(p + ".slf_attn.w_qs.bias", {d}, module);
+                add_param(p + ".slf_attn.w_ks.bias", {d}, module);
+                add_param(p + ".slf_attn.w_vs.bias", {d}, module);
+                add_param(p + ".slf_attn.layer_norm.weight", {d}, module);
+                add_param(p + ".slf_attn.layer_norm.bias", {d}, module);
+                add_param(p + ".slf_attn.fc.weight", {d, d}, module);
+                add_param(p + ".slf_attn.fc.bias", {d}, module);
+                add_param(p + ".pos_ffn.w_1.weight", {cfg.d_ff, d, cfg.k1}, module, 1);
+                add_param(p + ".pos_ffn.w_1.bias", {cfg.d_ff}, module);
+                add_param(p + ".pos_ffn.w_2.weight", {d, cfg.d_ff, cfg.k2}, module, 1);
+                add_param(p + ".pos_ffn.w_2.bias", {d}, module);
+                add_param(p + ".pos_ffn.layer_norm.weight", {d}, module);
+                add_param(p + ".pos_ffn.layer_norm.bias", {d}, module);
+            }
+        };
+        // module order: non-adapted modules first, adapted ones last => the fast weights of a
+        // task are one contiguous slice [adapt_start, n_total)
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int mod = 0; mod < MOD_COUNT; ++mod) {
+                const bool adapted = (cfg.adapt_mask >> mod) & 1;
+                if ((pass == 1) != adapted) continue;
+                if (mod == MOD_ENCODER) {
+                    add_param("encoder.src_word_emb.weight", {cfg.vocab, d}, mod);
+                    fft("encoder", cfg.enc_layers, mod);
+                } else if (mod == MOD_VA) {
+                    const int f = cfg.vp_filter, k = cfg.vp_kernel;
+                    for (const char* pr : {"duration_predictor", "pitch_predictor", "energy_predictor"}) {
+                        const std::string p = std::string("variance_adaptor.") + pr;
+                        add_param(p + ".conv_layer.conv1d_1.conv.weight", {f, d, k}, mod, 1);
+                        add_param(p + ".conv_layer.conv1d_1.conv.bias", {f}, mod);
+                        add_param(p + ".conv_layer.layer_norm_1.weight", {f}, mod);
+                        add_param(p + ".conv_layer.layer_norm_1.bias", {f}, mod);
+                        add_param(p + ".conv_layer.conv1d_2.conv.weight", {f, f, k}, mod, 1);
+                        add_param(p + ".conv_layer.conv1d_2.conv.bias", {f}, mod);
+                        add_param(p + ".conv_layer.layer_norm_2.weight", {f}, mod);
+                        add_param(p + ".conv_layer.layer_norm_2.bias", {f}, mod);
+                        add_param(p + ".linear_layer.weight", {1, f}, mod);
+                        add_param(p + ".linear_layer.bias", {1}, mod);
+                    }
+                    add_param("variance_adaptor.pitch_embedding.weight", {cfg.n_bins, d}, mod);
+                    add_param("variance_adaptor.energy_embedding.weight", {cfg.n_bins, d}, mod);
+                } else if (mod == MOD_DECODER) {
+                    fft("decoder", cfg.dec_layers, mod);
+                } else if (mod == MOD_MEL) {
+                    add_param("mel_linear.weight", {cfg.n_mel, d}, mod);
+                    add_param("mel_linear.bias", {cfg.n_mel}, mod);
+                } else if (mod == MOD_POSTNET) {
+                    for (int i = 0; i < cfg.postnet_layers; ++i) {
+                        const int cin = i == 0 ? cfg.n_mel : cfg.postnet_dim;
+                        const int cout = i == cfg.postnet_layers - 1 ? cfg.n_mel : cfg.postnet_dim;
+                        const std::string p = "postnet.convolutions." + std::to_string(i);
+                        add_param(p + ".0.conv.weight", {cout, cin, cfg.postnet_kernel}, mod, 1);
+                        add_param(p + ".0.conv.bias", {cout}, mod);
+                        add_param(p + ".1.weight", {cout}, mod);
+                        add_param(p + ".1.bias", {cout}, mod);
+                    }
+                } else if (mod == MOD_SPK) {
+                    add_param("speaker_emb.model.weight", {cfg.n_speaker, d}, mod);
+                }
+            }
+            if (pass == 0) {
+                long long off = 0;
+                for (auto& e : entries) off += (e.numel + 3) & ~3LL;
+                adapt_start = off;
+            }
+        }
+        long long off = 0;
+        for (size_t i = 0; i < entries.size(); ++i) {
+            entries[i].off = off;
+            off += (entries[i].numel + 3) & ~3LL;  // keep every tensor 16-byte aligned
+            by_name[entries[i].name] = (int)i;
+        }
+        n_total = off;
+        n_adapt = n_total - adapt_start;
+        auto O = [&](const std::string& n) { return entries[by_name.at(n)].off; };
+        auto fftp = [&](const std::string& pre, int layers, std::vector<FFTP>& out) {
+            for (int i = 0; i < layers; ++i) {
+                const std::string p = pre + ".layer_stack." + std::to_string(i);
+                FFTP f;
+                f.wqkv = O(p + ".slf_attn.w_qs.weight"); f.bqkv = O(p + ".slf_attn.w_qs.bias");
+                f.ln1g = O(p + ".slf_attn.layer_norm.weight"); f.ln1b = O(p + ".slf_attn.layer_norm.bias");
+                f.wfc = O(p + ".slf_attn.fc.weight"); f.bfc = O(p + ".slf_attn.fc.bias");
+                f.w1 = O(p + ".pos_ffn.w_1.weight"); f.b1 = O(p + ".pos_ffn.w_1.bias");
+                f.w2 = O(p + ".pos_ffn.w_2.weight"); f.b2 = O(p + ".pos_ffn.w_2.bias");
+                f.ln2g = O(p + ".pos_ffn.layer_norm.weight"); f.ln2b = O(p + ".pos_ffn.layer_norm.bias");
+                out.push_back(f);
+            }
+        };
+        fftp("encoder", cfg.enc_layers, encP);
+        fftp("decoder", cfg.dec_layers, decP);
+        auto pred = [&](const char* pr) {
+            const std::string p = std::string("variance_adaptor.") + pr;
+            PredP q;
+            q.c1w = O(p + ".conv_layer.conv1d_1.conv.weight"); q.c1b = O(p + ".conv_layer.conv1d_1.conv.bias");
+            q.l1g = O(p + ".conv_layer.layer_norm_1.weight"); q.l1b = O(p + ".conv_layer.layer_norm_1.bias");
+            q.c2w = O(p + ".conv_layer.conv1d_2.conv.weight"); q.c2b = O(p + ".conv_layer.conv1d_2.conv.bias");
+            q.l2g = O(p + ".conv_layer.layer_norm_2.weight"); q.l2b = O(p + ".conv_layer.layer_norm_2.bias");
+            q.lw = O(p + ".linear_layer.weight"); q.lb = O(p + ".linear_layer.bias");
+            return q;
+        };
+        durP = pred("duration_predictor"); pitP = pred("pitch_predictor"); eneP = pred("energy_predictor");
+        for (int i = 0; i < cfg.postnet_layers; ++i) {
+            const std::string p = "postnet.convolutions." + std::to_string(i);
+            PostP q;
+            q.w = O(p + ".0.conv.weight"); q.b = O(p + ".0.conv.bias"); q.g = O(p + ".1.weight"); q.beta = O(p + ".1.bias");
+            q.cin = i == 0 ? cfg.n_mel : cfg.postnet_dim;
+            q.cout = i == cfg.postnet_layers - 1 ? cfg.n_mel : cfg.postnet_dim;
+            postP.push_back(q);
+        }
+        word_emb = O("encoder.src_word_emb.weight");
+        pitch_emb = O("variance_adaptor.pitch_embedding.weight");
+        energy_emb = O("variance_adaptor.energy_embedding.weight");
+        mel_w = O("mel_linear.weight"); mel_b = O("mel_linear.bias");
+        spk_table = O("speaker_emb.model.weight");
+    }
+
+    // ---- arena -----------------------------------------------------------------------
+    size_t arena_off = 0;
+    bool arena_dry = true;
+    void* take(size_t bytes) {
+        arena_off = (arena_off + 255) & ~(size_t)255;
+        void* p = arena_dry ? nullptr : (void*)(arena + arena_off);
+        arena_off += bytes;
+        return p;
+    }
+    TS rows(int capM, int C) {  // [cap_tasks][G + capM + G][C], pointer at row 0
+        const long long ts = (long long)(capM + 2 * G) * C;
+        float* p = (float*)take((size_t)ts * cap_tasks * sizeof(float));
+        return TS{arena_dry ? nullptr : p + (long long)G * C, ts};
+    }
+    TS flat(long long n) {
+        n = (n + 3) & ~3LL;
+        return TS{(float*)take((size_t)n * cap_tasks * sizeof(float)), n};
+    }
+    template <class T> T* arr(long long n_per_task) { return (T*)take((size_t)n_per_task * cap_tasks * sizeof(T)); }
+
+    static long long attn_elems(int B, int H, int L) { return (long long)B * H * L * ((L + 3) & ~3); }
+
+    void layout() {
+        const int d = cfg.d_model, f = cfg.vp_filter, nt = cap_tasks;
+        (void)nt;
+        S_ts_p = attn_elems(cap_B, cfg.enc_heads, cap_S);
+        S_ts_f = attn_elems(cap_B, cfg.dec_heads, cap_Tc);
+        auto layer = [&](int capM, long long S_ts, std::vector<LayerBuf>& v, int n) {
+            v.resize(n);
+            for (int i = 0; i < n; ++i) {
+                v[i].qkv = rows(capM, 3 * d); v[i].P = flat(S_ts); v[i].O = rows(capM, d); v[i].z1 = rows(capM, d);
+                v[i].st1 = rows(capM, 2); v[i].y1 = rows(capM, d); v[i].h = rows(capM, cfg.d_ff); v[i].z2 = rows(capM, d);
+                v[i].st2 = rows(capM, 2); v[i].y2 = rows(capM, d);
+            }
+        };
+        emb_out = rows(capMp, d);
+        layer(capMp, S_ts_p, encB, cfg.enc_layers);
+        spk = flat((long long)cap_B * d);
+        x0 = rows(capMp, d); x1 = rows(capMp, d); x2 = rows(capMp, d);
+        for (PredBuf* pb : {&durB, &pitB, &eneB}) {
+            pb->r1 = rows(capMp, f); pb->st1 = rows(capMp, 2); pb->n1 = rows(capMp, f);
+            pb->r2 = rows(capMp, f); pb->st2 = rows(capMp, 2); pb->n2 = rows(capMp, f);
+            pb->out = rows(capMp, 1);
+        }
+        pidx = arr<int>(capMp); eidx = arr<int>(capMp);
+        d_rounded = rows(capMp, 1);
+        dec_in = rows(capMf, d);
+        layer(capMf, S_ts_f, decB, cfg.dec_layers);
+        mel = rows(capMr, cfg.n_mel); mel_post = rows(capMr, cfg.n_mel);
+        postB.resize(cfg.postnet_layers);
+        for (int i = 0; i < cfg.postnet_layers; ++i) {
+            const int c = postP[i].cout;
+            postB[i].c = rows(capMr, c); postB[i].a = rows(capMr, c); postB[i].stats = flat(3LL * c);
+            postB[i].dgamma_tmp = flat(2LL * c);
+        }
+        // backward scratch
+        gP0 = rows(capMp, d); gP1 = rows(capMp, d); gPqkv = rows(capMp, 3 * d); gPh = rows(capMp, cfg.d_ff);
+        gPf1 = rows(capMp, f); gPf2 = rows(capMp, f);
+        gF0 = rows(capMf, d); gF1 = rows(capMf, d); gFqkv = rows(capMf, 3 * d); gFh = rows(capMf, cfg.d_ff);
+        dSp = flat(S_ts_p); dSf = flat(S_ts_f);
+        const int pc = std::max(cfg.postnet_dim, cfg.n_mel);
+        gR0 = rows(capMr, pc); gR1 = rows(capMr, pc); gRm = rows(capMr, cfg.n_mel); gRp = rows(capMr, cfg.n_mel);
+        gMelF = rows(capMf, cfg.n_mel);
+        dspk = flat((long long)cap_B * d);
+        for (int i = 0; i < 3; ++i) dpred[i] = rows(capMp, 1);
+        loss_partial = (float*)take((size_t)cap_tasks * kLossBlocks * 5 * sizeof(float));
+        losses = (float*)take((size_t)cap_tasks * 6 * sizeof(float));
+        // plans
+        row_ts_p = capMp; row_ts_f = capMf; row_ts_r = capMr;
+        for (int s = 0; s < 2; ++s) {
+            Plan& p = plans[s];
+            p.meta = (int*)take((size_t)cap_tasks * META_STRIDE * sizeof(int));
+            p.p_row_b = arr<int>(capMp); p.p_row_t = arr<int>(capMp); p.p_tok = arr<int>(capMp);
+            p.p_first = arr<int>(capMp); p.p_count = arr<int>(capMp); p.p_dur = arr<int>(capMp);
+            p.p_seg_start = arr<int>(cap_B); p.p_seg_len = arr<int>(cap_B);
+            p.p_valid = arr<unsigned char>(capMp); p.p_inrect = arr<unsigned char>(capMp);
+            p.p_pitch_t = arr<float>(capMp); p.p_energy_t = arr<float>(capMp);
+            p.f_row_b = arr<int>(capMf); p.f_row_t = arr<int>(capMf); p.f_src = arr<int>(capMf);
+            p.f_seg_start = arr<int>(cap_B); p.f_seg_len = arr<int>(cap_B); p.f2r = arr<int>(capMf);
+            p.f_valid = arr<unsigned char>(capMf);
+            p.r2f = arr<int>(capMr); p.r_valid = arr<unsigned char>(capMr); p.r_inrect = arr<unsigned char>(capMr);
+            p.mel_tgt = rows(capMr, cfg.n_mel).p;
+            p.spk_ids = arr<int>(cap_B + 1);
+            p.enc_seqs = (AttnSeq*)take(sizeof(AttnSeq) * cap_tasks * cap_B * cfg.enc_heads);
+            p.dec_seqs = (AttnSeq*)take(sizeof(AttnSeq) * cap_tasks * cap_B * cfg.dec_heads);
+            for (int k = 0; k < 6; ++k) {
+                p.enc_tab[k] = (GemmGroupDesc*)take(sizeof(GemmGroupDesc) * cap_tasks * cap_B * cfg.enc_heads);
+                p.dec_tab[k] = (GemmGroupDesc*)take(sizeof(GemmGroupDesc) * cap_tasks * cap_B * cfg.dec_heads);
+            }
+        }
+    }
+
+    int init(const ModelCfg& c, int max_tasks, int max_B, int max_S, int max_T) {
+        cfg = c;
+        cap_tasks = max_tasks; cap_B = max_B; cap_S = max_S; cap_T = max_T;
+        cap_Tc = std::min(max_T, cfg.max_seq_len);
+        if (cfg.d_model % 4 || cfg.d_ff % 16 || cfg.vp_filter % 16 || cfg.n_mel % 16 || cfg.postnet_dim % 16 ||
+            cfg.d_model % 16 || cfg.d_model > 1024 || cfg.vp_filter > 1024 || cfg.postnet_dim > 1024 ||
+            (cfg.d_model / cfg.enc_heads) % 16 || (cfg.d_model / cfg.dec_heads) % 16 || cfg.k1 / 2 > G ||
+            cfg.k2 / 2 > G || cfg.vp_kernel / 2 > G || cfg.postnet_kernel / 2 > G) {
+            set_error("unsupported model dimensions (channels must be multiples of 16 and <= 1024, kernels <= 9)");
+            return -1;
+        }
+        capMp = G + cap_B * (cap_S + G);
+        capMf = G + cap_B * (cap_Tc + G);
+        capMr = capMf;
+        build_param_table();
+        HIP_CHECK(hipMalloc((void**)&theta, n_total * sizeof(float)));
+        HIP_CHECK(hipMalloc((void**)&adam_m, n_total * sizeof(float)));
+        HIP_CHECK(hipMalloc((void**)&adam_v, n_total * sizeof(float)));
+        HIP_CHECK(hipMalloc((void**)&outer, n_total * sizeof(float)));
+        HIP_CHECK(hipMalloc((void**)&fast, (size_t)std::max<long long>(n_adapt, 4) * cap_tasks * sizeof(float)));
+        HIP_CHECK(hipMalloc((void**)&grad, (size_t)n_total * cap_tasks * sizeof(float)));
+        HIP_CHECK(hipMemset(theta, 0, n_total * sizeof(float)));
+        HIP_CHECK(hipMemset(adam_m, 0, n_total * sizeof(float)));
+        HIP_CHECK(hipMemset(adam_v, 0, n_total * sizeof(float)));
+        HIP_CHECK(hipMemset(outer, 0, n_total * sizeof(float)));
+        HIP_CHECK(hipMemset(grad, 0, (size_t)n_total * cap_tasks * sizeof(float)));
+        HIP_CHECK(hipMalloc((void**)&norm_partial, 1024 * sizeof(float)));
+        HIP_CHECK(hipMalloc((void**)&norm_out, 4 * sizeof(float)));
+        // frozen tables: sinusoid positions (Models.py:10-30, float64 math), linear bins
+        pos_rows = std::max(cfg.max_seq_len + 1, std::max(cap_S, cap_T) + 1);
+        std::vector<float> pt((size_t)pos_rows * cfg.d_model);
+        for (int p = 0; p < pos_rows; ++p)
+            for (int j = 0; j < cfg.d_model; ++j) {
+                const double ang = (double)p / std::pow(10000.0, 2.0 * (double)(j / 2) / (double)cfg.d_model);
+                pt[(size_t)p * cfg.d_model + j] = (float)((j % 2 == 0) ? std::sin(ang) : std::cos(ang));
+            }
+        HIP_CHECK(hipMalloc((void**)&pos_table, pt.size() * sizeof(float)));
+        HIP_CHECK(hipMemcpy(pos_table, pt.data(), pt.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMalloc((void**)&pitch_bins, cfg.n_bins * sizeof(float)));
+        HIP_CHECK(hipMalloc((void**)&energy_bins, cfg.n_bins * sizeof(float)));
+        set_bins(cfg.pitch_min, cfg.pitch_max, cfg.energy_min, cfg.energy_max);
+        bn_rm.resize(cfg.postnet_layers); bn_rv.resize(cfg.postnet_layers); bn_tracked.assign(cfg.postnet_layers, 0);
+        for (int i = 0; i < cfg.postnet_layers; ++i) {
+            const int cc = postP[i].cout;
+            HIP_CHECK(hipMalloc((void**)&bn_rm[i], cc * sizeof(float)));
+            HIP_CHECK(hipMalloc((void**)&bn_rv[i], cc * sizeof(float)));
+        }
+        reset_bn();
+        arena_dry = true; arena_off = 0;
+        layout();
+        arena_bytes = arena_off + 256;
+        HIP_CHECK(hipMalloc((void**)&arena, arena_bytes));
+        HIP_CHECK(hipMemset(arena, 0, arena_bytes));
+        arena_dry = false; arena_off = 0;
+        layout();
+        return 0;
+    }
+
+    void set_bins(float pmin, float pmax, float emin, float emax) {
+        // np.linspace(min, max, n_bins - 1) in float64, cast to fp32 (meta_tts_amd.synth.make_params)
+        const int nb = cfg.n_bins - 1;
+        std::vector<float> pb(nb), eb(nb);
+        for (int i = 0; i < nb; ++i) {
+            const double t = nb > 1 ? (double)i / (double)(nb - 1) : 0.0;
+            pb[i] = (float)((double)pmin + ((double)pmax - (double)pmin) * t);
+            eb[i] = (float)((double)emin + ((double)emax - (double)emin) * t);
+        }
+        if (nb > 1) { pb[nb - 1] = pmax; eb[nb - 1] = emax; }
+        hipMemcpy(pitch_bins, pb.data(), nb * sizeof(float), hipMemcpyHostToDevice);
+        hipMemcpy(energy_bins, eb.data(), nb * sizeof(float), hipMemcpyHostToDevice);
+    }
+
+    void reset_bn() {
+        for (int i = 0; i < cfg.postnet_layers; ++i) {
+            const int cc = postP[i].cout;
+            std::vector<float> one(cc, 1.f);
+            hipMemset(bn_rm[i], 0, cc * sizeof(float));
+            hipMemcpy(bn_rv[i], one.data(), cc * sizeof(float), hipMemcpyHostToDevice);
+            bn_tracked[i] = 0;
+        }
+    }
+
+    void destroy() {
+        for (float* p : {theta, adam_m, adam_v, outer, fast, grad, norm_partial, norm_out, pos_table, pitch_bins, energy_bins})
+            if (p) hipFree(p);
+        for (float* p : bn_rm) hipFree(p);
+        for (float* p : bn_rv) hipFree(p);
+        if (arena) hipFree(arena);
+    }
+
+    // =================================================================================
+    // parameter import / export (torch layout <-> internal layout)
+    // =================================================================================
+    int load_param(const std::string& name, const float* host, long long numel) {
+        auto it = by_name.find(name);
+        if (it == by_name.end()) { set_error("unknown parameter: " + name); return -1; }
+        const ParamEntry& e = entries[it->second];
+        if (numel != e.numel) { set_error("size mismatch for " + name); return -1; }
+        std::vector<float> tmp;
+        const float* src = host;
+        if (e.conv) {
+            const int co = e.shape[0], ci = e.shape[1], k = e.shape[2];
+            tmp.resize(e.numel);
+            for (int o = 0; o < co; ++o)
+                for (int c = 0; c < ci; ++c)
+                    for (int kk = 0; kk < k; ++kk)
+                        tmp[((size_t)o * k + kk) * ci + c] = host[((size_t)o * ci + c) * k + kk];
+            src = tmp.data();
+        }
+        HIP_CHECK(hipMemcpy(theta + e.off, src, e.numel * sizeof(float), hipMemcpyHostToDevice));
+        return 0;
+    }
+
+    // which: 0 theta, 1 outer gradient, 2 per-task gradient, 3 fast weights of `task`, 4 adam m, 5 adam v
+    int export_param(const std::string& name, int which, int task, float* host, long long numel) {
+        auto it = by_name.find(name);
+        if (it == by_name.end()) { set_error("unknown parameter: " + name); return -1; }
+        const ParamEntry& e = entries[it->second];
+        if (numel != e.numel) { set_error("size mismatch for " + name); return -1; }
+        const float* src = nullptr;
+        if (which == 0) src = theta + e.off;
+        else if (which == 1) src = outer + e.off;
+        else if (which == 2) src = grad + (long long)task * n_total + e.off;
+        else if (which == 3) {
+            if (e.off < adapt_start) src = theta + e.off;
+            else src = fast + (long long)task * n_adapt + (e.off - adapt_start);
+        } else if (which == 4) src = adam_m + e.off;
+        else if (which == 5) src = adam_v + e.off;
+        else { set_error("bad export selector"); return -1; }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        std::vector<float> tmp(e.numel);
+        HIP_CHECK(hipMemcpy(tmp.data(), src, e.numel * sizeof(float), hipMemcpyDeviceToHost));
+        if (e.conv) {
+            const int co = e.shape[0], ci = e.shape[1], k = e.shape[2];
+            for (int o = 0; o < co; ++o)
+                for (int c = 0; c < ci; ++c)
+                    for (int kk = 0; kk < k; ++kk)
+                        host[((size_t)o * ci + c) * k + kk] = tmp[((size_t)o * k + kk) * ci + c];
+        } else {
+            memcpy(host, tmp.data(), e.numel * sizeof(float));
+        }
+        return 0;
+    }
+
+    // =================================================================================
+    // batch plans
+    // =================================================================================
+    template <class T> int upload(T* dst, long long ts, int task, const std::vector<T>& v) {
+        if (v.empty()) return 0;
+        HIP_CHECK(hipMemcpyAsync(dst + ts * task, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+        return 0;
+    }
+
+    // Build the row spaces of `tasks` batches into plan slot `slot` and upload inputs/targets.
+    // spk_override (optional, per task): ids whose table rows are averaged (query pass of MAML).
+    int set_batches(int slot, int tasks, const HostBatch* hb, const HostBatch* spk_from, int average_spk) {
+        if (tasks < 1 || tasks > cap_tasks) { set_error("task count exceeds capacity"); return -1; }
+        Plan& p = plans[slot];
+        p.tasks = tasks;
+        p.average_spk = average_spk;
+        p.hB.assign(tasks, 0); p.hSmax.assign(tasks, 0); p.hTcap.assign(tasks, 0);
+        p.hMp.assign(tasks, 0); p.hMf.assign(tasks, 0); p.hMr.assign(tasks, 0);
+        p.maxMp = p.maxMf = p.maxMr = p.maxB = p.enc_maxL = p.dec_maxL = 0;
+        p.has_targets = true;
+        std::vector<int> meta((size_t)tasks * META_STRIDE, 0);
+        std::vector<AttnSeq> eseq, dseq;
+        std::vector<GemmGroupDesc> etab[6], dtab[6];
+        const int d = cfg.d_model;
+        for (int t = 0; t < tasks; ++t) {
+            const HostBatch& b = hb[t];
+            if (b.B < 1 || b.B > cap_B || b.S_max > cap_S) { set_error("batch exceeds engine capacity (B or S_max)"); return -1; }
+            const bool tgt = b.durations && b.mel_lens && b.mels && b.pitches && b.energies;
+            if (!tgt) { set_error("teacher-forced batches need mels, mel_lens, pitches, energies, durations"); return -1; }
+            const int B = b.B, S = b.S_max;
+            const int Tcap = std::min(b.T_max, cfg.max_seq_len);
+            if (b.T_max > cap_T) { set_error("batch exceeds engine capacity (T_max)"); return -1; }
+            const int Mp = G + B * (S + G);
+            std::vector<int> row_b(Mp, 0), row_t(Mp, -1), tok(Mp, 0), first(Mp, 0), count(Mp, 0), dur(Mp, 0);
+            std::vector<unsigned char> valid(Mp, 0), inrect(Mp, 0);
+            std::vector<float> pt(Mp, 0.f), et(Mp, 0.f);
+            std::vector<int> pseg_s(B), pseg_l(B), fseg_s(B), fseg_l(B), flen(B);
+            // frame space: packed valid frames
+            int foff = G, nP = 0, nF = 0;
+            std::vector<int> foffs(B);
+            for (int i = 0; i < B; ++i) {
+                const int ml = (int)std::min<long long>(b.mel_lens[i], Tcap);
+                flen[i] = ml; foffs[i] = foff; fseg_s[i] = foff; fseg_l[i] = ml;
+                foff += ml + G;
+                nF += ml;
+            }
+            const int Mf = foff, Mr = G + B * (Tcap + G);
+            if (Mf > capMf || Mr > capMr || Mp > capMp) { set_error("row space exceeds capacity"); return -1; }
+            std::vector<int> f_row_b(Mf, 0), f_row_t(Mf, -1), f_src(Mf, -1), f2r(Mf, -1), r2f(Mr, -1);
+            std::vector<unsigned char> f_valid(Mf, 0), r_valid(Mr, 0), r_inrect(Mr, 0);
+            std::vector<float> mel_t((size_t)Mr * cfg.n_mel, 0.f);
+            long long soff[2] = {0, 0};  // running offsets inside this task's score buffers (enc, dec)
+            for (int i = 0; i < B; ++i) {
+                const int sl = (int)b.src_lens[i];
+                pseg_s[i] = G + i * (S + G); pseg_l[i] = S;
+                int cum = 0;
+                for (int s = 0; s < S; ++s) {
+                    const int r = G + i * (S + G) + s;
+                    row_b[r] = i; row_t[r] = s; inrect[r] = 1;
+                    const bool v = s < sl;
+                    valid[r] = v;
+                    tok[r] = v ? (int)b.texts[(size_t)i * S + s] : 0;
+                    pt[r] = b.pitches[(size_t)i * S + s];
+                    et[r] = b.energies[(size_t)i * S + s];
+                    long long dd = b.durations[(size_t)i * S + s];
+                    if (dd < 0) dd = 0;
+                    dur[r] = (int)dd;
+                    // frames of this phoneme inside the (possibly truncated) frame window
+                    const int lo = std::min(cum, flen[i]), hi = std::min(cum + (int)dd, flen[i]);
+                    first[r] = foffs[i] + lo; count[r] = hi - lo;
+                    for (int f = lo; f < hi; ++f) f_src[foffs[i] + f] = r;
+                    cum += (int)dd;
+                    if (v) ++nP;
+                }
+                for (int f = 0; f < flen[i]; ++f) {
+                    const int fr = foffs[i] + f, rr = G + i * (Tcap + G) + f;
+                    f_row_b[fr] = i; f_row_t[fr] = f; f_valid[fr] = 1; f2r[fr] = rr; r2f[rr] = fr; r_valid[rr] = 1;
+                    memcpy(&mel_t[(size_t)rr * cfg.n_mel], &b.mels[((size_t)i * b.T_max + f) * cfg.n_mel], cfg.n_mel * sizeof(float));
+                }
+                for (int f = 0; f < Tcap; ++f) r_inrect[G + i * (Tcap + G) + f] = 1;
+                // attention groups (valid rows only)
+                for (int which = 0; which < 2; ++which) {
+                    const int H = which ? cfg.dec_heads : cfg.enc_heads, dk = d / H;
+                    const int L = which ? flen[i] : sl, ro = which ? foffs[i] : G + i * (S + G);
+                    std::vector<AttnSeq>& sq = which ? dseq : eseq;
+                    std::vector<GemmGroupDesc>* tb = which ? dtab : etab;
+                    const long long task_s = which ? S_ts_f : S_ts_p;
+                    int& maxL = which ? p.dec_maxL : p.enc_maxL;
+                    maxL = std::max(maxL, L);
+                    const int ldS = (L + 3) & ~3;
+                    const int capM = which ? capMf : capMp;
+                    for (int h = 0; h < H; ++h) {
+                        const long long so = (long long)t * task_s + soff[which];
+                        soff[which] += (long long)L * ldS;
+                        sq.push_back(AttnSeq{so, L, ldS});
+                        const long long qo = (long long)t * ((long long)(capM + 2 * G) * 3 * d) + (long long)ro * 3 * d + h * dk;
+                        const long long oo = (long long)t * ((long long)(capM + 2 * G) * d) + (long long)ro * d + h * dk;
+                        tb[TAB_QK].push_back(GemmGroupDesc{qo, qo + d, so, L, L, dk, 0, 0, ldS});          // S  = Q K^T
+                        tb[TAB_PV].push_back(GemmGroupDesc{so, qo + 2 * d, oo, L, dk, L, ldS, 0, 0});     // O  = P V
+                        tb[TAB_DP].push_back(GemmGroupDesc{oo, qo + 2 * d, so, L, L, dk, 0, 0, ldS});     // dP = dO V^T
+                        tb[TAB_DV].push_back(GemmGroupDesc{so, oo, qo + 2 * d, L, dk, L, ldS, 0, 0});     // dV = P^T dO
+                        tb[TAB_DQ].push_back(GemmGroupDesc{so, qo + d, qo, L, dk, L, ldS, 0, 0});         // dQ = dS K
+                        tb[TAB_DK].push_back(GemmGroupDesc{so, qo, qo + d, L, dk, L, ldS, 0, 0});         // dK = dS^T Q
+                    }
+                }
+            }
+            p.hB[t] = B; p.hSmax[t] = S; p.hTcap[t] = Tcap; p.hMp[t] = Mp; p.hMf[t] = Mf; p.hMr[t] = Mr;
+            p.maxMp = std::max(p.maxMp, Mp); p.maxMf = std::max(p.maxMf, Mf); p.maxMr = std::max(p.maxMr, Mr);
+            p.maxB = std::max(p.maxB, B);
+            int* m = &meta[(size_t)t * META_STRIDE];
+            m[META_B] = B; m[META_SMAX] = S; m[META_TCAP] = Tcap; m[META_MP] = Mp; m[META_MF] = Mf; m[META_MR] = Mr;
+            m[META_NP] = nP; m[META_NF] = nF;
+            if (upload(p.p_row_b, row_ts_p, t, row_b) || upload(p.p_row_t, row_ts_p, t, row_t) || upload(p.p_tok, row_ts_p, t, tok) ||
+                upload(p.p_first, row_ts_p, t, first) || upload(p.p_count, row_ts_p, t, count) || upload(p.p_dur, row_ts_p, t, dur) ||
+                upload(p.p_valid, row_ts_p, t, valid) || upload(p.p_inrect, row_ts_p, t, inrect) ||
+                upload(p.p_pitch_t, row_ts_p, t, pt) || upload(p.p_energy_t, row_ts_p, t, et) ||
+                upload(p.p_seg_start, (long long)cap_B, t, pseg_s) || upload(p.p_seg_len, (long long)cap_B, t, pseg_l) ||
+                upload(p.f_seg_start, (long long)cap_B, t, fseg_s) || upload(p.f_seg_len, (long long)cap_B, t, fseg_l) ||
+                upload(p.f_row_b, row_ts_f, t, f_row_b) || upload(p.f_row_t, row_ts_f, t, f_row_t) || upload(p.f_src, row_ts_f, t, f_src) ||
+                upload(p.f2r, row_ts_f, t, f2r) || upload(p.f_valid, row_ts_f, t, f_valid) || upload(p.r2f, row_ts_r, t, r2f) ||
+                upload(p.r_valid, row_ts_r, t, r_valid) || upload(p.r_inrect, row_ts_r, t, r_inrect))
+                return -1;
+            HIP_CHECK(hipMemcpyAsync(p.mel_tgt + (long long)t * ((long long)(capMr + 2 * G) * cfg.n_mel), mel_t.data(),
+                                     mel_t.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+            // speaker ids (+ count at index cap_B)
+            const HostBatch& sb = spk_from ? spk_from[t] : b;
+            if (sb.B > cap_B) { set_error("speaker id list exceeds capacity"); return -1; }
+            std::vector<int> ids(cap_B + 1, 0);
+            for (int i = 0; i < sb.B; ++i) {
+                if (sb.speakers[i] < 0 || sb.speakers[i] >= cfg.n_speaker) { set_error("speaker id out of range"); return -1; }
+                ids[i] = (int)sb.speakers[i];
+            }
+            ids[cap_B] = sb.B;
+            if (!average_spk && sb.B != B) { set_error("speaker id count != batch size"); return -1; }
+            if (upload(p.spk_ids, (long long)cap_B + 1, t, ids)) return -1;
+            HIP_CHECK(hipStreamSynchronize(stream));  // host vectors go out of scope
+        }
+        HIP_CHECK(hipMemcpyAsync(p.meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        p.n_enc_groups = (int)eseq.size(); p.n_dec_groups = (int)dseq.size();
+        HIP_CHECK(hipMemcpyAsync(p.enc_seqs, eseq.data(), eseq.size() * sizeof(AttnSeq), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(p.dec_seqs, dseq.data(), dseq.size() * sizeof(AttnSeq), hipMemcpyHostToDevice, stream));
+        for (int k = 0; k < 6; ++k) {
+            HIP_CHECK(hipMemcpyAsync(p.enc_tab[k], etab[k].data(), etab[k].size() * sizeof(GemmGroupDesc), hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(p.dec_tab[k], dtab[k].data(), dtab[k].size() * sizeof(GemmGroupDesc), hipMemcpyHostToDevice, stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return 0;
+    }
+
+    // =================================================================================
+    // pass context + small launch helpers
+    // =================================================================================
+    struct Pass {
+        Plan* pl;
+        bool use_fast;   // adapted modules read the per-task fast weights
+        bool train;      // BatchNorm batch statistics (+ running update); decoder truncation
+        float p_control = 1.f, e_control = 1.f, d_control = 1.f;
+    };
+    enum Space { SP_P = 0, SP_F = 1, SP_R = 2 };
+
+    TS W(const Pass& ps, long long off) const {
+        if (ps.use_fast && off >= adapt_start) return TS{fast + (off - adapt_start), n_adapt};
+        return TS{theta + off, 0};
+    }
+    TS Gd(long long off) const { return TS{grad + off, n_total}; }
+    int mfield(Space s) const { return s == SP_P ? META_MP : (s == SP_F ? META_MF : META_MR); }
+    int maxM(const Plan& p, Space s) const { return s == SP_P ? p.maxMp : (s == SP_F ? p.maxMf : p.maxMr); }
+    const unsigned char* valid_mask(const Plan& p, Space s) const { return s == SP_P ? p.p_valid : (s == SP_F ? p.f_valid : p.r_valid); }
+    const unsigned char* inrect_mask(const Plan& p, Space s) const { return s == SP_P ? p.p_inrect : (s == SP_F ? p.f_valid : p.r_inrect); }
+    long long row_ts(Space s) const { return s == SP_P ? row_ts_p : (s == SP_F ? row_ts_f : row_ts_r); }
+
+    // row-space GEMM over all tasks: C[M,N] (+)= op(A, B); M (or the reduction length for TN) is
+    // the task's row count
+    GemmArgs rowgemm(const Plan& p, Space s, int form) const {
+        GemmArgs g;
+        g.dimptr = p.meta + mfield(s);
+        g.dim_stride = META_STRIDE;
+        g.dim_sel = (form == GEMM_TN) ? 2 : 0;
+        return g;
+    }
+
+    // Y[M,N] = conv_k(X)[M, k*Cin] * W[N][k*Cin]^T + b   (k = 1: Linear)
+    void conv_fwd(const Pass& ps, Space s, TS x, int cin, int k, TS w, TS b, int cout, TS y, int flags,
+                  const unsigned char* rowmask) {
+        const Plan& p = *ps.pl;
+        GemmArgs g = rowgemm(p, s, GEMM_NT);
+        const int pad = k / 2;
+        g.A = x.p - (long long)pad * cin; g.a_gs = x.ts; g.lda = cin;
+        g.B = w.p; g.b_gs = w.ts; g.ldb = k * cin;
+        g.C = y.p; g.c_gs = y.ts; g.ldc = cout;
+        g.N = cout; g.K = k * cin;
+        g.bias = b.p; g.bias_gs = b.ts;
+        g.flags = flags;
+        g.rowmask = rowmask; g.rowmask_gs = row_ts(s);
+        gemm_launch(GEMM_NT, g, maxM(p, s), cout, p.tasks, stream);
+    }
+    // dX[M,Cin] (+)= sum_taps dY[M +- tap, Cout] * W  (conv dgrad over the same [Cout][k][Cin] image)
+    void conv_dgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS w, int cin, TS dx, int flags,
+                    const unsigned char* rowmask, TS relu_ref = TS{nullptr, 0}) {
+        const Plan& p = *ps.pl;
+        GemmArgs g = rowgemm(p, s, GEMM_NN);
+        const int pad = k / 2;
+        g.A = dy.p - (long long)pad * cout; g.a_gs = dy.ts; g.lda = cout;
+        g.B = w.p; g.b_gs = w.ts; g.ldb = k * cin;
+        g.C = dx.p; g.c_gs = dx.ts; g.ldc = cin;
+        g.N = cin; g.K = k * cout;
+        g.taps = k; g.tap_k = cout; g.tap_bstride = cin;
+        g.flags = flags;
+        g.rowmask = rowmask; g.rowmask_gs = row_ts(s);
+        if (relu_ref.p) { g.relu_ref = relu_ref.p; g.relu_ref_gs = relu_ref.ts; g.ld_relu = cin; }
+        gemm_launch(GEMM_NN, g, maxM(p, s), cin, p.tasks, stream);
+    }
+    // dW[Cout][k*Cin] = dY^T * conv_k(X), db = colsum(dY)
+    void conv_wgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS x, int cin, long long w_off, long long b_off,
+                    const unsigned char* bias_mask) {
+        const Plan& p = *ps.pl;
+        GemmArgs g = rowgemm(p, s, GEMM_TN);
+        const int pad = k / 2;
+        g.A = dy.p; g.a_gs = dy.ts; g.lda = cout;
+        g.B = x.p - (long long)pad * cin; g.b_gs = x.ts; g.ldb = cin;
+        TS gw = Gd(w_off);
+        g.C = gw.p; g.c_gs = gw.ts; g.ldc = k * cin;
+        g.M = cout; g.N = k * cin;
+        gemm_launch(GEMM_TN, g, cout, k * cin, p.tasks, stream);
+        if (b_off >= 0) colsum(ps, s, dy, cout, bias_mask, TS{nullptr, 0}, Gd(b_off));
+    }
+    void colsum(const Pass& ps, Space s, TS x, int C, const unsigned char* mask, TS roww, TS out) {
+        const Plan& p = *ps.pl;
+        dim3 grid((C + 31) / 32, 1, p.tasks);
+        MTTS_LAUNCH(colreduce_kernel, grid, dim3(256), stream, (const int*)p.meta, mfield(s), 0, (const float*)x.p, x.ts, C,
+                    (const float*)nullptr, 0LL, (const float*)nullptr, 0LL, mask, row_ts(s), (const float*)roww.p, roww.ts,
+                    out.p, (float*)nullptr, out.ts, C);
+    }
+    void ln_fwd(const Pass& ps, Space s, TS a, TS res, long long g_off, long long b_off, const unsigned char* mask,
+                TS zout, TS y, TS st, int C) {
+        const Plan& p = *ps.pl;
+        TS gm = W(ps, g_off), bt = W(ps, b_off);
+        MTTS_LAUNCH(layernorm_fwd_kernel, row_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
+                    (const float*)a.p, a.ts, (const float*)res.p, res.ts, (const float*)gm.p, (const float*)bt.p, gm.ts, mask,
+                    row_ts(s), zout.p, zout.ts, y.p, y.ts, st.p, st.ts, C, 1e-5f);
+    }
+    // dz = LayerNorm backward (masked); parameter grads into the per-task grad buffer
+    void ln_bwd(const Pass& ps, Space s, TS dy, TS z, TS st, long long g_off, long long b_off, const unsigned char* mask,
+                TS dz, int C, int relu_on_z) {
+        const Plan& p = *ps.pl;
+        TS gm = W(ps, g_off);
+        dim3 grid((C + 31) / 32, 1, p.tasks);
+        TS gg = Gd(g_off), gb = Gd(b_off);
+        MTTS_LAUNCH(colreduce_kernel, grid, dim3(256), stream, (const int*)p.meta, mfield(s), 1, (const float*)dy.p, dy.ts, C,
+                    (const float*)z.p, z.ts, (const float*)st.p, st.ts, mask, row_ts(s), (const float*)nullptr, 0LL, gg.p, gb.p,
+                    gg.ts, C);
+        MTTS_LAUNCH(layernorm_bwd_kernel, row_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
+                    (const float*)dy.p, dy.ts, (const float*)z.p, z.ts, (const float*)st.p, st.ts, (const float*)gm.p, gm.ts,
+                    mask, row_ts(s), dz.p, dz.ts, C, relu_on_z);
+    }
+    void attn_gemm(const Pass& ps, Space s, int which, int form, const float* A, int lda, const float* B, int ldb,
+                   float* C, int ldc, float alpha, int heads) {
+        const Plan& p = *ps.pl;
+        GemmArgs g;
+        g.table = (s == SP_P) ? p.enc_tab[which] : p.dec_tab[which];
+        g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha;
+        const int L = (s == SP_P) ? p.enc_maxL : p.dec_maxL, dk = cfg.d_model / heads;
+        const int groups = (s == SP_P) ? p.n_enc_groups : p.n_dec_groups;
+        int mM = L, mN = L;
+        if (which == TAB_PV || which == TAB_DV || which == TAB_DQ || which == TAB_DK) mN = dk;
+        gemm_launch(form, g, mM, mN, groups, stream);
+    }
+
+    // =================================================================================
+    // FFT block (transformer/Layers.py:21-30)
+    // =================================================================================
+    void fft_fwd(const Pass& ps, Space s, int heads, const FFTP& P, LayerBuf& b, TS xin, TS S_unused) {
+        (void)S_unused;
+        const Plan& p = *ps.pl;
+        const int d = cfg.d_model, dk = d / heads;
+        const unsigned char* vm = valid_mask(p, s);
+        const unsigned char* im = inrect_mask(p, s);
+        conv_fwd(ps, s, xin, d, 1, W(ps, P.wqkv), W(ps, P.bqkv), 3 * d, b.qkv, 0, nullptr);
+        attn_gemm(ps, s, TAB_QK, GEMM_NT, b.qkv.p, 3 * d, b.qkv.p, 3 * d, b.P.p, 0, 1.f / sqrtf((float)dk), heads);
+        const int groups = (s == SP_P) ? p.n_enc_groups : p.n_dec_groups;
+        const int L = (s == SP_P) ? p.enc_maxL : p.dec_maxL;
+        const AttnSeq* seqs = (s == SP_P) ? p.enc_seqs : p.dec_seqs;
+        if (groups > 0 && L > 0)
+            MTTS_LAUNCH(softmax_fwd_kernel, dim3((L + 3) / 4, 1, groups), dim3(256), stream, seqs, b.P.p);
+        attn_gemm(ps, s, TAB_PV, GEMM_NN, b.P.p, 0, b.qkv.p, 3 * d, b.O.p, d, 1.f, heads);
+        conv_fwd(ps, s, b.O, d, 1, W(ps, P.wfc), W(ps, P.bfc), d, b.z1, 0, nullptr);
+        ln_fwd(ps, s, b.z1, xin, P.ln1g, P.ln1b, vm, b.z1, b.y1, b.st1, d);
+        conv_fwd(ps, s, b.y1, d, cfg.k1, W(ps, P.w1), W(ps, P.b1), cfg.d_ff, b.h, GEMM_RELU, im);
+        conv_fwd(ps, s, b.h, cfg.d_ff, cfg.k2, W(ps, P.w2), W(ps, P.b2), d, b.z2, 0, nullptr);
+        ln_fwd(ps, s, b.z2, b.y1, P.ln2g, P.ln2b, vm, b.z2, b.y2, b.st2, d);
+    }
+
+    // g0 holds dL/dy2 on entry and dL/dx on exit; g1, gqkv, gh, dS are scratch
+    void fft_bwd(const Pass& ps, Space s, int heads, const FFTP& P, LayerBuf& b, TS xin, TS g0, TS g1, TS gqkv, TS gh,
+                 TS dS) {
+        const Plan& p = *ps.pl;
+        const int d = cfg.d_model, dk = d / heads, ff = cfg.d_ff;
+        const unsigned char* vm = valid_mask(p, s);
+        const unsigned char* im = inrect_mask(p, s);
+        // LN2 (+ row mask) backward -> g1 = dz2
+        ln_bwd(ps, s, g0, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0);
+        // conv2
+        conv_wgrad(ps, s, g1, d, cfg.k2, b.h, ff, P.w2, P.b2, vm);
+        conv_dgrad(ps, s, g1, d, cfg.k2, W(ps, P.w2), ff, gh, 0, im, b.h);
+        // conv1: g1 += dgrad -> dy1
+        conv_wgrad(ps, s, gh, ff, cfg.k1, b.y1, d, P.w1, P.b1, im);
+        conv_dgrad(ps, s, gh, ff, cfg.k1, W(ps, P.w1), d, g1, GEMM_ACCUM, im);
+        // LN1 backward -> g0 = dz1
+        ln_bwd(ps, s, g1, b.z1, b.st1, P.ln1g, P.ln1b, vm, g0, d, 0);
+        // fc
+        conv_wgrad(ps, s, g0, d, 1, b.O, d, P.wfc, P.bfc, vm);
+        conv_dgrad(ps, s, g0, d, 1, W(ps, P.wfc), d, g1, 0, nullptr);  // g1 = dO
+        // attention
+        const int groups = (s == SP_P) ? p.n_enc_groups : p.n_dec_groups;
+        const int L = (s == SP_P) ? p.enc_maxL : p.dec_maxL;
+        const AttnSeq* seqs = (s == SP_P) ? p.enc_seqs : p.dec_seqs;
+        attn_gemm(ps, s, TAB_DP, GEMM_NT, g1.p, d, b.qkv.p, 3 * d, dS.p, 0, 1.f, heads);
+        attn_gemm(ps, s, TAB_DV, GEMM_TN, b.P.p, 0, g1.p, d, gqkv.p, 3 * d, 1.f, heads);
+        if (groups > 0 && L > 0)
+            MTTS_LAUNCH(softmax_bwd_kernel, dim3((L + 3) / 4, 1, groups), dim3(256), stream, seqs, (const float*)b.P.p, dS.p,
+                        1.f / sqrtf((float)dk));
+        attn_gemm(ps, s, TAB_DQ, GEMM_NN, dS.p, 0, b.qkv.p, 3 * d, gqkv.p, 3 * d, 1.f, heads);
+        attn_gemm(ps, s, TAB_DK, GEMM_TN, dS.p, 0, b.qkv.p, 3 * d, gqkv.p, 3 * d, 1.f, heads);
+        // fused q/k/v projection
+        conv_wgrad(ps, s, gqkv, 3 * d, 1, xin, d, P.wqkv, P.bqkv, vm);
+        conv_dgrad(ps, s, gqkv, 3 * d, 1, W(ps, P.wqkv), d, g0, GEMM_ACCUM, nullptr);
+    }
+
+    // =================================================================================
+    // variance predictor (lightning/model/modules.py:242-250)
+    // =================================================================================
+    void pred_fwd(const Pass& ps, const PredP& P, PredBuf& b, TS xin) {
+        const Plan& p = *ps.pl;
+        const int d = cfg.d_model, f = cfg.vp_filter, k = cfg.vp_kernel;
+        const unsigned char* im = p.p_inrect;
+        TS none{nullptr, 0};
+        conv_fwd(ps, SP_P, xin, d, k, W(ps, P.c1w), W(ps, P.c1b), f, b.r1, GEMM_RELU, im);
+        ln_fwd(ps, SP_P, b.r1, none, P.l1g, P.l1b, im, none, b.n1, b.st1, f);
+        conv_fwd(ps, SP_P, b.n1, f, k, W(ps, P.c2w), W(ps, P.c2b), f, b.r2, GEMM_RELU, im);
+        ln_fwd(ps, SP_P, b.r2, none, P.l2g, P.l2b, im, none, b.n2, b.st2, f);
+        TS w = W(ps, P.lw), bb = W(ps, P.lb);
+        MTTS_LAUNCH(rowdot_kernel, row_grid(p.maxMp, p.tasks), dim3(256), stream, (const int*)p.meta, (int)META_MP,
+                    (const float*)b.n2.p, b.n2.ts, (const float*)w.p, (const float*)bb.p, w.ts, (const unsigned char*)p.p_valid,
+                    row_ts_p, b.out.p, b.out.ts, f);
+    }
+    // dout: [Mp] gradient of the prediction (0 on masked rows); dx accumulates the input gradient
+    void pred_bwd(const Pass& ps, const PredP& P, PredBuf& b, TS xin, TS dout, TS dx) {
+        const Plan& p = *ps.pl;
+        const int d = cfg.d_model, f = cfg.vp_filter, k = cfg.vp_kernel;
+        const unsigned char* im = p.p_inrect;
+        TS none{nullptr, 0};
+        colsum(ps, SP_P, dout, 1, nullptr, none, Gd(P.lb));
+        colsum(ps, SP_P, b.n2, f, nullptr, dout, Gd(P.lw));
+        TS w = W(ps, P.lw);
+        MTTS_LAUNCH(rowdot_bwd_kernel, row_grid(p.maxMp, p.tasks), dim3(256), stream, (const int*)p.meta, (int)META_MP,
+                    (const float*)dout.p, dout.ts, (const float*)w.p, w.ts, gPf1.p, gPf1.ts, f);
+        ln_bwd(ps, SP_P, gPf1, b.r2, b.st2, P.l2g, P.l2b, im, gPf2, f, 1);       // gPf2 = d conv2 out
+        conv_wgrad(ps, SP_P, gPf2, f, k, b.n1, f, P.c2w, P.c2b, im);
+        conv_dgrad(ps, SP_P, gPf2, f, k, W(ps, P.c2w), f, gPf1, 0, im);         // gPf1 = d n1
+        ln_bwd(ps, SP_P, gPf1, b.r1, b.st1, P.l1g, P.l1b, im, gPf2, f, 1);       // gPf2 = d conv1 out
+        conv_wgrad(ps, SP_P, gPf2, f, k, xin, d, P.c1w, P.c1b, im);
+        conv_dgrad(ps, SP_P, gPf2, f, k, W(ps, P.c1w), d, dx, GEMM_ACCUM, im);
+    }
+
+    // =================================================================================
+    // full forward (fastspeech2.py:40-112 / base_adaptor.py:41-95), teacher-forced
+    // =================================================================================
+    int forward(const Pass& ps) {
+        const Plan& p = *ps.pl;
+        const int d = cfg.d_model, nt = p.tasks;
+        TS none{nullptr, 0};
+        // encoder
+        TS we = W(ps, word_emb);
+        MTTS_LAUNCH(embed_pos_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP, emb_out.p,
+                    emb_out.ts, (const float*)we.p, we.ts, (const float*)pos_table, (const int*)p.p_tok, (const int*)p.p_row_t,
+                    (const unsigned char*)p.p_valid, row_ts_p, d);
+        TS x = emb_out;
+        for (int l = 0; l < cfg.enc_layers; ++l) { fft_fwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], x, none); x = encB[l].y2; }
+        // speaker vector, added on every position of the phoneme rectangle
+        TS tb = W(ps, spk_table);
+        MTTS_LAUNCH(speaker_vec_kernel, dim3(p.maxB, 1, nt), dim3(64), stream, (const int*)p.meta, (const float*)tb.p, tb.ts,
+                    (const int*)p.spk_ids, (long long)cap_B + 1, cap_B, p.average_spk, spk.p, spk.ts, d);
+        MTTS_LAUNCH(add_rowvec_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
+                    (const float*)x.p, x.ts, (const float*)spk.p, spk.ts, (const int*)p.p_row_b, (const unsigned char*)p.p_inrect,
+                    row_ts_p, x0.p, x0.ts, d);
+        // variance adaptor (teacher-forced: targets select the embeddings)
+        pred_fwd(ps, durP, durB, x0);
+        pred_fwd(ps, pitP, pitB, x0);
+        TS pe = W(ps, pitch_emb), ee = W(ps, energy_emb);
+        MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
+                    (const float*)x0.p, x0.ts, (const float*)p.p_pitch_t, row_ts_p, 1.f, (const float*)pitch_bins, cfg.n_bins - 1,
+                    (const float*)pe.p, pe.ts, (const unsigned char*)p.p_inrect, row_ts_p, pidx, x1.p, x1.ts, d);
+        pred_fwd(ps, eneP, eneB, x1);
+        MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
+                    (const float*)x1.p, x1.ts, (const float*)p.p_energy_t, row_ts_p, 1.f, (const float*)energy_bins, cfg.n_bins - 1,
+                    (const float*)ee.p, ee.ts, (const unsigned char*)p.p_inrect, row_ts_p, eidx, x2.p, x2.ts, d);
+        // length regulator + speaker + decoder positions
+        MTTS_LAUNCH(length_regulate_fwd_kernel, row_grid(p.maxMf, nt), dim3(256), stream, (const int*)p.meta, (const float*)x2.p,
+                    x2.ts, (const int*)p.f_src, (const int*)p.f_row_b, (const int*)p.f_row_t, row_ts_f, (const float*)spk.p, spk.ts,
+                    (const float*)pos_table, dec_in.p, dec_in.ts, d);
+        x = dec_in;
+        for (int l = 0; l < cfg.dec_layers; ++l) { fft_fwd(ps, SP_F, cfg.dec_heads, decP[l], decB[l], x, none); x = decB[l].y2; }
+        // mel_linear: packed frames -> mel rectangle; padded frames carry the bias
+        {
+            GemmArgs g = rowgemm(p, SP_F, GEMM_NT);
+            TS w = W(ps, mel_w), b = W(ps, mel_b);
+            g.A = x.p; g.a_gs = x.ts; g.lda = d;
+            g.B = w.p; g.b_gs = w.ts; g.ldb = d;
+            g.C = mel.p; g.c_gs = mel.ts; g.ldc = cfg.n_mel;
+            g.N = cfg.n_mel; g.K = d;
+            g.bias = b.p; g.bias_gs = b.ts;
+            g.c_rowmap = p.f2r; g.c_rowmap_gs = row_ts_f;
+            gemm_launch(GEMM_NT, g, p.maxMf, cfg.n_mel, nt, stream);
+            MTTS_LAUNCH(fill_padded_rows_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, mel.p, mel.ts,
+                        (const float*)b.p, b.ts, (const unsigned char*)p.r_inrect, (const unsigned char*)p.r_valid, row_ts_r,
+                        cfg.n_mel);
+        }
+        // PostNet
+        TS cur = mel;
+        for (int i = 0; i < cfg.postnet_layers; ++i) {
+            const PostP& P = postP[i];
+            PostBuf& b = postB[i];
+            conv_fwd(ps, SP_R, cur, P.cin, cfg.postnet_kernel, W(ps, P.w), W(ps, P.b), P.cout, b.c, 0, p.r_inrect);
+            if (ps.train) {
+                MTTS_LAUNCH(bn_stats_kernel, dim3((P.cout + 31) / 32, 1, nt), dim3(256), stream, (const int*)p.meta,
+                            (const float*)b.c.p, b.c.ts, (const unsigned char*)p.r_inrect, row_ts_r, b.stats.p, b.stats.ts, P.cout,
+                            1e-5f);
+                MTTS_LAUNCH(bn_running_update_kernel, dim3((P.cout + 63) / 64), dim3(64), stream, (const float*)b.stats.p,
+                            b.stats.ts, nt, bn_rm[i], bn_rv[i], P.cout, 0.1f);
+                bn_tracked[i] += nt;
+            } else {
+                MTTS_LAUNCH(bn_eval_stats_kernel, dim3((P.cout + 63) / 64), dim3(64), stream, (const float*)bn_rm[i],
+                            (const float*)bn_rv[i], b.stats.p, b.stats.ts, nt, P.cout, 1e-5f);
+            }
+            TS gm = W(ps, P.g), bt = W(ps, P.beta);
+            MTTS_LAUNCH(bn_apply_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (const float*)b.c.p, b.c.ts,
+                        (const float*)b.stats.p, b.stats.ts, (const float*)gm.p, (const float*)bt.p, gm.ts,
+                        (const unsigned char*)p.r_inrect, row_ts_r, (int)(i < cfg.postnet_layers - 1), b.a.p, b.a.ts, P.cout);
+            cur = b.a;
+        }
+        // mel_post = postnet(mel) + mel   (whole [tasks][rows][n_mel] slab incl. guard rows: all zero there)
+        {
+            const long long n4 = (mel.ts * nt) / 4;
+            const float* base_a = cur.p - (long long)G * cfg.n_mel;
+            const float* base_b = mel.p - (long long)G * cfg.n_mel;
+            float* base_o = mel_post.p - (long long)G * cfg.n_mel;
+            MTTS_LAUNCH(add2_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), stream, base_a, base_b,
+                        base_o, n4);
+        }
+        return 0;
+    }
+
+    LossArgs loss_args(const Plan& p) const {
+        LossArgs a;
+        a.mel = mel.p; a.mel_post = mel_post.p; a.mel_tgt = p.mel_tgt;
+        a.rvalid = p.r_valid;
+        a.pp = pitB.out.p; a.ep = eneB.out.p; a.logd = durB.out.p;
+        a.p_tgt = p.p_pitch_t; a.e_tgt = p.p_energy_t; a.dur = p.p_dur; a.pvalid = p.p_valid;
+        a.mel_ts = mel.ts; a.rrow_ts = row_ts_r; a.prow_ts = row_ts_p; a.pred_ts = pitB.out.ts;
+        a.n_mel = cfg.n_mel;
+        return a;
+    }
+
+    // losses_out (device, [tasks][6]) of the last forward
+    int loss(const Pass& ps, float* losses_out) {
+        const Plan& p = *ps.pl;
+        if (durB.out.ts != row_ts_p + 2 * G || pitB.out.ts != durB.out.ts) { set_error("internal: prediction stride"); return -1; }
+        LossArgs a = loss_args(p);
+        MTTS_LAUNCH(loss_partial_kernel, dim3(kLossBlocks, 1, p.tasks), dim3(256), stream, (const int*)p.meta, a, loss_partial);
+        MTTS_LAUNCH(loss_final_kernel, dim3(p.tasks), dim3(64), stream, (const int*)p.meta, (const float*)loss_partial,
+                    (int)kLossBlocks, cfg.n_mel, losses_out);
+        return 0;
+    }
+
+    // =================================================================================
+    // full backward of (scale * total loss); writes every parameter gradient of the touched
+    // modules into grad[task][...] (fully overwritten, no accumulation across calls)
+    // =================================================================================
+    int backward(const Pass& ps, float scale, bool need_encoder) {
+        const Plan& p = *ps.pl;
+        const int d = cfg.d_model, nt = p.tasks, nm = cfg.n_mel;
+        if (!ps.train) { set_error("backward needs a train-mode forward (batch statistics)"); return -1; }
+        LossArgs a = loss_args(p);
+        // prediction strides in the phoneme space: the [Mp] vectors were allocated as rows(capMp, 1)
+        MTTS_LAUNCH(loss_grad_kernel, dim3(kLossBlocks, 1, nt), dim3(256), stream, (const int*)p.meta, a, scale, gRm.p, gRp.p,
+                    dpred[1].p, dpred[2].p, dpred[0].p);
+        // ---- PostNet: cur = dL/d(a_i), starts as dL/d(mel_post); dc -> gR0, layer-input grad -> gR1
+        TS cur = gRp;
+        for (int i = cfg.postnet_layers - 1; i >= 0; --i) {
+            const PostP& P = postP[i];
+            PostBuf& b = postB[i];
+            const int act = (i < cfg.postnet_layers - 1);
+            TS dgm = Gd(P.g), dbt = Gd(P.beta);
+            MTTS_LAUNCH(bn_bwd_reduce_kernel, dim3((P.cout + 31) / 32, 1, nt), dim3(256), stream, (const int*)p.meta,
+                        (const float*)cur.p, cur.ts, (const float*)b.a.p, b.a.ts, (const float*)b.c.p, b.c.ts,
+                        (const float*)b.stats.p, b.stats.ts, (const unsigned char*)p.r_inrect, row_ts_r, act, dgm.p, dbt.p, dgm.ts,
+                        P.cout);
+            TS gm = W(ps, P.g);
+            TS dc = gR0;  // [rows][Cout] inside a scratch sized for max(postnet_dim, n_mel) channels
+            MTTS_LAUNCH(bn_bwd_apply_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (const float*)cur.p,
+                        cur.ts, (const float*)b.a.p, b.a.ts, (const float*)b.c.p, b.c.ts, (const float*)b.stats.p, b.stats.ts,
+                        (const float*)gm.p, gm.ts, (const float*)dgm.p, (const float*)dbt.p, dgm.ts,
+                        (const unsigned char*)p.r_inrect, row_ts_r, act, dc.p, dc.ts, P.cout);
+            TS xin = (i == 0) ? mel : postB[i - 1].a;
+            conv_wgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, xin, P.cin, P.w, P.b, p.r_inrect);
+            if (i > 0) {
+                conv_dgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, W(ps, P.w), P.cin, gR1, 0, p.r_inrect);
+                cur = gR1;
+            } else {
+                // dL/d(mel) total = direct L1 term + residual path + PostNet input gradient
+                const long long n4 = (gRm.ts * nt) / 4;
+                MTTS_LAUNCH(add2_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), stream,
+                            (const float*)(gRm.p - (long long)G * nm), (const float*)(gRp.p - (long long)G * nm),
+                            gRm.p - (long long)G * nm, n4);
+                conv_dgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, W(ps, P.w), P.cin, gRm, GEMM_ACCUM, p.r_inrect);
+            }
+        }
+        // ---- mel_linear -------------------------------------------------------------------
+        TS none{nullptr, 0};
+        colsum(ps, SP_R, gRm, nm, nullptr, none, Gd(mel_b));
+        MTTS_LAUNCH(gather_rows_kernel, row_grid(p.maxMf, nt), dim3(256), stream, (const int*)p.meta, (int)META_MF,
+                    (const float*)gRm.p, gRm.ts, (const int*)p.f2r, row_ts_f, gMelF.p, gMelF.ts, nm);
+        TS dec_out = cfg.dec_layers ? decB[cfg.dec_layers - 1].y2 : dec_in;
+        conv_wgrad(ps, SP_F, gMelF, nm, 1, dec_out, d, mel_w, -1, nullptr);
+        conv_dgrad(ps, SP_F, gMelF, nm, 1, W(ps, mel_w), d, gF0, 0, nullptr);
+        // ---- decoder ----------------------------------------------------------------------
+        for (int l = cfg.dec_layers - 1; l >= 0; --l) {
+            TS xin = l == 0 ? dec_in : decB[l - 1].y2;
+            fft_bwd(ps, SP_F, cfg.dec_heads, decP[l], decB[l], xin, gF0, gF1, gFqkv, gFh, dSf);
+        }
+        // ---- length regulator -> gP0 = dL/d(x2) -------------------------------------------
+        MTTS_LAUNCH(length_regulate_bwd_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (const float*)gF0.p,
+                    gF0.ts, (const int*)p.p_first, (const int*)p.p_count, row_ts_p, gP0.p, gP0.ts, d, 0);
+        // speaker vector gradient, part 1: every valid frame
+        MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(64), stream, (const int*)p.meta, (const float*)gF0.p,
+                    gF0.ts, (const int*)p.f_seg_start, (const int*)p.f_seg_len, (long long)cap_B, dspk.p, dspk.ts, d, 0);
+        // ---- variance adaptor ---------------------------------------------------------------
+        const bool va_needed = true;
+        (void)va_needed;
+        MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MP,
+                    (const float*)gP0.p, gP0.ts, (const int*)eidx, row_ts_p, -1, Gd(energy_emb).p, n_total, d);
+        pred_bwd(ps, eneP, eneB, x1, dpred[2], gP0);
+        MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MP,
+                    (const float*)gP0.p, gP0.ts, (const int*)pidx, row_ts_p, -1, Gd(pitch_emb).p, n_total, d);
+        pred_bwd(ps, pitP, pitB, x0, dpred[1], gP0);
+        pred_bwd(ps, durP, durB, x0, dpred[0], gP0);
+        // speaker vector gradient, part 2: every position of the phoneme rectangle
+        MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(64), stream, (const int*)p.meta, (const float*)gP0.p,
+                    gP0.ts, (const int*)p.p_seg_start, (const int*)p.p_seg_len, (long long)cap_B, dspk.p, dspk.ts, d, 1);
+        MTTS_LAUNCH(speaker_table_grad_kernel, dim3(cfg.n_speaker, 1, nt), dim3(64), stream, (const int*)p.meta,
+                    (const float*)dspk.p, dspk.ts, (const int*)p.spk_ids, (long long)cap_B + 1, cap_B, p.average_spk,
+                    Gd(spk_table).p, n_total, d);
+        if (!need_encoder) return 0;
+        // ---- encoder ------------------------------------------------------------------------
+        for (int l = cfg.enc_layers - 1; l >= 0; --l) {
+            TS xin = l == 0 ? emb_out : encB[l - 1].y2;
+            fft_bwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], xin, gP0, gP1, gPqkv, gPh, dSp);
+        }
+        // word embedding (padding row 0 keeps a zero gradient); p_tok is 0 on invalid rows, and
+        // gP0 is only meaningful on valid rows -> scan with the token ids masked by validity
+        MTTS_LAUNCH(table_grad_kernel, dim3(cfg.vocab, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MP,
+                    (const float*)gP0.p, gP0.ts, (const int*)p.p_tok, row_ts_p, 0, Gd(word_emb).p, n_total, d);
+        return 0;
+    }
+
+    // =================================================================================
+    // MAML (base_adaptor.py:98-124) and the outer update
+    // =================================================================================
+    static unsigned blocks_for(long long n4) { return (unsigned)std::min<long long>(std::max<long long>((n4 + 255) / 256, 1), 4096); }
+
+    // One meta-gradient: `steps` inner SGD steps on plan 0 (support), query pass on plan 1 with the
+    // support speaker ids averaged.  First-order (the reference trains second-order: see DESIGN.md).
+    // grad_scale = 1 / (total tasks of the meta-batch across all ranks).  Result: outer[] = sum over
+    // local tasks of grad_scale * dL_query/dtheta; query losses in losses_out [tasks][6];
+    // support losses per step in sup_losses_out [steps][tasks][6] (optional).
+    int meta_grad(int steps, float inner_lr, float grad_scale, float* losses_out, float* sup_losses_out) {
+        Plan& sp = plans[0];
+        Plan& qp = plans[1];
+        if (sp.tasks != qp.tasks || sp.tasks < 1) { set_error("support/query plans not set"); return -1; }
+        const int nt = sp.tasks;
+        if (n_adapt > 0)
+            MTTS_LAUNCH(broadcast_kernel, dim3(blocks_for(n_adapt / 4), 1, nt), dim3(256), stream,
+                        (const float*)(theta + adapt_start), fast, n_adapt / 4, n_adapt);
+        Pass ps{&sp, true, true};
+        for (int s = 0; s < steps; ++s) {
+            if (forward(ps)) return -1;
+            if (sup_losses_out && loss(ps, sup_losses_out + (long long)s * nt * 6)) return -1;
+            if (backward(ps, 1.f, false)) return -1;
+            if (n_adapt > 0)
+                MTTS_LAUNCH(sgd_update_kernel, dim3(blocks_for(n_adapt / 4), 1, nt), dim3(256), stream, fast,
+                            (const float*)(grad + adapt_start), n_adapt / 4, inner_lr, n_adapt, n_total);
+        }
+        Pass pq{&qp, true, true};
+        if (forward(pq)) return -1;
+        if (loss(pq, losses_out ? losses_out : losses)) return -1;
+        if (backward(pq, grad_scale, true)) return -1;
+        MTTS_LAUNCH(sum_tasks_kernel, dim3(blocks_for(n_total / 4)), dim3(256), stream, (const float*)grad, n_total, nt, 1.f, outer,
+                    n_total / 4);
+        return 0;
+    }
+
+    // Plain multi-task step gradient (baseline.py:25-36 -> system.py:53-56) on plan `slot`
+    int plain_grad(int slot, float grad_scale, float* losses_out) {
+        Plan& p = plans[slot];
+        if (p.tasks < 1) { set_error("plan not set"); return -1; }
+        Pass ps{&p, false, true};
+        if (forward(ps)) return -1;
+        if (loss(ps, losses_out ? losses_out : losses)) return -1;
+        if (backward(ps, grad_scale, true)) return -1;
+        MTTS_LAUNCH(sum_tasks_kernel, dim3(blocks_for(n_total / 4)), dim3(256), stream, (const float*)grad, n_total, p.tasks, 1.f,
+                    outer, n_total / 4);
+        return 0;
+    }
+
+    // clip_grad_norm_(max_norm) + Adam on theta from `g` (device, n_total floats; usually outer[])
+    int outer_update(const float* g, float lr, float b1, float b2, float eps, float weight_decay, float max_norm,
+                     float* norm_out_host) {
+        const int nb = 512;
+        MTTS_LAUNCH(sumsq_partial_kernel, dim3(nb), dim3(256), stream, g, n_total / 4, norm_partial);
+        MTTS_LAUNCH(sumsq_final_kernel, dim3(1), dim3(64), stream, (const float*)norm_partial, nb, norm_out);
+        ++adam_step_count;
+        const float bc1 = 1.f - (float)std::pow((double)b1, (double)adam_step_count);
+        const float bc2 = 1.f - (float)std::pow((double)b2, (double)adam_step_count);
+        MTTS_LAUNCH(adam_clip_kernel, dim3(blocks_for(n_total / 4)), dim3(256), stream, theta, g, adam_m, adam_v, n_total / 4,
+                    (const float*)norm_out, max_norm, lr, b1, b2, eps, bc1, bc2, weight_decay);
+        if (norm_out_host) {
+            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(hipMemcpy(norm_out_host, norm_out, sizeof(float), hipMemcpyDeviceToHost));
+        }
+        return 0;
+    }
+};
+
+}  // namespace mtts

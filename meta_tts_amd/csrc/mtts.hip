@@ -1,0 +1,222 @@
+// libmtts translation unit: C ABI (include/mtts.h) over the engine.  Built with
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC mtts.hip -o libmtts.so
+// (tests/emu builds the same file for the host with -DMTTS_EMU; see compat.h).
+#include "../../include/mtts.h"
+
+#include "engine.h"
+
+using namespace mtts;
+
+struct mtts_handle {
+    Engine eng;
+    float* sup_losses_dev = nullptr;
+    int sup_losses_cap = 0;
+};
+
+static std::string g_create_error;
+
+extern "C" {
+
+int mtts_create(const mtts_model_cfg* c, int device, int max_tasks, int max_B, int max_S, int max_T, mtts_handle** out) {
+    if (!c || !out || max_tasks < 1 || max_B < 1 || max_S < 1 || max_T < 1) { g_create_error = "bad arguments"; return -1; }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed (no MI355X visible?)"; return -1; }
+    mtts_handle* h = new mtts_handle();
+    ModelCfg m;
+    m.d_model = c->d_model; m.enc_layers = c->enc_layers; m.dec_layers = c->dec_layers; m.enc_heads = c->enc_heads;
+    m.dec_heads = c->dec_heads; m.d_ff = c->d_ff; m.k1 = c->k1; m.k2 = c->k2; m.vp_filter = c->vp_filter;
+    m.vp_kernel = c->vp_kernel; m.n_bins = c->n_bins; m.max_seq_len = c->max_seq_len; m.n_mel = c->n_mel;
+    m.vocab = c->vocab; m.n_speaker = c->n_speaker; m.postnet_dim = c->postnet_dim; m.postnet_kernel = c->postnet_kernel;
+    m.postnet_layers = c->postnet_layers; m.pitch_min = c->pitch_min; m.pitch_max = c->pitch_max;
+    m.energy_min = c->energy_min; m.energy_max = c->energy_max; m.adapt_mask = c->adapt_mask;
+    if (h->eng.init(m, max_tasks, max_B, max_S, max_T) != 0) {
+        g_create_error = h->eng.last_error;
+        delete h;
+        return -1;
+    }
+    h->sup_losses_cap = 128;
+    if (hipMalloc((void**)&h->sup_losses_dev, (size_t)h->sup_losses_cap * max_tasks * 6 * sizeof(float)) != hipSuccess) {
+        g_create_error = "hipMalloc failed";
+        delete h;
+        return -1;
+    }
+    *out = h;
+    return 0;
+}
+
+void mtts_destroy(mtts_handle* h) {
+    if (!h) return;
+    hipDeviceSynchronize();
+    h->eng.destroy();
+    if (h->sup_losses_dev) hipFree(h->sup_losses_dev);
+    delete h;
+}
+
+const char* mtts_last_error(mtts_handle* h) { return h ? h->eng.last_error.c_str() : g_create_error.c_str(); }
+
+int mtts_set_stream(mtts_handle* h, void* s) { h->eng.stream = (hipStream_t)s; return 0; }
+int mtts_synchronize(mtts_handle* h) { return hipStreamSynchronize(h->eng.stream) == hipSuccess ? 0 : -1; }
+
+int mtts_param_count(mtts_handle* h) { return (int)h->eng.entries.size(); }
+int mtts_param_info(mtts_handle* h, int i, const char** name, int* ndim, int shape[4], int64_t* off, int* adapted) {
+    if (i < 0 || i >= (int)h->eng.entries.size()) { h->eng.set_error("param index out of range"); return -1; }
+    const ParamEntry& e = h->eng.entries[i];
+    if (name) *name = e.name.c_str();
+    if (ndim) *ndim = (int)e.shape.size();
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = k < (int)e.shape.size() ? e.shape[k] : 1;
+    if (off) *off = e.off;
+    if (adapted) *adapted = e.off >= h->eng.adapt_start;
+    return 0;
+}
+int64_t mtts_param_total(mtts_handle* h) { return h->eng.n_total; }
+int64_t mtts_adapt_start(mtts_handle* h) { return h->eng.adapt_start; }
+int mtts_load_param(mtts_handle* h, const char* name, const float* host, int64_t numel) { return h->eng.load_param(name, host, numel); }
+int mtts_export_param(mtts_handle* h, const char* name, int which, int task, float* host, int64_t numel) {
+    if (task < 0 || task >= h->eng.cap_tasks) { h->eng.set_error("task out of range"); return -1; }
+    return h->eng.export_param(name, which, task, host, numel);
+}
+int mtts_set_bn_buffers(mtts_handle* h, int layer, const float* mean, const float* var, int64_t tracked) {
+    Engine& e = h->eng;
+    if (layer < 0 || layer >= e.cfg.postnet_layers) { e.set_error("bn layer out of range"); return -1; }
+    const int c = e.postP[layer].cout;
+    if (hipMemcpy(e.bn_rm[layer], mean, c * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (hipMemcpy(e.bn_rv[layer], var, c * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    e.bn_tracked[layer] = tracked;
+    return 0;
+}
+int mtts_get_bn_buffers(mtts_handle* h, int layer, float* mean, float* var, int64_t* tracked) {
+    Engine& e = h->eng;
+    if (layer < 0 || layer >= e.cfg.postnet_layers) { e.set_error("bn layer out of range"); return -1; }
+    const int c = e.postP[layer].cout;
+    hipStreamSynchronize(e.stream);
+    if (mean && hipMemcpy(mean, e.bn_rm[layer], c * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (var && hipMemcpy(var, e.bn_rv[layer], c * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (tracked) *tracked = e.bn_tracked[layer];
+    return 0;
+}
+
+static HostBatch to_host_batch(const mtts_batch& b) {
+    HostBatch o;
+    o.B = b.B; o.S_max = b.S_max; o.T_max = b.T_max;
+    o.speakers = (const long long*)b.speakers; o.texts = (const long long*)b.texts; o.src_lens = (const long long*)b.src_lens;
+    o.mels = b.mels; o.mel_lens = (const long long*)b.mel_lens; o.pitches = b.pitches; o.energies = b.energies;
+    o.durations = (const long long*)b.durations;
+    return o;
+}
+
+int mtts_set_batches(mtts_handle* h, int slot, int n_tasks, const mtts_batch* batches, const mtts_batch* spk_from, int average_spk) {
+    if (slot < 0 || slot > 1 || !batches || n_tasks < 1) { h->eng.set_error("bad arguments"); return -1; }
+    std::vector<HostBatch> hb(n_tasks), sf(n_tasks);
+    for (int t = 0; t < n_tasks; ++t) { hb[t] = to_host_batch(batches[t]); if (spk_from) sf[t] = to_host_batch(spk_from[t]); }
+    return h->eng.set_batches(slot, n_tasks, hb.data(), spk_from ? sf.data() : nullptr, average_spk);
+}
+
+int mtts_forward(mtts_handle* h, int slot, int use_fast, int train) {
+    Engine& e = h->eng;
+    if (slot < 0 || slot > 1 || e.plans[slot].tasks < 1) { e.set_error("plan not set"); return -1; }
+    Engine::Pass ps{&e.plans[slot], use_fast != 0, train != 0};
+    return e.forward(ps);
+}
+
+int mtts_get_outputs(mtts_handle* h, int slot, int task, float* mel, float* mel_post, float* p, float* en, float* logd) {
+    Engine& e = h->eng;
+    if (slot < 0 || slot > 1 || task < 0 || task >= e.plans[slot].tasks) { e.set_error("bad slot/task"); return -1; }
+    const Engine::Plan& pl = e.plans[slot];
+    const int B = pl.hB[task], S = pl.hSmax[task], T = pl.hTcap[task], nm = e.cfg.n_mel;
+    if (hipStreamSynchronize(e.stream) != hipSuccess) return -1;
+    for (int b = 0; b < B; ++b) {
+        const long long r0 = G + (long long)b * (T + G);
+        if (mel && hipMemcpy(mel + (size_t)b * T * nm, e.mel.p + task * e.mel.ts + r0 * nm, (size_t)T * nm * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (mel_post && hipMemcpy(mel_post + (size_t)b * T * nm, e.mel_post.p + task * e.mel_post.ts + r0 * nm, (size_t)T * nm * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        const long long p0 = G + (long long)b * (S + G);
+        if (p && hipMemcpy(p + (size_t)b * S, e.pitB.out.p + task * e.pitB.out.ts + p0, S * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (en && hipMemcpy(en + (size_t)b * S, e.eneB.out.p + task * e.eneB.out.ts + p0, S * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (logd && hipMemcpy(logd + (size_t)b * S, e.durB.out.p + task * e.durB.out.ts + p0, S * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    return 0;
+}
+
+static int copy_losses(Engine& e, const float* dev, float* host, int n) {
+    if (!host) return 0;
+    if (hipStreamSynchronize(e.stream) != hipSuccess) return -1;
+    return hipMemcpy(host, dev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+
+int mtts_loss(mtts_handle* h, int slot, float* losses_host) {
+    Engine& e = h->eng;
+    if (slot < 0 || slot > 1 || e.plans[slot].tasks < 1) { e.set_error("plan not set"); return -1; }
+    Engine::Pass ps{&e.plans[slot], false, true};
+    if (e.loss(ps, e.losses)) return -1;
+    return copy_losses(e, e.losses, losses_host, e.plans[slot].tasks * 6);
+}
+
+int mtts_backward(mtts_handle* h, int slot, int use_fast, float scale, int need_encoder) {
+    Engine& e = h->eng;
+    if (slot < 0 || slot > 1 || e.plans[slot].tasks < 1) { e.set_error("plan not set"); return -1; }
+    Engine::Pass ps{&e.plans[slot], use_fast != 0, true};
+    return e.backward(ps, scale, need_encoder != 0);
+}
+
+int mtts_meta_grad(mtts_handle* h, int steps, float inner_lr, float grad_scale, int second_order, float* qry_losses_host,
+                   float* sup_losses_host) {
+    Engine& e = h->eng;
+    if (second_order) { e.set_error("second-order MAML is not implemented in this build (first-order only)"); return -1; }
+    if (steps < 0 || steps > h->sup_losses_cap) { e.set_error("too many inner steps"); return -1; }
+    if (e.meta_grad(steps, inner_lr, grad_scale, e.losses, h->sup_losses_dev)) return -1;
+    if (copy_losses(e, e.losses, qry_losses_host, e.plans[1].tasks * 6)) return -1;
+    return copy_losses(e, h->sup_losses_dev, sup_losses_host, steps * e.plans[0].tasks * 6);
+}
+
+int mtts_plain_grad(mtts_handle* h, int slot, float grad_scale, float* losses_host) {
+    Engine& e = h->eng;
+    if (slot < 0 || slot > 1) { e.set_error("bad slot"); return -1; }
+    if (e.plain_grad(slot, grad_scale, e.losses)) return -1;
+    return copy_losses(e, e.losses, losses_host, e.plans[slot].tasks * 6);
+}
+
+float* mtts_outer_grad_ptr(mtts_handle* h) { return h->eng.outer; }
+
+int mtts_outer_update(mtts_handle* h, const float* grad_dev, float lr, float b1, float b2, float eps, float wd, float max_norm,
+                      float* norm_host) {
+    return h->eng.outer_update(grad_dev ? grad_dev : h->eng.outer, lr, b1, b2, eps, wd, max_norm, norm_host);
+}
+
+int mtts_reset_optimizer(mtts_handle* h) {
+    Engine& e = h->eng;
+    e.adam_step_count = 0;
+    if (hipMemsetAsync(e.adam_m, 0, e.n_total * sizeof(float), e.stream) != hipSuccess) return -1;
+    if (hipMemsetAsync(e.adam_v, 0, e.n_total * sizeof(float), e.stream) != hipSuccess) return -1;
+    return 0;
+}
+
+int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                  const float* bias, float alpha, int flags, int tile, void* stream) {
+    if (form < 0 || form > 2 || (tile != 0 && tile != 64 && tile != 128)) return -1;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.alpha = alpha; g.flags = flags;
+    gemm_launch(form, g, M, N, 1, (hipStream_t)stream, tile);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* a, const float* b, float* out, const float* bias,
+                    int tile, void* stream) {
+    if (mode < 0 || mode > 2 || (k & 1) == 0 || k / 2 > G) return -1;
+    const int pad = k / 2;
+    GemmArgs g;
+    if (mode == 0) {         // y[L][Cout] = conv(x) + bias
+        g.A = a - (long long)pad * Cin; g.lda = Cin; g.B = b; g.ldb = k * Cin; g.C = out; g.ldc = Cout;
+        g.M = L; g.N = Cout; g.K = k * Cin; g.bias = bias;
+        gemm_launch(GEMM_NT, g, L, Cout, 1, (hipStream_t)stream, tile);
+    } else if (mode == 1) {  // dx[L][Cin] = dgrad(dy [L][Cout], w)
+        g.A = a - (long long)pad * Cout; g.lda = Cout; g.B = b; g.ldb = k * Cin; g.C = out; g.ldc = Cin;
+        g.M = L; g.N = Cin; g.K = k * Cout; g.taps = k; g.tap_k = Cout; g.tap_bstride = Cin;
+        gemm_launch(GEMM_NN, g, L, Cin, 1, (hipStream_t)stream, tile);
+    } else {                 // dw[Cout][k*Cin] = dy^T conv-rows(x)
+        g.A = a; g.lda = Cout; g.B = b - (long long)pad * Cin; g.ldb = Cin; g.C = out; g.ldc = k * Cin;
+        g.M = Cout; g.N = k * Cin; g.K = L;
+        gemm_launch(GEMM_TN, g, Cout, k * Cin, 1, (hipStream_t)stream, tile);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // extern "C"

@@ -1,0 +1,809 @@
+// HBM-bound row / column kernels of the FastSpeech2 hot path (everything that is not a
+// contraction): embedding + sinusoid add, residual + LayerNorm (+ row mask) forward/backward,
+// softmax forward/backward over per-sequence score matrices, variance-adaptor glue (speaker
+// add, bucketize + embedding add, 256->1 projections), length regulator gather / segment-sum,
+// PostNet BatchNorm(+tanh), the 5-term loss and its gradient, deterministic embedding-table
+// gradients, MAML SGD update and the fused clip + Adam outer update.
+//
+// Conventions: activations are row matrices [rows][C] (C % 4 == 0) in a "row space" (see
+// engine.h); blockIdx.z is the task of the meta-batch; every pointer comes with a per-task
+// stride (`*_ts`, elements).  Row kernels use one 64-lane wavefront per row (float4 per lane,
+// DPP/shuffle reductions); column reductions use one workgroup per 32-column stripe so results
+// are deterministic (no float atomics anywhere).
+#pragma once
+#include "compat.h"
+
+namespace mtts {
+
+struct TaskMeta {  // one per task, device-visible (int fields only; indexed as int[8])
+    int B, Smax, Tcap, Mp, Mf, Mr, nP, nF;
+};
+enum { META_B = 0, META_SMAX, META_TCAP, META_MP, META_MF, META_MR, META_NP, META_NF, META_STRIDE = 8 };
+
+#define ROW_PROLOGUE(Mfield)                                              \
+    const int z = blockIdx.z;                                             \
+    const int M_ = meta[z * META_STRIDE + (Mfield)];                      \
+    const int row = blockIdx.x * 4 + ((int)threadIdx.x >> 6);             \
+    const int lane = (int)threadIdx.x & 63;                               \
+    if (row >= M_) return;
+
+inline dim3 row_grid(int max_rows, int tasks) { return dim3((unsigned)((max_rows + 3) / 4), 1, (unsigned)tasks); }
+
+// ------------------------------------------------------------------------------------------
+// encoder input: word embedding (padding row 0) + sinusoid positions (transformer/Models.py:89-91)
+// ------------------------------------------------------------------------------------------
+__global__ void embed_pos_kernel(const int* meta, int mfield, float* out, long long out_ts, const float* emb,
+                                 long long emb_ts, const float* pos, const int* tok, const int* row_t,
+                                 const unsigned char* valid, long long row_ts, int C) {
+    ROW_PROLOGUE(mfield)
+    const long long r = (long long)z * row_ts + row;
+    float* o = out + (long long)z * out_ts + (long long)row * C;
+    const bool v = valid[r] != 0;
+    const float* e = emb + (long long)z * emb_ts + (long long)(v ? tok[r] : 0) * C;
+    const float* p = pos + (long long)(v ? row_t[r] : 0) * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 a = zero4();
+        if (v) { const float4 x = ld4(e + c), y = ld4(p + c); a = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); }
+        st4(o + c, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// y = mask ? LayerNorm(a (+ res)) : 0   (SubLayers.py:55,91 post-LN; modules.py:222,234)
+// z_out (optional) receives a + res; stats = (mean, rstd) per row.  C <= 1024.
+// ------------------------------------------------------------------------------------------
+__global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a, long long a_ts, const float* res,
+                                     long long res_ts, const float* gamma, const float* beta, long long par_ts,
+                                     const unsigned char* mask, long long mask_ts, float* z_out, long long z_ts,
+                                     float* y, long long y_ts, float* stats, long long st_ts, int C, float eps) {
+    ROW_PROLOGUE(mfield)
+    const float* pa = a + (long long)z * a_ts + (long long)row * C;
+    const float* pr = res ? res + (long long)z * res_ts + (long long)row * C : nullptr;
+    float4 v[4];
+    float s = 0.f;
+    int n = 0;
+    for (int c = lane * 4; c < C; c += 256, ++n) {
+        float4 x = ld4(pa + c);
+        if (pr) { const float4 r4 = ld4(pr + c); x = make_float4(x.x + r4.x, x.y + r4.y, x.z + r4.z, x.w + r4.w); }
+        v[n] = x;
+        s += (x.x + x.y) + (x.z + x.w);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    const float var = wave_sum(q) / (float)C;
+    const float rstd = rsqrtf(var + eps);
+    const bool keep = mask ? (mask[(long long)z * mask_ts + row] != 0) : true;
+    const float* g = gamma + (long long)z * par_ts;
+    const float* b = beta + (long long)z * par_ts;
+    float* py = y + (long long)z * y_ts + (long long)row * C;
+    float* pz = z_out ? z_out + (long long)z * z_ts + (long long)row * C : nullptr;
+    int i = 0;
+    for (int c = lane * 4; c < C; c += 256, ++i) {
+        if (pz) st4(pz + c, v[i]);
+        float4 o = zero4();
+        if (keep) {
+            const float4 g4 = ld4(g + c), b4 = ld4(b + c);
+            o = make_float4((v[i].x - mean) * rstd * g4.x + b4.x, (v[i].y - mean) * rstd * g4.y + b4.y,
+                            (v[i].z - mean) * rstd * g4.z + b4.z, (v[i].w - mean) * rstd * g4.w + b4.w);
+        }
+        st4(py + c, o);
+    }
+    if (lane == 0) {
+        float* st = stats + (long long)z * st_ts + (long long)row * 2;
+        st[0] = mean;
+        st[1] = rstd;
+    }
+}
+
+// dz = mask ? rstd * (g - mean(g) - xhat * mean(g * xhat)) : 0, g = dy * gamma
+// (relu_on_z additionally multiplies by [z > 0]: z = ReLU(conv) in the variance predictors)
+__global__ void layernorm_bwd_kernel(const int* meta, int mfield, const float* dy, long long dy_ts, const float* zin,
+                                     long long z_ts, const float* stats, long long st_ts, const float* gamma,
+                                     long long par_ts, const unsigned char* mask, long long mask_ts, float* dz,
+                                     long long dz_ts, int C, int relu_on_z) {
+    ROW_PROLOGUE(mfield)
+    float* pd = dz + (long long)z * dz_ts + (long long)row * C;
+    const bool keep = mask ? (mask[(long long)z * mask_ts + row] != 0) : true;
+    if (!keep) {
+        for (int c = lane * 4; c < C; c += 256) st4(pd + c, zero4());
+        return;
+    }
+    const float* pdy = dy + (long long)z * dy_ts + (long long)row * C;
+    const float* pz = zin + (long long)z * z_ts + (long long)row * C;
+    const float* st = stats + (long long)z * st_ts + (long long)row * 2;
+    const float mean = st[0], rstd = st[1];
+    const float* g = gamma + (long long)z * par_ts;
+    float4 gv[4], xh[4];
+    float s1 = 0.f, s2 = 0.f;
+    int n = 0;
+    for (int c = lane * 4; c < C; c += 256, ++n) {
+        const float4 d = ld4(pdy + c), x = ld4(pz + c), g4 = ld4(g + c);
+        gv[n] = make_float4(d.x * g4.x, d.y * g4.y, d.z * g4.z, d.w * g4.w);
+        xh[n] = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
+        s1 += (gv[n].x + gv[n].y) + (gv[n].z + gv[n].w);
+        s2 += (gv[n].x * xh[n].x + gv[n].y * xh[n].y) + (gv[n].z * xh[n].z + gv[n].w * xh[n].w);
+    }
+    const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+    int i = 0;
+    for (int c = lane * 4; c < C; c += 256, ++i) {
+        float4 o = make_float4(rstd * (gv[i].x - m1 - xh[i].x * m2), rstd * (gv[i].y - m1 - xh[i].y * m2),
+                               rstd * (gv[i].z - m1 - xh[i].z * m2), rstd * (gv[i].w - m1 - xh[i].w * m2));
+        if (relu_on_z) {  // z is a ReLU output: pass the gradient only where the pre-activation was > 0
+            const float4 x = ld4(pz + c);
+            o = make_float4(x.x > 0.f ? o.x : 0.f, x.y > 0.f ? o.y : 0.f, x.z > 0.f ? o.z : 0.f, x.w > 0.f ? o.w : 0.f);
+        }
+        st4(pd + c, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Column reductions over rows: one workgroup per 32-column stripe, 8 row lanes, fixed order.
+//   mode 0: out[c] = sum_m w(m) * X[m][c]                         (bias grads, 256->1 weight grad)
+//   mode 1: out0[c] = sum dy * xhat (dgamma), out1[c] = sum dy (dbeta)   (LayerNorm)
+// ------------------------------------------------------------------------------------------
+__global__ void colreduce_kernel(const int* meta, int mfield, int mode, const float* X, long long x_ts, int ldx,
+                                 const float* Z, long long z_ts, const float* stats, long long st_ts,
+                                 const unsigned char* mask, long long mask_ts, const float* roww, long long roww_ts,
+                                 float* out0, float* out1, long long out_ts, int C) {
+    __shared__ float red0[8][33], red1[8][33];
+    const int z = blockIdx.z;
+    const int M_ = meta[z * META_STRIDE + mfield];
+    const int cx = (int)threadIdx.x & 31, ry = (int)threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        const float* px = X + (long long)z * x_ts;
+        const float* pz = Z ? Z + (long long)z * z_ts : nullptr;
+        const float* ps = stats ? stats + (long long)z * st_ts : nullptr;
+        const unsigned char* pm = mask ? mask + (long long)z * mask_ts : nullptr;
+        const float* pw = roww ? roww + (long long)z * roww_ts : nullptr;
+        for (int m = ry; m < M_; m += 8) {
+            if (pm && !pm[m]) continue;
+            const float x = px[(long long)m * ldx + c];
+            if (mode == 0) {
+                a0 += pw ? pw[m] * x : x;
+            } else {
+                const float xh = (pz[(long long)m * ldx + c] - ps[2 * m]) * ps[2 * m + 1];
+                a0 += x * xh;
+                a1 += x;
+            }
+        }
+    }
+    red0[ry][cx] = a0;
+    red1[ry][cx] = a1;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int i = 0; i < 8; ++i) { s0 += red0[i][cx]; s1 += red1[i][cx]; }
+        out0[(long long)z * out_ts + c] = s0;
+        if (mode == 1) out1[(long long)z * out_ts + c] = s1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// attention softmax over per-(task, sequence, head) score matrices (Modules.py:16-22).  Only the
+// L valid query rows / key columns are ever computed (padded keys get -inf in the reference,
+// padded query rows are zeroed by FFTBlock's masked_fill), so no mask tensor exists here.
+// ------------------------------------------------------------------------------------------
+struct AttnSeq { long long s_off; int L, ldS; };
+
+__global__ void softmax_fwd_kernel(const AttnSeq* seqs, float* S) {
+    const AttnSeq q = seqs[blockIdx.z];
+    const int row = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    if (row >= q.L) return;
+    float* p = S + q.s_off + (long long)row * q.ldS;
+    float mx = -3.0e38f;
+    for (int c = lane; c < q.L; c += 64) mx = fmaxf(mx, p[c]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < q.L; c += 64) { const float e = expf(p[c] - mx); p[c] = e; s += e; }
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+    for (int c = lane; c < q.ldS; c += 64) p[c] = (c < q.L) ? p[c] * inv : 0.f;
+}
+
+// in place on dP: dS = alpha * P * (dP - sum_j dP_j P_j); pad columns zeroed
+__global__ void softmax_bwd_kernel(const AttnSeq* seqs, const float* P, float* dP, float alpha) {
+    const AttnSeq q = seqs[blockIdx.z];
+    const int row = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    if (row >= q.L) return;
+    const float* p = P + q.s_off + (long long)row * q.ldS;
+    float* d = dP + q.s_off + (long long)row * q.ldS;
+    float s = 0.f;
+    for (int c = lane; c < q.L; c += 64) s += d[c] * p[c];
+    s = wave_sum(s);
+    for (int c = lane; c < q.ldS; c += 64) d[c] = (c < q.L) ? alpha * p[c] * (d[c] - s) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// speaker vectors (speaker_encoder.py:62-65; base_adaptor.py:64-70 mean over the support ids)
+// ------------------------------------------------------------------------------------------
+__global__ void speaker_vec_kernel(const int* meta, const float* table, long long table_ts, const int* ids,
+                                   long long ids_ts, int n_ids_max, int average, float* spk, long long spk_ts,
+                                   int C) {
+    const int z = blockIdx.z, b = blockIdx.x, B = meta[z * META_STRIDE + META_B];
+    if (b >= B) return;
+    const float* t = table + (long long)z * table_ts;
+    const int* id = ids + (long long)z * ids_ts;
+    float* o = spk + (long long)z * spk_ts + (long long)b * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float v;
+        if (average) {
+            const int n = id[n_ids_max];  // count stored after the ids
+            v = 0.f;
+            for (int j = 0; j < n; ++j) v += t[(long long)id[j] * C + c];
+            v /= (float)n;
+        } else {
+            v = t[(long long)id[b] * C + c];
+        }
+        o[c] = v;
+    }
+}
+
+// out[row] = inrect ? x[row] + vec[row_b[row]] : 0      (fastspeech2.py:65-68)
+__global__ void add_rowvec_kernel(const int* meta, int mfield, const float* x, long long x_ts, const float* vec,
+                                  long long vec_ts, const int* row_b, const unsigned char* inrect, long long row_ts,
+                                  float* out, long long out_ts, int C) {
+    ROW_PROLOGUE(mfield)
+    const long long r = (long long)z * row_ts + row;
+    const bool in = inrect[r] != 0;
+    const float* px = x + (long long)z * x_ts + (long long)row * C;
+    const float* pv = vec + (long long)z * vec_ts + (long long)(in ? row_b[r] : 0) * C;
+    float* po = out + (long long)z * out_ts + (long long)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 o = zero4();
+        if (in) { const float4 a = ld4(px + c), b = ld4(pv + c); o = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+        st4(po + c, o);
+    }
+}
+
+// torch.bucketize(v, bins) (right=False): number of boundaries strictly below v (modules.py:83,94)
+__device__ __forceinline__ int bucketize(float v, const float* bins, int nb) {
+    int lo = 0, hi = nb;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (bins[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// x_out = x_in + table[bucketize(val * control)] on in-rect rows; idx saved for backward
+__global__ void bucket_embed_add_kernel(const int* meta, int mfield, const float* x, long long x_ts,
+                                        const float* val, long long val_ts, float control, const float* bins, int nb,
+                                        const float* table, long long table_ts, const unsigned char* inrect,
+                                        long long row_ts, int* idx_out, float* out, long long out_ts, int C) {
+    ROW_PROLOGUE(mfield)
+    const long long r = (long long)z * row_ts + row;
+    const bool in = inrect[r] != 0;
+    const int idx = in ? bucketize(val[(long long)z * val_ts + row] * control, bins, nb) : 0;
+    if (lane == 0) idx_out[r] = in ? idx : -1;
+    const float* px = x + (long long)z * x_ts + (long long)row * C;
+    const float* pt = table + (long long)z * table_ts + (long long)idx * C;
+    float* po = out + (long long)z * out_ts + (long long)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 o = zero4();
+        if (in) { const float4 a = ld4(px + c), b = ld4(pt + c); o = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+        st4(po + c, o);
+    }
+}
+
+// out[row] = valid ? dot(x[row], w) + b : 0       (modules.py:244-248 linear_layer + masked_fill)
+__global__ void rowdot_kernel(const int* meta, int mfield, const float* x, long long x_ts, const float* w,
+                              const float* b, long long par_ts, const unsigned char* valid, long long row_ts,
+                              float* out, long long out_ts, int C) {
+    ROW_PROLOGUE(mfield)
+    const float* px = x + (long long)z * x_ts + (long long)row * C;
+    const float* pw = w + (long long)z * par_ts;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 a = ld4(px + c), ww = ld4(pw + c);
+        s += (a.x * ww.x + a.y * ww.y) + (a.z * ww.z + a.w * ww.w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[(long long)z * out_ts + row] = valid[(long long)z * row_ts + row] ? s + b[(long long)z * par_ts] : 0.f;
+}
+
+// dx[row] = dout[row] * w
+__global__ void rowdot_bwd_kernel(const int* meta, int mfield, const float* dout, long long dout_ts, const float* w,
+                                  long long par_ts, float* dx, long long dx_ts, int C) {
+    ROW_PROLOGUE(mfield)
+    const float d = dout[(long long)z * dout_ts + row];
+    const float* pw = w + (long long)z * par_ts;
+    float* pd = dx + (long long)z * dx_ts + (long long)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 ww = ld4(pw + c);
+        st4(pd + c, make_float4(d * ww.x, d * ww.y, d * ww.z, d * ww.w));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// length regulator (modules.py:167-190): frame row r copies phoneme row src[r]; the speaker
+// vector (fastspeech2.py:91-94) and the decoder's sinusoid row (Models.py:157-159) are added in
+// the same pass.  Backward is a contiguous segment sum per phoneme (no atomics).
+// ------------------------------------------------------------------------------------------
+__global__ void length_regulate_fwd_kernel(const int* meta, const float* x, long long x_ts, const int* src,
+                                           const int* row_b, const int* row_t, long long row_ts, const float* spk,
+                                           long long spk_ts, const float* pos, float* out, long long out_ts, int C) {
+    ROW_PROLOGUE(META_MF)
+    const long long r = (long long)z * row_ts + row;
+    const int s = src[r];
+    float* po = out + (long long)z * out_ts + (long long)row * C;
+    if (s < 0) { for (int c = lane * 4; c < C; c += 256) st4(po + c, zero4()); return; }
+    const float* px = x + (long long)z * x_ts + (long long)s * C;
+    const float* pv = spk + (long long)z * spk_ts + (long long)row_b[r] * C;
+    const float* pp = pos + (long long)row_t[r] * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 a = ld4(px + c), b = ld4(pv + c), d = ld4(pp + c);
+        st4(po + c, make_float4(a.x + b.x + d.x, a.y + b.y + d.y, a.z + b.z + d.z, a.w + b.w + d.w));
+    }
+}
+
+// dx[p] (+)= sum_{r in [first[p], first[p]+count[p])} dout[r]   (rows of the phoneme space)
+__global__ void length_regulate_bwd_kernel(const int* meta, const float* dout, long long dout_ts, const int* first,
+                                           const int* count, long long row_ts, float* dx, long long dx_ts, int C,
+                                           int accumulate) {
+    ROW_PROLOGUE(META_MP)
+    const long long r = (long long)z * row_ts + row;
+    const int f = first[r], n = count[r];
+    const float* pd = dout + (long long)z * dout_ts;
+    float* po = dx + (long long)z * dx_ts + (long long)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 s = accumulate ? ld4(po + c) : zero4();
+        for (int i = 0; i < n; ++i) {
+            const float4 a = ld4(pd + (long long)(f + i) * C + c);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        st4(po + c, s);
+    }
+}
+
+// out[b][c] (+)= sum over rows [start[b], start[b]+len[b]) of X   (speaker-vector gradient)
+__global__ void segsum_rows_kernel(const int* meta, const float* X, long long x_ts, const int* start, const int* len,
+                                   long long seg_ts, float* out, long long out_ts, int C, int accumulate) {
+    const int z = blockIdx.z, b = blockIdx.y, B = meta[z * META_STRIDE + META_B];
+    if (b >= B) return;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int s0 = start[(long long)z * seg_ts + b], n = len[(long long)z * seg_ts + b];
+    const float* px = X + (long long)z * x_ts + (long long)s0 * C + c;
+    float s = accumulate ? out[(long long)z * out_ts + (long long)b * C + c] : 0.f;
+    for (int i = 0; i < n; ++i) s += px[(long long)i * C];
+    out[(long long)z * out_ts + (long long)b * C + c] = s;
+}
+
+// Deterministic embedding-table gradient: one workgroup per table row scans the index list in
+// order.  dtable[v] = sum_{m : idx[m] == v} dx[m]; rows never referenced (and `skip_row`, the
+// padding_idx of src_word_emb, Models.py:56-58) are written as zero, so no memset is needed.
+__global__ void table_grad_kernel(const int* meta, int mfield, const float* dx, long long dx_ts, const int* idx,
+                                  long long idx_ts, int skip_row, float* dtable, long long dt_ts, int C) {
+    const int z = blockIdx.z, v = blockIdx.x;
+    const int M_ = meta[z * META_STRIDE + mfield];
+    const int* pi = idx + (long long)z * idx_ts;
+    const float* pd = dx + (long long)z * dx_ts;
+    float* po = dtable + (long long)z * dt_ts + (long long)v * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        if (v != skip_row)
+            for (int m = 0; m < M_; ++m)
+                if (pi[m] == v) s += pd[(long long)m * C + c];
+        po[c] = s;
+    }
+}
+
+// speaker table gradient from per-utterance vector grads (table path; averaged path divides by
+// the number of support ids and gives every support id the summed gradient)
+__global__ void speaker_table_grad_kernel(const int* meta, const float* dspk, long long dspk_ts, const int* ids,
+                                          long long ids_ts, int n_ids_max, int average, float* dtable,
+                                          long long dt_ts, int C) {
+    const int z = blockIdx.z, v = blockIdx.x, B = meta[z * META_STRIDE + META_B];
+    const int* id = ids + (long long)z * ids_ts;
+    const float* pd = dspk + (long long)z * dspk_ts;
+    float* po = dtable + (long long)z * dt_ts + (long long)v * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        if (average) {
+            const int n = id[n_ids_max];
+            int hits = 0;
+            for (int j = 0; j < n; ++j) hits += (id[j] == v);
+            if (hits) {
+                float t = 0.f;
+                for (int b = 0; b < B; ++b) t += pd[(long long)b * C + c];
+                s = t * (float)hits / (float)n;
+            }
+        } else {
+            for (int b = 0; b < B; ++b)
+                if (id[b] == v) s += pd[(long long)b * C + c];
+        }
+        po[c] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// PostNet BatchNorm1d (+tanh) on the (B, T') rectangle incl. padded frames (Layers.py:129-137)
+// ------------------------------------------------------------------------------------------
+// per-channel batch statistics over in-rect rows (two-pass); stats_out = [mean | rstd | var_unbiased]
+__global__ void bn_stats_kernel(const int* meta, const float* X, long long x_ts, const unsigned char* inrect,
+                                long long row_ts, float* stats_out, long long st_ts, int C, float eps) {
+    __shared__ float red[8][33];
+    __shared__ float meansh[32];
+    const int z = blockIdx.z, M_ = meta[z * META_STRIDE + META_MR];
+    const int cx = (int)threadIdx.x & 31, ry = (int)threadIdx.x >> 5, c = blockIdx.x * 32 + cx;
+    const float* px = X + (long long)z * x_ts;
+    const unsigned char* pm = inrect + (long long)z * row_ts;
+    const float n = (float)(meta[z * META_STRIDE + META_B] * meta[z * META_STRIDE + META_TCAP]);
+    float a = 0.f;
+    if (c < C) for (int m = ry; m < M_; m += 8) if (pm[m]) a += px[(long long)m * C + c];
+    red[ry][cx] = a;
+    __syncthreads();
+    if (ry == 0) { float s = 0.f; for (int i = 0; i < 8; ++i) s += red[i][cx]; meansh[cx] = s / n; }
+    __syncthreads();
+    const float mean = meansh[cx];
+    a = 0.f;
+    if (c < C) for (int m = ry; m < M_; m += 8) if (pm[m]) { const float d = px[(long long)m * C + c] - mean; a += d * d; }
+    __syncthreads();
+    red[ry][cx] = a;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        float s = 0.f;
+        for (int i = 0; i < 8; ++i) s += red[i][cx];
+        float* so = stats_out + (long long)z * st_ts;
+        so[c] = mean;
+        so[C + c] = rsqrtf(s / n + eps);
+        so[2 * C + c] = s / fmaxf(n - 1.f, 1.f);
+    }
+}
+
+// running stats: momentum update applied task after task (deterministic order), one launch
+__global__ void bn_running_update_kernel(const float* stats, long long st_ts, int tasks, float* running_mean,
+                                         float* running_var, int C, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float rm = running_mean[c], rv = running_var[c];
+    for (int t = 0; t < tasks; ++t) {
+        const float* s = stats + (long long)t * st_ts;
+        rm = (1.f - momentum) * rm + momentum * s[c];
+        rv = (1.f - momentum) * rv + momentum * s[2 * C + c];
+    }
+    running_mean[c] = rm;
+    running_var[c] = rv;
+}
+
+// stats for eval mode from the running buffers: [mean | rstd]
+__global__ void bn_eval_stats_kernel(const float* running_mean, const float* running_var, float* stats_out,
+                                     long long st_ts, int tasks, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    for (int t = 0; t < tasks; ++t) {
+        float* so = stats_out + (long long)t * st_ts;
+        so[c] = running_mean[c];
+        so[C + c] = rsqrtf(running_var[c] + eps);
+        so[2 * C + c] = running_var[c];
+    }
+}
+
+// y = act((x - mean) * rstd * gamma + beta) on in-rect rows, 0 on guard rows
+__global__ void bn_apply_kernel(const int* meta, const float* X, long long x_ts, const float* stats, long long st_ts,
+                                const float* gamma, const float* beta, long long par_ts, const unsigned char* inrect,
+                                long long row_ts, int do_tanh, float* Y, long long y_ts, int C) {
+    ROW_PROLOGUE(META_MR)
+    const bool in = inrect[(long long)z * row_ts + row] != 0;
+    const float* px = X + (long long)z * x_ts + (long long)row * C;
+    float* py = Y + (long long)z * y_ts + (long long)row * C;
+    const float* st = stats + (long long)z * st_ts;
+    const float* g = gamma + (long long)z * par_ts;
+    const float* b = beta + (long long)z * par_ts;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 o = zero4();
+        if (in) {
+            const float4 x = ld4(px + c), mu = ld4(st + c), rs = ld4(st + C + c), g4 = ld4(g + c), b4 = ld4(b + c);
+            o = make_float4((x.x - mu.x) * rs.x * g4.x + b4.x, (x.y - mu.y) * rs.y * g4.y + b4.y,
+                            (x.z - mu.z) * rs.z * g4.z + b4.z, (x.w - mu.w) * rs.w * g4.w + b4.w);
+            if (do_tanh) o = make_float4(tanhf(o.x), tanhf(o.y), tanhf(o.z), tanhf(o.w));
+        }
+        st4(py + c, o);
+    }
+}
+
+// backward pass 1: per channel sum(dpre) and sum(dpre * xhat), dpre = dy * (1 - y^2) if tanh.
+// out = [dgamma | dbeta]
+__global__ void bn_bwd_reduce_kernel(const int* meta, const float* dY, long long dy_ts, const float* Yact,
+                                     long long ya_ts, const float* X, long long x_ts, const float* stats,
+                                     long long st_ts, const unsigned char* inrect, long long row_ts, int do_tanh,
+                                     float* dgamma, float* dbeta, long long out_ts, int C) {
+    __shared__ float red0[8][33], red1[8][33];
+    const int z = blockIdx.z, M_ = meta[z * META_STRIDE + META_MR];
+    const int cx = (int)threadIdx.x & 31, ry = (int)threadIdx.x >> 5, c = blockIdx.x * 32 + cx;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        const float* pdy = dY + (long long)z * dy_ts;
+        const float* pya = Yact + (long long)z * ya_ts;
+        const float* px = X + (long long)z * x_ts;
+        const unsigned char* pm = inrect + (long long)z * row_ts;
+        const float* st = stats + (long long)z * st_ts;
+        const float mean = st[c], rstd = st[C + c];
+        for (int m = ry; m < M_; m += 8) {
+            if (!pm[m]) continue;
+            float d = pdy[(long long)m * C + c];
+            if (do_tanh) { const float y = pya[(long long)m * C + c]; d *= (1.f - y * y); }
+            a1 += d;
+            a0 += d * (px[(long long)m * C + c] - mean) * rstd;
+        }
+    }
+    red0[ry][cx] = a0;
+    red1[ry][cx] = a1;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int i = 0; i < 8; ++i) { s0 += red0[i][cx]; s1 += red1[i][cx]; }
+        dgamma[(long long)z * out_ts + c] = s0;
+        dbeta[(long long)z * out_ts + c] = s1;
+    }
+}
+
+// backward pass 2: dx = gamma * rstd * (dpre - dbeta/n - xhat * dgamma/n) on in-rect rows
+__global__ void bn_bwd_apply_kernel(const int* meta, const float* dY, long long dy_ts, const float* Yact,
+                                    long long ya_ts, const float* X, long long x_ts, const float* stats,
+                                    long long st_ts, const float* gamma, long long par_ts, const float* dgamma,
+                                    const float* dbeta, long long dg_ts, const unsigned char* inrect,
+                                    long long row_ts, int do_tanh, float* dX, long long dx_ts, int C) {
+    ROW_PROLOGUE(META_MR)
+    float* pdx = dX + (long long)z * dx_ts + (long long)row * C;
+    if (!inrect[(long long)z * row_ts + row]) { for (int c = lane * 4; c < C; c += 256) st4(pdx + c, zero4()); return; }
+    const float inv_n = 1.f / (float)(meta[z * META_STRIDE + META_B] * meta[z * META_STRIDE + META_TCAP]);
+    const float* pdy = dY + (long long)z * dy_ts + (long long)row * C;
+    const float* pya = Yact + (long long)z * ya_ts + (long long)row * C;
+    const float* px = X + (long long)z * x_ts + (long long)row * C;
+    const float* st = stats + (long long)z * st_ts;
+    const float* g = gamma + (long long)z * par_ts;
+    const float* dg = dgamma + (long long)z * dg_ts;
+    const float* db = dbeta + (long long)z * dg_ts;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 d4 = ld4(pdy + c), x4 = ld4(px + c), mu = ld4(st + c), rs = ld4(st + C + c), g4 = ld4(g + c),
+                     dg4 = ld4(dg + c), db4 = ld4(db + c);
+        float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+        if (do_tanh) {
+            const float4 y4 = ld4(pya + c);
+            dd[0] *= (1.f - y4.x * y4.x); dd[1] *= (1.f - y4.y * y4.y);
+            dd[2] *= (1.f - y4.z * y4.z); dd[3] *= (1.f - y4.w * y4.w);
+        }
+        const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ms[4] = {mu.x, mu.y, mu.z, mu.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w};
+        const float gs[4] = {g4.x, g4.y, g4.z, g4.w}, dgs[4] = {dg4.x, dg4.y, dg4.z, dg4.w}, dbs[4] = {db4.x, db4.y, db4.z, db4.w};
+        float o[4];
+        for (int i = 0; i < 4; ++i) {
+            const float xh = (xs[i] - ms[i]) * rr[i];
+            o[i] = gs[i] * rr[i] * (dd[i] - dbs[i] * inv_n - xh * dgs[i] * inv_n);
+        }
+        st4(pdx + c, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+// mel rectangle: padded in-rect rows carry mel_linear.bias (decoder output is zero there);
+// guard rows are re-zeroed (the previous batch plan may have had frames there)
+__global__ void fill_padded_rows_kernel(const int* meta, float* X, long long x_ts, const float* bias, long long par_ts,
+                                        const unsigned char* inrect, const unsigned char* valid, long long row_ts, int C) {
+    ROW_PROLOGUE(META_MR)
+    const long long r = (long long)z * row_ts + row;
+    if (valid[r]) return;
+    const bool in = inrect[r] != 0;
+    float* px = X + (long long)z * x_ts + (long long)row * C;
+    const float* b = bias + (long long)z * par_ts;
+    for (int c = lane * 4; c < C; c += 256) st4(px + c, in ? ld4(b + c) : zero4());
+}
+
+// out[r] = rowmap[r] >= 0 ? src[rowmap[r]] : 0   (row gather between row spaces)
+__global__ void gather_rows_kernel(const int* meta, int mfield, const float* src, long long src_ts, const int* rowmap,
+                                   long long map_ts, float* out, long long out_ts, int C) {
+    ROW_PROLOGUE(mfield)
+    const int s = rowmap[(long long)z * map_ts + row];
+    float* po = out + (long long)z * out_ts + (long long)row * C;
+    const float* ps = src + (long long)z * src_ts + (long long)(s < 0 ? 0 : s) * C;
+    for (int c = lane * 4; c < C; c += 256) st4(po + c, s < 0 ? zero4() : ld4(ps + c));
+}
+
+// ------------------------------------------------------------------------------------------
+// elementwise helpers over [tasks][n] float arrays (n % 4 == 0)
+// ------------------------------------------------------------------------------------------
+__global__ void add2_kernel(const float* a, const float* b, float* out, long long n4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 x = ld4(a + i * 4), y = ld4(b + i * 4);
+        st4(out + i * 4, make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w));
+    }
+}
+
+// dst[t][i] = src[i]  (clone the adapted parameters into every task's fast weights)
+__global__ void broadcast_kernel(const float* src, float* dst, long long n4, long long dst_ts) {
+    float* d = dst + (long long)blockIdx.z * dst_ts;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+        st4(d + i * 4, ld4(src + i * 4));
+}
+
+// MAML inner update  theta' = theta - lr * g   (learn2learn maml_update via systems/utils.py:39-47)
+__global__ void sgd_update_kernel(float* w, const float* g, long long n4, float lr, long long w_ts, long long g_ts) {
+    float* pw = w + (long long)blockIdx.z * w_ts;
+    const float* pg = g + (long long)blockIdx.z * g_ts;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 x = ld4(pw + i * 4);
+        const float4 d = ld4(pg + i * 4);
+        x.x -= lr * d.x; x.y -= lr * d.y; x.z -= lr * d.z; x.w -= lr * d.w;
+        st4(pw + i * 4, x);
+    }
+}
+
+// out[i] = scale * sum_t g[t][i]   (fixed task order)
+__global__ void sum_tasks_kernel(const float* g, long long g_ts, int tasks, float scale, float* out, long long n4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 s = zero4();
+        for (int t = 0; t < tasks; ++t) {
+            const float4 x = ld4(g + (long long)t * g_ts + i * 4);
+            s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+        }
+        st4(out + i * 4, make_float4(s.x * scale, s.y * scale, s.z * scale, s.w * scale));
+    }
+}
+
+// global L2 norm, stage 1: per-block partial sums of squares (double accumulation in the
+// second stage keeps it deterministic and accurate)
+__global__ void sumsq_partial_kernel(const float* g, long long n4, float* partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 x = ld4(g + i * 4);
+        s += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+    }
+    s = wave_sum(s);
+    if (((int)threadIdx.x & 63) == 0) red[(int)threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void sumsq_final_kernel(const float* partial, int n, float* out_norm) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += (double)partial[i];
+        out_norm[0] = (float)sqrt(s);
+    }
+}
+
+// fused clip_grad_norm_(max_norm) + Adam (optimizer.py:9-15, main.py:61); norm read on device
+__global__ void adam_clip_kernel(float* w, const float* g, float* m, float* v, long long n4, const float* norm,
+                                 float max_norm, float lr, float b1, float b2, float eps, float bc1, float bc2,
+                                 float weight_decay) {
+    float coef = 1.f;
+    if (max_norm > 0.f) { coef = max_norm / (norm[0] + 1e-6f); coef = coef > 1.f ? 1.f : coef; }
+    const float step = lr / bc1, isq = 1.f / sqrtf(bc2);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 W = ld4(w + i * 4), G = ld4(g + i * 4), Mo = ld4(m + i * 4), Vo = ld4(v + i * 4);
+        float ws[4] = {W.x, W.y, W.z, W.w}, gs[4] = {G.x, G.y, G.z, G.w}, ms[4] = {Mo.x, Mo.y, Mo.z, Mo.w}, vs[4] = {Vo.x, Vo.y, Vo.z, Vo.w};
+        for (int k = 0; k < 4; ++k) {
+            float gg = gs[k] * coef;
+            if (weight_decay != 0.f) gg += weight_decay * ws[k];
+            ms[k] = b1 * ms[k] + (1.f - b1) * gg;
+            vs[k] = b2 * vs[k] + (1.f - b2) * gg * gg;
+            const float denom = sqrtf(vs[k]) * isq + eps;
+            ws[k] -= step * ms[k] / denom;
+        }
+        st4(w + i * 4, make_float4(ws[0], ws[1], ws[2], ws[3]));
+        st4(m + i * 4, make_float4(ms[0], ms[1], ms[2], ms[3]));
+        st4(v + i * 4, make_float4(vs[0], vs[1], vs[2], vs[3]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// loss (loss.py:19-92) on the mel rectangle and the phoneme rectangle
+// ------------------------------------------------------------------------------------------
+struct LossArgs {
+    const float *mel, *mel_post, *mel_tgt;       // [Mr][n_mel]
+    const unsigned char* rvalid;                 // mel rows
+    const float *pp, *ep, *logd, *p_tgt, *e_tgt; // [Mp]
+    const int* dur;                              // [Mp] duration targets
+    const unsigned char* pvalid;                 // phoneme rows
+    long long mel_ts, rrow_ts, prow_ts, pred_ts; // strides
+    int n_mel;
+};
+
+constexpr int kLossBlocks = 64;
+
+// partial[task][block][5]: sum|mel - t|, sum|post - t|, sum (pp-pt)^2, sum (ep-et)^2, sum (logd - log(d+1))^2
+__global__ void loss_partial_kernel(const int* meta, LossArgs a, float* partial) {
+    __shared__ float red[4][5];
+    const int z = blockIdx.z;
+    const int Mr = meta[z * META_STRIDE + META_MR], Mp = meta[z * META_STRIDE + META_MP];
+    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int n4 = a.n_mel / 4;
+    const long long tot = (long long)Mr * n4;
+    const float* mel = a.mel + (long long)z * a.mel_ts;
+    const float* post = a.mel_post + (long long)z * a.mel_ts;
+    const float* tgt = a.mel_tgt + (long long)z * a.mel_ts;
+    const unsigned char* rv = a.rvalid + (long long)z * a.rrow_ts;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / n4);
+        if (!rv[r]) continue;
+        const float4 m = ld4(mel + i * 4), p = ld4(post + i * 4), t = ld4(tgt + i * 4);
+        s[0] += (fabsf(m.x - t.x) + fabsf(m.y - t.y)) + (fabsf(m.z - t.z) + fabsf(m.w - t.w));
+        s[1] += (fabsf(p.x - t.x) + fabsf(p.y - t.y)) + (fabsf(p.z - t.z) + fabsf(p.w - t.w));
+    }
+    const unsigned char* pv = a.pvalid + (long long)z * a.prow_ts;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < Mp; r += gridDim.x * blockDim.x) {
+        if (!pv[r]) continue;
+        const long long q = (long long)z * a.pred_ts + r, qt = (long long)z * a.prow_ts + r;
+        const float dp = a.pp[q] - a.p_tgt[qt], de = a.ep[q] - a.e_tgt[qt];
+        const float dd = a.logd[q] - logf((float)a.dur[qt] + 1.f);
+        s[2] += dp * dp; s[3] += de * de; s[4] += dd * dd;
+    }
+    for (int k = 0; k < 5; ++k) s[k] = wave_sum(s[k]);
+    if (((int)threadIdx.x & 63) == 0) for (int k = 0; k < 5; ++k) red[(int)threadIdx.x >> 6][k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const int k = threadIdx.x;
+        partial[((long long)z * gridDim.x + blockIdx.x) * 5 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    }
+}
+
+// losses[task][6] = (total, mel, postnet mel, pitch, energy, duration)
+__global__ void loss_final_kernel(const int* meta, const float* partial, int nblocks, int n_mel, float* losses) {
+    const int z = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < nblocks; ++b) for (int k = 0; k < 5; ++k) s[k] += (double)partial[((long long)z * nblocks + b) * 5 + k];
+    const double nF = (double)meta[z * META_STRIDE + META_NF] * n_mel, nP = (double)meta[z * META_STRIDE + META_NP];
+    const float mel = (float)(s[0] / nF), post = (float)(s[1] / nF), p = (float)(s[2] / nP), e = (float)(s[3] / nP), d = (float)(s[4] / nP);
+    float* o = losses + (long long)z * 6;
+    o[0] = mel + post + d + p + e; o[1] = mel; o[2] = post; o[3] = p; o[4] = e; o[5] = d;
+}
+
+__device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+// d(total)/d(predictions) * scale.  dmel, dpost: [Mr][n_mel] (0 on padded / guard rows);
+// dpp, dep, dlogd: [Mp]
+__global__ void loss_grad_kernel(const int* meta, LossArgs a, float scale, float* dmel, float* dpost, float* dpp,
+                                 float* dep, float* dlogd) {
+    const int z = blockIdx.z;
+    const int Mr = meta[z * META_STRIDE + META_MR], Mp = meta[z * META_STRIDE + META_MP];
+    const float wF = scale / ((float)meta[z * META_STRIDE + META_NF] * (float)a.n_mel);
+    const float wP = 2.f * scale / (float)meta[z * META_STRIDE + META_NP];
+    const int n4 = a.n_mel / 4;
+    const long long tot = (long long)Mr * n4;
+    const float* mel = a.mel + (long long)z * a.mel_ts;
+    const float* post = a.mel_post + (long long)z * a.mel_ts;
+    const float* tgt = a.mel_tgt + (long long)z * a.mel_ts;
+    float* dm = dmel + (long long)z * a.mel_ts;
+    float* dq = dpost + (long long)z * a.mel_ts;
+    const unsigned char* rv = a.rvalid + (long long)z * a.rrow_ts;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / n4);
+        float4 o1 = zero4(), o2 = zero4();
+        if (rv[r]) {
+            const float4 m = ld4(mel + i * 4), p = ld4(post + i * 4), t = ld4(tgt + i * 4);
+            o1 = make_float4(wF * sgnf(m.x - t.x), wF * sgnf(m.y - t.y), wF * sgnf(m.z - t.z), wF * sgnf(m.w - t.w));
+            o2 = make_float4(wF * sgnf(p.x - t.x), wF * sgnf(p.y - t.y), wF * sgnf(p.z - t.z), wF * sgnf(p.w - t.w));
+        }
+        st4(dm + i * 4, o1);
+        st4(dq + i * 4, o2);
+    }
+    const unsigned char* pv = a.pvalid + (long long)z * a.prow_ts;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < Mp; r += gridDim.x * blockDim.x) {
+        const long long q = (long long)z * a.pred_ts + r, qt = (long long)z * a.prow_ts + r;
+        float gp = 0.f, ge = 0.f, gd = 0.f;
+        if (pv[r]) {
+            gp = wP * (a.pp[q] - a.p_tgt[qt]);
+            ge = wP * (a.ep[q] - a.e_tgt[qt]);
+            gd = wP * (a.logd[q] - logf((float)a.dur[qt] + 1.f));
+        }
+        dpp[q] = gp; dep[q] = ge; dlogd[q] = gd;
+    }
+}
+
+// free-running durations (modules.py:132-136): clamp(round(exp(logd) - 1) * d_control, min 0)
+__global__ void duration_round_kernel(const int* meta, const float* logd, long long pred_ts, float d_control,
+                                      const unsigned char* pvalid, long long prow_ts, float* d_rounded) {
+    const int z = blockIdx.z, Mp = meta[z * META_STRIDE + META_MP];
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < Mp; r += gridDim.x * blockDim.x) {
+        const long long q = (long long)z * pred_ts + r;
+        float d = rintf(expf(logd[q]) - 1.f) * d_control;
+        d_rounded[q] = (d > 0.f) ? d : 0.f;
+        (void)pvalid; (void)prow_ts;
+    }
+}
+
+}  // namespace mtts

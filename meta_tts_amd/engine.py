@@ -1,0 +1,210 @@
+"""Thin Python handle over libmtts (include/mtts.h): owns nothing but the handle pointer; all device
+memory and all compute live behind the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .config import ModelDims
+
+MODULE_BITS = {"encoder": 0, "variance_adaptor": 1, "decoder": 2, "mel_linear": 3, "postnet": 4, "speaker_emb": 5}
+LOSS_NAMES = ("Total Loss", "Mel Loss", "Mel-Postnet Loss", "Pitch Loss", "Energy Loss", "Duration Loss")
+
+
+class MttsError(RuntimeError):
+    pass
+
+
+def _arr(x, dtype):
+    a = np.ascontiguousarray(x, dtype=dtype)
+    return a
+
+
+class _DevView:
+    """Zero-copy view of a device buffer for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class Engine:
+    def __init__(self, dims: ModelDims, adapt_modules: Sequence[str] = (), max_tasks: int = 1, max_B: int = 16,
+                 max_S: int = 128, max_T: int = 1000, device: int = 0, lib_path: Optional[str] = None):
+        self.lib = _lib.load(lib_path)
+        self.dims = dims
+        cfg = _lib.ModelCfg()
+        for f in ("d_model", "enc_layers", "dec_layers", "enc_heads", "dec_heads", "d_ff", "k1", "k2", "vp_filter",
+                  "vp_kernel", "n_bins", "max_seq_len", "n_mel", "vocab", "n_speaker", "postnet_dim", "postnet_kernel",
+                  "postnet_layers", "pitch_min", "pitch_max", "energy_min", "energy_max"):
+            setattr(cfg, f, getattr(dims, f))
+        mask = 0
+        for m in adapt_modules:
+            if m not in MODULE_BITS:
+                raise MttsError(f"adapt module {m!r} is not supported (supported: {sorted(MODULE_BITS)})")
+            mask |= 1 << MODULE_BITS[m]
+        cfg.adapt_mask = mask
+        self.adapt_modules = tuple(adapt_modules)
+        self.max_tasks = max_tasks
+        h = C.c_void_p()
+        rc = self.lib.mtts_create(C.byref(cfg), device, max_tasks, max_B, max_S, max_T, C.byref(h))
+        if rc != 0:
+            raise MttsError("mtts_create: " + (self.lib.mtts_last_error(None) or b"").decode())
+        self.h = h
+        self._keep: List = []
+        self.n_tasks = [0, 0]
+        self.batch_shapes = [[], []]
+        # parameter table
+        self.params: Dict[str, tuple] = {}
+        name = C.c_char_p(); ndim = C.c_int(); shape = (C.c_int * 4)(); off = C.c_int64(); ad = C.c_int()
+        for i in range(self.lib.mtts_param_count(self.h)):
+            self._ck(self.lib.mtts_param_info(self.h, i, C.byref(name), C.byref(ndim), C.byref(shape), C.byref(off), C.byref(ad)))
+            self.params[name.value.decode()] = (tuple(shape[k] for k in range(ndim.value)), int(off.value), bool(ad.value))
+        self.n_total = int(self.lib.mtts_param_total(self.h))
+        self.adapt_start = int(self.lib.mtts_adapt_start(self.h))
+
+    # ------------------------------------------------------------------------------
+    def _ck(self, rc: int):
+        if rc != 0:
+            raise MttsError((self.lib.mtts_last_error(self.h) or b"unknown error").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mtts_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr: int):
+        self._ck(self.lib.mtts_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._ck(self.lib.mtts_synchronize(self.h))
+
+    # ---- parameters --------------------------------------------------------------
+    def load_params(self, params: Dict[str, np.ndarray], strict: bool = True):
+        for name, (shape, _, _) in self.params.items():
+            if name not in params:
+                if strict:
+                    raise MttsError(f"missing parameter {name}")
+                continue
+            a = _arr(params[name], np.float32)
+            if tuple(a.shape) != shape:
+                raise MttsError(f"shape mismatch for {name}: {a.shape} vs {shape}")
+            self._ck(self.lib.mtts_load_param(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+
+    def export(self, name: str, which: int = 0, task: int = 0) -> np.ndarray:
+        shape = self.params[name][0]
+        out = np.empty(shape, np.float32)
+        self._ck(self.lib.mtts_export_param(self.h, name.encode(), which, task, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def state_dict(self) -> Dict[str, np.ndarray]:
+        return {n: self.export(n, 0) for n in self.params}
+
+    def grads(self, which: int = 2, task: int = 0, names: Optional[Sequence[str]] = None) -> Dict[str, np.ndarray]:
+        return {n: self.export(n, which, task) for n in (names or self.params)}
+
+    def set_bn_buffers(self, layer: int, mean: np.ndarray, var: np.ndarray, tracked: int = 0):
+        m, v = _arr(mean, np.float32), _arr(var, np.float32)
+        self._ck(self.lib.mtts_set_bn_buffers(self.h, layer, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), tracked))
+
+    def get_bn_buffers(self, layer: int):
+        c = self.dims.n_mel if layer == self.dims.postnet_layers - 1 else self.dims.postnet_dim
+        m, v, t = np.empty(c, np.float32), np.empty(c, np.float32), C.c_int64()
+        self._ck(self.lib.mtts_get_bn_buffers(self.h, layer, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), C.byref(t)))
+        return m, v, int(t.value)
+
+    # ---- batches -----------------------------------------------------------------
+    def _cbatch(self, b, keep):
+        """12-tuple (collate.py:47-60) of numpy arrays / torch CPU tensors -> mtts_batch"""
+        def np_(x, dt):
+            if hasattr(x, "detach"):
+                x = x.detach().cpu().numpy()
+            a = _arr(x, dt)
+            keep.append(a)
+            return a
+        spk, texts, src_lens = np_(b[2], np.int64), np_(b[3], np.int64), np_(b[4], np.int64)
+        mels, mel_lens = np_(b[6], np.float32), np_(b[7], np.int64)
+        p, e, d = np_(b[9], np.float32), np_(b[10], np.float32), np_(b[11], np.int64)
+        cb = _lib.Batch()
+        cb.B, cb.S_max, cb.T_max = int(texts.shape[0]), int(b[5]), int(b[8])
+        assert texts.shape == (cb.B, cb.S_max) and mels.shape == (cb.B, cb.T_max, self.dims.n_mel), (texts.shape, mels.shape)
+        for f, a in (("speakers", spk), ("texts", texts), ("src_lens", src_lens), ("mels", mels), ("mel_lens", mel_lens),
+                     ("pitches", p), ("energies", e), ("durations", d)):
+            setattr(cb, f, a.ctypes.data_as(C.c_void_p))
+        return cb
+
+    def set_batches(self, slot: int, batches: Sequence[tuple], spk_from: Optional[Sequence[tuple]] = None,
+                    average_spk: bool = False):
+        keep: List = []
+        n = len(batches)
+        arr = (_lib.Batch * n)(*[self._cbatch(b, keep) for b in batches])
+        sarr = None
+        if spk_from is not None:
+            sarr = (_lib.Batch * n)(*[self._cbatch(b, keep) for b in spk_from])
+        self._ck(self.lib.mtts_set_batches(self.h, slot, n, arr, sarr, int(average_spk)))
+        self.n_tasks[slot] = n
+        self.batch_shapes[slot] = [(int(b[3].shape[0]), int(b[5]), min(int(b[8]), self.dims.max_seq_len)) for b in batches]
+
+    # ---- compute -----------------------------------------------------------------
+    def forward(self, slot: int = 0, use_fast: bool = False, train: bool = False):
+        self._ck(self.lib.mtts_forward(self.h, slot, int(use_fast), int(train)))
+
+    def outputs(self, slot: int = 0, task: int = 0) -> Dict[str, np.ndarray]:
+        B, S, T = self.batch_shapes[slot][task]
+        nm = self.dims.n_mel
+        o = {"mel": np.empty((B, T, nm), np.float32), "mel_post": np.empty((B, T, nm), np.float32),
+             "p": np.empty((B, S), np.float32), "e": np.empty((B, S), np.float32), "logd": np.empty((B, S), np.float32)}
+        self._ck(self.lib.mtts_get_outputs(self.h, slot, task, *[o[k].ctypes.data_as(C.c_void_p) for k in ("mel", "mel_post", "p", "e", "logd")]))
+        return o
+
+    def loss(self, slot: int = 0) -> np.ndarray:
+        out = np.empty((self.n_tasks[slot], 6), np.float32)
+        self._ck(self.lib.mtts_loss(self.h, slot, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def backward(self, slot: int = 0, use_fast: bool = False, scale: float = 1.0, need_encoder: bool = True):
+        self._ck(self.lib.mtts_backward(self.h, slot, int(use_fast), float(scale), int(need_encoder)))
+
+    def meta_grad(self, steps: int, inner_lr: float, grad_scale: float, second_order: bool = False, fetch_losses: bool = True):
+        nt = self.n_tasks[0]
+        if fetch_losses:
+            q = np.empty((nt, 6), np.float32)
+            s = np.empty((steps, nt, 6), np.float32)
+            self._ck(self.lib.mtts_meta_grad(self.h, steps, inner_lr, grad_scale, int(second_order),
+                                             q.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p)))
+            return q, s
+        self._ck(self.lib.mtts_meta_grad(self.h, steps, inner_lr, grad_scale, int(second_order), None, None))
+        return None, None
+
+    def plain_grad(self, slot: int = 0, grad_scale: float = 1.0, fetch_losses: bool = True):
+        if fetch_losses:
+            q = np.empty((self.n_tasks[slot], 6), np.float32)
+            self._ck(self.lib.mtts_plain_grad(self.h, slot, grad_scale, q.ctypes.data_as(C.c_void_p)))
+            return q
+        self._ck(self.lib.mtts_plain_grad(self.h, slot, grad_scale, None))
+        return None
+
+    def outer_grad_ptr(self) -> int:
+        return int(self.lib.mtts_outer_grad_ptr(self.h))
+
+    def outer_grad_view(self):
+        """Device buffer of the outer gradient as an object torch.as_tensor(..., device='cuda') can alias."""
+        return _DevView(self.outer_grad_ptr(), self.n_total)
+
+    def outer_update(self, lr: float, betas=(0.9, 0.98), eps: float = 1e-9, weight_decay: float = 0.0,
+                     max_norm: float = 1.0, grad_ptr: Optional[int] = None, fetch_norm: bool = False):
+        norm = C.c_float()
+        self._ck(self.lib.mtts_outer_update(self.h, C.c_void_p(grad_ptr) if grad_ptr else None, lr, betas[0], betas[1], eps,
+                                            weight_decay, max_norm, C.byref(norm) if fetch_norm else None))
+        return float(norm.value) if fetch_norm else None
+
+    def reset_optimizer(self):
+        self._ck(self.lib.mtts_reset_optimizer(self.h))

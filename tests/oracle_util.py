@@ -45,6 +45,6 @@ def tiny_dims(**over):
     mc["max_seq_len"] = 64
     mc["_postnet_dim"] = 48
     pc = default_preprocess_config()
-    pc["preprocessing"]["mel"]["n_mel_channels"] = 20
+    pc["preprocessing"]["mel"]["n_mel_channels"] = 32
     mc.update(over.pop("model", {}))
     return ModelDims(mc, pc, n_speaker=over.pop("n_speaker", 12), vocab=over.pop("vocab", 40))

@@ -1,0 +1,167 @@
+"""CPU execution of the *product's own kernel and orchestration sources* through the SIMT emulator
+(tests/emu) against the oracle: forward, loss, hand-derived backward, first-order MAML, clip + Adam.
+Validates indexing / layouts / masks / gradient formulas without a GPU; the MFMA operand mapping
+itself is only exercised by the -m gpu tests."""
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as ge
+from oracle_util import O, heads, synth, tiny_dims, torch_buffers, torch_params
+from meta_tts_amd.engine import Engine
+
+MODS = ["speaker_emb", "variance_adaptor", "decoder", "mel_linear", "postnet"]
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    return ge.build_emulator()
+
+
+def _kw(dims):
+    return dict(n_mel=dims.n_mel, vocab=dims.vocab, s_range=(5, 13), d_range=(1, 6), first_len=12)
+
+
+def _engine(dims, emu_lib, tasks=2, mods=MODS):
+    eng = Engine(dims, adapt_modules=mods, max_tasks=tasks, max_B=3, max_S=16, max_T=96, lib_path=emu_lib)
+    eng.load_params(synth.make_params(dims, 0))
+    return eng
+
+
+def test_param_roundtrip_and_layout(emu_lib):
+    dims = tiny_dims()
+    eng = _engine(dims, emu_lib)
+    ref = synth.make_params(dims, 0)
+    for n, (shape, off, adapted) in eng.params.items():
+        np.testing.assert_array_equal(eng.export(n), ref[n])
+        assert adapted == (n.split(".")[0] in MODS)
+        assert off % 4 == 0
+    assert set(eng.params) == {k for k in ref if not k.endswith(("position_enc", "pitch_bins", "energy_bins"))}
+    eng.close()
+
+
+def test_forward_loss_backward_two_ragged_tasks(emu_lib):
+    dims = tiny_dims()
+    eng = _engine(dims, emu_lib)
+    b0 = synth.make_batch(3, 3, speaker=2, **_kw(dims))
+    b1 = synth.make_batch(4, 2, speaker=5, **_kw(dims))
+    eng.set_batches(0, [b0, b1])
+    eng.forward(0, use_fast=False, train=True)
+    dev_loss = eng.loss(0)
+    eng.backward(0, use_fast=False, scale=1.0, need_encoder=True)
+    for ti, b in enumerate([b0, b1]):
+        p = torch_params(dims, requires_grad=True)
+        tb = O.to_torch_batch(b)
+        o = O.fs2_forward(p, torch_buffers(dims), *tb[2:], n_head=heads(dims), max_seq_len=dims.max_seq_len, training=True)
+        lo = O.fs2_loss(tb, o)
+        out = eng.outputs(0, ti)
+        for k, ref in (("mel", o[0]), ("mel_post", o[1]), ("p", o[2]), ("e", o[3]), ("logd", o[4])):
+            assert np.abs(out[k] - ref.detach().numpy()).max() < 5e-5, (ti, k)
+        np.testing.assert_allclose(dev_loss[ti], [float(x) for x in lo], rtol=2e-5)
+        names = list(eng.params)
+        gs = torch.autograd.grad(lo[0], [p[n] for n in names], allow_unused=True)
+        for n, g in zip(names, gs):
+            ref = g.numpy() if g is not None else np.zeros(eng.params[n][0], np.float32)
+            got = eng.export(n, 2, ti)
+            assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 2e-7, (ti, n)
+    eng.close()
+
+
+def test_eval_mode_uses_running_stats(emu_lib):
+    dims = tiny_dims()
+    eng = _engine(dims, emu_lib, tasks=1)
+    b0 = synth.make_batch(5, 2, speaker=1, **_kw(dims))
+    eng.set_batches(0, [b0])
+    p = torch_params(dims)
+    buf = torch_buffers(dims)
+    tb = O.to_torch_batch(b0)
+    eng.forward(0, train=True)  # updates running stats once
+    with torch.no_grad():
+        O.fs2_forward(p, buf, *tb[2:], n_head=heads(dims), max_seq_len=dims.max_seq_len, training=True)
+    for i in range(dims.postnet_layers):
+        m, v, t = eng.get_bn_buffers(i)
+        np.testing.assert_allclose(m, buf[f"postnet.convolutions.{i}.1.running_mean"].numpy(), atol=1e-6)
+        np.testing.assert_allclose(v, buf[f"postnet.convolutions.{i}.1.running_var"].numpy(), rtol=1e-5)
+        assert t == 1
+    eng.forward(0, train=False)
+    with torch.no_grad():
+        o = O.fs2_forward(p, buf, *tb[2:], n_head=heads(dims), max_seq_len=dims.max_seq_len, training=False)
+    assert np.abs(eng.outputs(0, 0)["mel_post"] - o[1].numpy()).max() < 5e-5
+    eng.close()
+
+
+def test_decoder_truncation_at_max_seq_len(emu_lib):
+    """Models.py:154-162: training truncates frames beyond max_seq_len (64 in the tiny config)."""
+    dims = tiny_dims()
+    eng = _engine(dims, emu_lib, tasks=1)
+    b0 = synth.make_batch(6, 2, speaker=1, n_mel=dims.n_mel, vocab=dims.vocab, s_range=(10, 14), d_range=(5, 9), first_len=13)
+    assert b0[8] > dims.max_seq_len
+    eng.set_batches(0, [b0])
+    eng.forward(0, train=True)
+    tb = O.to_torch_batch(b0)
+    p = torch_params(dims)
+    with torch.no_grad():
+        o = O.fs2_forward(p, torch_buffers(dims), *tb[2:], n_head=heads(dims), max_seq_len=dims.max_seq_len, training=True)
+        lo = O.fs2_loss(tb, o)
+    out = eng.outputs(0, 0)
+    assert out["mel_post"].shape == tuple(o[1].shape)
+    assert np.abs(out["mel_post"] - o[1].numpy()).max() < 5e-5
+    np.testing.assert_allclose(eng.loss(0)[0], [float(x) for x in lo], rtol=2e-5)
+    eng.close()
+
+
+def test_first_order_maml_and_outer_update(emu_lib):
+    dims = tiny_dims()
+    eng = _engine(dims, emu_lib)
+    tasks = [(synth.make_batch(10 + 2 * j, 3, speaker=2 + j, **_kw(dims)), synth.make_batch(11 + 2 * j, 2, speaker=2 + j, **_kw(dims)))
+             for j in range(2)]
+    eng.set_batches(0, [t[0] for t in tasks])
+    eng.set_batches(1, [t[1] for t in tasks], spk_from=[t[0] for t in tasks], average_spk=True)
+    lr = 0.01
+    q, s = eng.meta_grad(3, lr, 0.5)
+    tot = None
+    for j, (sup, qry) in enumerate(tasks):
+        p = torch_params(dims, requires_grad=True)
+        ql, sl, fast, _ = O.maml_task(p, torch_buffers(dims), O.to_torch_batch(sup), O.to_torch_batch(qry), steps=3, lr=lr,
+                                      second_order=False, modules=MODS, n_head=heads(dims), max_seq_len=dims.max_seq_len)
+        np.testing.assert_allclose(s[:, j, 0], [float(l[0]) for l in sl], rtol=5e-5)
+        np.testing.assert_allclose(q[j], [float(x) for x in ql], rtol=5e-5)
+        for n in O.adapted_names(p, MODS):
+            ref = fast[n].detach().numpy()
+            assert np.abs(eng.export(n, 3, j) - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3), n
+        names = list(eng.params)
+        gs = torch.autograd.grad(ql[0], [p[n] for n in names], allow_unused=True)
+        g = {n: (x.numpy() * 0.5 if x is not None else np.zeros(eng.params[n][0], np.float32)) for n, x in zip(names, gs)}
+        tot = g if tot is None else {n: tot[n] + g[n] for n in names}
+    for n in eng.params:
+        assert np.abs(eng.export(n, 1) - tot[n]).max() <= 2e-3 * np.abs(tot[n]).max() + 2e-7, n
+    before = eng.state_dict()
+    norm = eng.outer_update(lr=1e-3, fetch_norm=True)
+    ref_norm = float(np.sqrt(sum((tot[n].astype(np.float64) ** 2).sum() for n in tot)))
+    assert abs(norm - ref_norm) < 1e-4 * ref_norm
+    after = eng.state_dict()
+    coef = min(1.0, 1.0 / (ref_norm + 1e-6))
+    for n in eng.params:
+        x = torch.from_numpy(before[n].copy()); g = torch.from_numpy(tot[n].copy()) * coef
+        O.adam_step(x, g, torch.zeros_like(x), torch.zeros_like(x), 1, 1e-3)
+        big = np.abs(tot[n]) * coef > 1e-5  # Adam's first step is lr*sign(g): only meaningful off the noise floor
+        assert np.abs(after[n] - x.numpy())[big].max(initial=0.0) < 2e-5, n
+    eng.close()
+
+
+def test_non_default_adapt_modules(emu_lib):
+    """adapt.modules is configurable (config/algorithm/*.yaml): a different split moves the fast-weight slice."""
+    dims = tiny_dims()
+    eng = _engine(dims, emu_lib, tasks=1, mods=["speaker_emb", "decoder"])
+    assert all(a == (n.split(".")[0] in ("speaker_emb", "decoder")) for n, (_, _, a) in eng.params.items())
+    sup = synth.make_batch(30, 2, speaker=3, **_kw(dims)); qry = synth.make_batch(31, 2, speaker=3, **_kw(dims))
+    eng.set_batches(0, [sup]); eng.set_batches(1, [qry], spk_from=[sup], average_spk=True)
+    q, _ = eng.meta_grad(2, 0.01, 1.0)
+    p = torch_params(dims, requires_grad=True)
+    ql, _, _, _ = O.maml_task(p, torch_buffers(dims), O.to_torch_batch(sup), O.to_torch_batch(qry), steps=2, lr=0.01,
+                              second_order=False, modules=["speaker_emb", "decoder"], n_head=heads(dims), max_seq_len=dims.max_seq_len)
+    np.testing.assert_allclose(q[0], [float(x) for x in ql], rtol=5e-5)
+    for n in ("variance_adaptor.pitch_predictor.linear_layer.weight", "decoder.layer_stack.0.pos_ffn.w_1.weight"):
+        g = torch.autograd.grad(ql[0], p[n], retain_graph=True)[0].numpy()
+        assert np.abs(eng.export(n, 1) - g).max() <= 2e-3 * np.abs(g).max() + 2e-7, n
+    eng.close()
