@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — meta-steps/sec of the Meta-TTS hot path on MI355X (BASELINE.json metric).
+
+One "step" = one meta-step of config C3 (BASELINE.json configs[2]):
+8 tasks x [5 inner SGD steps on 5 support utterances + query pass on 5 query utterances]
+(first-order MAML, fp32), outer-gradient mean over the 8 tasks, clip_grad_norm_(1.0), Adam with the
+Noam schedule.  Synthetic LibriTTS-shaped batches (meta_tts_amd.synth), random-init weights, inputs
+resident in HBM before the timed region.  With --gpus N the 8 tasks are sharded 8/N per rank
+(one process per GPU, launched by torch.distributed.run) and the flat outer gradient is
+all-reduced over RCCL/xGMI; the meta-batch stays 8 tasks, so scaling is "strong".
+
+Extra legs (rank 0, N=1 only): `roofline` times every launch of the grouped fp32-MFMA GEMM family
+with HIP events on the launch stream (mtts_profile_gemm) over one more meta-step and reports the
+dominant instantiation against the 157.3 TFLOP/s fp32-matrix peak; `cpu_baseline` times the oracle
+(torch fp32 restatement, kind "port") on the host cores for a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+META_BATCH = 8
+INNER_STEPS = 5
+INNER_LR = 0.001
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+KERNEL_NAMES = ["gemm_f32<NT,64>", "gemm_f32<NT,128>", "gemm_f32<NN,64>", "gemm_f32<NN,128>", "gemm_f32<TN,64>", "gemm_f32<TN,128>"]
+
+
+def noam_lr(step, d_model=256, warm=4000, anneal=(300000, 400000, 500000), rate=0.3):
+    cur = step + 1
+    lr = min(cur ** -0.5, warm ** -1.5 * cur)
+    for s in anneal:
+        if cur > s:
+            lr *= rate
+    return d_model ** -0.5 * lr
+
+
+def cpu_baseline(dims, mods, budget_s=25.0):
+    """Oracle (oracle/fs2_oracle.py) on the host cores: whole first-order tasks of the same workload until
+    ~budget_s of CPU time is spent; meta-steps/s = 1 / (8 * mean task time)."""
+    import torch
+    from meta_tts_amd import synth
+    from oracle import fs2_oracle as O
+    cores = torch.get_num_threads()
+    params = {k: torch.from_numpy(v.copy()) for k, v in synth.make_params(dims, 0).items()}
+    for k, v in params.items():
+        if not k.endswith(("position_enc", "pitch_bins", "energy_bins")):
+            v.requires_grad_(True)
+    buffers = {k: torch.from_numpy(v.copy()) for k, v in synth.make_buffers(dims).items()}
+    names = [k for k, v in params.items() if v.requires_grad]
+    times = []
+    t_all = time.perf_counter()
+    j = 0
+    while j < META_BATCH and (time.perf_counter() - t_all) < budget_s:
+        sup, qry = synth.make_task(j)
+        t0 = time.perf_counter()
+        ql, _, _, _ = O.maml_task(params, buffers, O.to_torch_batch(sup), O.to_torch_batch(qry), steps=INNER_STEPS, lr=INNER_LR,
+                                  second_order=False, modules=mods, n_head=(dims.enc_heads, dims.dec_heads))
+        torch.autograd.grad(ql[0], [params[n] for n in names], allow_unused=True)
+        times.append(time.perf_counter() - t0)
+        j += 1
+    mean_t = float(np.mean(times))
+    return {"value": 1.0 / (META_BATCH * mean_t), "unit": "meta-steps/s", "cores": int(cores), "kind": "port",
+            "sample": f"{len(times)} of {META_BATCH} tasks (5 inner steps + query fwd/bwd each, first-order, fp32 torch-CPU oracle); "
+                      f"{mean_t:.2f} s/task, clip+Adam excluded (<1%)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    from meta_tts_amd import _lib, synth
+    from meta_tts_amd.config import ModelDims, default_algorithm_config, default_train_config
+    from meta_tts_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    n = world
+    assert META_BATCH % n == 0, "the 8-task meta-batch must split evenly over the ranks"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if n > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=n)
+    if rank == 0:
+        ge.build_device()
+    if n > 1:
+        dist.barrier()
+
+    dims = ModelDims()
+    alg = default_algorithm_config()
+    trn = default_train_config()["optimizer"]
+    mods = alg["adapt"]["modules"]
+    local = list(range(rank * META_BATCH // n, (rank + 1) * META_BATCH // n))
+    tasks = [synth.make_task(j) for j in local]
+    max_T = max(max(s[8], q[8]) for s, q in tasks)
+    eng = Engine(dims, adapt_modules=mods, max_tasks=len(local), max_B=5, max_S=80, max_T=max_T, device=local_rank)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.load_params(synth.make_params(dims, 0))
+    eng.set_batches(0, [t[0] for t in tasks])
+    eng.set_batches(1, [t[1] for t in tasks], spk_from=[t[0] for t in tasks], average_spk=True)
+    outer = torch.as_tensor(eng.outer_grad_view(), device=f"cuda:{local_rank}") if n > 1 else None
+
+    step_no = [0]
+
+    def meta_step():
+        eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=False, fetch_losses=False)
+        if n > 1:
+            dist.all_reduce(outer, op=dist.ReduceOp.SUM)
+        eng.outer_update(lr=noam_lr(step_no[0], dims.d_model, trn["warm_up_step"], trn["anneal_steps"], trn["anneal_rate"]),
+                         betas=tuple(trn["betas"]), eps=trn["eps"], weight_decay=trn["weight_decay"],
+                         max_norm=trn["grad_clip_thresh"])
+        step_no[0] += 1
+
+    for _ in range(args.warmup):
+        meta_step()
+    torch.cuda.synchronize()
+    if n > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        meta_step()
+    torch.cuda.synchronize()
+    if n > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if n > 1:
+        tt = torch.tensor([dt], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    q_losses = None
+    roof = None
+    if rank == 0:
+        q_losses, _ = eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, fetch_losses=True)
+    if rank == 0 and n == 1 and not args.no_roofline:
+        lib = _lib.load()
+        import ctypes as C
+        lib.mtts_profile_gemm(1)
+        eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, fetch_losses=False)
+        torch.cuda.synchronize()
+        rep = (C.c_double * 18)()
+        lib.mtts_profile_report(rep)
+        lib.mtts_profile_gemm(0)
+        rows = [(KERNEL_NAMES[k], rep[3 * k], rep[3 * k + 1], rep[3 * k + 2]) for k in range(6)]
+        dom = max(rows, key=lambda r: r[2])
+        tot_ms = sum(r[2] for r in rows)
+        tot_fl = sum(r[3] for r in rows)
+        ach = dom[3] / (dom[2] * 1e-3) / 1e12 if dom[2] > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None, "kernel": dom[0],
+                "launches": int(dom[1]), "avg_launch_us": round(1e3 * dom[2] / max(dom[1], 1), 2),
+                "alg_gflop_per_launch": round(dom[3] / max(dom[1], 1) / 1e9, 3),
+                "all_gemm": {"ms_per_meta_step": round(tot_ms, 2), "alg_tflop_per_meta_step": round(tot_fl / 1e12, 3),
+                             "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
+                             "per_kernel": {r[0]: {"launches": int(r[1]), "ms": round(r[2], 2), "tflop": round(r[3] / 1e12, 3)} for r in rows}}}
+    cpu = None
+    if rank == 0 and n == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(dims, mods)
+    eng.close()
+    if n > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        line = {"metric": "meta-steps/sec (8-task meta-batch, 5 inner steps)", "value": round(args.steps / dt, 4), "unit": "meta-steps/s",
+                "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "C3: Meta-TTS MAML first-order (algorithm=meta_emb_vad, inner=5, meta-batch=8 tasks x (5 support + 5 query utts)), "
+                                       "FastSpeech2 base.yaml, outer mean + clip(1.0) + Adam/Noam", "meta_batch": META_BATCH,
+                           "tasks_per_gpu": META_BATCH // n, "inner_steps": INNER_STEPS, "order": "first", "parallelism": f"task-dp{n}",
+                           "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
+                "query_total_loss_mean": round(float(q_losses[:, 0].mean()), 5) if q_losses is not None else None}
+        if roof is not None:
+            line["roofline"] = roof
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+            line["speedup_vs_cpu_baseline"] = round((args.steps / dt) / cpu["value"], 1)
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

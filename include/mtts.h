@@ -106,6 +106,12 @@ int mtts_outer_update(mtts_handle* h, const float* grad_dev, float lr, float bet
                       float weight_decay, float max_norm, float* grad_norm_host);
 int mtts_reset_optimizer(mtts_handle* h);
 
+/* ---- measurement: per-launch HIP-event timing of the GEMM kernel family on the launch stream.
+ * report: out[kernel][3] = {launches, total ms, total algorithmic flops}, kernel = form*2 + (tile==128),
+ * form 0 NT / 1 NN / 2 TN.  (bench.py roofline leg) */
+int mtts_profile_gemm(int enable);
+int mtts_profile_report(double* out18);
+
 /* ---- kernel-level entry points (parity tests; dev pointers; stream may be NULL) ----------------
  * form 0: C[M,N] = alpha*A[M,K]*B[N,K]^T + bias   1: C = A[M,K]*B[K,N]   2: C[M,N] = A[K,M]^T*B[K,N]
  * flags bit0 ReLU, bit1 accumulate; tile 0 (auto) / 64 / 128 */

@@ -57,6 +57,8 @@ EXPORTS = {
     "mtts_outer_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_void_p]),
     "mtts_reset_optimizer": (C.c_int, [C.c_void_p]),
+    "mtts_profile_gemm": (C.c_int, [C.c_int]),
+    "mtts_profile_report": (C.c_int, [C.POINTER(C.c_double)]),
     "mtts_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                 C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "mtts_conv1d_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -76,6 +78,13 @@ def load(path: str | None = None) -> C.CDLL:
         raise RuntimeError(
             f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()'). "
             "meta_tts_amd has no CPU fallback.")
+    # libmtts links the ROCm HIP runtime by soname.  torch ships its own copy of that runtime; if
+    # torch is going to be used in this process (device memory, streams, torch.distributed) it must
+    # be imported first so both share ONE runtime instance (two instances cannot both own the GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in EXPORTS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -28,6 +28,8 @@
 //  * fused epilogue: alpha, bias, ReLU, ReLU-mask of a saved activation (dgrad through ReLU),
 //    row mask (guard / padded rows), output row remap, accumulate.
 #pragma once
+#include <vector>
+
 #include "compat.h"
 
 namespace mtts {
@@ -264,20 +266,54 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
 }
 
+// Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg):
+// one record per launch, aggregated per (form, tile) kernel instantiation.
+struct GemmProfiler {
+    struct Rec { int kernel; double flops; hipEvent_t e0, e1; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    bool enabled = false;
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t e; hipEventCreate(&e); pool.push_back(e); }
+        return pool[used++];
+    }
+    void reset() { recs.clear(); used = 0; }
+    // out[kernel][3] = launches, total ms, total algorithmic flops; kernel = form * 2 + (tile == 128)
+    void report(double out[6][3]) {
+        for (int k = 0; k < 6; ++k) out[k][0] = out[k][1] = out[k][2] = 0.0;
+        for (auto& r : recs) {
+            hipEventSynchronize(r.e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, r.e0, r.e1);
+            out[r.kernel][0] += 1.0; out[r.kernel][1] += ms; out[r.kernel][2] += r.flops;
+        }
+    }
+};
+inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
+
 // Host launcher.  max_M / max_N bound the tile grid over all groups; tile = 0 picks 128x128 when
-// that already fills the chip (>= 256 workgroups), else 64x64.
+// that already fills the chip (>= 256 workgroups), else 64x64.  alg_flops: algorithmic (unpadded)
+// flops of this launch, only used by the profiler.
 inline void gemm_launch(int form, const GemmArgs& g, int max_M, int max_N, int groups, hipStream_t stream,
-                        int tile = 0) {
+                        int tile = 0, double alg_flops = 0.0) {
     if (max_M <= 0 || max_N <= 0 || groups <= 0) return;
     auto ntiles = [&](int t) { return (long)((max_M + t - 1) / t) * ((max_N + t - 1) / t); };
     if (tile == 0) tile = (ntiles(128) * groups >= 256) ? 128 : 64;
     dim3 block(256), grid((unsigned)ntiles(tile), 1, (unsigned)groups);
+    GemmProfiler& prof = gemm_profiler();
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
 #define MTTS_GEMM_CASE(F, T) \
-    if (form == F && tile == T) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T>), grid, block, stream, g); return; }
+    if (form == F && tile == T) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T>), grid, block, stream, g); }
     MTTS_GEMM_CASE(GEMM_NT, 128) MTTS_GEMM_CASE(GEMM_NT, 64)
     MTTS_GEMM_CASE(GEMM_NN, 128) MTTS_GEMM_CASE(GEMM_NN, 64)
     MTTS_GEMM_CASE(GEMM_TN, 128) MTTS_GEMM_CASE(GEMM_TN, 64)
 #undef MTTS_GEMM_CASE
+    if (prof.enabled) {
+        hipEventRecord(e1, stream);
+        prof.recs.push_back(GemmProfiler::Rec{form * 2 + (tile == 128 ? 1 : 0), alg_flops, e0, e1});
+    }
 }
 
 }  // namespace mtts

@@ -188,6 +188,20 @@ int mtts_reset_optimizer(mtts_handle* h) {
     return 0;
 }
 
+int mtts_profile_gemm(int enable) {
+    GemmProfiler& p = gemm_profiler();
+    p.reset();
+    p.enabled = enable != 0;
+    return 0;
+}
+
+int mtts_profile_report(double* out18) {
+    double r[6][3];
+    gemm_profiler().report(r);
+    for (int k = 0; k < 6; ++k) for (int j = 0; j < 3; ++j) out18[k * 3 + j] = r[k][j];
+    return 0;
+}
+
 int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, float alpha, int flags, int tile, void* stream) {
     if (form < 0 || form > 2 || (tile != 0 && tile != 64 && tile != 128)) return -1;
