@@ -137,7 +137,8 @@ public:
     TS d_rounded;
     // backward scratch
     TS gP0, gP1, gPqkv, gPh, gPf1, gPf2, gF0, gF1, gFqkv, gFh, dSp, dSf, gR0, gR1, gRm, gRp, gMelF, dspk, dpred[3];
-    float *loss_partial = nullptr, *losses = nullptr;
+    float *loss_partial = nullptr, *losses = nullptr, *col_partial = nullptr;
+    int col_max_chunks = 0;
     long long S_ts_p = 0, S_ts_f = 0;
 
     char* arena = nullptr;
@@ -347,6 +348,8 @@ public:
         gMelF = rows(capMf, cfg.n_mel);
         dspk = flat((long long)cap_B * d);
         for (int i = 0; i < 3; ++i) dpred[i] = rows(capMp, 1);
+        col_max_chunks = (std::max(capMp, capMf) + kRC - 1) / kRC;
+        col_partial = (float*)take((size_t)cap_tasks * col_max_chunks * 3 * 1024 * sizeof(float));
         loss_partial = (float*)take((size_t)cap_tasks * kLossBlocks * 5 * sizeof(float));
         losses = (float*)take((size_t)cap_tasks * 6 * sizeof(float));
         // plans
@@ -748,12 +751,20 @@ public:
         gemm_launch(GEMM_TN, g, cout, k * cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin);
         if (b_off >= 0) colsum(ps, s, dy, cout, bias_mask, TS{nullptr, 0}, Gd(b_off));
     }
+    // two-stage deterministic column reduction (rowops.h colpart/colfinal)
+    void colreduce(const Plan& p, ColArgs a, float* out0, float* out1, long long out_ts, int maxM) {
+        const int chunks = (maxM + kRC - 1) / kRC;
+        MTTS_LAUNCH(colpart_kernel, dim3((a.C + 127) / 128, chunks, p.tasks), dim3(256), stream, (const int*)p.meta, a, col_partial,
+                    col_max_chunks);
+        MTTS_LAUNCH(colfinal_kernel, dim3((a.C + 255) / 256, 1, p.tasks), dim3(256), stream, (const int*)p.meta, a.mfield, a.mode,
+                    (const float*)col_partial, col_max_chunks, a.C, out0, out1, out_ts, 1e-5f);
+    }
     void colsum(const Pass& ps, Space s, TS x, int C, const unsigned char* mask, TS roww, TS out) {
         const Plan& p = *ps.pl;
-        dim3 grid((C + 31) / 32, 1, p.tasks);
-        MTTS_LAUNCH(colreduce_kernel, grid, dim3(256), stream, (const int*)p.meta, mfield(s), 0, (const float*)x.p, x.ts, C,
-                    (const float*)nullptr, 0LL, (const float*)nullptr, 0LL, mask, row_ts(s), (const float*)roww.p, roww.ts,
-                    out.p, (float*)nullptr, out.ts, C);
+        ColArgs a;
+        a.X = x.p; a.x_ts = x.ts; a.mask = mask; a.mask_ts = row_ts(s); a.roww = roww.p; a.roww_ts = roww.ts;
+        a.C = C; a.mode = 0; a.mfield = mfield(s);
+        colreduce(p, a, out.p, nullptr, out.ts, maxM(p, s));
     }
     void ln_fwd(const Pass& ps, Space s, TS a, TS res, long long g_off, long long b_off, const unsigned char* mask,
                 TS zout, TS y, TS st, int C) {
@@ -768,11 +779,11 @@ public:
                 TS dz, int C, int relu_on_z) {
         const Plan& p = *ps.pl;
         TS gm = W(ps, g_off);
-        dim3 grid((C + 31) / 32, 1, p.tasks);
         TS gg = Gd(g_off), gb = Gd(b_off);
-        MTTS_LAUNCH(colreduce_kernel, grid, dim3(256), stream, (const int*)p.meta, mfield(s), 1, (const float*)dy.p, dy.ts, C,
-                    (const float*)z.p, z.ts, (const float*)st.p, st.ts, mask, row_ts(s), (const float*)nullptr, 0LL, gg.p, gb.p,
-                    gg.ts, C);
+        ColArgs a;
+        a.X = dy.p; a.x_ts = dy.ts; a.Z = z.p; a.z_ts = z.ts; a.stats = st.p; a.st_ts = st.ts;
+        a.mask = mask; a.mask_ts = row_ts(s); a.C = C; a.mode = 1; a.mfield = mfield(s);
+        colreduce(p, a, gg.p, gb.p, gg.ts, maxM(p, s));
         MTTS_LAUNCH(layernorm_bwd_kernel, row_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
                     (const float*)dy.p, dy.ts, (const float*)z.p, z.ts, (const float*)st.p, st.ts, (const float*)gm.p, gm.ts,
                     mask, row_ts(s), dz.p, dz.ts, C, relu_on_z);
@@ -946,9 +957,10 @@ public:
             PostBuf& b = postB[i];
             conv_fwd(ps, SP_R, cur, P.cin, cfg.postnet_kernel, W(ps, P.w), W(ps, P.b), P.cout, b.c, 0, p.r_inrect);
             if (ps.train) {
-                MTTS_LAUNCH(bn_stats_kernel, dim3((P.cout + 31) / 32, 1, nt), dim3(256), stream, (const int*)p.meta,
-                            (const float*)b.c.p, b.c.ts, (const unsigned char*)p.r_inrect, row_ts_r, b.stats.p, b.stats.ts, P.cout,
-                            1e-5f);
+                ColArgs ca;
+                ca.X = b.c.p; ca.x_ts = b.c.ts; ca.mask = p.r_inrect; ca.mask_ts = row_ts_r; ca.C = P.cout; ca.mode = 2;
+                ca.mfield = META_MR;
+                colreduce(p, ca, b.stats.p, nullptr, b.stats.ts, p.maxMr);
                 MTTS_LAUNCH(bn_running_update_kernel, dim3((P.cout + 63) / 64), dim3(64), stream, (const float*)b.stats.p,
                             b.stats.ts, nt, bn_rm[i], bn_rv[i], P.cout, 0.1f);
                 bn_tracked[i] += nt;
@@ -1015,10 +1027,11 @@ public:
             PostBuf& b = postB[i];
             const int act = (i < cfg.postnet_layers - 1);
             TS dgm = Gd(P.g), dbt = Gd(P.beta);
-            MTTS_LAUNCH(bn_bwd_reduce_kernel, dim3((P.cout + 31) / 32, 1, nt), dim3(256), stream, (const int*)p.meta,
-                        (const float*)cur.p, cur.ts, (const float*)b.a.p, b.a.ts, (const float*)b.c.p, b.c.ts,
-                        (const float*)b.stats.p, b.stats.ts, (const unsigned char*)p.r_inrect, row_ts_r, act, dgm.p, dbt.p, dgm.ts,
-                        P.cout);
+            ColArgs ca;
+            ca.X = cur.p; ca.x_ts = cur.ts; ca.Y = b.a.p; ca.y_ts = b.a.ts; ca.Z = b.c.p; ca.z_ts = b.c.ts;
+            ca.stats = b.stats.p; ca.st_ts = b.stats.ts; ca.mask = p.r_inrect; ca.mask_ts = row_ts_r; ca.C = P.cout;
+            ca.mode = 3; ca.do_tanh = act; ca.mfield = META_MR;
+            colreduce(p, ca, dgm.p, dbt.p, dgm.ts, p.maxMr);
             TS gm = W(ps, P.g);
             TS dc = gR0;  // [rows][Cout] inside a scratch sized for max(postnet_dim, n_mel) channels
             MTTS_LAUNCH(bn_bwd_apply_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (const float*)cur.p,

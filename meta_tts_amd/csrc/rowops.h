@@ -141,47 +141,142 @@ __global__ void layernorm_bwd_kernel(const int* meta, int mfield, const float* d
 }
 
 // ------------------------------------------------------------------------------------------
-// Column reductions over rows: one workgroup per 32-column stripe, 8 row lanes, fixed order.
-//   mode 0: out[c] = sum_m w(m) * X[m][c]                         (bias grads, 256->1 weight grad)
-//   mode 1: out0[c] = sum dy * xhat (dgamma), out1[c] = sum dy (dbeta)   (LayerNorm)
+// Column reductions over rows, two deterministic stages (no float atomics):
+//   stage 1  colpart_kernel: grid (C/128, row chunks of 128, tasks); 8 row lanes x 32 float4 column
+//            groups per workgroup -> partial[task][chunk][k][C]
+//   stage 2  colfinal_kernel: one thread per column folds the chunks in order.
+// modes: 0  out0[c] = sum_m w(m) X[m][c]                                   (bias / 256->1 weight grads)
+//        1  out0 = sum dy*xhat (dgamma), out1 = sum dy (dbeta), xhat from per-row LayerNorm stats
+//        2  BatchNorm batch statistics over masked rows: per-chunk (count, mean, M2) merged with
+//           Chan's formula -> out0 = [mean | rstd | unbiased var]
+//        3  BatchNorm backward sums: out0 = sum dpre*xhat, out1 = sum dpre, dpre = dy*(1-y^2) if tanh,
+//           xhat from per-column stats [mean | rstd]
 // ------------------------------------------------------------------------------------------
-__global__ void colreduce_kernel(const int* meta, int mfield, int mode, const float* X, long long x_ts, int ldx,
-                                 const float* Z, long long z_ts, const float* stats, long long st_ts,
-                                 const unsigned char* mask, long long mask_ts, const float* roww, long long roww_ts,
-                                 float* out0, float* out1, long long out_ts, int C) {
-    __shared__ float red0[8][33], red1[8][33];
-    const int z = blockIdx.z;
-    const int M_ = meta[z * META_STRIDE + mfield];
-    const int cx = (int)threadIdx.x & 31, ry = (int)threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
-    float a0 = 0.f, a1 = 0.f;
-    if (c < C) {
-        const float* px = X + (long long)z * x_ts;
-        const float* pz = Z ? Z + (long long)z * z_ts : nullptr;
-        const float* ps = stats ? stats + (long long)z * st_ts : nullptr;
-        const unsigned char* pm = mask ? mask + (long long)z * mask_ts : nullptr;
-        const float* pw = roww ? roww + (long long)z * roww_ts : nullptr;
-        for (int m = ry; m < M_; m += 8) {
-            if (pm && !pm[m]) continue;
-            const float x = px[(long long)m * ldx + c];
-            if (mode == 0) {
-                a0 += pw ? pw[m] * x : x;
-            } else {
-                const float xh = (pz[(long long)m * ldx + c] - ps[2 * m]) * ps[2 * m + 1];
-                a0 += x * xh;
-                a1 += x;
+constexpr int kRC = 128;  // rows per chunk
+
+struct ColArgs {
+    const float* X = nullptr; long long x_ts = 0;      // primary operand [M][C] (dy for modes 1, 3)
+    const float* Z = nullptr; long long z_ts = 0;      // mode 1: LN input; mode 3: pre-BN conv output
+    const float* Y = nullptr; long long y_ts = 0;      // mode 3: post-tanh activation
+    const float* stats = nullptr; long long st_ts = 0; // mode 1: per-row (mean, rstd); mode 3: per-column [mean|rstd]
+    const unsigned char* mask = nullptr; long long mask_ts = 0;
+    const float* roww = nullptr; long long roww_ts = 0;
+    int C = 0, mode = 0, do_tanh = 0, mfield = 0;
+};
+
+__global__ void colpart_kernel(const int* meta, ColArgs a, float* partial, int max_chunks) {
+    __shared__ __attribute__((aligned(16))) float red[3][8][132];
+    const int z = blockIdx.z, chunk = blockIdx.y;
+    const int M_ = meta[z * META_STRIDE + a.mfield];
+    const int r0 = chunk * kRC;
+    if (r0 >= M_) return;
+    const int r1 = (r0 + kRC < M_) ? r0 + kRC : M_;
+    const int cg = (int)threadIdx.x & 31, ry = (int)threadIdx.x >> 5;
+    const int c = blockIdx.x * 128 + cg * 4;
+    const bool cin = c < a.C;
+    const int C = a.C;
+    const float* px = a.X + (long long)z * a.x_ts;
+    const float* pz = a.Z ? a.Z + (long long)z * a.z_ts : nullptr;
+    const float* py = a.Y ? a.Y + (long long)z * a.y_ts : nullptr;
+    const float* ps = a.stats ? a.stats + (long long)z * a.st_ts : nullptr;
+    const unsigned char* pm = a.mask ? a.mask + (long long)z * a.mask_ts : nullptr;
+    const float* pw = a.roww ? a.roww + (long long)z * a.roww_ts : nullptr;
+    float acc0[4] = {0.f, 0.f, 0.f, 0.f}, acc1[4] = {0.f, 0.f, 0.f, 0.f};
+    float cnt = 0.f;
+    // C may be < 4-aligned only for C == 1 (scalar bias of the 256->1 projections)
+    const bool vec = (C & 3) == 0;
+    auto ldv = [&](const float* base, int m, float (&v)[4]) {
+        if (vec) { const float4 t = ld4(base + (long long)m * C + c); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+        else { for (int k = 0; k < 4; ++k) v[k] = (c + k < C) ? base[(long long)m * C + c + k] : 0.f; }
+    };
+    if (cin) {
+        if (a.mode == 2) {
+            float mean[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int m = r0 + ry; m < r1; m += 8) if (!pm || pm[m]) { float v[4]; ldv(px, m, v); for (int k = 0; k < 4; ++k) acc0[k] += v[k]; cnt += 1.f; }
+            (void)mean;
+        } else {
+            float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f};
+            if (a.mode == 3) { ldv(ps, 0, mu); float t[4]; const float* p2 = ps + C; ldv(p2, 0, t); for (int k = 0; k < 4; ++k) rs[k] = t[k]; }
+            for (int m = r0 + ry; m < r1; m += 8) {
+                if (pm && !pm[m]) continue;
+                float x[4]; ldv(px, m, x);
+                if (a.mode == 0) {
+                    const float w = pw ? pw[m] : 1.f;
+                    for (int k = 0; k < 4; ++k) acc0[k] += w * x[k];
+                } else if (a.mode == 1) {
+                    float zz[4]; ldv(pz, m, zz);
+                    const float mean = ps[2 * m], rstd = ps[2 * m + 1];
+                    for (int k = 0; k < 4; ++k) { acc0[k] += x[k] * (zz[k] - mean) * rstd; acc1[k] += x[k]; }
+                } else {
+                    float zz[4]; ldv(pz, m, zz);
+                    if (a.do_tanh) { float y[4]; ldv(py, m, y); for (int k = 0; k < 4; ++k) x[k] *= (1.f - y[k] * y[k]); }
+                    for (int k = 0; k < 4; ++k) { acc0[k] += x[k] * (zz[k] - mu[k]) * rs[k]; acc1[k] += x[k]; }
+                }
             }
         }
     }
-    red0[ry][cx] = a0;
-    red1[ry][cx] = a1;
+    for (int k = 0; k < 4; ++k) { red[0][ry][cg * 4 + k] = acc0[k]; red[1][ry][cg * 4 + k] = acc1[k]; }
+    if (cg == 0) red[2][ry][0] = cnt;
     __syncthreads();
-    if (ry == 0 && c < C) {
-        float s0 = 0.f, s1 = 0.f;
-        for (int i = 0; i < 8; ++i) { s0 += red0[i][cx]; s1 += red1[i][cx]; }
-        out0[(long long)z * out_ts + c] = s0;
-        if (mode == 1) out1[(long long)z * out_ts + c] = s1;
+    float* out = partial + ((long long)z * max_chunks + chunk) * 3 * C;
+    if (a.mode != 2) {
+        if (ry < 2) {  // row lane 0 folds acc0, row lane 1 folds acc1
+            for (int k = 0; k < 4; ++k) {
+                if (c + k >= C) break;
+                float s0 = 0.f;
+                for (int i = 0; i < 8; ++i) s0 += red[ry][i][cg * 4 + k];
+                out[(long long)ry * C + c + k] = s0;
+            }
+        }
+        return;
     }
+    // mode 2: chunk mean, then chunk M2 (second pass over the same rows)
+    float n = 0.f;
+    for (int i = 0; i < 8; ++i) n += red[2][i][0];
+    float mean[4];
+    for (int k = 0; k < 4; ++k) { float s0 = 0.f; for (int i = 0; i < 8; ++i) s0 += red[0][i][cg * 4 + k]; mean[k] = n > 0.f ? s0 / n : 0.f; }
+    float m2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cin)
+        for (int m = r0 + ry; m < r1; m += 8) if (!pm || pm[m]) { float v[4]; ldv(px, m, v); for (int k = 0; k < 4; ++k) { const float d = v[k] - mean[k]; m2[k] += d * d; } }
+    __syncthreads();
+    for (int k = 0; k < 4; ++k) red[1][ry][cg * 4 + k] = m2[k];
+    __syncthreads();
+    if (ry == 0 && cin)
+        for (int k = 0; k < 4; ++k) {
+            if (c + k >= C) break;
+            float s = 0.f;
+            for (int i = 0; i < 8; ++i) s += red[1][i][cg * 4 + k];
+            out[c + k] = n; out[(long long)C + c + k] = mean[k]; out[2LL * C + c + k] = s;
+        }
+}
+
+__global__ void colfinal_kernel(const int* meta, int mfield, int mode, const float* partial, int max_chunks, int C,
+                                float* out0, float* out1, long long out_ts, float eps) {
+    const int z = blockIdx.z, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int M_ = meta[z * META_STRIDE + mfield];
+    const int nch = (M_ + kRC - 1) / kRC;
+    const float* p = partial + (long long)z * max_chunks * 3 * C;
+    if (mode != 2) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int i = 0; i < nch; ++i) { s0 += p[(long long)i * 3 * C + c]; s1 += p[(long long)i * 3 * C + C + c]; }
+        out0[(long long)z * out_ts + c] = s0;
+        if (out1) out1[(long long)z * out_ts + c] = s1;
+        return;
+    }
+    float n = 0.f, mean = 0.f, m2 = 0.f;  // Chan et al. pairwise merge, chunks in order
+    for (int i = 0; i < nch; ++i) {
+        const float nb = p[(long long)i * 3 * C + c], mb = p[(long long)i * 3 * C + C + c], sb = p[(long long)i * 3 * C + 2 * C + c];
+        if (nb <= 0.f) continue;
+        const float nn = n + nb, d = mb - mean;
+        mean += d * nb / nn;
+        m2 += sb + d * d * n * nb / nn;
+        n = nn;
+    }
+    float* so = out0 + (long long)z * out_ts;
+    so[c] = mean;
+    so[C + c] = rsqrtf(m2 / n + eps);
+    so[2 * C + c] = m2 / fmaxf(n - 1.f, 1.f);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -422,38 +517,6 @@ __global__ void speaker_table_grad_kernel(const int* meta, const float* dspk, lo
 // ------------------------------------------------------------------------------------------
 // PostNet BatchNorm1d (+tanh) on the (B, T') rectangle incl. padded frames (Layers.py:129-137)
 // ------------------------------------------------------------------------------------------
-// per-channel batch statistics over in-rect rows (two-pass); stats_out = [mean | rstd | var_unbiased]
-__global__ void bn_stats_kernel(const int* meta, const float* X, long long x_ts, const unsigned char* inrect,
-                                long long row_ts, float* stats_out, long long st_ts, int C, float eps) {
-    __shared__ float red[8][33];
-    __shared__ float meansh[32];
-    const int z = blockIdx.z, M_ = meta[z * META_STRIDE + META_MR];
-    const int cx = (int)threadIdx.x & 31, ry = (int)threadIdx.x >> 5, c = blockIdx.x * 32 + cx;
-    const float* px = X + (long long)z * x_ts;
-    const unsigned char* pm = inrect + (long long)z * row_ts;
-    const float n = (float)(meta[z * META_STRIDE + META_B] * meta[z * META_STRIDE + META_TCAP]);
-    float a = 0.f;
-    if (c < C) for (int m = ry; m < M_; m += 8) if (pm[m]) a += px[(long long)m * C + c];
-    red[ry][cx] = a;
-    __syncthreads();
-    if (ry == 0) { float s = 0.f; for (int i = 0; i < 8; ++i) s += red[i][cx]; meansh[cx] = s / n; }
-    __syncthreads();
-    const float mean = meansh[cx];
-    a = 0.f;
-    if (c < C) for (int m = ry; m < M_; m += 8) if (pm[m]) { const float d = px[(long long)m * C + c] - mean; a += d * d; }
-    __syncthreads();
-    red[ry][cx] = a;
-    __syncthreads();
-    if (ry == 0 && c < C) {
-        float s = 0.f;
-        for (int i = 0; i < 8; ++i) s += red[i][cx];
-        float* so = stats_out + (long long)z * st_ts;
-        so[c] = mean;
-        so[C + c] = rsqrtf(s / n + eps);
-        so[2 * C + c] = s / fmaxf(n - 1.f, 1.f);
-    }
-}
-
 // running stats: momentum update applied task after task (deterministic order), one launch
 __global__ void bn_running_update_kernel(const float* stats, long long st_ts, int tasks, float* running_mean,
                                          float* running_var, int C, float momentum) {
@@ -502,42 +565,6 @@ __global__ void bn_apply_kernel(const int* meta, const float* X, long long x_ts,
             if (do_tanh) o = make_float4(tanhf(o.x), tanhf(o.y), tanhf(o.z), tanhf(o.w));
         }
         st4(py + c, o);
-    }
-}
-
-// backward pass 1: per channel sum(dpre) and sum(dpre * xhat), dpre = dy * (1 - y^2) if tanh.
-// out = [dgamma | dbeta]
-__global__ void bn_bwd_reduce_kernel(const int* meta, const float* dY, long long dy_ts, const float* Yact,
-                                     long long ya_ts, const float* X, long long x_ts, const float* stats,
-                                     long long st_ts, const unsigned char* inrect, long long row_ts, int do_tanh,
-                                     float* dgamma, float* dbeta, long long out_ts, int C) {
-    __shared__ float red0[8][33], red1[8][33];
-    const int z = blockIdx.z, M_ = meta[z * META_STRIDE + META_MR];
-    const int cx = (int)threadIdx.x & 31, ry = (int)threadIdx.x >> 5, c = blockIdx.x * 32 + cx;
-    float a0 = 0.f, a1 = 0.f;
-    if (c < C) {
-        const float* pdy = dY + (long long)z * dy_ts;
-        const float* pya = Yact + (long long)z * ya_ts;
-        const float* px = X + (long long)z * x_ts;
-        const unsigned char* pm = inrect + (long long)z * row_ts;
-        const float* st = stats + (long long)z * st_ts;
-        const float mean = st[c], rstd = st[C + c];
-        for (int m = ry; m < M_; m += 8) {
-            if (!pm[m]) continue;
-            float d = pdy[(long long)m * C + c];
-            if (do_tanh) { const float y = pya[(long long)m * C + c]; d *= (1.f - y * y); }
-            a1 += d;
-            a0 += d * (px[(long long)m * C + c] - mean) * rstd;
-        }
-    }
-    red0[ry][cx] = a0;
-    red1[ry][cx] = a1;
-    __syncthreads();
-    if (ry == 0 && c < C) {
-        float s0 = 0.f, s1 = 0.f;
-        for (int i = 0; i < 8; ++i) { s0 += red0[i][cx]; s1 += red1[i][cx]; }
-        dgamma[(long long)z * out_ts + c] = s0;
-        dbeta[(long long)z * out_ts + c] = s1;
     }
 }
 

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the grouped fp32-MFMA GEMM through the C ABI (single group): intrinsic TFLOP/s per
+form / tile on large squares and on the model's own shapes.  GPU only."""
+import ctypes as C
+import sys, os
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from meta_tts_amd import _lib
+
+lib = _lib.load()
+P = lambda t: C.c_void_p(t.data_ptr())
+
+
+def bench(form, tile, M, N, K, reps=5):
+    if form == 0:
+        A = torch.randn(M, K, device="cuda"); B = torch.randn(N, K, device="cuda"); lda, ldb = K, K
+    elif form == 1:
+        A = torch.randn(M, K, device="cuda"); B = torch.randn(K, N, device="cuda"); lda, ldb = K, N
+    else:
+        A = torch.randn(K, M, device="cuda"); B = torch.randn(K, N, device="cuda"); lda, ldb = M, N
+    Cm = torch.empty(M, N, device="cuda")
+    lib.mtts_gemm_f32(form, M, N, K, P(A), lda, P(B), ldb, P(Cm), N, None, 1.0, 0, tile, None)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        lib.mtts_gemm_f32(form, M, N, K, P(A), lda, P(B), ldb, P(Cm), N, None, 1.0, 0, tile, None)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return 2.0 * M * N * K / (ms * 1e-3) / 1e12, ms
+
+
+shapes = [("square4096", 4096, 4096, 4096), ("conv1_fwd 8 tasks", 26400, 1024, 2304), ("conv2_fwd", 26400, 256, 1024),
+          ("qkv", 26400, 768, 256), ("out_proj", 26400, 256, 256), ("postnet_mid", 24000, 512, 2560)]
+for name, M, N, K in shapes:
+    for form in (0, 1, 2):
+        for tile in (64, 128):
+            if form == 2:  # TN: output [M', N'] small, reduction long — use wgrad-like shapes
+                m2, n2, k2 = N, K, M // 8 if M > 8192 else M
+            else:
+                m2, n2, k2 = M, N, K
+            tf, ms = bench(form, tile, m2, n2, k2)
+            print(f"{name:20s} form={'NT NN TN'.split()[form]} tile={tile:3d} M={m2:6d} N={n2:5d} K={k2:5d}  {ms:8.3f} ms  {tf:6.1f} TF/s", flush=True)
