@@ -114,7 +114,7 @@ int mtts_profile_report(double* out18);
 
 /* ---- kernel-level entry points (parity tests; dev pointers; stream may be NULL) ----------------
  * form 0: C[M,N] = alpha*A[M,K]*B[N,K]^T + bias   1: C = A[M,K]*B[K,N]   2: C[M,N] = A[K,M]^T*B[K,N]
- * flags bit0 ReLU, bit1 accumulate; tile 0 (auto) / 64 / 128 */
+ * flags bit0 ReLU, bit1 accumulate; tile 0 (auto) / 64 / 128, +1000 = software-pipelined variant */
 int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, float alpha, int flags, int tile, void* hip_stream);
 /* Conv1d over one zero-guarded sequence, channels-last: x [L][Cin] with >= k/2 zero rows before and

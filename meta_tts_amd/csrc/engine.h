@@ -104,7 +104,8 @@ public:
         int maxMp = 0, maxMf = 0, maxMr = 0, maxB = 0, enc_maxL = 0, dec_maxL = 0, n_enc_groups = 0, n_dec_groups = 0;
         int average_spk = 0;
         bool has_targets = false;
-        double sum_nP = 0, sum_nF = 0, sum_attn_p = 0, sum_attn_f = 0;  // valid rows / sum L^2 (algorithmic flop accounting)
+        double sum_nP = 0, sum_nF = 0, sum_attn_p = 0, sum_attn_f = 0;
+        long long sumMp = 0, sumMf = 0, sumMr = 0, sumLp = 0, sumLf = 0;  // total rows over tasks (tile heuristic)  // valid rows / sum L^2 (algorithmic flop accounting)
         int* meta = nullptr;
         // P space
         int *p_row_b, *p_row_t, *p_tok, *p_first, *p_count, *p_dur, *p_seg_start, *p_seg_len;
@@ -542,6 +543,7 @@ public:
         p.maxMp = p.maxMf = p.maxMr = p.maxB = p.enc_maxL = p.dec_maxL = 0;
         p.has_targets = true;
         p.sum_nP = p.sum_nF = p.sum_attn_p = p.sum_attn_f = 0;
+        p.sumMp = p.sumMf = p.sumMr = p.sumLp = p.sumLf = 0;
         std::vector<int> meta((size_t)tasks * META_STRIDE, 0);
         std::vector<AttnSeq> eseq, dseq;
         std::vector<GemmGroupDesc> etab[6], dtab[6];
@@ -612,6 +614,7 @@ public:
                     int& maxL = which ? p.dec_maxL : p.enc_maxL;
                     maxL = std::max(maxL, L);
                     (which ? p.sum_attn_f : p.sum_attn_p) += (double)H * L * L;
+                    (which ? p.sumLf : p.sumLp) += (long long)H * L;
                     const int ldS = (L + 3) & ~3;
                     const int capM = which ? capMf : capMp;
                     for (int h = 0; h < H; ++h) {
@@ -636,6 +639,7 @@ public:
             m[META_B] = B; m[META_SMAX] = S; m[META_TCAP] = Tcap; m[META_MP] = Mp; m[META_MF] = Mf; m[META_MR] = Mr;
             m[META_NP] = nP; m[META_NF] = nF;
             p.sum_nP += nP; p.sum_nF += nF;
+            p.sumMp += Mp; p.sumMf += Mf; p.sumMr += Mr;
             if (upload(p.p_row_b, row_ts_p, t, row_b) || upload(p.p_row_t, row_ts_p, t, row_t) || upload(p.p_tok, row_ts_p, t, tok) ||
                 upload(p.p_first, row_ts_p, t, first) || upload(p.p_count, row_ts_p, t, count) || upload(p.p_dur, row_ts_p, t, dur) ||
                 upload(p.p_valid, row_ts_p, t, valid) || upload(p.p_inrect, row_ts_p, t, inrect) ||
@@ -693,6 +697,7 @@ public:
     int maxM(const Plan& p, Space s) const { return s == SP_P ? p.maxMp : (s == SP_F ? p.maxMf : p.maxMr); }
     const unsigned char* valid_mask(const Plan& p, Space s) const { return s == SP_P ? p.p_valid : (s == SP_F ? p.f_valid : p.r_valid); }
     const unsigned char* inrect_mask(const Plan& p, Space s) const { return s == SP_P ? p.p_inrect : (s == SP_F ? p.f_valid : p.r_inrect); }
+    long long sumM(const Plan& p, Space s) const { return s == SP_P ? p.sumMp : (s == SP_F ? p.sumMf : p.sumMr); }
     double alg_rows(const Plan& p, Space s) const { return s == SP_P ? p.sum_nP : p.sum_nF; }
     long long row_ts(Space s) const { return s == SP_P ? row_ts_p : (s == SP_F ? row_ts_f : row_ts_r); }
 
@@ -719,7 +724,7 @@ public:
         g.bias = b.p; g.bias_gs = b.ts;
         g.flags = flags;
         g.rowmask = rowmask; g.rowmask_gs = row_ts(s);
-        gemm_launch(GEMM_NT, g, maxM(p, s), cout, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin);
+        gemm_launch(GEMM_NT, g, maxM(p, s), cout, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s));
     }
     // dX[M,Cin] (+)= sum_taps dY[M +- tap, Cout] * W  (conv dgrad over the same [Cout][k][Cin] image)
     void conv_dgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS w, int cin, TS dx, int flags,
@@ -735,7 +740,7 @@ public:
         g.flags = flags;
         g.rowmask = rowmask; g.rowmask_gs = row_ts(s);
         if (relu_ref.p) { g.relu_ref = relu_ref.p; g.relu_ref_gs = relu_ref.ts; g.ld_relu = cin; }
-        gemm_launch(GEMM_NN, g, maxM(p, s), cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin);
+        gemm_launch(GEMM_NN, g, maxM(p, s), cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s));
     }
     // dW[Cout][k*Cin] = dY^T * conv_k(X), db = colsum(dY)
     void conv_wgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS x, int cin, long long w_off, long long b_off,
@@ -748,7 +753,7 @@ public:
         TS gw = Gd(w_off);
         g.C = gw.p; g.c_gs = gw.ts; g.ldc = k * cin;
         g.M = cout; g.N = k * cin;
-        gemm_launch(GEMM_TN, g, cout, k * cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin);
+        gemm_launch(GEMM_TN, g, cout, k * cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, (long long)cout * p.tasks);
         if (b_off >= 0) colsum(ps, s, dy, cout, bias_mask, TS{nullptr, 0}, Gd(b_off));
     }
     // two-stage deterministic column reduction (rowops.h colpart/colfinal)
@@ -798,7 +803,8 @@ public:
         const int groups = (s == SP_P) ? p.n_enc_groups : p.n_dec_groups;
         int mM = L, mN = L;
         if (which == TAB_PV || which == TAB_DV || which == TAB_DQ || which == TAB_DK) mN = dk;
-        gemm_launch(form, g, mM, mN, groups, stream, 0, 2.0 * ((s == SP_P) ? p.sum_attn_p : p.sum_attn_f) * dk);
+        gemm_launch(form, g, mM, mN, groups, stream, 0, 2.0 * ((s == SP_P) ? p.sum_attn_p : p.sum_attn_f) * dk,
+                    (s == SP_P) ? p.sumLp : p.sumLf);
     }
 
     // =================================================================================
@@ -945,7 +951,7 @@ public:
             g.N = cfg.n_mel; g.K = d;
             g.bias = b.p; g.bias_gs = b.ts;
             g.c_rowmap = p.f2r; g.c_rowmap_gs = row_ts_f;
-            gemm_launch(GEMM_NT, g, p.maxMf, cfg.n_mel, nt, stream, 0, 2.0 * p.sum_nF * cfg.n_mel * d);
+            gemm_launch(GEMM_NT, g, p.maxMf, cfg.n_mel, nt, stream, 0, 2.0 * p.sum_nF * cfg.n_mel * d, p.sumMf);
             MTTS_LAUNCH(fill_padded_rows_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, mel.p, mel.ts,
                         (const float*)b.p, b.ts, (const unsigned char*)p.r_inrect, (const unsigned char*)p.r_valid, row_ts_r,
                         cfg.n_mel);

@@ -28,6 +28,8 @@
 //  * fused epilogue: alpha, bias, ReLU, ReLU-mask of a saved activation (dgrad through ReLU),
 //    row mask (guard / padded rows), output row remap, accumulate.
 #pragma once
+#include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "compat.h"
@@ -70,64 +72,84 @@ struct GemmArgs {
 constexpr int kBK = 16;
 constexpr int kLDK = kBK + 4;  // K-contiguous LDS row stride (floats)
 
-// One BK=16 slice of the wave tile.  A_KC/B_KC: operand tile is [row][kLDK] (K-contiguous) or
-// [k][LD] (reduction-major).  acc[i][j] is the 32x32 MFMA C tile (lane l, reg r) ->
-// row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
+// Register fragments of one BK=16 slice of the wave tile.  A_KC/B_KC: operand tile is [row][kLDK]
+// (K-contiguous: two ds_read_b128 per 32-row subtile) or [k][LD] (reduction-major: ds_read_b32).
+// Lane half h = lane>>5 holds k = 8*j2 + 4*h + e for MFMA step (j2, e) of both operands.
+// acc[i][j] is the 32x32 MFMA C tile: (lane l, reg r) -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
+template <int TM, int TN>
+struct Frags {
+#if defined(MTTS_EMU)
+    float a[TM][16][kBK];  // the 16 A rows this lane's accumulators need, all k
+    float b[TN][kBK];      // the B column this lane's accumulators need, all k
+#else
+    float a[2][TM][4], b[2][TN][4];
+#endif
+};
+
 template <int TM, int TN, bool A_KC, bool B_KC, int LDA, int LDB>
-__device__ __forceinline__ void mma_chunk(const float* As, const float* Bs, int wm0, int wn0, int lane,
-                                          f32x16 (&acc)[TM][TN]) {
+__device__ __forceinline__ void read_frags(const float* As, const float* Bs, int wm0, int wn0, int lane, Frags<TM, TN>& f) {
     const int l31 = lane & 31, h = lane >> 5;
 #if defined(MTTS_EMU)
     for (int i = 0; i < TM; ++i)
-        for (int j = 0; j < TN; ++j)
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int col = wn0 + j * 32 + l31;
-                float s = acc[i][j][r];
-                for (int k = 0; k < kBK; ++k) {
-                    const float a = A_KC ? As[row * LDA + k] : As[k * LDA + row];
-                    const float b = B_KC ? Bs[col * LDB + k] : Bs[k * LDB + col];
-                    s = fmaf(a, b, s);
-                }
-                acc[i][j][r] = s;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            for (int k = 0; k < kBK; ++k) f.a[i][r][k] = A_KC ? As[row * LDA + k] : As[k * LDA + row];
+        }
+    for (int j = 0; j < TN; ++j) {
+        const int col = wn0 + j * 32 + l31;
+        for (int k = 0; k < kBK; ++k) f.b[j][k] = B_KC ? Bs[col * LDB + k] : Bs[k * LDB + col];
+    }
 #else
 #pragma unroll
     for (int j2 = 0; j2 < 2; ++j2) {
-        float a[TM][4], b[TN][4];
         const int kb = 8 * j2 + 4 * h;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if (A_KC) {
                 const float4 v = ld4(As + (wm0 + i * 32 + l31) * LDA + kb);
-                a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
+                f.a[j2][i][0] = v.x; f.a[j2][i][1] = v.y; f.a[j2][i][2] = v.z; f.a[j2][i][3] = v.w;
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a[i][e] = As[(kb + e) * LDA + wm0 + i * 32 + l31];
+                for (int e = 0; e < 4; ++e) f.a[j2][i][e] = As[(kb + e) * LDA + wm0 + i * 32 + l31];
             }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             if (B_KC) {
                 const float4 v = ld4(Bs + (wn0 + j * 32 + l31) * LDB + kb);
-                b[j][0] = v.x; b[j][1] = v.y; b[j][2] = v.z; b[j][3] = v.w;
+                f.b[j2][j][0] = v.x; f.b[j2][j][1] = v.y; f.b[j2][j][2] = v.z; f.b[j2][j][3] = v.w;
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) b[j][e] = Bs[(kb + e) * LDB + wn0 + j * 32 + l31];
+                for (int e = 0; e < 4; ++e) f.b[j2][j][e] = Bs[(kb + e) * LDB + wn0 + j * 32 + l31];
             }
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
     }
 #endif
 }
 
-template <int FORM, int BM, int BN>
+// MFMA steps (j2, 0..3) of the slice: k = 8*j2 .. 8*j2+7
+template <int TM, int TN>
+__device__ __forceinline__ void mma_half(const Frags<TM, TN>& f, int j2, f32x16 (&acc)[TM][TN]) {
+#if defined(MTTS_EMU)
+    for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j)
+            for (int r = 0; r < 16; ++r) {
+                float s = acc[i][j][r];
+                for (int k = 8 * j2; k < 8 * j2 + 8; ++k) s = fmaf(f.a[i][r][k], f.b[j][k], s);
+                acc[i][j][r] = s;
+            }
+#else
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[j2][i][e], f.b[j2][j][e], acc[i][j], 0, 0, 0);
+#endif
+}
+
+template <int FORM, int BM, int BN, bool PIPE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr bool A_KC = (FORM != GEMM_TN);
     constexpr bool B_KC = (FORM == GEMM_NT);
@@ -228,13 +250,42 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     load_b(0);
     store_ab(0);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) { load_a((c + 1) * kBK); load_b((c + 1) * kBK); }
-        const float* As = smem + buf * (A_TILE + B_TILE);
-        mma_chunk<TM, TN, A_KC, B_KC, LDA_S, LDB_S>(As, As + A_TILE, wm0, wn0, lane, acc);
-        if (c + 1 < nchunks) store_ab(buf ^ 1);
-        __syncthreads();
+    if (!PIPE) {
+        // simple double buffer: fragments read and consumed inside one barrier interval
+        Frags<TM, TN> f;
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunks) { load_a((c + 1) * kBK); load_b((c + 1) * kBK); }
+            const float* As = smem + buf * (A_TILE + B_TILE);
+            read_frags<TM, TN, A_KC, B_KC, LDA_S, LDB_S>(As, As + A_TILE, wm0, wn0, lane, f);
+            mma_half<TM, TN>(f, 0, acc);
+            mma_half<TM, TN>(f, 1, acc);
+            if (c + 1 < nchunks) store_ab(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // software pipeline: the LDS store of slice c+1, the barrier and the fragment reads of slice
+        // c+1 are issued between the two MFMA halves of slice c, whose operands already sit in
+        // registers — the wave's MFMA stream never waits on LDS or HBM, only on barrier skew.
+        Frags<TM, TN> f0, f1;
+        if (nchunks > 1) { load_a(kBK); load_b(kBK); }
+        read_frags<TM, TN, A_KC, B_KC, LDA_S, LDB_S>(smem, smem + A_TILE, wm0, wn0, lane, f0);
+        auto step = [&](int c, const Frags<TM, TN>& fc, Frags<TM, TN>& fn) {
+            const int nb = (c & 1) ^ 1;
+            if (c + 1 < nchunks) store_ab(nb);
+            if (c + 2 < nchunks) { load_a((c + 2) * kBK); load_b((c + 2) * kBK); }
+            mma_half<TM, TN>(fc, 0, acc);
+            __syncthreads();
+            if (c + 1 < nchunks) {
+                const float* As = smem + nb * (A_TILE + B_TILE);
+                read_frags<TM, TN, A_KC, B_KC, LDA_S, LDB_S>(As, As + A_TILE, wm0, wn0, lane, fn);
+            }
+            mma_half<TM, TN>(fc, 1, acc);
+        };
+        for (int c = 0; c < nchunks; c += 2) {
+            step(c, f0, f1);
+            if (c + 1 < nchunks) step(c + 1, f1, f0);
+        }
     }
 
     // ---- epilogue ----------------------------------------------------------------------
@@ -291,21 +342,39 @@ struct GemmProfiler {
     }
 };
 inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
+inline bool& gemm_default_pipe() {  // MTTS_GEMM_PIPE=0/1 overrides the built-in default (A/B runs)
+    static bool v = [] { const char* e = getenv("MTTS_GEMM_PIPE"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
 
-// Host launcher.  max_M / max_N bound the tile grid over all groups; tile = 0 picks 128x128 when
-// that already fills the chip (>= 256 workgroups), else 64x64.  alg_flops: algorithmic (unpadded)
-// flops of this launch, only used by the profiler.
+// Host launcher.  max_M / max_N bound the tile grid over all groups.  tile = 0 picks the tile by a
+// wave-quantisation model: one 4-wave workgroup saturates a CU's four MFMA pipes, so B workgroups
+// on 256 CUs take ceil(B/256) rounds; the 64x64 tile quarters the quantum at ~0.97x the per-tile
+// efficiency of 128x128 (software-pipelined variants, measured with tools/gemm_bench.py).  total_M = sum of the groups' row counts
+// (0: max_M * groups).  alg_flops: algorithmic (unpadded) flops of this launch, profiler only.
 inline void gemm_launch(int form, const GemmArgs& g, int max_M, int max_N, int groups, hipStream_t stream,
-                        int tile = 0, double alg_flops = 0.0) {
+                        int tile = 0, double alg_flops = 0.0, long long total_M = 0) {
     if (max_M <= 0 || max_N <= 0 || groups <= 0) return;
     auto ntiles = [&](int t) { return (long)((max_M + t - 1) / t) * ((max_N + t - 1) / t); };
-    if (tile == 0) tile = (ntiles(128) * groups >= 256) ? 128 : 64;
+    if (tile == 0) {
+        const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
+        auto eff = [&](int t, double base) {
+            const double b = std::ceil(rows / t) * ((max_N + t - 1) / t) / 256.0;
+            return base * b / std::ceil(b);
+        };
+        tile = eff(128, 1.0) >= eff(64, 0.97) ? 128 : 64;
+    }
+    const bool pipe = tile >= 1000 ? true : (tile > 0 && tile < 1000 ? gemm_default_pipe() : false);
+    if (tile >= 1000) tile -= 1000;
     dim3 block(256), grid((unsigned)ntiles(tile), 1, (unsigned)groups);
     GemmProfiler& prof = gemm_profiler();
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
-#define MTTS_GEMM_CASE(F, T) \
-    if (form == F && tile == T) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T>), grid, block, stream, g); }
+#define MTTS_GEMM_CASE(F, T)                                                                              \
+    if (form == F && tile == T) {                                                                         \
+        if (pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, true>), grid, block, stream, g); }               \
+        else { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, false>), grid, block, stream, g); }                   \
+    }
     MTTS_GEMM_CASE(GEMM_NT, 128) MTTS_GEMM_CASE(GEMM_NT, 64)
     MTTS_GEMM_CASE(GEMM_NN, 128) MTTS_GEMM_CASE(GEMM_NN, 64)
     MTTS_GEMM_CASE(GEMM_TN, 128) MTTS_GEMM_CASE(GEMM_TN, 64)
