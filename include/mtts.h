@@ -69,6 +69,10 @@ int64_t mtts_adapt_start(mtts_handle* h);  /* first float of the adapted (fast-w
 int mtts_load_param(mtts_handle* h, const char* name, const float* host, int64_t numel);
 /* which: 0 parameter, 1 outer gradient, 2 per-task gradient, 3 fast weight of `task`, 4 Adam m, 5 Adam v */
 int mtts_export_param(mtts_handle* h, const char* name, int which, int task, float* host, int64_t numel);
+/* checkpoint resume: which = 0 parameter, 4 Adam exp_avg, 5 Adam exp_avg_sq; and the Adam step count
+ * (PL ckpt["optimizer_states"], main.py:63 resume_from_checkpoint) */
+int mtts_import_state(mtts_handle* h, const char* name, int which, const float* host, int64_t numel);
+int mtts_set_optimizer_step(mtts_handle* h, int64_t step);
 /* BatchNorm1d buffers of PostNet layer `layer` (running_mean, running_var, num_batches_tracked) */
 int mtts_set_bn_buffers(mtts_handle* h, int layer, const float* mean_host, const float* var_host, int64_t tracked);
 int mtts_get_bn_buffers(mtts_handle* h, int layer, float* mean_host, float* var_host, int64_t* tracked);

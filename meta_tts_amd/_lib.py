@@ -43,6 +43,8 @@ EXPORTS = {
     "mtts_param_total": (C.c_int64, [C.c_void_p]),
     "mtts_adapt_start": (C.c_int64, [C.c_void_p]),
     "mtts_load_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "mtts_import_state": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64]),
+    "mtts_set_optimizer_step": (C.c_int, [C.c_void_p, C.c_int64]),
     "mtts_export_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "mtts_set_bn_buffers": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
     "mtts_get_bn_buffers": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),

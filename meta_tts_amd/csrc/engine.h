@@ -471,7 +471,8 @@ public:
     // =================================================================================
     // parameter import / export (torch layout <-> internal layout)
     // =================================================================================
-    int load_param(const std::string& name, const float* host, long long numel) {
+    // which: 0 theta, 4 Adam exp_avg, 5 Adam exp_avg_sq (checkpoint resume)
+    int load_param(const std::string& name, const float* host, long long numel, int which = 0) {
         auto it = by_name.find(name);
         if (it == by_name.end()) { set_error("unknown parameter: " + name); return -1; }
         const ParamEntry& e = entries[it->second];
@@ -487,7 +488,9 @@ public:
                         tmp[((size_t)o * k + kk) * ci + c] = host[((size_t)o * ci + c) * k + kk];
             src = tmp.data();
         }
-        HIP_CHECK(hipMemcpy(theta + e.off, src, e.numel * sizeof(float), hipMemcpyHostToDevice));
+        float* dst = which == 0 ? theta : (which == 4 ? adam_m : (which == 5 ? adam_v : nullptr));
+        if (!dst) { set_error("bad import selector"); return -1; }
+        HIP_CHECK(hipMemcpy(dst + e.off, src, e.numel * sizeof(float), hipMemcpyHostToDevice));
         return 0;
     }
 

@@ -69,39 +69,37 @@ struct GemmArgs {
     int taps = 1, tap_k = 0x40000000, tap_bstride = 0;  // NN conv dgrad tap walk
 };
 
-constexpr int kBK = 16;
-constexpr int kLDK = kBK + 4;  // K-contiguous LDS row stride (floats)
 
 // Register fragments of one BK=16 slice of the wave tile.  A_KC/B_KC: operand tile is [row][kLDK]
 // (K-contiguous: two ds_read_b128 per 32-row subtile) or [k][LD] (reduction-major: ds_read_b32).
 // Lane half h = lane>>5 holds k = 8*j2 + 4*h + e for MFMA step (j2, e) of both operands.
 // acc[i][j] is the 32x32 MFMA C tile: (lane l, reg r) -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
-template <int TM, int TN>
+template <int TM, int TN, int BK>
 struct Frags {
 #if defined(MTTS_EMU)
-    float a[TM][16][kBK];  // the 16 A rows this lane's accumulators need, all k
-    float b[TN][kBK];      // the B column this lane's accumulators need, all k
+    float a[TM][16][BK];  // the 16 A rows this lane's accumulators need, all k
+    float b[TN][BK];      // the B column this lane's accumulators need, all k
 #else
-    float a[2][TM][4], b[2][TN][4];
+    float a[BK / 8][TM][4], b[BK / 8][TN][4];
 #endif
 };
 
-template <int TM, int TN, bool A_KC, bool B_KC, int LDA, int LDB>
-__device__ __forceinline__ void read_frags(const float* As, const float* Bs, int wm0, int wn0, int lane, Frags<TM, TN>& f) {
+template <int TM, int TN, int BK, bool A_KC, bool B_KC, int LDA, int LDB>
+__device__ __forceinline__ void read_frags(const float* As, const float* Bs, int wm0, int wn0, int lane, Frags<TM, TN, BK>& f) {
     const int l31 = lane & 31, h = lane >> 5;
 #if defined(MTTS_EMU)
     for (int i = 0; i < TM; ++i)
         for (int r = 0; r < 16; ++r) {
             const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            for (int k = 0; k < kBK; ++k) f.a[i][r][k] = A_KC ? As[row * LDA + k] : As[k * LDA + row];
+            for (int k = 0; k < BK; ++k) f.a[i][r][k] = A_KC ? As[row * LDA + k] : As[k * LDA + row];
         }
     for (int j = 0; j < TN; ++j) {
         const int col = wn0 + j * 32 + l31;
-        for (int k = 0; k < kBK; ++k) f.b[j][k] = B_KC ? Bs[col * LDB + k] : Bs[k * LDB + col];
+        for (int k = 0; k < BK; ++k) f.b[j][k] = B_KC ? Bs[col * LDB + k] : Bs[k * LDB + col];
     }
 #else
 #pragma unroll
-    for (int j2 = 0; j2 < 2; ++j2) {
+    for (int j2 = 0; j2 < BK / 8; ++j2) {
         const int kb = 8 * j2 + 4 * h;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -127,39 +125,46 @@ __device__ __forceinline__ void read_frags(const float* As, const float* Bs, int
 #endif
 }
 
-// MFMA steps (j2, 0..3) of the slice: k = 8*j2 .. 8*j2+7
-template <int TM, int TN>
-__device__ __forceinline__ void mma_half(const Frags<TM, TN>& f, int j2, f32x16 (&acc)[TM][TN]) {
+// MFMA steps of half `hf` (0/1) of the slice: k = hf*BK/2 .. (hf+1)*BK/2 - 1
+template <int TM, int TN, int BK>
+__device__ __forceinline__ void mma_half(const Frags<TM, TN, BK>& f, int hf, f32x16 (&acc)[TM][TN]) {
 #if defined(MTTS_EMU)
     for (int i = 0; i < TM; ++i)
         for (int j = 0; j < TN; ++j)
             for (int r = 0; r < 16; ++r) {
                 float s = acc[i][j][r];
-                for (int k = 8 * j2; k < 8 * j2 + 8; ++k) s = fmaf(f.a[i][r][k], f.b[j][k], s);
+                for (int k = hf * (BK / 2); k < (hf + 1) * (BK / 2); ++k) s = fmaf(f.a[i][r][k], f.b[j][k], s);
                 acc[i][j][r] = s;
             }
 #else
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int q = 0; q < BK / 16; ++q) {
+        const int j2 = hf * (BK / 16) + q;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[j2][i][e], f.b[j2][j][e], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[j2][i][e], f.b[j2][j][e], acc[i][j], 0, 0, 0);
+    }
 #endif
 }
 
-template <int FORM, int BM, int BN, bool PIPE>
+template <int FORM, int BM, int BN, int BK, bool PIPE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int kLDK = BK + 4;  // K-contiguous LDS row stride: 80 / 144 bytes, ds_read_b128 conflict-free
+    constexpr int KQ = BK / 4;    // float4 per K-contiguous row
     constexpr bool A_KC = (FORM != GEMM_TN);
     constexpr bool B_KC = (FORM == GEMM_NT);
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int LDA_S = A_KC ? kLDK : BM;
     constexpr int LDB_S = B_KC ? kLDK : BN;
-    constexpr int A_TILE = A_KC ? BM * kLDK : kBK * BM;
-    constexpr int B_TILE = B_KC ? BN * kLDK : kBK * BN;
-    constexpr int A_LD4 = (A_KC ? BM * 4 : BM * 4) / 256;  // float4 loads per thread (both forms: 4*BM float4 per tile)
-    constexpr int B_LD4 = (BN * 4) / 256;
+    constexpr int A_TILE = A_KC ? BM * kLDK : BK * BM;
+    constexpr int B_TILE = B_KC ? BN * kLDK : BK * BN;
+    constexpr int A_LD4 = (BM * KQ) / 256;  // float4 loads per thread (both layouts: BM*BK/4 float4 per tile)
+    constexpr int B_LD4 = (BN * KQ) / 256;
+    constexpr int RPP = 256 / KQ;           // K-contiguous rows covered per pass
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
 
     const int z = blockIdx.z;
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < A_LD4; ++i) {
             if (A_KC) {
-                const int row = (tid >> 2) + 64 * i, gk = k0 + (tid & 3) * 4;
+                const int row = tid / KQ + RPP * i, gk = k0 + (tid % KQ) * 4;
                 const int gm = m0 + row;
                 areg[i] = (gm < M && gk < K4) ? ld4(A + (long long)gm * lda + gk) : zero4();
             } else {
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < B_LD4; ++i) {
             if (B_KC) {
-                const int row = (tid >> 2) + 64 * i, gk = k0 + (tid & 3) * 4;
+                const int row = tid / KQ + RPP * i, gk = k0 + (tid % KQ) * 4;
                 const int gn = n0 + row;
                 breg[i] = (gn < N && gk < K4) ? ld4(B + (long long)gn * ldb + gk) : zero4();
             } else {
@@ -227,12 +232,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         float* Bs = As + A_TILE;
 #pragma unroll
         for (int i = 0; i < A_LD4; ++i) {
-            if (A_KC) st4(As + ((tid >> 2) + 64 * i) * kLDK + (tid & 3) * 4, areg[i]);
+            if (A_KC) st4(As + (tid / KQ + RPP * i) * kLDK + (tid % KQ) * 4, areg[i]);
             else { const int idx = tid + 256 * i; st4(As + (idx / (BM / 4)) * BM + (idx % (BM / 4)) * 4, areg[i]); }
         }
 #pragma unroll
         for (int i = 0; i < B_LD4; ++i) {
-            if (B_KC) st4(Bs + ((tid >> 2) + 64 * i) * kLDK + (tid & 3) * 4, breg[i]);
+            if (B_KC) st4(Bs + (tid / KQ + RPP * i) * kLDK + (tid % KQ) * 4, breg[i]);
             else { const int idx = tid + 256 * i; st4(Bs + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4, breg[i]); }
         }
     };
@@ -245,21 +250,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = (K + kBK - 1) / kBK;
+    const int nchunks = (K + BK - 1) / BK;
     load_a(0);
     load_b(0);
     store_ab(0);
     __syncthreads();
     if (!PIPE) {
         // simple double buffer: fragments read and consumed inside one barrier interval
-        Frags<TM, TN> f;
+        Frags<TM, TN, BK> f;
         for (int c = 0; c < nchunks; ++c) {
             const int buf = c & 1;
-            if (c + 1 < nchunks) { load_a((c + 1) * kBK); load_b((c + 1) * kBK); }
+            if (c + 1 < nchunks) { load_a((c + 1) * BK); load_b((c + 1) * BK); }
             const float* As = smem + buf * (A_TILE + B_TILE);
-            read_frags<TM, TN, A_KC, B_KC, LDA_S, LDB_S>(As, As + A_TILE, wm0, wn0, lane, f);
-            mma_half<TM, TN>(f, 0, acc);
-            mma_half<TM, TN>(f, 1, acc);
+            read_frags<TM, TN, BK, A_KC, B_KC, LDA_S, LDB_S>(As, As + A_TILE, wm0, wn0, lane, f);
+            mma_half<TM, TN, BK>(f, 0, acc);
+            mma_half<TM, TN, BK>(f, 1, acc);
             if (c + 1 < nchunks) store_ab(buf ^ 1);
             __syncthreads();
         }
@@ -267,20 +272,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         // software pipeline: the LDS store of slice c+1, the barrier and the fragment reads of slice
         // c+1 are issued between the two MFMA halves of slice c, whose operands already sit in
         // registers — the wave's MFMA stream never waits on LDS or HBM, only on barrier skew.
-        Frags<TM, TN> f0, f1;
-        if (nchunks > 1) { load_a(kBK); load_b(kBK); }
-        read_frags<TM, TN, A_KC, B_KC, LDA_S, LDB_S>(smem, smem + A_TILE, wm0, wn0, lane, f0);
-        auto step = [&](int c, const Frags<TM, TN>& fc, Frags<TM, TN>& fn) {
+        Frags<TM, TN, BK> f0, f1;
+        if (nchunks > 1) { load_a(BK); load_b(BK); }
+        read_frags<TM, TN, BK, A_KC, B_KC, LDA_S, LDB_S>(smem, smem + A_TILE, wm0, wn0, lane, f0);
+        auto step = [&](int c, const Frags<TM, TN, BK>& fc, Frags<TM, TN, BK>& fn) {
             const int nb = (c & 1) ^ 1;
             if (c + 1 < nchunks) store_ab(nb);
-            if (c + 2 < nchunks) { load_a((c + 2) * kBK); load_b((c + 2) * kBK); }
-            mma_half<TM, TN>(fc, 0, acc);
+            if (c + 2 < nchunks) { load_a((c + 2) * BK); load_b((c + 2) * BK); }
+            mma_half<TM, TN, BK>(fc, 0, acc);
             __syncthreads();
             if (c + 1 < nchunks) {
                 const float* As = smem + nb * (A_TILE + B_TILE);
-                read_frags<TM, TN, A_KC, B_KC, LDA_S, LDB_S>(As, As + A_TILE, wm0, wn0, lane, fn);
+                read_frags<TM, TN, BK, A_KC, B_KC, LDA_S, LDB_S>(As, As + A_TILE, wm0, wn0, lane, fn);
             }
-            mma_half<TM, TN>(fc, 1, acc);
+            mma_half<TM, TN, BK>(fc, 1, acc);
         };
         for (int c = 0; c < nchunks; c += 2) {
             step(c, f0, f1);
@@ -342,6 +347,10 @@ struct GemmProfiler {
     }
 };
 inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
+inline int& gemm_default_bk() {  // MTTS_GEMM_BK=16/32
+    static int v = [] { const char* e = getenv("MTTS_GEMM_BK"); return (e && atoi(e) == 32) ? 32 : 16; }();
+    return v;
+}
 inline bool& gemm_default_pipe() {  // MTTS_GEMM_PIPE=0/1 overrides the built-in default (A/B runs)
     static bool v = [] { const char* e = getenv("MTTS_GEMM_PIPE"); return e ? atoi(e) != 0 : true; }();
     return v;
@@ -364,16 +373,21 @@ inline void gemm_launch(int form, const GemmArgs& g, int max_M, int max_N, int g
         };
         tile = eff(128, 1.0) >= eff(64, 0.97) ? 128 : 64;
     }
-    const bool pipe = tile >= 1000 ? true : (tile > 0 && tile < 1000 ? gemm_default_pipe() : false);
-    if (tile >= 1000) tile -= 1000;
+    // tile code: 64 / 128 (+1000 software pipeline, +2000 BK=32); plain 64 / 128 take the defaults
+    bool pipe = gemm_default_pipe();
+    int bk = gemm_default_bk();
+    if (tile >= 1000) { pipe = (tile / 1000) & 1; bk = (tile / 2000) ? 32 : 16; tile %= 1000; }
+    if (g.taps > 1 && g.tap_k % 32 != 0) bk = 16;  // a K-slice must not straddle two conv taps
     dim3 block(256), grid((unsigned)ntiles(tile), 1, (unsigned)groups);
     GemmProfiler& prof = gemm_profiler();
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
 #define MTTS_GEMM_CASE(F, T)                                                                              \
     if (form == F && tile == T) {                                                                         \
-        if (pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, true>), grid, block, stream, g); }               \
-        else { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, false>), grid, block, stream, g); }                   \
+        if (bk == 32 && pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 32, true>), grid, block, stream, g); }   \
+        else if (bk == 32) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 32, false>), grid, block, stream, g); }     \
+        else if (pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, true>), grid, block, stream, g); }          \
+        else { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, false>), grid, block, stream, g); }                   \
     }
     MTTS_GEMM_CASE(GEMM_NT, 128) MTTS_GEMM_CASE(GEMM_NT, 64)
     MTTS_GEMM_CASE(GEMM_NN, 128) MTTS_GEMM_CASE(GEMM_NN, 64)

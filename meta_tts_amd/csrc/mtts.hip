@@ -70,6 +70,10 @@ int mtts_param_info(mtts_handle* h, int i, const char** name, int* ndim, int sha
 int64_t mtts_param_total(mtts_handle* h) { return h->eng.n_total; }
 int64_t mtts_adapt_start(mtts_handle* h) { return h->eng.adapt_start; }
 int mtts_load_param(mtts_handle* h, const char* name, const float* host, int64_t numel) { return h->eng.load_param(name, host, numel); }
+int mtts_import_state(mtts_handle* h, const char* name, int which, const float* host, int64_t numel) {
+    return h->eng.load_param(name, host, numel, which);
+}
+int mtts_set_optimizer_step(mtts_handle* h, int64_t step) { h->eng.adam_step_count = step; return 0; }
 int mtts_export_param(mtts_handle* h, const char* name, int which, int task, float* host, int64_t numel) {
     if (task < 0 || task >= h->eng.cap_tasks) { h->eng.set_error("task out of range"); return -1; }
     return h->eng.export_param(name, which, task, host, numel);
@@ -204,7 +208,7 @@ int mtts_profile_report(double* out18) {
 
 int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, float alpha, int flags, int tile, void* stream) {
-    if (form < 0 || form > 2 || (tile != 0 && tile != 64 && tile != 128 && tile != 1064 && tile != 1128)) return -1;
+    if (form < 0 || form > 2 || (tile != 0 && tile % 1000 != 64 && tile % 1000 != 128) || tile >= 4000) return -1;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.alpha = alpha; g.flags = flags;

@@ -99,6 +99,15 @@ class Engine:
                 raise MttsError(f"shape mismatch for {name}: {a.shape} vs {shape}")
             self._ck(self.lib.mtts_load_param(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
 
+    def import_state(self, name: str, which: int, value: np.ndarray):
+        a = _arr(value, np.float32)
+        if tuple(a.shape) != self.params[name][0]:
+            raise MttsError(f"shape mismatch for {name}")
+        self._ck(self.lib.mtts_import_state(self.h, name.encode(), which, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def set_optimizer_step(self, step: int):
+        self._ck(self.lib.mtts_set_optimizer_step(self.h, int(step)))
+
     def export(self, name: str, which: int = 0, task: int = 0) -> np.ndarray:
         shape = self.params[name][0]
         out = np.empty(shape, np.float32)

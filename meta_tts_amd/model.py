@@ -1,0 +1,140 @@
+"""Reference-shaped Python face of the hot path (the drop-in boundary of SURVEY.md section 8(b)).
+
+Class names, constructor / forward signatures, the 12-tuple batch and 10-tuple prediction layouts and
+the state_dict key names are the reference's (lightning/model/fastspeech2.py:16-112,
+lightning/model/loss.py:5-92); every number is produced by libmtts on the MI355X — these classes
+hold no arithmetic of their own and raise if the library or a GPU is missing.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import synth
+from .config import ModelDims, SYNTH_N_SPEAKER, SYNTH_STATS
+from .engine import LOSS_NAMES, Engine, MttsError
+
+
+class Predictions(tuple):
+    """The reference's 10-tuple (fastspeech2.py:101-112) plus the handle that produced it, so that
+    FastSpeech2Loss can evaluate the loss where the data lives (device) instead of re-reading it."""
+    engine: Engine
+    slot: int
+    task: int
+
+
+def _read_preprocessed(preprocess_config) -> tuple:
+    """stats.json / speakers.json under preprocessed_path (modules.py:41-46, speaker_encoder.py:49-50);
+    the synthetic defaults are used when the directory does not exist (no corpus in this image)."""
+    path = preprocess_config.get("path", {}).get("preprocessed_path", "")
+    stats, n_spk = SYNTH_STATS, SYNTH_N_SPEAKER
+    sp = os.path.join(path, "stats.json")
+    if os.path.exists(sp):
+        with open(sp) as f:
+            stats = json.load(f)
+    kp = os.path.join(path, "speakers.json")
+    if os.path.exists(kp):
+        with open(kp) as f:
+            n_spk = len(json.load(f))
+    return stats, n_spk
+
+
+class FastSpeech2:
+    """lightning/model/fastspeech2.py:16 — engine-backed.  ``forward`` is teacher-forced (targets
+    given); free-running synthesis is the C5 row of SURVEY.md section 8 (not built yet)."""
+
+    def __init__(self, preprocess_config, model_config, algorithm_config, *, max_tasks: int = 1, max_batch: int = 16,
+                 max_src_len: int = 128, max_mel_len: Optional[int] = None, device: int = 0, lib_path: Optional[str] = None):
+        if algorithm_config["adapt"]["speaker_emb"] != "table":
+            raise MttsError("only adapt.speaker_emb == 'table' is on the hot path (SURVEY.md #3)")
+        if algorithm_config["adapt"]["type"] != "spk":
+            raise MttsError("adapt.type == 'lang' (codebook phoneme embedding) is out of scope (SURVEY.md #8)")
+        stats, n_spk = _read_preprocessed(preprocess_config)
+        self.dims = ModelDims(model_config, preprocess_config, n_speaker=n_spk, stats=stats)
+        self.model_config, self.preprocess_config, self.algorithm_config = model_config, preprocess_config, algorithm_config
+        self.adapt_modules = tuple(algorithm_config["adapt"].get("modules", ()))
+        self.engine = Engine(self.dims, adapt_modules=self.adapt_modules, max_tasks=max_tasks, max_B=max_batch,
+                             max_S=max_src_len, max_T=max_mel_len or self.dims.max_seq_len, device=device, lib_path=lib_path)
+        self.training = True
+        self.load_state_dict(synth.make_params(self.dims, seed=0))
+
+    # -- nn.Module-like surface ---------------------------------------------------------
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def state_dict(self) -> Dict[str, np.ndarray]:
+        sd = dict(self.engine.state_dict())
+        frozen = synth.make_params(self.dims, 0)
+        for k in ("encoder.position_enc", "decoder.position_enc", "variance_adaptor.pitch_bins", "variance_adaptor.energy_bins"):
+            sd[k] = frozen[k]
+        for i in range(self.dims.postnet_layers):
+            m, v, t = self.engine.get_bn_buffers(i)
+            sd[f"postnet.convolutions.{i}.1.running_mean"] = m
+            sd[f"postnet.convolutions.{i}.1.running_var"] = v
+            sd[f"postnet.convolutions.{i}.1.num_batches_tracked"] = np.array(t, np.int64)
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, np.ndarray], strict: bool = True):
+        sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()}
+        self.engine.load_params(sd, strict=strict)
+        for i in range(self.dims.postnet_layers):
+            km, kv, kt = (f"postnet.convolutions.{i}.1.{s}" for s in ("running_mean", "running_var", "num_batches_tracked"))
+            if km in sd and kv in sd:
+                self.engine.set_bn_buffers(i, sd[km], sd[kv], int(sd.get(kt, 0)))
+
+    # -- forward ------------------------------------------------------------------------
+    def forward(self, speaker_args, texts, src_lens, max_src_len, mels=None, mel_lens=None, max_mel_len=None,
+                p_targets=None, e_targets=None, d_targets=None, p_control=1.0, e_control=1.0, d_control=1.0,
+                *, slot: int = 0, use_fast: bool = False, spk_from=None, average_spk_emb: bool = False):
+        if d_targets is None or mels is None:
+            raise NotImplementedError("free-running synthesis (no duration targets) is not built yet (SURVEY.md 8: C5)")
+        batch = (None, None, speaker_args, texts, src_lens, max_src_len, mels, mel_lens, max_mel_len, p_targets, e_targets, d_targets)
+        self.engine.set_batches(slot, [batch], spk_from=[spk_from] if spk_from is not None else None, average_spk=average_spk_emb)
+        self.engine.forward(slot, use_fast=use_fast, train=self.training)
+        return self._predictions(slot, 0, batch)
+
+    __call__ = forward
+
+    def _predictions(self, slot: int, task: int, batch) -> Predictions:
+        import torch
+        o = self.engine.outputs(slot, task)
+        B, S, T = self.engine.batch_shapes[slot][task]
+        src_lens = torch.as_tensor(np.asarray(batch[4]), dtype=torch.int64)
+        mel_lens = torch.clamp(torch.as_tensor(np.asarray(batch[7]), dtype=torch.int64), max=self.dims.max_seq_len)
+        src_masks = torch.arange(S)[None, :] >= src_lens[:, None]
+        mel_masks = torch.arange(T)[None, :] >= mel_lens[:, None]
+        d_rounded = torch.as_tensor(np.asarray(batch[11]))
+        p = Predictions((torch.from_numpy(o["mel"]), torch.from_numpy(o["mel_post"]), torch.from_numpy(o["p"]),
+                         torch.from_numpy(o["e"]), torch.from_numpy(o["logd"]), d_rounded, src_masks, mel_masks, src_lens, mel_lens))
+        p.engine, p.slot, p.task = self.engine, slot, task
+        return p
+
+
+class FastSpeech2Loss:
+    """lightning/model/loss.py:5 — (total, mel, postnet mel, pitch, energy, duration), evaluated by the
+    device-side reduction over the predictions still resident in HBM."""
+
+    def __init__(self, preprocess_config, model_config):
+        assert preprocess_config["preprocessing"]["pitch"]["feature"] == "phoneme_level"
+        assert preprocess_config["preprocessing"]["energy"]["feature"] == "phoneme_level"
+
+    def forward(self, inputs, predictions):
+        import torch
+        if not isinstance(predictions, Predictions):
+            raise MttsError("FastSpeech2Loss needs the Predictions object returned by FastSpeech2.forward")
+        vals = predictions.engine.loss(predictions.slot)[predictions.task]
+        return tuple(torch.tensor(float(v)) for v in vals)
+
+    __call__ = forward
+
+
+def loss2dict(loss) -> Dict[str, float]:
+    """lightning/utils.py:65-74"""
+    return {k: float(v) for k, v in zip(LOSS_NAMES, loss)}

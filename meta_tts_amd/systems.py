@@ -1,0 +1,187 @@
+"""Training systems with the reference's registry and hook names (lightning/systems/__init__.py:5-14,
+system.py:26-112, base_adaptor.py:21-124, meta.py:17-97, baseline.py:15-53), minus PyTorch-Lightning:
+the Trainer's job on this path — one process per GPU, outer-gradient mean over ranks, clip, Adam,
+Noam schedule, checkpoint cadence — is the ~60-line :class:`Trainer` below over torch.distributed
+(backend "nccl" == RCCL over xGMI on MI355X, "gloo" in the CPU tests).
+
+Everything numerical (forward, backward, inner SGD, fast weights, outer reduction over the local
+tasks, clip + Adam) runs inside libmtts; the only tensor this file touches is the flat outer-gradient
+buffer handed to ``all_reduce``.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .engine import LOSS_NAMES
+from .model import FastSpeech2, FastSpeech2Loss, loss2dict
+
+
+def noam_lr(step: int, d_model: int, train_config) -> float:
+    """lightning/optimizer.py:7 (init_lr = d_model^-0.5) x lightning/scheduler.py:11-23 (LambdaLR factor);
+    ``step`` is the 0-based scheduler step."""
+    o = train_config["optimizer"]
+    cur = step + 1
+    lr = min(cur ** -0.5, o["warm_up_step"] ** -1.5 * cur)
+    for s in o["anneal_steps"]:
+        if cur > s:
+            lr *= o["anneal_rate"]
+    return float(d_model ** -0.5 * lr)
+
+
+class System:
+    """lightning/systems/system.py:26 — owns the model, the loss and the outer optimiser state."""
+
+    def __init__(self, preprocess_config, model_config, train_config, algorithm_config, log_dir=None, result_dir=None,
+                 *, max_tasks: int = 1, max_batch: int = 16, max_src_len: int = 128, max_mel_len: Optional[int] = None,
+                 device: int = 0, lib_path: Optional[str] = None):
+        self.preprocess_config, self.model_config = preprocess_config, model_config
+        self.train_config, self.algorithm_config = train_config, algorithm_config
+        self.log_dir, self.result_dir = log_dir, result_dir
+        self.model = FastSpeech2(preprocess_config, model_config, algorithm_config, max_tasks=max_tasks, max_batch=max_batch,
+                                 max_src_len=max_src_len, max_mel_len=max_mel_len, device=device, lib_path=lib_path)
+        self.loss_func = FastSpeech2Loss(preprocess_config, model_config)
+        self.engine = self.model.engine
+        self.global_step = 0
+        self.world_size = 1
+
+    # system.py:53-56
+    def common_step(self, batch, batch_idx, train=True):
+        self.model.train(train)
+        output = self.model(*(batch[2:]))
+        loss = self.loss_func(batch, output)
+        return loss, output
+
+    def training_step(self, batch, batch_idx):
+        """system.py:58-64 / baseline.py:25-36 — plain multi-task gradient of one batch."""
+        losses = self.engine_plain_grad([batch])
+        return {"loss": losses[0][0], "losses": losses[0], "_batch": batch}
+
+    def engine_plain_grad(self, batches: Sequence[tuple], total_batches: Optional[int] = None):
+        self.engine.set_batches(0, list(batches))
+        scale = 1.0 / (total_batches or (len(batches) * self.world_size))
+        return self.engine.plain_grad(0, scale)
+
+    def optimizer_step(self, grad_ptr: Optional[int] = None):
+        o = self.train_config["optimizer"]
+        lr = noam_lr(self.global_step, self.model.dims.d_model, self.train_config)
+        self.engine.outer_update(lr=lr, betas=tuple(o["betas"]), eps=o["eps"], weight_decay=o["weight_decay"],
+                                 max_norm=o["grad_clip_thresh"], grad_ptr=grad_ptr)
+        self.global_step += 1
+        return lr
+
+    # checkpoint surface (system.py:115-192 loader surgery lives in checkpoint.py)
+    def state_dict(self) -> Dict[str, np.ndarray]:
+        sd = {f"model.{k}": v for k, v in self.model.state_dict().items()}
+        for k, v in list(sd.items()):
+            mod = k.split(".")[1]
+            if mod in getattr(self.model, "adapt_modules", ()):
+                sd["learner.module." + k[len("model."):]] = v  # same tensors, aliased (base_adaptor.py:31-35)
+        return sd
+
+
+class BaseAdaptorSystem(System):
+    """lightning/systems/base_adaptor.py:21"""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        a = self.algorithm_config["adapt"]
+        self.adaptation_lr = a["task"]["lr"]
+        self.adaptation_steps = a["train"]["steps"]
+        self.test_adaptation_steps = a["test"]["steps"]
+        assert self.test_adaptation_steps % self.adaptation_steps == 0  # base_adaptor.py:39
+
+    @staticmethod
+    def _on_meta_batch_start(batch):
+        """base_adaptor.py:126-131"""
+        assert len(batch) == 1, "meta_batch_per_gpu"
+        assert len(batch[0]) == 2, "sup + qry"
+        assert len(batch[0][0]) == 1, "n_batch == 1"
+        assert len(batch[0][0][0]) == 12, "data with 12 elements"
+
+    def meta_learn_tasks(self, tasks: Sequence[tuple], train: bool = True, total_tasks: Optional[int] = None):
+        """adapt + meta_learn (base_adaptor.py:100-124) for all local tasks in one grouped pass.
+        tasks: [(sup12, qry12), ...].  Leaves sum_t dL_q,t/dtheta / total_tasks in the outer-gradient buffer;
+        returns (query losses [n][6], support losses [steps][n][6])."""
+        if train and self.algorithm_config.get("_second_order", False):
+            raise NotImplementedError("second-order MAML")
+        sup = [t[0] for t in tasks]
+        qry = [t[1] for t in tasks]
+        self.engine.set_batches(0, sup)
+        self.engine.set_batches(1, qry, spk_from=sup, average_spk=True)
+        scale = 1.0 / (total_tasks or (len(tasks) * self.world_size))
+        steps = min(self.adaptation_steps, self.test_adaptation_steps)
+        return self.engine.meta_grad(steps, self.adaptation_lr, scale)
+
+
+class MetaSystem(BaseAdaptorSystem):
+    """lightning/systems/meta.py:17"""
+
+    def training_step(self, batch, batch_idx):
+        self._on_meta_batch_start(batch)
+        q, s = self.meta_learn_tasks([(batch[0][0][0], batch[0][1][0])])
+        logs = {f"Train/{k}": float(v) for k, v in zip(LOSS_NAMES, q[0])}
+        return {"loss": float(q[0][0]), "losses": q[0], "log": logs, "_batch": batch[0][1][0]}
+
+    def validation_step(self, batch, batch_idx):
+        self._on_meta_batch_start(batch)
+        q, s = self.meta_learn_tasks([(batch[0][0][0], batch[0][1][0])], train=False)
+        return {"losses": q[0], "log": {f"Val/{k}": float(v) for k, v in zip(LOSS_NAMES, q[0])}}
+
+
+class BaselineSystem(BaseAdaptorSystem):
+    """lightning/systems/baseline.py:15"""
+
+    def training_step(self, batch, batch_idx):
+        assert len(batch) == 12, "data with 12 elements"
+        return System.training_step(self, batch, batch_idx)
+
+    def validation_step(self, batch, batch_idx):
+        return MetaSystem.validation_step(self, batch, batch_idx)
+
+
+SYSTEM = {"meta": MetaSystem, "baseline": BaselineSystem}
+
+
+def get_system(algorithm: str):
+    """lightning/systems/__init__.py:13-14 ('imaml' is a later row of SURVEY.md section 8(f))."""
+    if algorithm not in SYSTEM:
+        raise KeyError(f"system type {algorithm!r} is not on the hot path (supported: {sorted(SYSTEM)})")
+    return SYSTEM[algorithm]
+
+
+class Trainer:
+    """The slice of pl.Trainer(strategy='ddp', gradient_clip_val=...) this path needs (main.py:30-38,57-64):
+    one process per GPU, every rank runs its share of the meta-batch, the flat outer gradient is summed over
+    ranks (each rank already scaled by 1/total_tasks => mean, as DDP does), then every rank applies the same
+    clip + Adam step."""
+
+    def __init__(self, system: System, outer_grad_tensor=None, process_group=None):
+        import torch.distributed as dist
+        self.system = system
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.group = process_group
+        self.system.world_size = self.dist.get_world_size(self.group) if self.dist else 1
+        self.outer = outer_grad_tensor  # torch view of engine.outer_grad_ptr() (zero copy on GPU)
+
+    def _allreduce(self):
+        if self.dist is None or self.system.world_size == 1:
+            return
+        if self.outer is None:
+            import torch
+            self.outer = torch.as_tensor(self.system.engine.outer_grad_view(), device="cuda")
+        self.dist.all_reduce(self.outer, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def meta_step(self, local_tasks: Sequence[tuple], total_tasks: int):
+        q, s = self.system.meta_learn_tasks(local_tasks, total_tasks=total_tasks)
+        self._allreduce()
+        lr = self.system.optimizer_step()
+        return q, s, lr
+
+    def plain_step(self, local_batches: Sequence[tuple], total_batches: int):
+        losses = self.system.engine_plain_grad(local_batches, total_batches)
+        self._allreduce()
+        lr = self.system.optimizer_step()
+        return losses, lr

@@ -13,5 +13,5 @@ for name, calls, dur, avg, pct in rows:
     name = name.replace("mtts::", "").replace("void ", "")
     if len(name) > 90:
         name = name[:87] + "..."
-    print(f"| `{name}` | {calls} | {dur / 1e6:.2f} | {avg / 1e3:.1f} | {pct:.2f} |")
-print(f"\ntotal kernel time {tot / 1e6:.1f} ms over {sum(r[1] for r in rows)} dispatches")
+    print(f"| `{name}` | {calls} | {dur / 1e3:.2f} | {avg:.1f} | {pct:.2f} |")
+print(f"\ntotal kernel time {tot / 1e3:.1f} ms over {sum(r[1] for r in rows)} dispatches")

@@ -1,0 +1,131 @@
+"""Reference-shaped host layer (model.py / systems.py / checkpoint.py) driven on CPU through the SIMT
+emulator build: registry, hook names, 12-tuple / 10-tuple layouts, state_dict + checkpoint key layout,
+loader surgery (system.py:115-192), Noam schedule."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as ge
+from oracle_util import O, heads, synth, tiny_dims, torch_buffers
+from meta_tts_amd import checkpoint
+from meta_tts_amd.config import default_algorithm_config, default_train_config
+from meta_tts_amd.systems import Trainer, get_system, noam_lr
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    return ge.build_emulator()
+
+
+@pytest.fixture()
+def cfgs(tmp_path):
+    dims = tiny_dims()
+    pre = dims.preprocess_config
+    pre["path"] = {"preprocessed_path": str(tmp_path)}
+    pre["dataset"] = "LibriTTS"
+    (tmp_path / "stats.json").write_text(json.dumps({"pitch": [-2.0, 8.0, 0.0, 1.0], "energy": [-1.5, 7.0, 0.0, 1.0]}))
+    (tmp_path / "speakers.json").write_text(json.dumps({str(i): i for i in range(12)}))
+    return pre, dims.model_config, default_train_config(), default_algorithm_config()
+
+
+def _kw(n_mel):
+    return dict(n_mel=n_mel, s_range=(5, 13), d_range=(1, 6), first_len=12)
+
+
+def _system(cfgs, emu_lib, kind="meta", tasks=1):
+    return get_system(kind)(*cfgs, max_tasks=tasks, max_batch=3, max_src_len=16, max_mel_len=96, lib_path=emu_lib)
+
+
+def test_registry_and_schedule():
+    assert get_system("meta").__name__ == "MetaSystem" and get_system("baseline").__name__ == "BaselineSystem"
+    with pytest.raises(KeyError):
+        get_system("imaml")
+    trn = default_train_config()
+    for s in (0, 1, 3999, 4000, 300001):
+        assert abs(noam_lr(s, 256, trn) - O.noam_lr(s)) < 1e-15
+
+
+def test_forward_signature_and_tuple_layouts(cfgs, emu_lib):
+    sysm = _system(cfgs, emu_lib)
+    dims = sysm.model.dims
+    assert dims.n_speaker == 12  # read from speakers.json
+    b = synth.make_batch(3, 2, speaker=4, vocab=dims.vocab, **_kw(dims.n_mel))
+    loss, out = sysm.common_step(tuple(torch.from_numpy(x) if isinstance(x, np.ndarray) else x for x in b), 0, train=True)
+    assert len(out) == 10 and len(loss) == 6
+    mel, mel_post, p, e, logd, d_rounded, src_masks, mel_masks, src_lens, mel_lens = out
+    assert mel.shape == (2, b[8], dims.n_mel) and p.shape == (2, b[5]) and src_masks.dtype == torch.bool
+    # against the oracle with the same (seed-0) parameters
+    prm = {k: torch.from_numpy(v.copy()) for k, v in synth.make_params(dims, 0).items()}
+    tb = O.to_torch_batch(b)
+    with torch.no_grad():
+        o = O.fs2_forward(prm, torch_buffers(dims), *tb[2:], n_head=heads(dims), max_seq_len=dims.max_seq_len, training=True)
+        lo = O.fs2_loss(tb, o)
+    assert (mel_post - o[1]).abs().max() < 5e-5
+    np.testing.assert_allclose([float(x) for x in loss], [float(x) for x in lo], rtol=2e-5)
+    assert torch.equal(src_masks, o[6]) and torch.equal(mel_masks, o[7])
+    with pytest.raises(NotImplementedError):
+        sysm.model(*b[2:6])
+
+
+def test_meta_training_step_and_checkpoint_roundtrip(cfgs, emu_lib, tmp_path):
+    sysm = _system(cfgs, emu_lib)
+    dims = sysm.model.dims
+    sup = synth.make_batch(5, 3, speaker=2, vocab=dims.vocab, **_kw(dims.n_mel))
+    qry = synth.make_batch(6, 2, speaker=2, vocab=dims.vocab, **_kw(dims.n_mel))
+    out = sysm.training_step([([sup], [qry])], 0)
+    assert set(out["log"]) == {f"Train/{k}" for k in ("Total Loss", "Mel Loss", "Mel-Postnet Loss", "Pitch Loss", "Energy Loss", "Duration Loss")}
+    with pytest.raises(AssertionError):
+        sysm.training_step([([sup], [qry]), ([sup], [qry])], 0)  # one task per process (base_adaptor.py:128)
+    sysm.optimizer_step()
+    sd = sysm.state_dict()
+    assert "model.decoder.layer_stack.1.pos_ffn.w_1.weight" in sd and "learner.module.decoder.layer_stack.1.pos_ffn.w_1.weight" in sd
+    assert "learner.module.encoder.src_word_emb.weight" not in sd  # the encoder is not adapted
+    assert sd["model.encoder.position_enc"].shape == (1, dims.max_seq_len + 1, dims.d_model)
+    assert "model.postnet.convolutions.0.1.running_mean" in sd
+    path = str(tmp_path / "last.ckpt")
+    checkpoint.save_checkpoint(sysm, path)
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert raw["global_step"] == 1 and "state_dict" in raw and "optimizer_states" in raw
+    other = _system(cfgs, emu_lib)
+    changes = checkpoint.load_checkpoint(other, path)
+    assert changes == {"skip": [], "drop": [], "replace": [], "miss": []}
+    for k, v in sysm.state_dict().items():
+        np.testing.assert_array_equal(other.state_dict()[k], v)
+    # resumed optimiser: the next identical step lands on identical parameters
+    for s in (sysm, other):
+        s.training_step([([sup], [qry])], 1)
+        s.optimizer_step()
+    np.testing.assert_array_equal(sysm.engine.export("mel_linear.weight"), other.engine.export("mel_linear.weight"))
+
+
+def test_loader_surgery_old_key_and_speaker_table():
+    """system.py:122-148: rename model.speaker_emb.weight; 326-row table -> 2390-row table keeps rows [:247] and [-79:]."""
+    g = np.random.RandomState(0)
+    model_sd = {"model.speaker_emb.model.weight": g.randn(2390, 4).astype(np.float32), "model.mel_linear.bias": np.zeros(3, np.float32)}
+    old = {"model.speaker_emb.weight": g.randn(326, 4).astype(np.float32), "model.mel_linear.bias": np.ones(3, np.float32),
+           "vocoder.mel2wav.x": np.zeros(2, np.float32)}
+    sd, changes, changed = checkpoint.adapt_state_dict(old, model_sd, "LibriTTS")
+    assert changed and changes["replace"] == [["model.speaker_emb.weight", "model.speaker_emb.model.weight"]]
+    assert changes["drop"] == ["vocoder.mel2wav.x"]
+    t = sd["model.speaker_emb.model.weight"]
+    assert t.shape == (2390, 4)
+    np.testing.assert_array_equal(t[:247], old["model.speaker_emb.weight"][:247])
+    np.testing.assert_array_equal(t[-79:], old["model.speaker_emb.weight"][-79:])
+    np.testing.assert_array_equal(t[247:-79], model_sd["model.speaker_emb.model.weight"][247:-79])
+
+
+def test_baseline_step_matches_oracle_gradient(cfgs, emu_lib):
+    sysm = _system(cfgs, emu_lib, kind="baseline")
+    dims = sysm.model.dims
+    b = synth.make_batch(8, 3, speaker=1, vocab=dims.vocab, **_kw(dims.n_mel))
+    out = sysm.training_step(b, 0)
+    prm = {k: torch.from_numpy(v.copy()) for k, v in synth.make_params(dims, 0).items()}
+    prm["mel_linear.weight"].requires_grad_(True)
+    tb = O.to_torch_batch(b)
+    lo = O.fs2_loss(tb, O.fs2_forward(prm, torch_buffers(dims), *tb[2:], n_head=heads(dims), max_seq_len=dims.max_seq_len, training=True))
+    g = torch.autograd.grad(lo[0], prm["mel_linear.weight"])[0].numpy()
+    assert abs(out["loss"] - float(lo[0])) < 1e-4
+    assert np.abs(sysm.engine.export("mel_linear.weight", 1) - g).max() < 1e-3 * np.abs(g).max()

@@ -34,7 +34,7 @@ shapes = [("square4096", 4096, 4096, 4096), ("conv1_fwd 8 tasks", 26400, 1024, 2
           ("qkv", 26400, 768, 256), ("out_proj", 26400, 256, 256), ("postnet_mid", 24000, 512, 2560)]
 for name, M, N, K in shapes:
     for form in (0, 1, 2):
-        for tile in (64, 128, 1064, 1128):
+        for tile in (1064, 1128, 3064, 3128, 2064):
             if form == 2:  # TN: output [M', N'] small, reduction long — use wgrad-like shapes
                 m2, n2, k2 = N, K, M // 8 if M > 8192 else M
             else:
