@@ -73,6 +73,43 @@ def cpu_baseline(dims, mods, budget_s=25.0):
                       f"{mean_t:.2f} s/task, clip+Adam excluded (<1%)"}
 
 
+def inference_leg(dims, mods, device, iters=5):
+    """BASELINE config 5 without the vocoder (MelGAN is not built): 5-shot speaker adaptation (5 first-order inner steps
+    on the 5 support utterances of task 0) followed by free-running synthesis (predicted durations) of the 5 query texts
+    with the adapted weights in train mode, as the reference's test loop does (base_adaptor.py:170-189).  The random-init
+    duration predictor emits ~0 frames, so its output bias is set to ln(8) (about 7 frames per phoneme, LibriTTS-like)."""
+    import torch
+    from meta_tts_amd import synth
+    from meta_tts_amd.engine import Engine
+    sup, qry = synth.make_task(0)
+    params = synth.make_params(dims, 0)
+    params["variance_adaptor.duration_predictor.linear_layer.bias"][:] = np.log(8.0)
+    params["variance_adaptor.duration_predictor.linear_layer.weight"] *= 0.25
+    eng = Engine(dims, adapt_modules=mods, max_tasks=1, max_B=5, max_S=80, max_T=1000, device=device)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.load_params(params)
+    eng.set_batches(0, [sup])
+    res = {}
+    for name, with_adapt in (("adapt5_plus_synthesis", True), ("synthesis_only", False)):
+        frames = 0
+        for it in range(iters + 1):
+            if it == 1:
+                torch.cuda.synchronize(); t0 = time.perf_counter(); frames = 0
+            if with_adapt:
+                eng.adapt(INNER_STEPS, INNER_LR, reset=True, fetch_losses=False)
+            eng.set_batches(1, [qry[:6]], spk_from=[sup], average_spk=True)
+            eng.synthesize(1, use_fast=True, train=True)
+            d, mel_lens, tcap = eng.durations(1, 0)
+            frames += int(mel_lens.sum())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[name] = {"mels_per_sec": round(frames / dt, 1), "ms_per_iter": round(1e3 * dt / iters, 2), "frames_per_iter": frames // iters,
+                     "rtf_acoustic_only": round(dt / (frames * 256 / 22050.0), 5)}
+    eng.close()
+    res["note"] = "acoustic model only (no vocoder); 5 query utterances per iteration; host->device batch upload and the one duration read-back are inside the timed loop"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +117,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-inference", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -176,6 +214,9 @@ def main():
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(dims, mods)
     eng.close()
+    infer = None
+    if rank == 0 and n == 1 and not args.no_inference:
+        infer = inference_leg(dims, mods, local_rank)
     if n > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -189,6 +230,8 @@ def main():
                            "tasks_per_gpu": META_BATCH // n, "inner_steps": INNER_STEPS, "order": "first", "parallelism": f"task-dp{n}",
                            "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
                 "query_total_loss_mean": round(float(q_losses[:, 0].mean()), 5) if q_losses is not None else None}
+        if infer is not None:
+            line["inference_c5"] = infer
         if roof is not None:
             line["roofline"] = roof
         if cpu is not None:

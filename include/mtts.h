@@ -86,6 +86,15 @@ int mtts_set_batches(mtts_handle* h, int slot, int n_tasks, const mtts_batch* ba
 /* ---- FastSpeech2.forward, teacher-forced (lightning/model/fastspeech2.py:40-112) and
  * FastSpeech2Loss.forward (lightning/model/loss.py:19-92) ---------------------------------------- */
 int mtts_forward(mtts_handle* h, int slot, int use_fast_weights, int train_mode);
+/* Same forward with the reference's p/e/d_control arguments.  A batch set without mels/durations runs
+ * free-running (modules.py:132-137): durations = clamp(round(exp(logd)-1)*d_control, 0) on device, ONE
+ * device->host copy per task sizes the frame spaces (the reference syncs once per phoneme), then the
+ * decoder / PostNet run on the predicted length.  train_mode != 0 reproduces the reference's
+ * post-adaptation synthesis (clone left in .train(): batch-stat BatchNorm, truncation at max_seq_len). */
+int mtts_synthesize(mtts_handle* h, int slot, int use_fast_weights, int train_mode, float p_control, float e_control,
+                    float d_control);
+/* d_rounded [B][S_max] (duration_rounded of the 10-tuple), mel_lens [B], T_cap = width of mel / mel_post rows */
+int mtts_get_durations(mtts_handle* h, int slot, int task, float* d_rounded, int64_t* mel_lens, int* t_cap);
 /* copy the outputs of task `task` to host: mel, mel_post [B][T_cap][n_mel] (T_cap = min(T_max, max_seq_len));
  * p, e, logd [B][S_max].  Any pointer may be NULL. */
 int mtts_get_outputs(mtts_handle* h, int slot, int task, float* mel, float* mel_post, float* p, float* e, float* logd);
@@ -99,6 +108,9 @@ int mtts_backward(mtts_handle* h, int slot, int use_fast_weights, float scale, i
  * be NULL (then nothing synchronises). ------------------------------------------------------------ */
 int mtts_meta_grad(mtts_handle* h, int steps, float inner_lr, float grad_scale, int second_order,
                    float* qry_losses_host /* [n_tasks][6] */, float* sup_losses_host /* [steps][n_tasks][6] */);
+/* BaseAdaptorSystem.adapt alone (few-shot test loop, base_adaptor.py:155-189): `steps` first-order inner steps
+ * on slot 0; reset != 0 starts from a fresh clone of theta, else continues on the current fast weights. */
+int mtts_adapt(mtts_handle* h, int steps, float inner_lr, int reset, float* sup_losses_host /* [steps][n_tasks][6] */);
 /* BaselineSystem.training_step (lightning/systems/baseline.py:25-36): plain gradient of slot's batches */
 int mtts_plain_grad(mtts_handle* h, int slot, float grad_scale, float* losses_host);
 /* device pointer of the outer gradient (mtts_param_total floats) — the buffer the host all-reduces

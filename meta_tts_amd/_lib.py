@@ -50,6 +50,9 @@ EXPORTS = {
     "mtts_get_bn_buffers": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "mtts_set_batches": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Batch), C.POINTER(Batch), C.c_int]),
     "mtts_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mtts_synthesize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]),
+    "mtts_get_durations": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "mtts_adapt": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "mtts_get_outputs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_loss": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mtts_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]),

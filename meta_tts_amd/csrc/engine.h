@@ -98,12 +98,21 @@ public:
     long long word_emb, pitch_emb, energy_emb, mel_w, mel_b, spk_table;
 
     // ---------------- plans -----------------------------------------------------------
+    struct TaskIn {  // host copy of one batch (the caller's 12-tuple memory is only borrowed during set_batches)
+        int B = 0, S = 0, T_max = 0;
+        bool has_targets = false;
+        std::vector<long long> texts, src_lens, mel_lens, durations;
+        std::vector<float> pitches, energies;
+        const float* mels = nullptr;
+        std::vector<int> spk_ids;
+    };
     struct Plan {
         int tasks = 0;
         std::vector<int> hB, hSmax, hTcap, hMp, hMf, hMr;
         int maxMp = 0, maxMf = 0, maxMr = 0, maxB = 0, enc_maxL = 0, dec_maxL = 0, n_enc_groups = 0, n_dec_groups = 0;
         int average_spk = 0;
-        bool has_targets = false;
+        bool has_targets = false, frames_ready = false;
+        std::vector<TaskIn> in;
         double sum_nP = 0, sum_nF = 0, sum_attn_p = 0, sum_attn_f = 0;
         long long sumMp = 0, sumMf = 0, sumMr = 0, sumLp = 0, sumLf = 0;  // total rows over tasks (tile heuristic)  // valid rows / sum L^2 (algorithmic flop accounting)
         int* meta = nullptr;
@@ -381,7 +390,7 @@ public:
     int init(const ModelCfg& c, int max_tasks, int max_B, int max_S, int max_T) {
         cfg = c;
         cap_tasks = max_tasks; cap_B = max_B; cap_S = max_S; cap_T = max_T;
-        cap_Tc = std::min(max_T, cfg.max_seq_len);
+        cap_Tc = max_T;  // eval-mode synthesis may exceed max_seq_len (Models.py:145-152 extends the table)
         if (cfg.d_model % 4 || cfg.d_ff % 16 || cfg.vp_filter % 16 || cfg.n_mel % 16 || cfg.postnet_dim % 16 ||
             cfg.d_model % 16 || cfg.d_model > 1024 || cfg.vp_filter > 1024 || cfg.postnet_dim > 1024 ||
             (cfg.d_model / cfg.enc_heads) % 16 || (cfg.d_model / cfg.dec_heads) % 16 || cfg.k1 / 2 > G ||
@@ -534,17 +543,64 @@ public:
         return 0;
     }
 
-    // Build the row spaces of `tasks` batches into plan slot `slot` and upload inputs/targets.
-    // spk_override (optional, per task): ids whose table rows are averaged (query pass of MAML).
+    // Copy `tasks` host batches into plan slot `slot` and build its row spaces.  Teacher-forced batches
+    // (durations given) get all three spaces now; free-running batches (no durations) get the phoneme
+    // space only — forward() sizes the frame spaces once the predicted durations are known.
+    // spk_from (optional, per task): ids whose table rows are averaged (query pass of MAML).
     int set_batches(int slot, int tasks, const HostBatch* hb, const HostBatch* spk_from, int average_spk) {
         if (tasks < 1 || tasks > cap_tasks) { set_error("task count exceeds capacity"); return -1; }
         Plan& p = plans[slot];
         p.tasks = tasks;
         p.average_spk = average_spk;
+        p.in.assign(tasks, TaskIn());
+        bool any_tf = false, any_fr = false;
+        for (int t = 0; t < tasks; ++t) {
+            const HostBatch& b = hb[t];
+            TaskIn& in = p.in[t];
+            if (b.B < 1 || b.B > cap_B || b.S_max < 1 || b.S_max > cap_S) { set_error("batch exceeds engine capacity (B or S_max)"); return -1; }
+            in.B = b.B; in.S = b.S_max; in.T_max = b.T_max;
+            in.has_targets = b.durations && b.mel_lens && b.mels && b.pitches && b.energies;
+            if (!in.has_targets && (b.durations || b.mels)) { set_error("teacher-forced batches need mels, mel_lens, pitches, energies, durations"); return -1; }
+            (in.has_targets ? any_tf : any_fr) = true;
+            const size_t BS = (size_t)b.B * b.S_max;
+            in.texts.assign(b.texts, b.texts + BS);
+            in.src_lens.assign(b.src_lens, b.src_lens + b.B);
+            for (int i = 0; i < b.B; ++i)
+                if (in.src_lens[i] < 1 || in.src_lens[i] > b.S_max) { set_error("src_len out of range"); return -1; }
+            if (in.has_targets) {
+                if (b.T_max < 1 || b.T_max > cap_T) { set_error("batch exceeds engine capacity (T_max)"); return -1; }
+                in.pitches.assign(b.pitches, b.pitches + BS);
+                in.energies.assign(b.energies, b.energies + BS);
+                in.durations.assign(b.durations, b.durations + BS);
+                in.mel_lens.assign(b.mel_lens, b.mel_lens + b.B);
+                in.mels = b.mels;
+            }
+            const HostBatch& sb = spk_from ? spk_from[t] : b;
+            if (sb.B > cap_B) { set_error("speaker id list exceeds capacity"); return -1; }
+            in.spk_ids.assign(cap_B + 1, 0);
+            for (int i = 0; i < sb.B; ++i) {
+                if (sb.speakers[i] < 0 || sb.speakers[i] >= cfg.n_speaker) { set_error("speaker id out of range"); return -1; }
+                in.spk_ids[i] = (int)sb.speakers[i];
+            }
+            in.spk_ids[cap_B] = sb.B;
+            if (!average_spk && sb.B != b.B) { set_error("speaker id count != batch size"); return -1; }
+        }
+        if (any_tf && any_fr) { set_error("cannot mix teacher-forced and free-running batches in one slot"); return -1; }
+        p.has_targets = any_tf;
+        const int rc = build_plan(slot, any_tf, true);
+        for (auto& in : p.in) in.mels = nullptr;  // caller memory: valid during this call only
+        return rc;
+    }
+
+    // (Re)build the row spaces of plan `slot` from p.in.  with_frames: durations / mel_lens are known.
+    // truncate: frames beyond max_seq_len are dropped (Decoder in training mode, Models.py:154-162).
+    int build_plan(int slot, bool with_frames, bool truncate) {
+        Plan& p = plans[slot];
+        const int tasks = p.tasks;
         p.hB.assign(tasks, 0); p.hSmax.assign(tasks, 0); p.hTcap.assign(tasks, 0);
         p.hMp.assign(tasks, 0); p.hMf.assign(tasks, 0); p.hMr.assign(tasks, 0);
         p.maxMp = p.maxMf = p.maxMr = p.maxB = p.enc_maxL = p.dec_maxL = 0;
-        p.has_targets = true;
+        p.frames_ready = with_frames;
         p.sum_nP = p.sum_nF = p.sum_attn_p = p.sum_attn_f = 0;
         p.sumMp = p.sumMf = p.sumMr = p.sumLp = p.sumLf = 0;
         std::vector<int> meta((size_t)tasks * META_STRIDE, 0);
@@ -552,32 +608,30 @@ public:
         std::vector<GemmGroupDesc> etab[6], dtab[6];
         const int d = cfg.d_model;
         for (int t = 0; t < tasks; ++t) {
-            const HostBatch& b = hb[t];
-            if (b.B < 1 || b.B > cap_B || b.S_max > cap_S) { set_error("batch exceeds engine capacity (B or S_max)"); return -1; }
-            const bool tgt = b.durations && b.mel_lens && b.mels && b.pitches && b.energies;
-            if (!tgt) { set_error("teacher-forced batches need mels, mel_lens, pitches, energies, durations"); return -1; }
-            const int B = b.B, S = b.S_max;
-            const int Tcap = std::min(b.T_max, cfg.max_seq_len);
-            if (b.T_max > cap_T) { set_error("batch exceeds engine capacity (T_max)"); return -1; }
+            const TaskIn& b = p.in[t];
+            const int B = b.B, S = b.S;
+            const int Tcap = with_frames ? (truncate ? std::min(b.T_max, cfg.max_seq_len) : b.T_max) : 0;
+            if (with_frames && (Tcap < 1 || Tcap > cap_T)) { set_error("mel length exceeds engine capacity (T_max)"); return -1; }
             const int Mp = G + B * (S + G);
             std::vector<int> row_b(Mp, 0), row_t(Mp, -1), tok(Mp, 0), first(Mp, 0), count(Mp, 0), dur(Mp, 0);
             std::vector<unsigned char> valid(Mp, 0), inrect(Mp, 0);
             std::vector<float> pt(Mp, 0.f), et(Mp, 0.f);
-            std::vector<int> pseg_s(B), pseg_l(B), fseg_s(B), fseg_l(B), flen(B);
+            std::vector<int> pseg_s(B), pseg_l(B), fseg_s(B, 0), fseg_l(B, 0), flen(B, 0);
             // frame space: packed valid frames
             int foff = G, nP = 0, nF = 0;
-            std::vector<int> foffs(B);
-            for (int i = 0; i < B; ++i) {
-                const int ml = (int)std::min<long long>(b.mel_lens[i], Tcap);
-                flen[i] = ml; foffs[i] = foff; fseg_s[i] = foff; fseg_l[i] = ml;
-                foff += ml + G;
-                nF += ml;
-            }
-            const int Mf = foff, Mr = G + B * (Tcap + G);
+            std::vector<int> foffs(B, 0);
+            if (with_frames)
+                for (int i = 0; i < B; ++i) {
+                    const int ml = (int)std::max<long long>(0, std::min<long long>(b.mel_lens[i], Tcap));
+                    flen[i] = ml; foffs[i] = foff; fseg_s[i] = foff; fseg_l[i] = ml;
+                    foff += ml + G;
+                    nF += ml;
+                }
+            const int Mf = with_frames ? foff : 0, Mr = with_frames ? G + B * (Tcap + G) : 0;
             if (Mf > capMf || Mr > capMr || Mp > capMp) { set_error("row space exceeds capacity"); return -1; }
             std::vector<int> f_row_b(Mf, 0), f_row_t(Mf, -1), f_src(Mf, -1), f2r(Mf, -1), r2f(Mr, -1);
             std::vector<unsigned char> f_valid(Mf, 0), r_valid(Mr, 0), r_inrect(Mr, 0);
-            std::vector<float> mel_t((size_t)Mr * cfg.n_mel, 0.f);
+            std::vector<float> mel_t(b.mels ? (size_t)Mr * cfg.n_mel : 0, 0.f);
             long long soff[2] = {0, 0};  // running offsets inside this task's score buffers (enc, dec)
             for (int i = 0; i < B; ++i) {
                 const int sl = (int)b.src_lens[i];
@@ -589,26 +643,26 @@ public:
                     const bool v = s < sl;
                     valid[r] = v;
                     tok[r] = v ? (int)b.texts[(size_t)i * S + s] : 0;
-                    pt[r] = b.pitches[(size_t)i * S + s];
-                    et[r] = b.energies[(size_t)i * S + s];
+                    if (!b.pitches.empty()) { pt[r] = b.pitches[(size_t)i * S + s]; et[r] = b.energies[(size_t)i * S + s]; }
+                    if (!with_frames) { if (v) ++nP; continue; }
                     long long dd = b.durations[(size_t)i * S + s];
                     if (dd < 0) dd = 0;
                     dur[r] = (int)dd;
                     // frames of this phoneme inside the (possibly truncated) frame window
-                    const int lo = std::min(cum, flen[i]), hi = std::min(cum + (int)dd, flen[i]);
+                    const int lo = std::min(cum, flen[i]), hi = (int)std::min<long long>(cum + dd, flen[i]);
                     first[r] = foffs[i] + lo; count[r] = hi - lo;
                     for (int f = lo; f < hi; ++f) f_src[foffs[i] + f] = r;
-                    cum += (int)dd;
+                    cum = (int)std::min<long long>(cum + dd, 1 << 28);
                     if (v) ++nP;
                 }
                 for (int f = 0; f < flen[i]; ++f) {
                     const int fr = foffs[i] + f, rr = G + i * (Tcap + G) + f;
                     f_row_b[fr] = i; f_row_t[fr] = f; f_valid[fr] = 1; f2r[fr] = rr; r2f[rr] = fr; r_valid[rr] = 1;
-                    memcpy(&mel_t[(size_t)rr * cfg.n_mel], &b.mels[((size_t)i * b.T_max + f) * cfg.n_mel], cfg.n_mel * sizeof(float));
+                    if (b.mels) memcpy(&mel_t[(size_t)rr * cfg.n_mel], &b.mels[((size_t)i * b.T_max + f) * cfg.n_mel], cfg.n_mel * sizeof(float));
                 }
                 for (int f = 0; f < Tcap; ++f) r_inrect[G + i * (Tcap + G) + f] = 1;
                 // attention groups (valid rows only)
-                for (int which = 0; which < 2; ++which) {
+                for (int which = 0; which < (with_frames ? 2 : 1); ++which) {
                     const int H = which ? cfg.dec_heads : cfg.enc_heads, dk = d / H;
                     const int L = which ? flen[i] : sl, ro = which ? foffs[i] : G + i * (S + G);
                     std::vector<AttnSeq>& sq = which ? dseq : eseq;
@@ -651,21 +705,12 @@ public:
                 upload(p.f_seg_start, (long long)cap_B, t, fseg_s) || upload(p.f_seg_len, (long long)cap_B, t, fseg_l) ||
                 upload(p.f_row_b, row_ts_f, t, f_row_b) || upload(p.f_row_t, row_ts_f, t, f_row_t) || upload(p.f_src, row_ts_f, t, f_src) ||
                 upload(p.f2r, row_ts_f, t, f2r) || upload(p.f_valid, row_ts_f, t, f_valid) || upload(p.r2f, row_ts_r, t, r2f) ||
-                upload(p.r_valid, row_ts_r, t, r_valid) || upload(p.r_inrect, row_ts_r, t, r_inrect))
+                upload(p.r_valid, row_ts_r, t, r_valid) || upload(p.r_inrect, row_ts_r, t, r_inrect) ||
+                upload(p.spk_ids, (long long)cap_B + 1, t, b.spk_ids))
                 return -1;
-            HIP_CHECK(hipMemcpyAsync(p.mel_tgt + (long long)t * ((long long)(capMr + 2 * G) * cfg.n_mel), mel_t.data(),
-                                     mel_t.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-            // speaker ids (+ count at index cap_B)
-            const HostBatch& sb = spk_from ? spk_from[t] : b;
-            if (sb.B > cap_B) { set_error("speaker id list exceeds capacity"); return -1; }
-            std::vector<int> ids(cap_B + 1, 0);
-            for (int i = 0; i < sb.B; ++i) {
-                if (sb.speakers[i] < 0 || sb.speakers[i] >= cfg.n_speaker) { set_error("speaker id out of range"); return -1; }
-                ids[i] = (int)sb.speakers[i];
-            }
-            ids[cap_B] = sb.B;
-            if (!average_spk && sb.B != B) { set_error("speaker id count != batch size"); return -1; }
-            if (upload(p.spk_ids, (long long)cap_B + 1, t, ids)) return -1;
+            if (!mel_t.empty())
+                HIP_CHECK(hipMemcpyAsync(p.mel_tgt + (long long)t * ((long long)(capMr + 2 * G) * cfg.n_mel), mel_t.data(),
+                                         mel_t.size() * sizeof(float), hipMemcpyHostToDevice, stream));
             HIP_CHECK(hipStreamSynchronize(stream));  // host vectors go out of scope
         }
         HIP_CHECK(hipMemcpyAsync(p.meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -679,6 +724,9 @@ public:
         HIP_CHECK(hipStreamSynchronize(stream));
         return 0;
     }
+
+    // free-running: predicted durations (device) -> host, then size and build the frame spaces
+    // (modules.py:132-137,167-190: the reference reads every duration with .item(); here one copy per task)
 
     // =================================================================================
     // pass context + small launch helpers
@@ -927,17 +975,21 @@ public:
         MTTS_LAUNCH(add_rowvec_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
                     (const float*)x.p, x.ts, (const float*)spk.p, spk.ts, (const int*)p.p_row_b, (const unsigned char*)p.p_inrect,
                     row_ts_p, x0.p, x0.ts, d);
-        // variance adaptor (teacher-forced: targets select the embeddings)
+        // variance adaptor: targets select the embeddings when given, else the (controlled) predictions
         pred_fwd(ps, durP, durB, x0);
         pred_fwd(ps, pitP, pitB, x0);
         TS pe = W(ps, pitch_emb), ee = W(ps, energy_emb);
+        const bool tf = p.has_targets;
         MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
-                    (const float*)x0.p, x0.ts, (const float*)p.p_pitch_t, row_ts_p, 1.f, (const float*)pitch_bins, cfg.n_bins - 1,
-                    (const float*)pe.p, pe.ts, (const unsigned char*)p.p_inrect, row_ts_p, pidx, x1.p, x1.ts, d);
+                    (const float*)x0.p, x0.ts, tf ? (const float*)p.p_pitch_t : (const float*)pitB.out.p, tf ? row_ts_p : pitB.out.ts,
+                    tf ? 1.f : ps.p_control, (const float*)pitch_bins, cfg.n_bins - 1, (const float*)pe.p, pe.ts,
+                    (const unsigned char*)p.p_inrect, row_ts_p, pidx, x1.p, x1.ts, d);
         pred_fwd(ps, eneP, eneB, x1);
         MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
-                    (const float*)x1.p, x1.ts, (const float*)p.p_energy_t, row_ts_p, 1.f, (const float*)energy_bins, cfg.n_bins - 1,
-                    (const float*)ee.p, ee.ts, (const unsigned char*)p.p_inrect, row_ts_p, eidx, x2.p, x2.ts, d);
+                    (const float*)x1.p, x1.ts, tf ? (const float*)p.p_energy_t : (const float*)eneB.out.p, tf ? row_ts_p : eneB.out.ts,
+                    tf ? 1.f : ps.e_control, (const float*)energy_bins, cfg.n_bins - 1, (const float*)ee.p, ee.ts,
+                    (const unsigned char*)p.p_inrect, row_ts_p, eidx, x2.p, x2.ts, d);
+        if (!tf && frames_from_predictions_impl(ps)) return -1;
         // length regulator + speaker + decoder positions
         MTTS_LAUNCH(length_regulate_fwd_kernel, row_grid(p.maxMf, nt), dim3(256), stream, (const int*)p.meta, (const float*)x2.p,
                     x2.ts, (const int*)p.f_src, (const int*)p.f_row_b, (const int*)p.f_row_t, row_ts_f, (const float*)spk.p, spk.ts,
@@ -995,6 +1047,37 @@ public:
         return 0;
     }
 
+    int frames_from_predictions_impl(const Pass& ps) {
+        Plan& p = *ps.pl;
+        const int nt = p.tasks;
+        MTTS_LAUNCH(duration_round_kernel, dim3(4, 1, nt), dim3(256), stream, (const int*)p.meta, (const float*)durB.out.p, durB.out.ts,
+                    ps.d_control, (const unsigned char*)p.p_valid, row_ts_p, d_rounded.p);
+        HIP_CHECK(hipStreamSynchronize(stream));
+        const int slot = (int)(&p - &plans[0]);
+        for (int t = 0; t < nt; ++t) {
+            TaskIn& in = p.in[t];
+            std::vector<float> dr(p.hMp[t]);
+            HIP_CHECK(hipMemcpy(dr.data(), d_rounded.p + (long long)t * d_rounded.ts, dr.size() * sizeof(float), hipMemcpyDeviceToHost));
+            in.durations.assign((size_t)in.B * in.S, 0);
+            in.mel_lens.assign(in.B, 0);
+            long long tmax = 0;
+            for (int i = 0; i < in.B; ++i) {
+                long long tot = 0;
+                for (int s2 = 0; s2 < in.S; ++s2) {
+                    const long long dd = std::max<long long>((long long)dr[G + i * (in.S + G) + s2], 0);  // max(int(expand_size), 0)
+                    in.durations[(size_t)i * in.S + s2] = dd;
+                    tot += dd;
+                }
+                in.mel_lens[i] = tot;
+                tmax = std::max(tmax, tot);
+            }
+            if (tmax < 1) { set_error("free-running synthesis produced no frames (all predicted durations are 0)"); return -1; }
+            if (tmax > cap_T) { set_error("predicted mel length exceeds engine capacity (T_max)"); return -1; }
+            in.T_max = (int)tmax;
+        }
+        return build_plan(slot, true, ps.train);
+    }
+
     LossArgs loss_args(const Plan& p) const {
         LossArgs a;
         a.mel = mel.p; a.mel_post = mel_post.p; a.mel_tgt = p.mel_tgt;
@@ -1009,6 +1092,7 @@ public:
     // losses_out (device, [tasks][6]) of the last forward
     int loss(const Pass& ps, float* losses_out) {
         const Plan& p = *ps.pl;
+        if (!p.has_targets) { set_error("loss needs a teacher-forced batch (targets)"); return -1; }
         if (durB.out.ts != row_ts_p + 2 * G || pitB.out.ts != durB.out.ts) { set_error("internal: prediction stride"); return -1; }
         LossArgs a = loss_args(p);
         MTTS_LAUNCH(loss_partial_kernel, dim3(kLossBlocks, 1, p.tasks), dim3(256), stream, (const int*)p.meta, a, loss_partial);
@@ -1025,6 +1109,7 @@ public:
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, nt = p.tasks, nm = cfg.n_mel;
         if (!ps.train) { set_error("backward needs a train-mode forward (batch statistics)"); return -1; }
+        if (!p.has_targets) { set_error("backward needs a teacher-forced batch (targets)"); return -1; }
         LossArgs a = loss_args(p);
         // prediction strides in the phoneme space: the [Mp] vectors were allocated as rows(capMp, 1)
         MTTS_LAUNCH(loss_grad_kernel, dim3(kLossBlocks, 1, nt), dim3(256), stream, (const int*)p.meta, a, scale, gRm.p, gRp.p,
@@ -1142,6 +1227,27 @@ public:
         if (backward(pq, grad_scale, true)) return -1;
         MTTS_LAUNCH(sum_tasks_kernel, dim3(blocks_for(n_total / 4)), dim3(256), stream, (const float*)grad, n_total, nt, 1.f, outer,
                     n_total / 4);
+        return 0;
+    }
+
+    // Inner loop only (few-shot test loop, base_adaptor.py:170-173: cumulative first-order adaptation on the
+    // same clone).  reset: start from theta (learner = self.learner.clone()), else continue on the fast weights.
+    int adapt(int steps, float inner_lr, bool reset, float* sup_losses_out) {
+        Plan& sp = plans[0];
+        if (sp.tasks < 1 || !sp.has_targets) { set_error("support plan not set"); return -1; }
+        const int nt = sp.tasks;
+        if (reset && n_adapt > 0)
+            MTTS_LAUNCH(broadcast_kernel, dim3(blocks_for(n_adapt / 4), 1, nt), dim3(256), stream,
+                        (const float*)(theta + adapt_start), fast, n_adapt / 4, n_adapt);
+        Pass ps{&sp, true, true};
+        for (int s2 = 0; s2 < steps; ++s2) {
+            if (forward(ps)) return -1;
+            if (sup_losses_out && loss(ps, sup_losses_out + (long long)s2 * nt * 6)) return -1;
+            if (backward(ps, 1.f, false)) return -1;
+            if (n_adapt > 0)
+                MTTS_LAUNCH(sgd_update_kernel, dim3(blocks_for(n_adapt / 4), 1, nt), dim3(256), stream, fast,
+                            (const float*)(grad + adapt_start), n_adapt / 4, inner_lr, n_adapt, n_total);
+        }
         return 0;
     }
 

@@ -7,6 +7,9 @@
 
 using namespace mtts;
 
+static int copy_losses_impl(Engine& e, const float* dev, float* host, int n);
+static int copy_losses(Engine& e, const float* dev, float* host, int n) { return copy_losses_impl(e, dev, host, n); }
+
 struct mtts_handle {
     Engine eng;
     float* sup_losses_dev = nullptr;
@@ -121,6 +124,32 @@ int mtts_forward(mtts_handle* h, int slot, int use_fast, int train) {
     return e.forward(ps);
 }
 
+int mtts_synthesize(mtts_handle* h, int slot, int use_fast, int train, float p_control, float e_control, float d_control) {
+    Engine& e = h->eng;
+    if (slot < 0 || slot > 1 || e.plans[slot].tasks < 1) { e.set_error("plan not set"); return -1; }
+    Engine::Pass ps{&e.plans[slot], use_fast != 0, train != 0, p_control, e_control, d_control};
+    return e.forward(ps);
+}
+
+int mtts_get_durations(mtts_handle* h, int slot, int task, float* d_rounded, int64_t* mel_lens, int* t_cap) {
+    Engine& e = h->eng;
+    if (slot < 0 || slot > 1 || task < 0 || task >= e.plans[slot].tasks) { e.set_error("bad slot/task"); return -1; }
+    const Engine::Plan& pl = e.plans[slot];
+    if (!pl.frames_ready) { e.set_error("durations are not known yet (run mtts_forward / mtts_synthesize first)"); return -1; }
+    const Engine::TaskIn& in = pl.in[task];
+    if (d_rounded) for (size_t i = 0; i < in.durations.size(); ++i) d_rounded[i] = (float)in.durations[i];
+    if (mel_lens) for (int i = 0; i < in.B; ++i) mel_lens[i] = std::min<long long>(in.mel_lens[i], pl.hTcap[task]);
+    if (t_cap) *t_cap = pl.hTcap[task];
+    return 0;
+}
+
+int mtts_adapt(mtts_handle* h, int steps, float inner_lr, int reset, float* sup_losses_host) {
+    Engine& e = h->eng;
+    if (steps < 0 || steps > h->sup_losses_cap) { e.set_error("too many inner steps"); return -1; }
+    if (e.adapt(steps, inner_lr, reset != 0, h->sup_losses_dev)) return -1;
+    return copy_losses(e, h->sup_losses_dev, sup_losses_host, steps * e.plans[0].tasks * 6);
+}
+
 int mtts_get_outputs(mtts_handle* h, int slot, int task, float* mel, float* mel_post, float* p, float* en, float* logd) {
     Engine& e = h->eng;
     if (slot < 0 || slot > 1 || task < 0 || task >= e.plans[slot].tasks) { e.set_error("bad slot/task"); return -1; }
@@ -139,7 +168,7 @@ int mtts_get_outputs(mtts_handle* h, int slot, int task, float* mel, float* mel_
     return 0;
 }
 
-static int copy_losses(Engine& e, const float* dev, float* host, int n) {
+static int copy_losses_impl(Engine& e, const float* dev, float* host, int n) {
     if (!host) return 0;
     if (hipStreamSynchronize(e.stream) != hipSuccess) return -1;
     return hipMemcpy(host, dev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;

@@ -132,21 +132,27 @@ class Engine:
 
     # ---- batches -----------------------------------------------------------------
     def _cbatch(self, b, keep):
-        """12-tuple (collate.py:47-60) of numpy arrays / torch CPU tensors -> mtts_batch"""
+        """12-tuple (collate.py:47-60) of numpy arrays / torch CPU tensors -> mtts_batch.  A tuple whose
+        mels / durations are None (or that stops after max_src_len, i.e. ``batch[:6]``) is a free-running batch."""
         def np_(x, dt):
             if hasattr(x, "detach"):
                 x = x.detach().cpu().numpy()
             a = _arr(x, dt)
             keep.append(a)
             return a
+        b = tuple(b) + (None,) * (12 - len(b))
         spk, texts, src_lens = np_(b[2], np.int64), np_(b[3], np.int64), np_(b[4], np.int64)
-        mels, mel_lens = np_(b[6], np.float32), np_(b[7], np.int64)
-        p, e, d = np_(b[9], np.float32), np_(b[10], np.float32), np_(b[11], np.int64)
         cb = _lib.Batch()
-        cb.B, cb.S_max, cb.T_max = int(texts.shape[0]), int(b[5]), int(b[8])
-        assert texts.shape == (cb.B, cb.S_max) and mels.shape == (cb.B, cb.T_max, self.dims.n_mel), (texts.shape, mels.shape)
-        for f, a in (("speakers", spk), ("texts", texts), ("src_lens", src_lens), ("mels", mels), ("mel_lens", mel_lens),
-                     ("pitches", p), ("energies", e), ("durations", d)):
+        cb.B, cb.S_max = int(texts.shape[0]), int(b[5])
+        assert texts.shape == (cb.B, cb.S_max), texts.shape
+        fields = [("speakers", spk), ("texts", texts), ("src_lens", src_lens)]
+        if b[11] is not None and b[6] is not None:
+            mels, mel_lens = np_(b[6], np.float32), np_(b[7], np.int64)
+            p, e, d = np_(b[9], np.float32), np_(b[10], np.float32), np_(b[11], np.int64)
+            cb.T_max = int(b[8])
+            assert mels.shape == (cb.B, cb.T_max, self.dims.n_mel), mels.shape
+            fields += [("mels", mels), ("mel_lens", mel_lens), ("pitches", p), ("energies", e), ("durations", d)]
+        for f, a in fields:
             setattr(cb, f, a.ctypes.data_as(C.c_void_p))
         return cb
 
@@ -160,19 +166,41 @@ class Engine:
             sarr = (_lib.Batch * n)(*[self._cbatch(b, keep) for b in spk_from])
         self._ck(self.lib.mtts_set_batches(self.h, slot, n, arr, sarr, int(average_spk)))
         self.n_tasks[slot] = n
-        self.batch_shapes[slot] = [(int(b[3].shape[0]), int(b[5]), min(int(b[8]), self.dims.max_seq_len)) for b in batches]
+        self.batch_shapes[slot] = [(int(np.shape(b[3])[0]), int(b[5])) for b in batches]
 
     # ---- compute -----------------------------------------------------------------
     def forward(self, slot: int = 0, use_fast: bool = False, train: bool = False):
         self._ck(self.lib.mtts_forward(self.h, slot, int(use_fast), int(train)))
 
+    def synthesize(self, slot: int = 0, use_fast: bool = False, train: bool = False, p_control: float = 1.0,
+                   e_control: float = 1.0, d_control: float = 1.0):
+        self._ck(self.lib.mtts_synthesize(self.h, slot, int(use_fast), int(train), p_control, e_control, d_control))
+
+    def durations(self, slot: int = 0, task: int = 0):
+        B, S = self.batch_shapes[slot][task]
+        d = np.empty((B, S), np.float32)
+        ml = np.empty((B,), np.int64)
+        tc = C.c_int()
+        self._ck(self.lib.mtts_get_durations(self.h, slot, task, d.ctypes.data_as(C.c_void_p), ml.ctypes.data_as(C.c_void_p), C.byref(tc)))
+        return d, ml, int(tc.value)
+
     def outputs(self, slot: int = 0, task: int = 0) -> Dict[str, np.ndarray]:
-        B, S, T = self.batch_shapes[slot][task]
+        B, S = self.batch_shapes[slot][task]
+        d_rounded, mel_lens, T = self.durations(slot, task)
         nm = self.dims.n_mel
         o = {"mel": np.empty((B, T, nm), np.float32), "mel_post": np.empty((B, T, nm), np.float32),
              "p": np.empty((B, S), np.float32), "e": np.empty((B, S), np.float32), "logd": np.empty((B, S), np.float32)}
         self._ck(self.lib.mtts_get_outputs(self.h, slot, task, *[o[k].ctypes.data_as(C.c_void_p) for k in ("mel", "mel_post", "p", "e", "logd")]))
+        o["d_rounded"], o["mel_lens"] = d_rounded, mel_lens
         return o
+
+    def adapt(self, steps: int, inner_lr: float, reset: bool = True, fetch_losses: bool = True):
+        if fetch_losses:
+            s = np.empty((steps, self.n_tasks[0], 6), np.float32)
+            self._ck(self.lib.mtts_adapt(self.h, steps, inner_lr, int(reset), s.ctypes.data_as(C.c_void_p)))
+            return s
+        self._ck(self.lib.mtts_adapt(self.h, steps, inner_lr, int(reset), None))
+        return None
 
     def loss(self, slot: int = 0) -> np.ndarray:
         out = np.empty((self.n_tasks[slot], 6), np.float32)

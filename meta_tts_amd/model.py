@@ -43,8 +43,8 @@ def _read_preprocessed(preprocess_config) -> tuple:
 
 
 class FastSpeech2:
-    """lightning/model/fastspeech2.py:16 — engine-backed.  ``forward`` is teacher-forced (targets
-    given); free-running synthesis is the C5 row of SURVEY.md section 8 (not built yet)."""
+    """lightning/model/fastspeech2.py:16 — engine-backed.  ``forward`` is teacher-forced when duration targets
+    and mels are given, free-running otherwise (predicted durations size the output)."""
 
     def __init__(self, preprocess_config, model_config, algorithm_config, *, max_tasks: int = 1, max_batch: int = 16,
                  max_src_len: int = 128, max_mel_len: Optional[int] = None, device: int = 0, lib_path: Optional[str] = None):
@@ -93,24 +93,31 @@ class FastSpeech2:
     def forward(self, speaker_args, texts, src_lens, max_src_len, mels=None, mel_lens=None, max_mel_len=None,
                 p_targets=None, e_targets=None, d_targets=None, p_control=1.0, e_control=1.0, d_control=1.0,
                 *, slot: int = 0, use_fast: bool = False, spk_from=None, average_spk_emb: bool = False):
-        if d_targets is None or mels is None:
-            raise NotImplementedError("free-running synthesis (no duration targets) is not built yet (SURVEY.md 8: C5)")
         batch = (None, None, speaker_args, texts, src_lens, max_src_len, mels, mel_lens, max_mel_len, p_targets, e_targets, d_targets)
         self.engine.set_batches(slot, [batch], spk_from=[spk_from] if spk_from is not None else None, average_spk=average_spk_emb)
-        self.engine.forward(slot, use_fast=use_fast, train=self.training)
-        return self._predictions(slot, 0, batch)
+        if d_targets is None or mels is None:  # free-running (fastspeech2.py forward without targets; modules.py:132-137)
+            self.engine.synthesize(slot, use_fast=use_fast, train=self.training, p_control=p_control, e_control=e_control,
+                                   d_control=d_control)
+        else:
+            self.engine.forward(slot, use_fast=use_fast, train=self.training)
+        preds = self._predictions(slot, 0, batch)
+        if d_targets is None or mels is None:  # the reference returns prediction * control (modules.py:86,97)
+            preds[2].mul_(p_control)
+            preds[3].mul_(e_control)
+        return preds
 
     __call__ = forward
 
     def _predictions(self, slot: int, task: int, batch) -> Predictions:
         import torch
         o = self.engine.outputs(slot, task)
-        B, S, T = self.engine.batch_shapes[slot][task]
+        B, S = self.engine.batch_shapes[slot][task]
+        T = o["mel"].shape[1]
         src_lens = torch.as_tensor(np.asarray(batch[4]), dtype=torch.int64)
-        mel_lens = torch.clamp(torch.as_tensor(np.asarray(batch[7]), dtype=torch.int64), max=self.dims.max_seq_len)
+        mel_lens = torch.from_numpy(o["mel_lens"])
         src_masks = torch.arange(S)[None, :] >= src_lens[:, None]
         mel_masks = torch.arange(T)[None, :] >= mel_lens[:, None]
-        d_rounded = torch.as_tensor(np.asarray(batch[11]))
+        d_rounded = torch.as_tensor(np.asarray(batch[11])) if batch[11] is not None else torch.from_numpy(o["d_rounded"])
         p = Predictions((torch.from_numpy(o["mel"]), torch.from_numpy(o["mel_post"]), torch.from_numpy(o["p"]),
                          torch.from_numpy(o["e"]), torch.from_numpy(o["logd"]), d_rounded, src_masks, mel_masks, src_lens, mel_lens))
         p.engine, p.slot, p.task = self.engine, slot, task

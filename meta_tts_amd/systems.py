@@ -116,6 +116,44 @@ class BaseAdaptorSystem(System):
         return self.engine.meta_grad(steps, self.adaptation_lr, scale)
 
 
+    # -- few-shot test loop (base_adaptor.py:136-189) ---------------------------------------------
+    def _forward_learner(self, sup_batch, qry_batch, use_fast: bool, train: bool, teacher_forced: bool):
+        """forward_learner(learner, sup_batch[2], *qry_batch[3:] or [3:6], average_spk_emb=True)"""
+        self.model.train(train)
+        q = tuple(qry_batch) if teacher_forced else tuple(qry_batch[:6])
+        args = q[2:] if teacher_forced else (q[2], q[3], q[4], q[5])
+        return self.model.forward(*args, slot=1, use_fast=use_fast, spk_from=sup_batch, average_spk_emb=True)
+
+    def _test_step(self, batch, batch_idx):
+        """Step 0 with the un-adapted weights in eval mode, then cumulative first-order adaptation in chunks of
+        `adapt.train.steps` up to `adapt.test.steps`; reconstruction (teacher-forced) after every chunk, free-running
+        synthesis at `saving_steps`.  As in the reference the adapted clone stays in train mode."""
+        outputs = {}
+        test_cfg = self.algorithm_config["adapt"]["test"]
+        saving_steps = test_cfg.get("saving_steps", [5, 10, 20, 50, 100])
+        sup_batch, qry_batch = batch[0][0][0], batch[0][1][0]
+        outputs["_batch"] = qry_batch
+        preds = self._forward_learner(sup_batch, qry_batch, use_fast=False, train=False, teacher_forced=True)
+        outputs["step_0"] = {"recon": {"losses": self.loss_func(qry_batch, preds), "output": preds}}
+        outputs["step_0"]["synth"] = {"output": self._forward_learner(sup_batch, qry_batch, False, False, teacher_forced=False)}
+        self.engine.set_batches(0, [sup_batch])
+        first = True
+        for ft_step in range(self.adaptation_steps, self.test_adaptation_steps + 1, self.adaptation_steps):
+            self.engine.adapt(self.adaptation_steps, self.adaptation_lr, reset=first, fetch_losses=False)
+            first = False
+            preds = self._forward_learner(sup_batch, qry_batch, use_fast=True, train=True, teacher_forced=True)
+            outputs[f"step_{ft_step}"] = {"recon": {"losses": self.loss_func(qry_batch, preds), "output": preds}}
+            if ft_step in saving_steps:
+                outputs[f"step_{ft_step}"]["synth"] = {"output": self._forward_learner(sup_batch, qry_batch, True, True, False)}
+        return outputs
+
+    def test_step(self, batch, batch_idx):
+        self._on_meta_batch_start(batch)
+        if self.algorithm_config["adapt"]["test"].get("1-shot", False):
+            raise NotImplementedError("1-shot test mode (base_adaptor.py:139-147) is a later row (SURVEY.md 8(f).2)")
+        return [self._test_step(batch, batch_idx)]
+
+
 class MetaSystem(BaseAdaptorSystem):
     """lightning/systems/meta.py:17"""
 

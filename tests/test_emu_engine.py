@@ -165,3 +165,31 @@ def test_non_default_adapt_modules(emu_lib):
         g = torch.autograd.grad(ql[0], p[n], retain_graph=True)[0].numpy()
         assert np.abs(eng.export(n, 1) - g).max() <= 2e-3 * np.abs(g).max() + 2e-7, n
     eng.close()
+
+
+def test_free_running_synthesis_matches_oracle(emu_lib):
+    """modules.py:132-137 path: predicted durations size the frame spaces (one device->host copy per task);
+    p/e controls; a zero-length utterance; eval and train (post-adaptation) modes."""
+    dims = tiny_dims()
+    params = synth.make_params(dims, 0)
+    params["variance_adaptor.duration_predictor.linear_layer.bias"][:] = 1.2  # some non-zero durations at random init
+    eng = Engine(dims, adapt_modules=[], max_tasks=2, max_B=3, max_S=16, max_T=96, lib_path=emu_lib)
+    eng.load_params(params)
+    b0 = synth.make_batch(3, 3, speaker=2, **_kw(dims)); b1 = synth.make_batch(4, 2, speaker=5, **_kw(dims))
+    p = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
+    for train in (False, True):
+        eng.set_batches(0, [b0[:6], b1[:6]])
+        eng.synthesize(0, train=train, p_control=1.1, e_control=0.9, d_control=1.0)
+        for ti, b in enumerate([b0, b1]):
+            tb = O.to_torch_batch(b)
+            with torch.no_grad():
+                o = O.fs2_forward(p, torch_buffers(dims), *tb[2:6], p_control=1.1, e_control=0.9, n_head=heads(dims),
+                                  max_seq_len=dims.max_seq_len, training=train)
+            out = eng.outputs(0, ti)
+            np.testing.assert_array_equal(out["d_rounded"], o[5].numpy())
+            np.testing.assert_array_equal(out["mel_lens"], o[9].numpy())
+            assert out["mel_post"].shape == tuple(o[1].shape)
+            assert np.abs(out["mel_post"] - o[1].numpy()).max() < 5e-5
+    with pytest.raises(Exception):
+        eng.loss(0)  # no targets
+    eng.close()

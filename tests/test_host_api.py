@@ -66,8 +66,6 @@ def test_forward_signature_and_tuple_layouts(cfgs, emu_lib):
     assert (mel_post - o[1]).abs().max() < 5e-5
     np.testing.assert_allclose([float(x) for x in loss], [float(x) for x in lo], rtol=2e-5)
     assert torch.equal(src_masks, o[6]) and torch.equal(mel_masks, o[7])
-    with pytest.raises(NotImplementedError):
-        sysm.model(*b[2:6])
 
 
 def test_meta_training_step_and_checkpoint_roundtrip(cfgs, emu_lib, tmp_path):
@@ -129,3 +127,47 @@ def test_baseline_step_matches_oracle_gradient(cfgs, emu_lib):
     g = torch.autograd.grad(lo[0], prm["mel_linear.weight"])[0].numpy()
     assert abs(out["loss"] - float(lo[0])) < 1e-4
     assert np.abs(sysm.engine.export("mel_linear.weight", 1) - g).max() < 1e-3 * np.abs(g).max()
+
+
+def test_few_shot_test_step_matches_oracle(cfgs, emu_lib):
+    """base_adaptor.py:155-189 — step 0 (eval), cumulative first-order adaptation in chunks, recon in train mode."""
+    pre, mod, trn, alg = cfgs
+    alg["adapt"]["train"]["steps"] = 2
+    alg["adapt"]["test"]["steps"] = 4
+    alg["adapt"]["test"]["saving_steps"] = [4]
+    alg["adapt"]["task"]["lr"] = 0.01
+    alg["adapt"]["train"]["lr"] = alg["adapt"]["test"]["lr"] = 0.01
+    sysm = _system((pre, mod, trn, alg), emu_lib)
+    dims = sysm.model.dims
+    sup = synth.make_batch(5, 3, speaker=2, vocab=dims.vocab, **_kw(dims.n_mel))
+    qry = synth.make_batch(6, 1, speaker=2, vocab=dims.vocab, **_kw(dims.n_mel))
+    out = sysm.test_step([([sup], [qry])], 0)[0]
+    assert set(out) == {"_batch", "step_0", "step_2", "step_4"}
+    assert "synth" in out["step_0"] and "synth" in out["step_4"] and "synth" not in out["step_2"]
+    # oracle
+    prm = {k: torch.from_numpy(v.copy()) for k, v in synth.make_params(dims, 0).items()}
+    for k, v in prm.items():
+        if not k.endswith(("position_enc", "pitch_bins", "energy_bins")):
+            v.requires_grad_(True)
+    buf = torch_buffers(dims)
+    ts, tq = O.to_torch_batch(sup), O.to_torch_batch(qry)
+    kw = dict(n_head=heads(dims), max_seq_len=dims.max_seq_len)
+    with torch.no_grad():
+        o0 = O.fs2_forward(prm, buf, ts[2], *tq[3:], training=False, average_spk_emb=True, **kw)
+        l0 = O.fs2_loss(tq, o0)
+        s0 = O.fs2_forward(prm, buf, ts[2], *tq[3:6], training=False, average_spk_emb=True, **kw)
+    np.testing.assert_allclose([float(x) for x in out["step_0"]["recon"]["losses"]], [float(x) for x in l0], rtol=5e-5)
+    assert out["step_0"]["synth"]["output"][1].shape == s0[1].shape
+    assert (out["step_0"]["synth"]["output"][1] - s0[1]).abs().max() < 5e-5
+    names = O.adapted_names(prm, alg["adapt"]["modules"])
+    fast = {k: prm[k] for k in names}
+    for chunk in (2, 4):
+        for _ in range(2):
+            cur = dict(prm); cur.update(fast)
+            l = O.fs2_loss(ts, O.fs2_forward(cur, buf, *ts[2:], training=True, **kw))
+            g = torch.autograd.grad(l[0], [fast[k] for k in names])
+            fast = {k: (fast[k] - 0.01 * gi).detach().requires_grad_(True) for k, gi in zip(names, g)}
+        cur = dict(prm); cur.update(fast)
+        with torch.no_grad():
+            lq = O.fs2_loss(tq, O.fs2_forward(cur, buf, ts[2], *tq[3:], training=True, average_spk_emb=True, **kw))
+        np.testing.assert_allclose([float(x) for x in out[f"step_{chunk}"]["recon"]["losses"]], [float(x) for x in lq], rtol=2e-4)
