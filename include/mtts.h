@@ -67,7 +67,8 @@ int mtts_param_info(mtts_handle* h, int index, const char** name, int* ndim, int
 int64_t mtts_param_total(mtts_handle* h);  /* floats in the flat parameter / gradient space */
 int64_t mtts_adapt_start(mtts_handle* h);  /* first float of the adapted (fast-weight) slice */
 int mtts_load_param(mtts_handle* h, const char* name, const float* host, int64_t numel);
-/* which: 0 parameter, 1 outer gradient, 2 per-task gradient, 3 fast weight of `task`, 4 Adam m, 5 Adam v */
+/* which: 0 parameter, 1 outer gradient, 2 per-task gradient, 3 fast weight of `task`, 4 Adam m, 5 Adam v,
+ * 6 Hessian-vector product of `task` (after mtts_hvp_support / a second-order mtts_meta_grad) */
 int mtts_export_param(mtts_handle* h, const char* name, int which, int task, float* host, int64_t numel);
 /* checkpoint resume: which = 0 parameter, 4 Adam exp_avg, 5 Adam exp_avg_sq; and the Adam step count
  * (PL ckpt["optimizer_states"], main.py:63 resume_from_checkpoint) */
@@ -103,11 +104,17 @@ int mtts_loss(mtts_handle* h, int slot, float* losses_host /* [n_tasks][6]: tota
 int mtts_backward(mtts_handle* h, int slot, int use_fast_weights, float scale, int need_encoder);
 
 /* ---- MAML: BaseAdaptorSystem.adapt + meta_learn (lightning/systems/base_adaptor.py:98-124),
- * learn2learn MAML.clone/adapt (lightning/systems/utils.py:17-77).  Produces the outer gradient
+ * learn2learn MAML.clone/adapt (lightning/systems/utils.py:17-77).  second_order = 1 is the reference's training
+ * mode (`first_order = not train`, base_adaptor.py:107): the query gradient is propagated back through the inner
+ * SGD steps by a Hessian-vector-product recursion (forward-over-reverse, csrc/engine_so.inc).  Produces the outer gradient
  * sum_t grad_scale * dL_query,t/dtheta in the handle's outer-gradient buffer.  Host loss pointers may
  * be NULL (then nothing synchronises). ------------------------------------------------------------ */
 int mtts_meta_grad(mtts_handle* h, int steps, float inner_lr, float grad_scale, int second_order,
                    float* qry_losses_host /* [n_tasks][6] */, float* sup_losses_host /* [steps][n_tasks][6] */);
+/* Hessian-vector product of the support loss (slot 0) at the current fast weights in the direction currently held
+ * in the per-task gradient buffer (e.g. after mtts_backward): the building block of the second-order sweep,
+ * exposed for parity tests against torch.autograd (export with which = 6). */
+int mtts_hvp_support(mtts_handle* h);
 /* BaseAdaptorSystem.adapt alone (few-shot test loop, base_adaptor.py:155-189): `steps` first-order inner steps
  * on slot 0; reset != 0 starts from a fresh clone of theta, else continues on the current fast weights. */
 int mtts_adapt(mtts_handle* h, int steps, float inner_lr, int reset, float* sup_losses_host /* [steps][n_tasks][6] */);

@@ -57,6 +57,7 @@ EXPORTS = {
     "mtts_loss": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mtts_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]),
     "mtts_meta_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "mtts_hvp_support": (C.c_int, [C.c_void_p]),
     "mtts_plain_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "mtts_outer_grad_ptr": (C.c_void_p, [C.c_void_p]),
     "mtts_outer_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -28,6 +28,7 @@
 
 #include "gemm.h"
 #include "rowops.h"
+#include "tangent.h"
 
 namespace mtts {
 
@@ -82,6 +83,7 @@ public:
     std::map<std::string, int> by_name;
     long long n_total = 0, adapt_start = 0, n_adapt = 0;
     float *theta = nullptr, *adam_m = nullptr, *adam_v = nullptr, *fast = nullptr, *grad = nullptr, *outer = nullptr;
+    float *fast_cur = nullptr, *grad_dst = nullptr;  // what W() / Gd() resolve to (second-order sweep redirects them)
     float *pos_table = nullptr, *pitch_bins = nullptr, *energy_bins = nullptr;
     int pos_rows = 0;
     std::vector<float*> bn_rm, bn_rv;
@@ -413,6 +415,7 @@ public:
         HIP_CHECK(hipMemset(adam_v, 0, n_total * sizeof(float)));
         HIP_CHECK(hipMemset(outer, 0, n_total * sizeof(float)));
         HIP_CHECK(hipMemset(grad, 0, (size_t)n_total * cap_tasks * sizeof(float)));
+        fast_cur = fast; grad_dst = grad;
         HIP_CHECK(hipMalloc((void**)&norm_partial, 1024 * sizeof(float)));
         HIP_CHECK(hipMalloc((void**)&norm_out, 4 * sizeof(float)));
         // frozen tables: sinusoid positions (Models.py:10-30, float64 math), linear bins
@@ -475,6 +478,9 @@ public:
         for (float* p : bn_rm) hipFree(p);
         for (float* p : bn_rv) hipFree(p);
         if (arena) hipFree(arena);
+        if (arena_so) hipFree(arena_so);
+        if (hv) hipFree(hv);
+        if (fast_hist) hipFree(fast_hist);
     }
 
     // =================================================================================
@@ -518,6 +524,7 @@ public:
             else src = fast + (long long)task * n_adapt + (e.off - adapt_start);
         } else if (which == 4) src = adam_m + e.off;
         else if (which == 5) src = adam_v + e.off;
+        else if (which == 6 && hv) src = hv + (long long)task * n_total + e.off;
         else { set_error("bad export selector"); return -1; }
         HIP_CHECK(hipStreamSynchronize(stream));
         std::vector<float> tmp(e.numel);
@@ -736,14 +743,15 @@ public:
         bool use_fast;   // adapted modules read the per-task fast weights
         bool train;      // BatchNorm batch statistics (+ running update); decoder truncation
         float p_control = 1.f, e_control = 1.f, d_control = 1.f;
+        bool update_bn = true;  // momentum update of the BatchNorm running buffers (off when a pass is re-run for a HVP)
     };
     enum Space { SP_P = 0, SP_F = 1, SP_R = 2 };
 
     TS W(const Pass& ps, long long off) const {
-        if (ps.use_fast && off >= adapt_start) return TS{fast + (off - adapt_start), n_adapt};
+        if (ps.use_fast && off >= adapt_start) return TS{fast_cur + (off - adapt_start), n_adapt};
         return TS{theta + off, 0};
     }
-    TS Gd(long long off) const { return TS{grad + off, n_total}; }
+    TS Gd(long long off) const { return TS{grad_dst + off, n_total}; }
     int mfield(Space s) const { return s == SP_P ? META_MP : (s == SP_F ? META_MF : META_MR); }
     int maxM(const Plan& p, Space s) const { return s == SP_P ? p.maxMp : (s == SP_F ? p.maxMf : p.maxMr); }
     const unsigned char* valid_mask(const Plan& p, Space s) const { return s == SP_P ? p.p_valid : (s == SP_F ? p.f_valid : p.r_valid); }
@@ -764,7 +772,7 @@ public:
 
     // Y[M,N] = conv_k(X)[M, k*Cin] * W[N][k*Cin]^T + b   (k = 1: Linear)
     void conv_fwd(const Pass& ps, Space s, TS x, int cin, int k, TS w, TS b, int cout, TS y, int flags,
-                  const unsigned char* rowmask) {
+                  const unsigned char* rowmask, TS relu_ref = TS{nullptr, 0}) {
         const Plan& p = *ps.pl;
         GemmArgs g = rowgemm(p, s, GEMM_NT);
         const int pad = k / 2;
@@ -775,6 +783,7 @@ public:
         g.bias = b.p; g.bias_gs = b.ts;
         g.flags = flags;
         g.rowmask = rowmask; g.rowmask_gs = row_ts(s);
+        if (relu_ref.p) { g.relu_ref = relu_ref.p; g.relu_ref_gs = relu_ref.ts; g.ld_relu = cout; }
         gemm_launch(GEMM_NT, g, maxM(p, s), cout, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s));
     }
     // dX[M,Cin] (+)= sum_taps dY[M +- tap, Cout] * W  (conv dgrad over the same [Cout][k][Cin] image)
@@ -795,7 +804,7 @@ public:
     }
     // dW[Cout][k*Cin] = dY^T * conv_k(X), db = colsum(dY)
     void conv_wgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS x, int cin, long long w_off, long long b_off,
-                    const unsigned char* bias_mask) {
+                    const unsigned char* bias_mask, int flags = 0) {
         const Plan& p = *ps.pl;
         GemmArgs g = rowgemm(p, s, GEMM_TN);
         const int pad = k / 2;
@@ -804,6 +813,7 @@ public:
         TS gw = Gd(w_off);
         g.C = gw.p; g.c_gs = gw.ts; g.ldc = k * cin;
         g.M = cout; g.N = k * cin;
+        g.flags = flags;
         gemm_launch(GEMM_TN, g, cout, k * cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, (long long)cout * p.tasks);
         if (b_off >= 0) colsum(ps, s, dy, cout, bias_mask, TS{nullptr, 0}, Gd(b_off));
     }
@@ -813,7 +823,7 @@ public:
         MTTS_LAUNCH(colpart_kernel, dim3((a.C + 127) / 128, chunks, p.tasks), dim3(256), stream, (const int*)p.meta, a, col_partial,
                     col_max_chunks);
         MTTS_LAUNCH(colfinal_kernel, dim3((a.C + 255) / 256, 1, p.tasks), dim3(256), stream, (const int*)p.meta, a.mfield, a.mode,
-                    (const float*)col_partial, col_max_chunks, a.C, out0, out1, out_ts, 1e-5f);
+                    (const float*)col_partial, col_max_chunks, a.C, out0, out1, out_ts, 1e-5f, a.accumulate);
     }
     void colsum(const Pass& ps, Space s, TS x, int C, const unsigned char* mask, TS roww, TS out) {
         const Plan& p = *ps.pl;
@@ -845,11 +855,11 @@ public:
                     mask, row_ts(s), dz.p, dz.ts, C, relu_on_z);
     }
     void attn_gemm(const Pass& ps, Space s, int which, int form, const float* A, int lda, const float* B, int ldb,
-                   float* C, int ldc, float alpha, int heads) {
+                   float* C, int ldc, float alpha, int heads, int flags = 0) {
         const Plan& p = *ps.pl;
         GemmArgs g;
         g.table = (s == SP_P) ? p.enc_tab[which] : p.dec_tab[which];
-        g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha;
+        g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha; g.flags = flags;
         const int L = (s == SP_P) ? p.enc_maxL : p.dec_maxL, dk = cfg.d_model / heads;
         const int groups = (s == SP_P) ? p.n_enc_groups : p.n_dec_groups;
         int mM = L, mN = L;
@@ -1022,9 +1032,11 @@ public:
                 ca.X = b.c.p; ca.x_ts = b.c.ts; ca.mask = p.r_inrect; ca.mask_ts = row_ts_r; ca.C = P.cout; ca.mode = 2;
                 ca.mfield = META_MR;
                 colreduce(p, ca, b.stats.p, nullptr, b.stats.ts, p.maxMr);
-                MTTS_LAUNCH(bn_running_update_kernel, dim3((P.cout + 63) / 64), dim3(64), stream, (const float*)b.stats.p,
-                            b.stats.ts, nt, bn_rm[i], bn_rv[i], P.cout, 0.1f);
-                bn_tracked[i] += nt;
+                if (ps.update_bn) {
+                    MTTS_LAUNCH(bn_running_update_kernel, dim3((P.cout + 63) / 64), dim3(64), stream, (const float*)b.stats.p,
+                                b.stats.ts, nt, bn_rm[i], bn_rv[i], P.cout, 0.1f);
+                    bn_tracked[i] += nt;
+                }
             } else {
                 MTTS_LAUNCH(bn_eval_stats_kernel, dim3((P.cout + 63) / 64), dim3(64), stream, (const float*)bn_rm[i],
                             (const float*)bn_rv[i], b.stats.p, b.stats.ts, nt, P.cout, 1e-5f);
@@ -1281,6 +1293,8 @@ public:
         }
         return 0;
     }
+
+#include "engine_so.inc"
 };
 
 }  // namespace mtts

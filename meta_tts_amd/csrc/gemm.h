@@ -309,14 +309,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m >= M || n >= N) continue;
-                float v = g.alpha * acc[i][j][r] + bv;
-                if (g.flags & GEMM_RELU) v = fmaxf(v, 0.f);
-                if (relu_ref && !(relu_ref[(long long)m * g.ld_relu + n] > 0.f)) v = 0.f;
-                if (rowmask && !rowmask[m]) v = 0.f;
                 int mo = m;
                 if (rowmap) { mo = rowmap[m]; if (mo < 0) continue; }
                 float* p = C + (long long)mo * ldc + n;
-                if (g.flags & GEMM_ACCUM) v += *p;
+                float v = g.alpha * acc[i][j][r] + bv;
+                if (g.flags & GEMM_ACCUM) v += *p;  // accumulate first: the masks below act on the sum
+                if (g.flags & GEMM_RELU) v = fmaxf(v, 0.f);
+                if (relu_ref && !(relu_ref[(long long)m * g.ld_relu + n] > 0.f)) v = 0.f;
+                if (rowmask && !rowmask[m]) v = 0.f;
                 *p = v;
             }
         }

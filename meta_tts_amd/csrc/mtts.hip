@@ -192,12 +192,14 @@ int mtts_backward(mtts_handle* h, int slot, int use_fast, float scale, int need_
 int mtts_meta_grad(mtts_handle* h, int steps, float inner_lr, float grad_scale, int second_order, float* qry_losses_host,
                    float* sup_losses_host) {
     Engine& e = h->eng;
-    if (second_order) { e.set_error("second-order MAML is not implemented in this build (first-order only)"); return -1; }
     if (steps < 0 || steps > h->sup_losses_cap) { e.set_error("too many inner steps"); return -1; }
-    if (e.meta_grad(steps, inner_lr, grad_scale, e.losses, h->sup_losses_dev)) return -1;
+    if (second_order ? e.meta_grad_so(steps, inner_lr, grad_scale, e.losses, h->sup_losses_dev)
+                     : e.meta_grad(steps, inner_lr, grad_scale, e.losses, h->sup_losses_dev)) return -1;
     if (copy_losses(e, e.losses, qry_losses_host, e.plans[1].tasks * 6)) return -1;
     return copy_losses(e, h->sup_losses_dev, sup_losses_host, steps * e.plans[0].tasks * 6);
 }
+
+int mtts_hvp_support(mtts_handle* h) { return h->eng.hvp_support(); }
 
 int mtts_plain_grad(mtts_handle* h, int slot, float grad_scale, float* losses_host) {
     Engine& e = h->eng;

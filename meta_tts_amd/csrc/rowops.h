@@ -161,7 +161,14 @@ struct ColArgs {
     const float* stats = nullptr; long long st_ts = 0; // mode 1: per-row (mean, rstd); mode 3: per-column [mean|rstd]
     const unsigned char* mask = nullptr; long long mask_ts = 0;
     const float* roww = nullptr; long long roww_ts = 0;
-    int C = 0, mode = 0, do_tanh = 0, mfield = 0;
+    // tangent modes (second-order MAML, tangent.h):
+    //   5  LayerNorm: out0 = sum (X xhat + X2 t_xhat), out1 = sum X     X = tg_y, X2 = dy, Z2 = tz, stats2 = per-row (m1, m2)
+    //   6  BatchNorm: out0 = sum (tg xhat + g t_xhat), out1 = sum tg    X = tg_dy, X2 = dy, Y2 = ta, Z2 = tc, stats2 = per-column [S1 | S0]
+    const float* X2 = nullptr; long long x2_ts = 0;
+    const float* Z2 = nullptr; long long z2_ts = 0;
+    const float* Y2 = nullptr; long long y2_ts = 0;
+    const float* stats2 = nullptr; long long st2_ts = 0;
+    int C = 0, mode = 0, do_tanh = 0, mfield = 0, accumulate = 0;
 };
 
 __global__ void colpart_kernel(const int* meta, ColArgs a, float* partial, int max_chunks) {
@@ -195,8 +202,14 @@ __global__ void colpart_kernel(const int* meta, ColArgs a, float* partial, int m
             for (int m = r0 + ry; m < r1; m += 8) if (!pm || pm[m]) { float v[4]; ldv(px, m, v); for (int k = 0; k < 4; ++k) acc0[k] += v[k]; cnt += 1.f; }
             (void)mean;
         } else {
-            float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f};
-            if (a.mode == 3) { ldv(ps, 0, mu); float t[4]; const float* p2 = ps + C; ldv(p2, 0, t); for (int k = 0; k < 4; ++k) rs[k] = t[k]; }
+            float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f}, q1[4] = {0.f, 0.f, 0.f, 0.f}, q0[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.mode == 3 || a.mode == 6) { ldv(ps, 0, mu); float t[4]; const float* p2 = ps + C; ldv(p2, 0, t); for (int k = 0; k < 4; ++k) rs[k] = t[k]; }
+            const float* px2 = a.X2 ? a.X2 + (long long)z * a.x2_ts : nullptr;
+            const float* pz2 = a.Z2 ? a.Z2 + (long long)z * a.z2_ts : nullptr;
+            const float* py2 = a.Y2 ? a.Y2 + (long long)z * a.y2_ts : nullptr;
+            const float* ps2 = a.stats2 ? a.stats2 + (long long)z * a.st2_ts : nullptr;
+            if (a.mode == 6) { ldv(ps2, 0, q1); const float* p3 = ps2 + C; ldv(p3, 0, q0); }
+            const float inv_n6 = 1.f / (float)(meta[z * META_STRIDE + META_B] * meta[z * META_STRIDE + META_TCAP]);
             for (int m = r0 + ry; m < r1; m += 8) {
                 if (pm && !pm[m]) continue;
                 float x[4]; ldv(px, m, x);
@@ -207,10 +220,32 @@ __global__ void colpart_kernel(const int* meta, ColArgs a, float* partial, int m
                     float zz[4]; ldv(pz, m, zz);
                     const float mean = ps[2 * m], rstd = ps[2 * m + 1];
                     for (int k = 0; k < 4; ++k) { acc0[k] += x[k] * (zz[k] - mean) * rstd; acc1[k] += x[k]; }
-                } else {
+                } else if (a.mode == 3) {
                     float zz[4]; ldv(pz, m, zz);
                     if (a.do_tanh) { float y[4]; ldv(py, m, y); for (int k = 0; k < 4; ++k) x[k] *= (1.f - y[k] * y[k]); }
                     for (int k = 0; k < 4; ++k) { acc0[k] += x[k] * (zz[k] - mu[k]) * rs[k]; acc1[k] += x[k]; }
+                } else if (a.mode == 5) {
+                    float zz[4], dy[4], tz[4]; ldv(pz, m, zz); ldv(px2, m, dy); ldv(pz2, m, tz);
+                    const float mean = ps[2 * m], rstd = ps[2 * m + 1], m1 = ps2[2 * m], m2 = ps2[2 * m + 1];
+                    for (int k = 0; k < 4; ++k) {
+                        const float xh = (zz[k] - mean) * rstd, txh = rstd * (tz[k] - m1 - xh * m2);
+                        acc0[k] += x[k] * xh + dy[k] * txh;
+                        acc1[k] += x[k];
+                    }
+                } else {  // mode 6
+                    float zz[4], dy[4], tc[4]; ldv(pz, m, zz); ldv(px2, m, dy); ldv(pz2, m, tc);
+                    float g[4], tg[4];
+                    for (int k = 0; k < 4; ++k) { g[k] = dy[k]; tg[k] = x[k]; }
+                    if (a.do_tanh) {
+                        float y[4], ty[4]; ldv(py, m, y); ldv(py2, m, ty);
+                        for (int k = 0; k < 4; ++k) { const float sq = 1.f - y[k] * y[k]; tg[k] = x[k] * sq - 2.f * y[k] * ty[k] * dy[k]; g[k] = dy[k] * sq; }
+                    }
+                    for (int k = 0; k < 4; ++k) {
+                        const float xh = (zz[k] - mu[k]) * rs[k];
+                        const float txh = rs[k] * (tc[k] - q0[k] * inv_n6 - xh * q1[k] * inv_n6);
+                        acc0[k] += tg[k] * xh + g[k] * txh;
+                        acc1[k] += tg[k];
+                    }
                 }
             }
         }
@@ -251,7 +286,7 @@ __global__ void colpart_kernel(const int* meta, ColArgs a, float* partial, int m
 }
 
 __global__ void colfinal_kernel(const int* meta, int mfield, int mode, const float* partial, int max_chunks, int C,
-                                float* out0, float* out1, long long out_ts, float eps) {
+                                float* out0, float* out1, long long out_ts, float eps, int accumulate) {
     const int z = blockIdx.z, c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const int M_ = meta[z * META_STRIDE + mfield];
@@ -260,6 +295,7 @@ __global__ void colfinal_kernel(const int* meta, int mfield, int mode, const flo
     if (mode != 2) {
         float s0 = 0.f, s1 = 0.f;
         for (int i = 0; i < nch; ++i) { s0 += p[(long long)i * 3 * C + c]; s1 += p[(long long)i * 3 * C + C + c]; }
+        if (accumulate) { s0 += out0[(long long)z * out_ts + c]; if (out1) s1 += out1[(long long)z * out_ts + c]; }
         out0[(long long)z * out_ts + c] = s0;
         if (out1) out1[(long long)z * out_ts + c] = s1;
         return;
@@ -427,9 +463,9 @@ __global__ void length_regulate_fwd_kernel(const int* meta, const float* x, long
     if (s < 0) { for (int c = lane * 4; c < C; c += 256) st4(po + c, zero4()); return; }
     const float* px = x + (long long)z * x_ts + (long long)s * C;
     const float* pv = spk + (long long)z * spk_ts + (long long)row_b[r] * C;
-    const float* pp = pos + (long long)row_t[r] * C;
+    const float* pp = pos ? pos + (long long)row_t[r] * C : nullptr;  // null: tangent pass (positions carry no tangent)
     for (int c = lane * 4; c < C; c += 256) {
-        const float4 a = ld4(px + c), b = ld4(pv + c), d = ld4(pp + c);
+        const float4 a = ld4(px + c), b = ld4(pv + c), d = pp ? ld4(pp + c) : zero4();
         st4(po + c, make_float4(a.x + b.x + d.x, a.y + b.y + d.y, a.z + b.z + d.z, a.w + b.w + d.w));
     }
 }

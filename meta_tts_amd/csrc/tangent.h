@@ -1,0 +1,377 @@
+// Tangent (forward-over-reverse) companions of the row kernels: what second-order MAML needs beyond
+// GEMMs.  The second-order meta-gradient (reference: learn2learn `create_graph=True` double backward,
+// lightning/systems/base_adaptor.py:107 `first_order = not train`) is obtained here WITHOUT autograd as a
+// backward recursion over the stored inner steps, each step needing one Hessian-vector product
+//     (H v) = d/de  grad L_support(phi + e v, theta_enc) |_{e=0}
+// = the tangent of the whole forward+backward pass in direction v.  Linear ops (Linear / Conv1d /
+// attention products, gathers, segment sums) reuse the grouped GEMM and row kernels on tangent data;
+// the non-linear ops get the closed-form tangents below.  Conventions as in rowops.h; "t" prefixes the
+// tangent of a forward value, "tg" the tangent of a gradient.  ReLU and L1 are piecewise linear: their
+// tangents are the same masks / zero.
+#pragma once
+#include "rowops.h"
+
+namespace mtts {
+
+__device__ __forceinline__ float4 f4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+
+// ---- LayerNorm --------------------------------------------------------------------------------
+// forward tangent: tz = ta (+ tres); m1 = mean(tz), m2 = mean(xhat tz); t_xhat = r (tz - m1 - xhat m2);
+// ty = mask ? tgamma*xhat + gamma*t_xhat + tbeta : 0.   tstats = (m1, m2) per row.
+__global__ void ln_jvp_fwd_kernel(const int* meta, int mfield, const float* ta, long long ta_ts, const float* tres,
+                                  long long tres_ts, const float* zin, long long z_ts, const float* stats, long long st_ts,
+                                  const float* gamma, long long par_ts, const float* tgamma, const float* tbeta,
+                                  long long tpar_ts, const unsigned char* mask, long long mask_ts, float* tz_out,
+                                  long long tz_ts, float* ty, long long ty_ts, float* tstats, long long tst_ts, int C) {
+    ROW_PROLOGUE(mfield)
+    const float* pa = ta + (long long)z * ta_ts + (long long)row * C;
+    const float* pr = tres ? tres + (long long)z * tres_ts + (long long)row * C : nullptr;
+    const float* pz = zin + (long long)z * z_ts + (long long)row * C;
+    const float* st = stats + (long long)z * st_ts + (long long)row * 2;
+    const float mean = st[0], rstd = st[1];
+    float4 tv[4], xh[4];
+    float s1 = 0.f, s2 = 0.f;
+    int n = 0;
+    for (int c = lane * 4; c < C; c += 256, ++n) {
+        float4 t = ld4(pa + c);
+        if (pr) { const float4 r4 = ld4(pr + c); t = f4(t.x + r4.x, t.y + r4.y, t.z + r4.z, t.w + r4.w); }
+        const float4 x = ld4(pz + c);
+        tv[n] = t;
+        xh[n] = f4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
+        s1 += (t.x + t.y) + (t.z + t.w);
+        s2 += (t.x * xh[n].x + t.y * xh[n].y) + (t.z * xh[n].z + t.w * xh[n].w);
+    }
+    const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+    const bool keep = mask ? (mask[(long long)z * mask_ts + row] != 0) : true;
+    const float* g = gamma + (long long)z * par_ts;
+    const float* tg = tgamma ? tgamma + (long long)z * tpar_ts : nullptr;
+    const float* tb = tbeta ? tbeta + (long long)z * tpar_ts : nullptr;
+    float* po = ty + (long long)z * ty_ts + (long long)row * C;
+    float* ptz = tz_out ? tz_out + (long long)z * tz_ts + (long long)row * C : nullptr;
+    int i = 0;
+    for (int c = lane * 4; c < C; c += 256, ++i) {
+        if (ptz) st4(ptz + c, tv[i]);
+        float4 o = zero4();
+        if (keep) {
+            const float4 g4 = ld4(g + c);
+            const float4 tg4 = tg ? ld4(tg + c) : zero4(), tb4 = tb ? ld4(tb + c) : zero4();
+            const float tv_[4] = {tv[i].x, tv[i].y, tv[i].z, tv[i].w}, xh_[4] = {xh[i].x, xh[i].y, xh[i].z, xh[i].w};
+            const float g_[4] = {g4.x, g4.y, g4.z, g4.w}, tg_[4] = {tg4.x, tg4.y, tg4.z, tg4.w}, tb_[4] = {tb4.x, tb4.y, tb4.z, tb4.w};
+            float r_[4];
+            for (int k = 0; k < 4; ++k) r_[k] = tg_[k] * xh_[k] + g_[k] * rstd * (tv_[k] - m1 - xh_[k] * m2) + tb_[k];
+            o = f4(r_[0], r_[1], r_[2], r_[3]);
+        }
+        st4(po + c, o);
+    }
+    if (lane == 0) {
+        float* ts = tstats + (long long)z * tst_ts + (long long)row * 2;
+        ts[0] = m1;
+        ts[1] = m2;
+    }
+}
+
+// backward, primal + tangent in one pass:
+//   g = dy*gamma, a1 = mean(g), a2 = mean(g xhat):          dz    = r (g - a1 - xhat a2)
+//   tg = tg_y*gamma + dy*tgamma, t_xhat = r (tz - m1 - xhat m2), rdot/r = -r m2:
+//   tg_z = -r m2 dz + r (tg - mean(tg) - t_xhat a2 - xhat (mean(tg xhat) + mean(g t_xhat)))
+// masked rows give 0 for both; relu_on_z multiplies both by [z > 0].
+__global__ void ln_jvp_bwd_kernel(const int* meta, int mfield, const float* dy, long long dy_ts, const float* tgy,
+                                  long long tgy_ts, const float* zin, long long z_ts, const float* stats, long long st_ts,
+                                  const float* tz, long long tz_ts, const float* tstats, long long tst_ts, const float* gamma,
+                                  long long par_ts, const float* tgamma, long long tpar_ts, const unsigned char* mask,
+                                  long long mask_ts, float* dz, long long dz_ts, float* tgz, long long tgz_ts, int C,
+                                  int relu_on_z) {
+    ROW_PROLOGUE(mfield)
+    float* pdz = dz + (long long)z * dz_ts + (long long)row * C;
+    float* ptg = tgz + (long long)z * tgz_ts + (long long)row * C;
+    const bool keep = mask ? (mask[(long long)z * mask_ts + row] != 0) : true;
+    if (!keep) {
+        for (int c = lane * 4; c < C; c += 256) { st4(pdz + c, zero4()); st4(ptg + c, zero4()); }
+        return;
+    }
+    const float* pdy = dy + (long long)z * dy_ts + (long long)row * C;
+    const float* ptgy = tgy + (long long)z * tgy_ts + (long long)row * C;
+    const float* pz = zin + (long long)z * z_ts + (long long)row * C;
+    const float* ptz = tz + (long long)z * tz_ts + (long long)row * C;
+    const float* st = stats + (long long)z * st_ts + (long long)row * 2;
+    const float* ts = tstats + (long long)z * tst_ts + (long long)row * 2;
+    const float mean = st[0], rstd = st[1], m1 = ts[0], m2 = ts[1];
+    const float* g = gamma + (long long)z * par_ts;
+    const float* tgm = tgamma ? tgamma + (long long)z * tpar_ts : nullptr;
+    float gv[4][4], tgv[4][4], xh[4][4], txh[4][4], zz[4][4];
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+    int n = 0;
+    for (int c = lane * 4; c < C; c += 256, ++n) {
+        const float4 d4 = ld4(pdy + c), t4 = ld4(ptgy + c), x4 = ld4(pz + c), tz4 = ld4(ptz + c), g4 = ld4(g + c);
+        const float4 tg4 = tgm ? ld4(tgm + c) : zero4();
+        const float d_[4] = {d4.x, d4.y, d4.z, d4.w}, t_[4] = {t4.x, t4.y, t4.z, t4.w}, x_[4] = {x4.x, x4.y, x4.z, x4.w};
+        const float tz_[4] = {tz4.x, tz4.y, tz4.z, tz4.w}, g_[4] = {g4.x, g4.y, g4.z, g4.w}, tgm_[4] = {tg4.x, tg4.y, tg4.z, tg4.w};
+        for (int k = 0; k < 4; ++k) {
+            zz[n][k] = x_[k];
+            xh[n][k] = (x_[k] - mean) * rstd;
+            txh[n][k] = rstd * (tz_[k] - m1 - xh[n][k] * m2);
+            gv[n][k] = d_[k] * g_[k];
+            tgv[n][k] = t_[k] * g_[k] + d_[k] * tgm_[k];
+            a1 += gv[n][k];
+            a2 += gv[n][k] * xh[n][k];
+            b1 += tgv[n][k];
+            b2 += tgv[n][k] * xh[n][k] + gv[n][k] * txh[n][k];
+        }
+    }
+    const float invC = 1.f / (float)C;
+    a1 = wave_sum(a1) * invC; a2 = wave_sum(a2) * invC; b1 = wave_sum(b1) * invC; b2 = wave_sum(b2) * invC;
+    int i = 0;
+    for (int c = lane * 4; c < C; c += 256, ++i) {
+        float o1[4], o2[4];
+        for (int k = 0; k < 4; ++k) {
+            const float dzk = rstd * (gv[i][k] - a1 - xh[i][k] * a2);
+            float tk = -rstd * m2 * dzk + rstd * (tgv[i][k] - b1 - txh[i][k] * a2 - xh[i][k] * b2);
+            float pk = dzk;
+            if (relu_on_z && !(zz[i][k] > 0.f)) { pk = 0.f; tk = 0.f; }
+            o1[k] = pk; o2[k] = tk;
+        }
+        st4(pdz + c, f4(o1[0], o1[1], o1[2], o1[3]));
+        st4(ptg + c, f4(o2[0], o2[1], o2[2], o2[3]));
+    }
+}
+
+// ---- softmax ----------------------------------------------------------------------------------
+// in place on tS: tP = P (tS - sum_j P_j tS_j)
+__global__ void softmax_jvp_fwd_kernel(const AttnSeq* seqs, const float* P, float* tS) {
+    const AttnSeq q = seqs[blockIdx.z];
+    const int row = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    if (row >= q.L) return;
+    const float* p = P + q.s_off + (long long)row * q.ldS;
+    float* t = tS + q.s_off + (long long)row * q.ldS;
+    float s = 0.f;
+    for (int c = lane; c < q.L; c += 64) s += p[c] * t[c];
+    s = wave_sum(s);
+    for (int c = lane; c < q.ldS; c += 64) t[c] = (c < q.L) ? p[c] * (t[c] - s) : 0.f;
+}
+
+// in place: dP -> dS = alpha P (dP - c), tgP -> tg_S = alpha [tP (dP - c) + P (tgP - cdot)],
+// c = sum dP P, cdot = sum (tgP P + dP tP)
+__global__ void softmax_jvp_bwd_kernel(const AttnSeq* seqs, const float* P, const float* tP, float* dP, float* tgP, float alpha) {
+    const AttnSeq q = seqs[blockIdx.z];
+    const int row = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    if (row >= q.L) return;
+    const long long o = q.s_off + (long long)row * q.ldS;
+    const float* p = P + o;
+    const float* tp = tP + o;
+    float* d = dP + o;
+    float* tg = tgP + o;
+    float c0 = 0.f, c1 = 0.f;
+    for (int c = lane; c < q.L; c += 64) { c0 += d[c] * p[c]; c1 += tg[c] * p[c] + d[c] * tp[c]; }
+    c0 = wave_sum(c0);
+    c1 = wave_sum(c1);
+    for (int c = lane; c < q.ldS; c += 64) {
+        float o0 = 0.f, o1 = 0.f;
+        if (c < q.L) {
+            o0 = alpha * p[c] * (d[c] - c0);
+            o1 = alpha * (tp[c] * (d[c] - c0) + p[c] * (tg[c] - c1));
+        }
+        d[c] = o0;
+        tg[c] = o1;
+    }
+}
+
+// ---- BatchNorm (+tanh) ------------------------------------------------------------------------
+// forward tangent.  tsum = [S1 | S0] = [sum tc*xhat | sum tc] per channel (colreduce mode 3 on tc, no tanh);
+// t_xhat = r (tc - S0/n - xhat S1/n); ty = tgamma xhat + gamma t_xhat + tbeta; ta = act ? (1 - a^2) ty : ty
+__global__ void bn_jvp_apply_kernel(const int* meta, const float* X, long long x_ts, const float* tX, long long tx_ts,
+                                    const float* stats, long long st_ts, const float* tsum1, const float* tsum0,
+                                    long long tsum_ts, const float* gamma, long long par_ts, const float* tgamma,
+                                    const float* tbeta, long long tpar_ts, const float* A, long long a_ts,
+                                    const unsigned char* inrect, long long row_ts, int do_tanh, float* tA, long long ta_ts,
+                                    int C) {
+    ROW_PROLOGUE(META_MR)
+    float* po = tA + (long long)z * ta_ts + (long long)row * C;
+    if (!inrect[(long long)z * row_ts + row]) { for (int c = lane * 4; c < C; c += 256) st4(po + c, zero4()); return; }
+    const float inv_n = 1.f / (float)(meta[z * META_STRIDE + META_B] * meta[z * META_STRIDE + META_TCAP]);
+    const float* px = X + (long long)z * x_ts + (long long)row * C;
+    const float* ptx = tX + (long long)z * tx_ts + (long long)row * C;
+    const float* pa = A + (long long)z * a_ts + (long long)row * C;
+    const float* st = stats + (long long)z * st_ts;
+    const float* s1 = tsum1 + (long long)z * tsum_ts;
+    const float* s0 = tsum0 + (long long)z * tsum_ts;
+    const float* g = gamma + (long long)z * par_ts;
+    const float* tg = tgamma ? tgamma + (long long)z * tpar_ts : nullptr;
+    const float* tb = tbeta ? tbeta + (long long)z * tpar_ts : nullptr;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 x4 = ld4(px + c), t4 = ld4(ptx + c), mu = ld4(st + c), rs = ld4(st + C + c), g4 = ld4(g + c);
+        const float4 q1 = ld4(s1 + c), q0 = ld4(s0 + c), a4 = ld4(pa + c);
+        const float4 tg4 = tg ? ld4(tg + c) : zero4(), tb4 = tb ? ld4(tb + c) : zero4();
+        const float x_[4] = {x4.x, x4.y, x4.z, x4.w}, t_[4] = {t4.x, t4.y, t4.z, t4.w}, mu_[4] = {mu.x, mu.y, mu.z, mu.w};
+        const float rs_[4] = {rs.x, rs.y, rs.z, rs.w}, g_[4] = {g4.x, g4.y, g4.z, g4.w}, q1_[4] = {q1.x, q1.y, q1.z, q1.w};
+        const float q0_[4] = {q0.x, q0.y, q0.z, q0.w}, a_[4] = {a4.x, a4.y, a4.z, a4.w}, tg_[4] = {tg4.x, tg4.y, tg4.z, tg4.w};
+        const float tb_[4] = {tb4.x, tb4.y, tb4.z, tb4.w};
+        float o[4];
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (x_[k] - mu_[k]) * rs_[k];
+            const float txh = rs_[k] * (t_[k] - q0_[k] * inv_n - xh * q1_[k] * inv_n);
+            float ty = tg_[k] * xh + g_[k] * txh + tb_[k];
+            if (do_tanh) ty *= (1.f - a_[k] * a_[k]);
+            o[k] = ty;
+        }
+        st4(po + c, f4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+// backward, primal + tangent.  Per channel inputs: primal sums dgamma = sum g xhat, dbeta = sum g
+// (g = dy (1-a^2) if tanh), tangent sums tA0 = sum (tg xhat + g t_xhat), tA1 = sum tg with
+// tg = tgdy (1-a^2) - 2 a ta dy (tanh) or tgdy, and the forward-tangent sums S1, S0.
+//   dc  = gamma r (g - dbeta/n - xhat dgamma/n)
+//   tdc = r (tgamma - gamma r m2)(g - dbeta/n - xhat dgamma/n)
+//         + gamma r (tg - tA1/n - t_xhat dgamma/n - xhat tA0/n),        m2 = S1/n
+__global__ void bn_jvp_bwd_kernel(const int* meta, const float* dY, long long dy_ts, const float* tgY, long long tgy_ts,
+                                  const float* A, long long a_ts, const float* tA, long long ta_ts, const float* X,
+                                  long long x_ts, const float* tX, long long tx_ts, const float* stats, long long st_ts,
+                                  const float* tsum1, const float* tsum0, long long tsum_ts, const float* gamma,
+                                  long long par_ts, const float* tgamma, long long tpar_ts, const float* dgamma,
+                                  const float* dbeta, long long dg_ts, const float* tA0, const float* tA1, long long tA_ts,
+                                  const unsigned char* inrect, long long row_ts, int do_tanh, float* dX, long long dx_ts,
+                                  float* tdX, long long tdx_ts, int C) {
+    ROW_PROLOGUE(META_MR)
+    float* pdx = dX + (long long)z * dx_ts + (long long)row * C;
+    float* ptd = tdX + (long long)z * tdx_ts + (long long)row * C;
+    if (!inrect[(long long)z * row_ts + row]) {
+        for (int c = lane * 4; c < C; c += 256) { st4(pdx + c, zero4()); st4(ptd + c, zero4()); }
+        return;
+    }
+    const float inv_n = 1.f / (float)(meta[z * META_STRIDE + META_B] * meta[z * META_STRIDE + META_TCAP]);
+    const long long ro = (long long)row * C;
+    const float *pdy = dY + (long long)z * dy_ts + ro, *ptgy = tgY + (long long)z * tgy_ts + ro, *pa = A + (long long)z * a_ts + ro;
+    const float *pta = tA + (long long)z * ta_ts + ro, *px = X + (long long)z * x_ts + ro, *ptx = tX + (long long)z * tx_ts + ro;
+    const float* st = stats + (long long)z * st_ts;
+    const float *s1 = tsum1 + (long long)z * tsum_ts, *s0 = tsum0 + (long long)z * tsum_ts;
+    const float* g = gamma + (long long)z * par_ts;
+    const float* tgm = tgamma ? tgamma + (long long)z * tpar_ts : nullptr;
+    const float *dg = dgamma + (long long)z * dg_ts, *db = dbeta + (long long)z * dg_ts;
+    const float *a0 = tA0 + (long long)z * tA_ts, *a1 = tA1 + (long long)z * tA_ts;
+    for (int c = lane * 4; c < C; c += 256) {
+        float dy_[4], tgy_[4], a_[4], ta_[4], x_[4], tx_[4], mu_[4], rs_[4], q1_[4], q0_[4], g_[4], tgm_[4], dg_[4], db_[4], a0_[4], a1_[4];
+        auto L = [&](const float* p, float (&v)[4]) { const float4 t = ld4(p + c); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; };
+        L(pdy, dy_); L(ptgy, tgy_); L(pa, a_); L(pta, ta_); L(px, x_); L(ptx, tx_); L(st, mu_); L(st + C, rs_);
+        L(s1, q1_); L(s0, q0_); L(g, g_); L(dg, dg_); L(db, db_); L(a0, a0_); L(a1, a1_);
+        if (tgm) L(tgm, tgm_); else { tgm_[0] = tgm_[1] = tgm_[2] = tgm_[3] = 0.f; }
+        float o0[4], o1[4];
+        for (int k = 0; k < 4; ++k) {
+            const float r = rs_[k];
+            const float xh = (x_[k] - mu_[k]) * r;
+            const float m2 = q1_[k] * inv_n;
+            const float txh = r * (tx_[k] - q0_[k] * inv_n - xh * m2);
+            float gk = dy_[k], tgk = tgy_[k];
+            if (do_tanh) { const float s = 1.f - a_[k] * a_[k]; tgk = tgy_[k] * s - 2.f * a_[k] * ta_[k] * dy_[k]; gk = dy_[k] * s; }
+            const float core = gk - db_[k] * inv_n - xh * dg_[k] * inv_n;
+            o0[k] = g_[k] * r * core;
+            o1[k] = r * (tgm_[k] - g_[k] * r * m2) * core + g_[k] * r * (tgk - a1_[k] * inv_n - txh * dg_[k] * inv_n - xh * a0_[k] * inv_n);
+        }
+        st4(pdx + c, f4(o0[0], o0[1], o0[2], o0[3]));
+        st4(ptd + c, f4(o1[0], o1[1], o1[2], o1[3]));
+    }
+}
+
+// ---- 256 -> 1 projection ------------------------------------------------------------------------
+// tout[row] = valid ? dot(tx, w) + dot(x, tw) + tb : 0
+__global__ void rowdot_jvp_kernel(const int* meta, int mfield, const float* x, long long x_ts, const float* tx, long long tx_ts,
+                                  const float* w, long long par_ts, const float* tw, const float* tb, long long tpar_ts,
+                                  const unsigned char* valid, long long row_ts, float* tout, long long out_ts, int C) {
+    ROW_PROLOGUE(mfield)
+    const float* px = x + (long long)z * x_ts + (long long)row * C;
+    const float* ptx = tx + (long long)z * tx_ts + (long long)row * C;
+    const float* pw = w + (long long)z * par_ts;
+    const float* ptw = tw ? tw + (long long)z * tpar_ts : nullptr;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 a = ld4(px + c), ta = ld4(ptx + c), ww = ld4(pw + c);
+        s += (ta.x * ww.x + ta.y * ww.y) + (ta.z * ww.z + ta.w * ww.w);
+        if (ptw) { const float4 t = ld4(ptw + c); s += (a.x * t.x + a.y * t.y) + (a.z * t.z + a.w * t.w); }
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        const float b = tb ? tb[(long long)z * tpar_ts] : 0.f;
+        tout[(long long)z * out_ts + row] = valid[(long long)z * row_ts + row] ? s + b : 0.f;
+    }
+}
+
+// dx = dout w (primal) ; tdx = tgout w + dout tw
+__global__ void rowdot_jvp_bwd_kernel(const int* meta, int mfield, const float* dout, const float* tgout, long long dout_ts,
+                                      const float* w, long long par_ts, const float* tw, long long tpar_ts, float* dx,
+                                      long long dx_ts, float* tdx, long long tdx_ts, int C) {
+    ROW_PROLOGUE(mfield)
+    const float d = dout[(long long)z * dout_ts + row], td = tgout[(long long)z * dout_ts + row];
+    const float* pw = w + (long long)z * par_ts;
+    const float* ptw = tw ? tw + (long long)z * tpar_ts : nullptr;
+    float* pd = dx + (long long)z * dx_ts + (long long)row * C;
+    float* pt = tdx + (long long)z * tdx_ts + (long long)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 ww = ld4(pw + c);
+        const float4 t = ptw ? ld4(ptw + c) : zero4();
+        st4(pd + c, f4(d * ww.x, d * ww.y, d * ww.z, d * ww.w));
+        st4(pt + c, f4(td * ww.x + d * t.x, td * ww.y + d * t.y, td * ww.z + d * t.z, td * ww.w + d * t.w));
+    }
+}
+
+// ---- loss: tangent of the prediction gradients (MSE terms; the L1 terms have zero second derivative) ----
+__global__ void loss_tangent_kernel(const int* meta, const float* tpp, const float* tep, const float* tlogd, long long pred_ts,
+                                    const unsigned char* pvalid, long long prow_ts, float scale, float* tgpp, float* tgep,
+                                    float* tglogd) {
+    const int z = blockIdx.z, Mp = meta[z * META_STRIDE + META_MP];
+    const float wP = 2.f * scale / (float)meta[z * META_STRIDE + META_NP];
+    const unsigned char* pv = pvalid + (long long)z * prow_ts;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < Mp; r += gridDim.x * blockDim.x) {
+        const long long q = (long long)z * pred_ts + r;
+        const bool v = pv[r] != 0;
+        tgpp[q] = v ? wP * tpp[q] : 0.f;
+        tgep[q] = v ? wP * tep[q] : 0.f;
+        tglogd[q] = v ? wP * tlogd[q] : 0.f;
+    }
+}
+
+// ---- elementwise: dst[t][i] += alpha * src[t][i];  dst = a + b over row-space slabs ---------------------
+__global__ void axpy_kernel(float* dst, long long dst_ts, const float* src, long long src_ts, float alpha, long long n4) {
+    float* d = dst + (long long)blockIdx.z * dst_ts;
+    const float* s = src + (long long)blockIdx.z * src_ts;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 x = ld4(d + i * 4);
+        const float4 y = ld4(s + i * 4);
+        x.x += alpha * y.x; x.y += alpha * y.y; x.z += alpha * y.z; x.w += alpha * y.w;
+        st4(d + i * 4, x);
+    }
+}
+
+// out[row] = (x ? x[row] : 0) + (table && idx[row] >= 0 ? table[idx[row]] : 0)   (tangent of x + emb[bucket])
+__global__ void embed_add_idx_kernel(const int* meta, int mfield, const float* x, long long x_ts, const float* table,
+                                     long long table_ts, const int* idx, long long idx_ts, float* out, long long out_ts, int C) {
+    ROW_PROLOGUE(mfield)
+    const int id = idx[(long long)z * idx_ts + row];
+    const float* px = x ? x + (long long)z * x_ts + (long long)row * C : nullptr;
+    const float* pt = (table && id >= 0) ? table + (long long)z * table_ts + (long long)id * C : nullptr;
+    float* po = out + (long long)z * out_ts + (long long)row * C;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 o = px ? ld4(px + c) : zero4();
+        if (pt) { const float4 t = ld4(pt + c); o = f4(o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w); }
+        st4(po + c, o);
+    }
+}
+
+// out[row] = inrect ? vec[row_b[row]] : 0   (tangent of enc_out + spk: the encoder carries no tangent)
+__global__ void bcast_rowvec_kernel(const int* meta, int mfield, const float* vec, long long vec_ts, const int* row_b,
+                                    const unsigned char* inrect, long long row_ts, float* out, long long out_ts, int C) {
+    ROW_PROLOGUE(mfield)
+    const long long r = (long long)z * row_ts + row;
+    const bool in = inrect[r] != 0;
+    const float* pv = vec + (long long)z * vec_ts + (long long)(in ? row_b[r] : 0) * C;
+    float* po = out + (long long)z * out_ts + (long long)row * C;
+    for (int c = lane * 4; c < C; c += 256) st4(po + c, in ? ld4(pv + c) : zero4());
+}
+
+// row-space copy: out[r] = in[r] for r < M (all channels)
+__global__ void copy_rows_kernel(const int* meta, int mfield, const float* in, long long in_ts, float* out, long long out_ts, int C) {
+    ROW_PROLOGUE(mfield)
+    const float* pi = in + (long long)z * in_ts + (long long)row * C;
+    float* po = out + (long long)z * out_ts + (long long)row * C;
+    for (int c = lane * 4; c < C; c += 256) st4(po + c, ld4(pi + c));
+}
+
+}  // namespace mtts

@@ -221,6 +221,10 @@ class Engine:
         self._ck(self.lib.mtts_meta_grad(self.h, steps, inner_lr, grad_scale, int(second_order), None, None))
         return None, None
 
+    def hvp_support(self):
+        """H v of the support loss at the current fast weights, v = per-task gradient buffer (export with which=6)."""
+        self._ck(self.lib.mtts_hvp_support(self.h))
+
     def plain_grad(self, slot: int = 0, grad_scale: float = 1.0, fetch_losses: bool = True):
         if fetch_losses:
             q = np.empty((self.n_tasks[slot], 6), np.float32)

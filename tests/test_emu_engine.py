@@ -193,3 +193,68 @@ def test_free_running_synthesis_matches_oracle(emu_lib):
     with pytest.raises(Exception):
         eng.loss(0)  # no targets
     eng.close()
+
+
+def test_hessian_vector_product_matches_double_backward(emu_lib):
+    """The forward-over-reverse HVP (csrc/engine_so.inc) against torch's create_graph double backward, every tensor,
+    two ragged tasks; direction v = the support gradient itself (adapted slice)."""
+    dims = tiny_dims()
+    eng = _engine(dims, emu_lib)
+    b0 = synth.make_batch(3, 3, speaker=2, **_kw(dims)); b1 = synth.make_batch(4, 2, speaker=5, **_kw(dims))
+    eng.set_batches(0, [b0, b1])
+    eng.adapt(0, 0.0, reset=True)  # fast weights := theta
+    eng.forward(0, use_fast=True, train=True)
+    eng.backward(0, use_fast=True, scale=1.0, need_encoder=True)
+    eng.hvp_support()
+    for ti, b in enumerate([b0, b1]):
+        p = torch_params(dims, requires_grad=True)
+        tb = O.to_torch_batch(b)
+        lo = O.fs2_loss(tb, O.fs2_forward(p, torch_buffers(dims), *tb[2:], n_head=heads(dims), max_seq_len=dims.max_seq_len, training=True))
+        an = O.adapted_names(p, MODS)
+        g = torch.autograd.grad(lo[0], [p[n] for n in an], create_graph=True)
+        dot = sum((gi * gi.detach()).sum() for gi in g)
+        names = list(eng.params)
+        hv = torch.autograd.grad(dot, [p[n] for n in names], allow_unused=True)
+        scale = max(float(h.abs().max()) for h in hv if h is not None)
+        for n, h in zip(names, hv):
+            ref = h.numpy() if h is not None else np.zeros(eng.params[n][0], np.float32)
+            got = eng.export(n, 6, ti)
+            assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7 * scale, (ti, n)
+    eng.close()
+
+
+def test_second_order_maml_matches_oracle(emu_lib):
+    """Training mode of the reference (first_order = not train, base_adaptor.py:107): outer gradient through 3 inner steps."""
+    dims = tiny_dims()
+    eng = _engine(dims, emu_lib)
+    tasks = [(synth.make_batch(10 + 2 * j, 3, speaker=2 + j, **_kw(dims)), synth.make_batch(11 + 2 * j, 2, speaker=2 + j, **_kw(dims)))
+             for j in range(2)]
+    eng.set_batches(0, [t[0] for t in tasks])
+    eng.set_batches(1, [t[1] for t in tasks], spk_from=[t[0] for t in tasks], average_spk=True)
+    lr = 0.01
+    q, s = eng.meta_grad(3, lr, 0.5, second_order=True)
+    tot, fo = None, None
+    for j, (sup, qry) in enumerate(tasks):
+        for so in (True, False):
+            p = torch_params(dims, requires_grad=True)
+            ql, sl, _, _ = O.maml_task(p, torch_buffers(dims), O.to_torch_batch(sup), O.to_torch_batch(qry), steps=3, lr=lr,
+                                       second_order=so, modules=MODS, n_head=heads(dims), max_seq_len=dims.max_seq_len)
+            names = list(eng.params)
+            gs = torch.autograd.grad(ql[0], [p[n] for n in names], allow_unused=True)
+            g = {n: (x.numpy() * 0.5 if x is not None else np.zeros(eng.params[n][0], np.float32)) for n, x in zip(names, gs)}
+            if so:
+                np.testing.assert_allclose(q[j], [float(x) for x in ql], rtol=5e-5)
+                tot = g if tot is None else {n: tot[n] + g[n] for n in names}
+            else:
+                fo = g if fo is None else {n: fo[n] + g[n] for n in names}
+    scale = max(np.abs(v).max() for v in tot.values())
+    for n in eng.params:
+        assert np.abs(eng.export(n, 1) - tot[n]).max() <= 3e-3 * np.abs(tot[n]).max() + 1e-7 * scale, n
+    # and it is genuinely different from the first-order gradient (incl. the non-adapted encoder)
+    assert np.abs(fo["encoder.layer_stack.0.pos_ffn.w_1.weight"] - tot["encoder.layer_stack.0.pos_ffn.w_1.weight"]).max() > \
+        0.05 * np.abs(tot["encoder.layer_stack.0.pos_ffn.w_1.weight"]).max()
+    # first-order call afterwards still gives the first-order answer (indirections restored)
+    eng.meta_grad(3, lr, 0.5, second_order=False)
+    n = "decoder.layer_stack.1.pos_ffn.w_2.weight"
+    assert np.abs(eng.export(n, 1) - fo[n]).max() <= 2e-3 * np.abs(fo[n]).max()
+    eng.close()

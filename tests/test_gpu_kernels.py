@@ -56,7 +56,7 @@ def test_gemm_forms(lib, form, tile, M, N, K):
     C2 = torch.ones((M, pad4(N)), device="cuda")
     assert lib.mtts_gemm_f32(form, M, N, K, P(A), lda, P(B), ldb, P(C2), pad4(N), None, 1.0, 3, tile, None) == 0
     torch.cuda.synchronize()
-    want2 = torch.relu(ref) + 1.0
+    want2 = torch.relu(ref + 1.0)  # accumulate first, then the activation acts on the sum
     assert (C2[:, :N].double() - want2).abs().max().item() < 2e-5 * max(1.0, want2.abs().max().item())
 
 

@@ -123,6 +123,34 @@ def test_first_order_maml_matches_reference_fixture(golden_dir, tag, lr, rtol):
     eng.close()
 
 
+@pytest.mark.parametrize("tag,lr,rtol", [("lr1e-3", 0.001, 5e-3), ("lr2e-3", 0.002, 5e-2)])
+def test_second_order_maml_matches_reference_fixture(golden_dir, tag, lr, rtol):
+    """The reference's training mode (first_order = not train): outer gradient THROUGH the 5 inner steps, against the
+    fixture produced with create_graph=True on the reference model."""
+    g = _load(golden_dir, f"maml_small_{tag}.npz")
+    sup = synth.make_batch(21, 3, speaker=9, **SMALL)
+    qry = synth.make_batch(22, 3, speaker=9, **SMALL)
+    eng = _engine(1, 3, 16, 96)
+    eng.set_batches(0, [sup])
+    eng.set_batches(1, [qry], spk_from=[sup], average_spk=True)
+    q, s = eng.meta_grad(5, lr, 1.0, second_order=True)
+    np.testing.assert_allclose(s[:, 0, :], g["so_sup_losses"], rtol=rtol / 4)
+    np.testing.assert_allclose(q[0], g["so_qry_losses"], rtol=rtol / 4)
+    names = [str(n) for n in g["so_outer_names"]]
+    norms = np.array([float(np.linalg.norm(eng.export(n, 1).astype(np.float64))) for n in names])
+    np.testing.assert_allclose(norms, g["so_outer_norms"], rtol=rtol, atol=1e-5)
+    assert np.abs(norms - g["fo_outer_norms"]).max() > 1e-3  # not the first-order answer
+    for key in g.files:
+        if not key.startswith("so_grad::"):
+            continue
+        n = key[len("so_grad::"):]
+        got = eng.export("speaker_emb.model.weight", 1)[9] if n == "speaker_row" else eng.export(n, 1)
+        got = got[:4] if (n != "speaker_row" and got.ndim >= 2) else got
+        ref = g[key]
+        assert np.abs(got - ref).max() <= 2 * rtol * max(1e-3, np.abs(ref).max()), key
+    eng.close()
+
+
 def test_two_ragged_tasks_vs_oracle_with_outer_update():
     """Different shapes per task in one grouped launch + the fused clip/Adam update."""
     tasks = [(synth.make_batch(40 + 2 * j, 2 + j, speaker=3 + j, s_range=(8, 20), d_range=(1, 8), first_len=20 - 3 * j),
