@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-inference", action="store_true")
+    ap.add_argument("--order", type=int, default=1, choices=(1, 2),
+                    help="MAML order of the timed meta-step: 1 = BASELINE config C3 (first-order), 2 = the reference's training mode / config C4")
+    ap.add_argument("--no-second-order", action="store_true", help="skip the extra second-order measurement")
     args = ap.parse_args()
 
     import torch
@@ -160,8 +163,8 @@ def main():
 
     step_no = [0]
 
-    def meta_step():
-        eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=False, fetch_losses=False)
+    def meta_step(order=None):
+        eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=((order or args.order) == 2), fetch_losses=False)
         if n > 1:
             dist.all_reduce(outer, op=dist.ReduceOp.SUM)
         eng.outer_update(lr=noam_lr(step_no[0], dims.d_model, trn["warm_up_step"], trn["anneal_steps"], trn["anneal_rate"]),
@@ -185,6 +188,27 @@ def main():
         tt = torch.tensor([dt], device=f"cuda:{local_rank}", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    so = None
+    if args.order == 1 and not args.no_second_order:
+        # the same meta-step in the reference's training mode (second-order, config C4 per-GPU work), all ranks
+        meta_step(2)
+        torch.cuda.synchronize()
+        if n > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        so_steps = max(1, min(args.steps, 3))
+        for _ in range(so_steps):
+            meta_step(2)
+        torch.cuda.synchronize()
+        if n > 1:
+            dist.barrier()
+        dso = time.perf_counter() - t1
+        if n > 1:
+            tt = torch.tensor([dso], device=f"cuda:{local_rank}", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dso = float(tt.item())
+        so = {"value": round(so_steps / dso, 4), "unit": "meta-steps/s", "ms_per_step": round(1e3 * dso / so_steps, 2), "steps": so_steps,
+              "workload": "same 8-task meta-step, second-order MAML (Hessian-vector recursion through the 5 inner steps)"}
     q_losses = None
     roof = None
     if rank == 0:
@@ -225,11 +249,13 @@ def main():
         line = {"metric": "meta-steps/sec (8-task meta-batch, 5 inner steps)", "value": round(args.steps / dt, 4), "unit": "meta-steps/s",
                 "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "C3: Meta-TTS MAML first-order (algorithm=meta_emb_vad, inner=5, meta-batch=8 tasks x (5 support + 5 query utts)), "
+                "config": {"workload": ("C3: Meta-TTS MAML first-order" if args.order == 1 else "C4-style: Meta-TTS MAML second-order") + " (algorithm=meta_emb_vad, inner=5, meta-batch=8 tasks x (5 support + 5 query utts)), "
                                        "FastSpeech2 base.yaml, outer mean + clip(1.0) + Adam/Noam", "meta_batch": META_BATCH,
-                           "tasks_per_gpu": META_BATCH // n, "inner_steps": INNER_STEPS, "order": "first", "parallelism": f"task-dp{n}",
+                           "tasks_per_gpu": META_BATCH // n, "inner_steps": INNER_STEPS, "order": "first" if args.order == 1 else "second", "parallelism": f"task-dp{n}",
                            "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
                 "query_total_loss_mean": round(float(q_losses[:, 0].mean()), 5) if q_losses is not None else None}
+        if so is not None:
+            line["second_order"] = so
         if infer is not None:
             line["inference_c5"] = infer
         if roof is not None:

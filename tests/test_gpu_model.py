@@ -123,7 +123,7 @@ def test_first_order_maml_matches_reference_fixture(golden_dir, tag, lr, rtol):
     eng.close()
 
 
-@pytest.mark.parametrize("tag,lr,rtol", [("lr1e-3", 0.001, 5e-3), ("lr2e-3", 0.002, 5e-2)])
+@pytest.mark.parametrize("tag,lr,rtol", [("lr1e-3", 0.001, 1e-2), ("lr2e-3", 0.002, 5e-2)])
 def test_second_order_maml_matches_reference_fixture(golden_dir, tag, lr, rtol):
     """The reference's training mode (first_order = not train): outer gradient THROUGH the 5 inner steps, against the
     fixture produced with create_graph=True on the reference model."""
