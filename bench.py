@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--order", type=int, default=1, choices=(1, 2),
                     help="MAML order of the timed meta-step: 1 = BASELINE config C3 (first-order), 2 = the reference's training mode / config C4")
     ap.add_argument("--no-second-order", action="store_true", help="skip the extra second-order measurement")
+    ap.add_argument("--no-dropout", action="store_true", help="parity configuration (dropout = identity) instead of train-mode dropout")
     args = ap.parse_args()
 
     import torch
@@ -157,6 +158,7 @@ def main():
     eng = Engine(dims, adapt_modules=mods, max_tasks=len(local), max_B=5, max_S=80, max_T=max_T, device=local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.load_params(synth.make_params(dims, 0))
+    eng.set_dropout(not args.no_dropout, 1234 + rank)  # train-mode dropout as in the reference's inner/outer loop (per-rank stream)
     eng.set_batches(0, [t[0] for t in tasks])
     eng.set_batches(1, [t[1] for t in tasks], spk_from=[t[0] for t in tasks], average_spk=True)
     outer = torch.as_tensor(eng.outer_grad_view(), device=f"cuda:{local_rank}") if n > 1 else None
@@ -252,7 +254,7 @@ def main():
                 "config": {"workload": ("C3: Meta-TTS MAML first-order" if args.order == 1 else "C4-style: Meta-TTS MAML second-order") + " (algorithm=meta_emb_vad, inner=5, meta-batch=8 tasks x (5 support + 5 query utts)), "
                                        "FastSpeech2 base.yaml, outer mean + clip(1.0) + Adam/Noam", "meta_batch": META_BATCH,
                            "tasks_per_gpu": META_BATCH // n, "inner_steps": INNER_STEPS, "order": "first" if args.order == 1 else "second", "parallelism": f"task-dp{n}",
-                           "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
+                           "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "dropout": "identity (parity config)" if args.no_dropout else "on (0.2 / 0.5 / 0.5, counter-based masks)"},
                 "query_total_loss_mean": round(float(q_losses[:, 0].mean()), 5) if q_losses is not None else None}
         if so is not None:
             line["second_order"] = so

@@ -35,6 +35,9 @@ typedef struct mtts_model_cfg {
      * {0 encoder, 1 variance_adaptor, 2 decoder, 3 mel_linear, 4 postnet, 5 speaker_emb}
      * (lightning/systems/base_adaptor.py:31-35) */
     int adapt_mask;
+    /* transformer.{encoder,decoder}_dropout, variance_predictor.dropout (config/model/base.yaml:10-11,16); the PostNet's
+     * 0.5 is hard-coded in the reference (transformer/Layers.py:133-134).  Only used after mtts_set_dropout(h, 1, seed). */
+    float enc_dropout, dec_dropout, vp_dropout;
 } mtts_model_cfg;
 
 /* One padded batch: elements [2:] of the reference 12-tuple (lightning/collate.py:47-60), host memory,
@@ -57,6 +60,10 @@ int mtts_create(const mtts_model_cfg* cfg, int device, int max_tasks, int max_B,
 void mtts_destroy(mtts_handle* h);
 const char* mtts_last_error(mtts_handle* h); /* h may be NULL: error of the last failed mtts_create */
 int mtts_set_stream(mtts_handle* h, void* hip_stream);
+/* Train-mode dropout (nn.Dropout / F.dropout sites of SubLayers.py:54,90, modules.py:223,235, Layers.py:133-134).
+ * Off by default — the parity configuration (SURVEY.md Appendix B.5 patches dropout to identity).  When on, masks are a
+ * counter-based function of (seed, pass, site, element) regenerated in backward and in the second-order replay. */
+int mtts_set_dropout(mtts_handle* h, int enable, unsigned seed);
 int mtts_synchronize(mtts_handle* h);
 
 /* ---- parameters: reference state_dict names without the "model." prefix,

@@ -20,7 +20,7 @@ class ModelCfg(C.Structure):
         "vp_filter", "vp_kernel", "n_bins", "max_seq_len", "n_mel", "vocab", "n_speaker",
         "postnet_dim", "postnet_kernel", "postnet_layers")] + [
         ("pitch_min", C.c_float), ("pitch_max", C.c_float), ("energy_min", C.c_float), ("energy_max", C.c_float),
-        ("adapt_mask", C.c_int)]
+        ("adapt_mask", C.c_int), ("enc_dropout", C.c_float), ("dec_dropout", C.c_float), ("vp_dropout", C.c_float)]
 
 
 class Batch(C.Structure):
@@ -36,6 +36,7 @@ EXPORTS = {
     "mtts_destroy": (None, [C.c_void_p]),
     "mtts_last_error": (C.c_char_p, [C.c_void_p]),
     "mtts_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mtts_set_dropout": (C.c_int, [C.c_void_p, C.c_int, C.c_uint]),
     "mtts_synchronize": (C.c_int, [C.c_void_p]),
     "mtts_param_count": (C.c_int, [C.c_void_p]),
     "mtts_param_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int * 4),

@@ -39,6 +39,7 @@ struct ModelCfg {
     int vp_filter, vp_kernel, n_bins, max_seq_len, n_mel, vocab, n_speaker;
     int postnet_dim, postnet_kernel, postnet_layers;
     float pitch_min, pitch_max, energy_min, energy_max;
+    float enc_dropout = 0.f, dec_dropout = 0.f, vp_dropout = 0.f, postnet_dropout = 0.5f;
     // which top-level modules are adapted in the inner loop (bit i of: encoder,
     // variance_adaptor, decoder, mel_linear, postnet, speaker_emb)
     int adapt_mask;
@@ -114,6 +115,7 @@ public:
         int maxMp = 0, maxMf = 0, maxMr = 0, maxB = 0, enc_maxL = 0, dec_maxL = 0, n_enc_groups = 0, n_dec_groups = 0;
         int average_spk = 0;
         bool has_targets = false, frames_ready = false;
+        unsigned drop_seed = 0;  // seed of the last train-mode forward on this plan (backward replays it)
         std::vector<TaskIn> in;
         double sum_nP = 0, sum_nF = 0, sum_attn_p = 0, sum_attn_f = 0;
         long long sumMp = 0, sumMf = 0, sumMr = 0, sumLp = 0, sumLf = 0;  // total rows over tasks (tile heuristic)  // valid rows / sum L^2 (algorithmic flop accounting)
@@ -148,6 +150,7 @@ public:
     int *pidx = nullptr, *eidx = nullptr;
     TS d_rounded;
     // backward scratch
+    TS gPm, gFm;  // dropout-masked copies of a LayerNorm input gradient
     TS gP0, gP1, gPqkv, gPh, gPf1, gPf2, gF0, gF1, gFqkv, gFh, dSp, dSf, gR0, gR1, gRm, gRp, gMelF, dspk, dpred[3];
     float *loss_partial = nullptr, *losses = nullptr, *col_partial = nullptr;
     int col_max_chunks = 0;
@@ -155,6 +158,13 @@ public:
 
     char* arena = nullptr;
     size_t arena_bytes = 0;
+
+    struct Pass;
+    // dropout (off by default: parity runs patch it to identity)
+    bool dropout_on = false;
+    unsigned drop_base = 0x1234567u, drop_counter = 0;
+    int site_base = 0;  // set by the caller of fft_* / pred_*: identifies the layer for the mask stream
+    bool drop_active(const Pass& ps) const { return dropout_on && ps.train; }
 
     void set_error(const std::string& s) { last_error = s; }
 
@@ -351,6 +361,7 @@ public:
             postB[i].dgamma_tmp = flat(2LL * c);
         }
         // backward scratch
+        gPm = rows(capMp, d); gFm = rows(capMf, d);
         gP0 = rows(capMp, d); gP1 = rows(capMp, d); gPqkv = rows(capMp, 3 * d); gPh = rows(capMp, cfg.d_ff);
         gPf1 = rows(capMp, f); gPf2 = rows(capMp, f);
         gF0 = rows(capMf, d); gF1 = rows(capMf, d); gFqkv = rows(capMf, 3 * d); gFh = rows(capMf, cfg.d_ff);
@@ -743,6 +754,7 @@ public:
         bool use_fast;   // adapted modules read the per-task fast weights
         bool train;      // BatchNorm batch statistics (+ running update); decoder truncation
         float p_control = 1.f, e_control = 1.f, d_control = 1.f;
+        unsigned seed_override = 0;  // != 0: replay this dropout seed (second-order HVP re-runs inner step k)
         bool update_bn = true;  // momentum update of the BatchNorm running buffers (off when a pass is re-run for a HVP)
     };
     enum Space { SP_P = 0, SP_F = 1, SP_R = 2 };
@@ -759,6 +771,18 @@ public:
     long long sumM(const Plan& p, Space s) const { return s == SP_P ? p.sumMp : (s == SP_F ? p.sumMf : p.sumMr); }
     double alg_rows(const Plan& p, Space s) const { return s == SP_P ? p.sum_nP : p.sum_nF; }
     long long row_ts(Space s) const { return s == SP_P ? row_ts_p : (s == SP_F ? row_ts_f : row_ts_r); }
+
+    // dst = dropout(src) with the mask stream (plan seed, site); no-op alias when dropout is off
+    TS drop(const Pass& ps, Space s, TS src, TS dst, int C, float prob, int site) {
+        if (!drop_active(ps) || prob <= 0.f) return src;
+        const Plan& p = *ps.pl;
+        const unsigned seed = p.drop_seed * 0x9E3779B1u + (unsigned)site * 0x85EBCA6Bu + 0xC2B2AE35u;
+        const unsigned thr = (unsigned)std::lround((double)prob * 65536.0);
+        MTTS_LAUNCH(dropout_kernel, row_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s), (const float*)src.p,
+                    src.ts, dst.p, dst.ts, C, seed, thr, 1.f / (1.f - prob));
+        return dst;
+    }
+    float block_dropout(Space s) const { return s == SP_P ? cfg.enc_dropout : cfg.dec_dropout; }
 
     // row-space GEMM over all tasks: C[M,N] (+)= op(A, B); M (or the reduction length for TN) is
     // the task's row count
@@ -886,9 +910,11 @@ public:
             MTTS_LAUNCH(softmax_fwd_kernel, dim3((L + 3) / 4, 1, groups), dim3(256), stream, seqs, b.P.p);
         attn_gemm(ps, s, TAB_PV, GEMM_NN, b.P.p, 0, b.qkv.p, 3 * d, b.O.p, d, 1.f, heads);
         conv_fwd(ps, s, b.O, d, 1, W(ps, P.wfc), W(ps, P.bfc), d, b.z1, 0, nullptr);
+        drop(ps, s, b.z1, b.z1, d, block_dropout(s), site_base);          // self.dropout(self.fc(output)), SubLayers.py:54
         ln_fwd(ps, s, b.z1, xin, P.ln1g, P.ln1b, vm, b.z1, b.y1, b.st1, d);
         conv_fwd(ps, s, b.y1, d, cfg.k1, W(ps, P.w1), W(ps, P.b1), cfg.d_ff, b.h, GEMM_RELU, im);
         conv_fwd(ps, s, b.h, cfg.d_ff, cfg.k2, W(ps, P.w2), W(ps, P.b2), d, b.z2, 0, nullptr);
+        drop(ps, s, b.z2, b.z2, d, block_dropout(s), site_base + 1);      // self.dropout(output), SubLayers.py:90
         ln_fwd(ps, s, b.z2, b.y1, P.ln2g, P.ln2b, vm, b.z2, b.y2, b.st2, d);
     }
 
@@ -901,17 +927,20 @@ public:
         const unsigned char* im = inrect_mask(p, s);
         // LN2 (+ row mask) backward -> g1 = dz2
         ln_bwd(ps, s, g0, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0);
+        TS gm = (s == SP_P) ? gPm : gFm;                                   // masked copy feeds the conv branch, g1 the residual
+        TS dc = drop(ps, s, g1, gm, d, block_dropout(s), site_base + 1);
         // conv2
-        conv_wgrad(ps, s, g1, d, cfg.k2, b.h, ff, P.w2, P.b2, vm);
-        conv_dgrad(ps, s, g1, d, cfg.k2, W(ps, P.w2), ff, gh, 0, im, b.h);
+        conv_wgrad(ps, s, dc, d, cfg.k2, b.h, ff, P.w2, P.b2, vm);
+        conv_dgrad(ps, s, dc, d, cfg.k2, W(ps, P.w2), ff, gh, 0, im, b.h);
         // conv1: g1 += dgrad -> dy1
         conv_wgrad(ps, s, gh, ff, cfg.k1, b.y1, d, P.w1, P.b1, im);
         conv_dgrad(ps, s, gh, ff, cfg.k1, W(ps, P.w1), d, g1, GEMM_ACCUM, im);
         // LN1 backward -> g0 = dz1
         ln_bwd(ps, s, g1, b.z1, b.st1, P.ln1g, P.ln1b, vm, g0, d, 0);
+        TS da = drop(ps, s, g0, gm, d, block_dropout(s), site_base);
         // fc
-        conv_wgrad(ps, s, g0, d, 1, b.O, d, P.wfc, P.bfc, vm);
-        conv_dgrad(ps, s, g0, d, 1, W(ps, P.wfc), d, g1, 0, nullptr);  // g1 = dO
+        conv_wgrad(ps, s, da, d, 1, b.O, d, P.wfc, P.bfc, vm);
+        conv_dgrad(ps, s, da, d, 1, W(ps, P.wfc), d, g1, 0, nullptr);  // g1 = dO
         // attention
         const int groups = (s == SP_P) ? p.n_enc_groups : p.n_dec_groups;
         const int L = (s == SP_P) ? p.enc_maxL : p.dec_maxL;
@@ -938,8 +967,10 @@ public:
         TS none{nullptr, 0};
         conv_fwd(ps, SP_P, xin, d, k, W(ps, P.c1w), W(ps, P.c1b), f, b.r1, GEMM_RELU, im);
         ln_fwd(ps, SP_P, b.r1, none, P.l1g, P.l1b, im, none, b.n1, b.st1, f);
+        drop(ps, SP_P, b.n1, b.n1, f, cfg.vp_dropout, site_base);
         conv_fwd(ps, SP_P, b.n1, f, k, W(ps, P.c2w), W(ps, P.c2b), f, b.r2, GEMM_RELU, im);
         ln_fwd(ps, SP_P, b.r2, none, P.l2g, P.l2b, im, none, b.n2, b.st2, f);
+        drop(ps, SP_P, b.n2, b.n2, f, cfg.vp_dropout, site_base + 1);
         TS w = W(ps, P.lw), bb = W(ps, P.lb);
         MTTS_LAUNCH(rowdot_kernel, row_grid(p.maxMp, p.tasks), dim3(256), stream, (const int*)p.meta, (int)META_MP,
                     (const float*)b.n2.p, b.n2.ts, (const float*)w.p, (const float*)bb.p, w.ts, (const unsigned char*)p.p_valid,
@@ -956,9 +987,11 @@ public:
         TS w = W(ps, P.lw);
         MTTS_LAUNCH(rowdot_bwd_kernel, row_grid(p.maxMp, p.tasks), dim3(256), stream, (const int*)p.meta, (int)META_MP,
                     (const float*)dout.p, dout.ts, (const float*)w.p, w.ts, gPf1.p, gPf1.ts, f);
+        drop(ps, SP_P, gPf1, gPf1, f, cfg.vp_dropout, site_base + 1);
         ln_bwd(ps, SP_P, gPf1, b.r2, b.st2, P.l2g, P.l2b, im, gPf2, f, 1);       // gPf2 = d conv2 out
         conv_wgrad(ps, SP_P, gPf2, f, k, b.n1, f, P.c2w, P.c2b, im);
         conv_dgrad(ps, SP_P, gPf2, f, k, W(ps, P.c2w), f, gPf1, 0, im);         // gPf1 = d n1
+        drop(ps, SP_P, gPf1, gPf1, f, cfg.vp_dropout, site_base);
         ln_bwd(ps, SP_P, gPf1, b.r1, b.st1, P.l1g, P.l1b, im, gPf2, f, 1);       // gPf2 = d conv1 out
         conv_wgrad(ps, SP_P, gPf2, f, k, xin, d, P.c1w, P.c1b, im);
         conv_dgrad(ps, SP_P, gPf2, f, k, W(ps, P.c1w), d, dx, GEMM_ACCUM, im);
@@ -976,8 +1009,17 @@ public:
         MTTS_LAUNCH(embed_pos_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP, emb_out.p,
                     emb_out.ts, (const float*)we.p, we.ts, (const float*)pos_table, (const int*)p.p_tok, (const int*)p.p_row_t,
                     (const unsigned char*)p.p_valid, row_ts_p, d);
+        if (ps.train) {
+            unsigned sd = ps.seed_override;
+            if (!sd) {
+                sd = ((drop_base + 0x9E3779B9u) * 0x85EBCA6Bu) ^ (0x632BE5ABu * ++drop_counter);
+                sd ^= sd >> 15;
+                if (!sd) sd = 1u;
+            }
+            ps.pl->drop_seed = sd;
+        }
         TS x = emb_out;
-        for (int l = 0; l < cfg.enc_layers; ++l) { fft_fwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], x, none); x = encB[l].y2; }
+        for (int l = 0; l < cfg.enc_layers; ++l) { site_base = 2 * l; fft_fwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], x, none); x = encB[l].y2; }
         // speaker vector, added on every position of the phoneme rectangle
         TS tb = W(ps, spk_table);
         MTTS_LAUNCH(speaker_vec_kernel, dim3(p.maxB, 1, nt), dim3(64), stream, (const int*)p.meta, (const float*)tb.p, tb.ts,
@@ -986,15 +1028,15 @@ public:
                     (const float*)x.p, x.ts, (const float*)spk.p, spk.ts, (const int*)p.p_row_b, (const unsigned char*)p.p_inrect,
                     row_ts_p, x0.p, x0.ts, d);
         // variance adaptor: targets select the embeddings when given, else the (controlled) predictions
-        pred_fwd(ps, durP, durB, x0);
-        pred_fwd(ps, pitP, pitB, x0);
+        site_base = 128; pred_fwd(ps, durP, durB, x0);
+        site_base = 132; pred_fwd(ps, pitP, pitB, x0);
         TS pe = W(ps, pitch_emb), ee = W(ps, energy_emb);
         const bool tf = p.has_targets;
         MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
                     (const float*)x0.p, x0.ts, tf ? (const float*)p.p_pitch_t : (const float*)pitB.out.p, tf ? row_ts_p : pitB.out.ts,
                     tf ? 1.f : ps.p_control, (const float*)pitch_bins, cfg.n_bins - 1, (const float*)pe.p, pe.ts,
                     (const unsigned char*)p.p_inrect, row_ts_p, pidx, x1.p, x1.ts, d);
-        pred_fwd(ps, eneP, eneB, x1);
+        site_base = 136; pred_fwd(ps, eneP, eneB, x1);
         MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
                     (const float*)x1.p, x1.ts, tf ? (const float*)p.p_energy_t : (const float*)eneB.out.p, tf ? row_ts_p : eneB.out.ts,
                     tf ? 1.f : ps.e_control, (const float*)energy_bins, cfg.n_bins - 1, (const float*)ee.p, ee.ts,
@@ -1005,7 +1047,7 @@ public:
                     x2.ts, (const int*)p.f_src, (const int*)p.f_row_b, (const int*)p.f_row_t, row_ts_f, (const float*)spk.p, spk.ts,
                     (const float*)pos_table, dec_in.p, dec_in.ts, d);
         x = dec_in;
-        for (int l = 0; l < cfg.dec_layers; ++l) { fft_fwd(ps, SP_F, cfg.dec_heads, decP[l], decB[l], x, none); x = decB[l].y2; }
+        for (int l = 0; l < cfg.dec_layers; ++l) { site_base = 64 + 2 * l; fft_fwd(ps, SP_F, cfg.dec_heads, decP[l], decB[l], x, none); x = decB[l].y2; }
         // mel_linear: packed frames -> mel rectangle; padded frames carry the bias
         {
             GemmArgs g = rowgemm(p, SP_F, GEMM_NT);
@@ -1045,6 +1087,7 @@ public:
             MTTS_LAUNCH(bn_apply_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (const float*)b.c.p, b.c.ts,
                         (const float*)b.stats.p, b.stats.ts, (const float*)gm.p, (const float*)bt.p, gm.ts,
                         (const unsigned char*)p.r_inrect, row_ts_r, (int)(i < cfg.postnet_layers - 1), b.a.p, b.a.ts, P.cout);
+            drop(ps, SP_R, b.a, b.a, P.cout, cfg.postnet_dropout, 192 + i);  // F.dropout(..., 0.5, self.training), Layers.py:133-134
             cur = b.a;
         }
         // mel_post = postnet(mel) + mel   (whole [tasks][rows][n_mel] slab incl. guard rows: all zero there)
@@ -1132,8 +1175,11 @@ public:
             const PostP& P = postP[i];
             PostBuf& b = postB[i];
             const int act = (i < cfg.postnet_layers - 1);
+            const float ysc = drop_active(ps) ? 1.f - cfg.postnet_dropout : 1.f;
+            cur = drop(ps, SP_R, cur, gR1, P.cout, cfg.postnet_dropout, 192 + i);  // gradient through the mask (gRp itself is kept)
             TS dgm = Gd(P.g), dbt = Gd(P.beta);
             ColArgs ca;
+            ca.yscale = ysc;
             ca.X = cur.p; ca.x_ts = cur.ts; ca.Y = b.a.p; ca.y_ts = b.a.ts; ca.Z = b.c.p; ca.z_ts = b.c.ts;
             ca.stats = b.stats.p; ca.st_ts = b.stats.ts; ca.mask = p.r_inrect; ca.mask_ts = row_ts_r; ca.C = P.cout;
             ca.mode = 3; ca.do_tanh = act; ca.mfield = META_MR;
@@ -1143,7 +1189,7 @@ public:
             MTTS_LAUNCH(bn_bwd_apply_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (const float*)cur.p,
                         cur.ts, (const float*)b.a.p, b.a.ts, (const float*)b.c.p, b.c.ts, (const float*)b.stats.p, b.stats.ts,
                         (const float*)gm.p, gm.ts, (const float*)dgm.p, (const float*)dbt.p, dgm.ts,
-                        (const unsigned char*)p.r_inrect, row_ts_r, act, dc.p, dc.ts, P.cout);
+                        (const unsigned char*)p.r_inrect, row_ts_r, act, dc.p, dc.ts, P.cout, ysc);
             TS xin = (i == 0) ? mel : postB[i - 1].a;
             conv_wgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, xin, P.cin, P.w, P.b, p.r_inrect);
             if (i > 0) {
@@ -1169,6 +1215,7 @@ public:
         // ---- decoder ----------------------------------------------------------------------
         for (int l = cfg.dec_layers - 1; l >= 0; --l) {
             TS xin = l == 0 ? dec_in : decB[l - 1].y2;
+            site_base = 64 + 2 * l;
             fft_bwd(ps, SP_F, cfg.dec_heads, decP[l], decB[l], xin, gF0, gF1, gFqkv, gFh, dSf);
         }
         // ---- length regulator -> gP0 = dL/d(x2) -------------------------------------------
@@ -1182,11 +1229,11 @@ public:
         (void)va_needed;
         MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MP,
                     (const float*)gP0.p, gP0.ts, (const int*)eidx, row_ts_p, -1, Gd(energy_emb).p, n_total, d);
-        pred_bwd(ps, eneP, eneB, x1, dpred[2], gP0);
+        site_base = 136; pred_bwd(ps, eneP, eneB, x1, dpred[2], gP0);
         MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MP,
                     (const float*)gP0.p, gP0.ts, (const int*)pidx, row_ts_p, -1, Gd(pitch_emb).p, n_total, d);
-        pred_bwd(ps, pitP, pitB, x0, dpred[1], gP0);
-        pred_bwd(ps, durP, durB, x0, dpred[0], gP0);
+        site_base = 132; pred_bwd(ps, pitP, pitB, x0, dpred[1], gP0);
+        site_base = 128; pred_bwd(ps, durP, durB, x0, dpred[0], gP0);
         // speaker vector gradient, part 2: every position of the phoneme rectangle
         MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(64), stream, (const int*)p.meta, (const float*)gP0.p,
                     gP0.ts, (const int*)p.p_seg_start, (const int*)p.p_seg_len, (long long)cap_B, dspk.p, dspk.ts, d, 1);
@@ -1197,6 +1244,7 @@ public:
         // ---- encoder ------------------------------------------------------------------------
         for (int l = cfg.enc_layers - 1; l >= 0; --l) {
             TS xin = l == 0 ? emb_out : encB[l - 1].y2;
+            site_base = 2 * l;
             fft_bwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], xin, gP0, gP1, gPqkv, gPh, dSp);
         }
         // word embedding (padding row 0 keeps a zero gradient); p_tok is 0 on invalid rows, and

@@ -31,6 +31,7 @@ int mtts_create(const mtts_model_cfg* c, int device, int max_tasks, int max_B, i
     m.vocab = c->vocab; m.n_speaker = c->n_speaker; m.postnet_dim = c->postnet_dim; m.postnet_kernel = c->postnet_kernel;
     m.postnet_layers = c->postnet_layers; m.pitch_min = c->pitch_min; m.pitch_max = c->pitch_max;
     m.energy_min = c->energy_min; m.energy_max = c->energy_max; m.adapt_mask = c->adapt_mask;
+    m.enc_dropout = c->enc_dropout; m.dec_dropout = c->dec_dropout; m.vp_dropout = c->vp_dropout;
     if (h->eng.init(m, max_tasks, max_B, max_S, max_T) != 0) {
         g_create_error = h->eng.last_error;
         delete h;
@@ -57,6 +58,15 @@ void mtts_destroy(mtts_handle* h) {
 const char* mtts_last_error(mtts_handle* h) { return h ? h->eng.last_error.c_str() : g_create_error.c_str(); }
 
 int mtts_set_stream(mtts_handle* h, void* s) { h->eng.stream = (hipStream_t)s; return 0; }
+int mtts_set_dropout(mtts_handle* h, int enable, unsigned seed) {
+    Engine& e = h->eng;
+    for (float p : {e.cfg.enc_dropout, e.cfg.dec_dropout, e.cfg.vp_dropout})
+        if (p < 0.f || p >= 1.f) { e.set_error("dropout probability out of range"); return -1; }
+    e.dropout_on = enable != 0;
+    e.drop_base = seed;
+    e.drop_counter = 0;
+    return 0;
+}
 int mtts_synchronize(mtts_handle* h) { return hipStreamSynchronize(h->eng.stream) == hipSuccess ? 0 : -1; }
 
 int mtts_param_count(mtts_handle* h) { return (int)h->eng.entries.size(); }

@@ -168,6 +168,7 @@ struct ColArgs {
     const float* Z2 = nullptr; long long z2_ts = 0;
     const float* Y2 = nullptr; long long y2_ts = 0;
     const float* stats2 = nullptr; long long st2_ts = 0;
+    float yscale = 1.f;  // Y holds dropout(tanh(.)): y = Y * yscale with yscale = 1 - p (modes 3, 6)
     int C = 0, mode = 0, do_tanh = 0, mfield = 0, accumulate = 0;
 };
 
@@ -222,7 +223,7 @@ __global__ void colpart_kernel(const int* meta, ColArgs a, float* partial, int m
                     for (int k = 0; k < 4; ++k) { acc0[k] += x[k] * (zz[k] - mean) * rstd; acc1[k] += x[k]; }
                 } else if (a.mode == 3) {
                     float zz[4]; ldv(pz, m, zz);
-                    if (a.do_tanh) { float y[4]; ldv(py, m, y); for (int k = 0; k < 4; ++k) x[k] *= (1.f - y[k] * y[k]); }
+                    if (a.do_tanh) { float y[4]; ldv(py, m, y); for (int k = 0; k < 4; ++k) { const float yy = y[k] * a.yscale; x[k] *= (1.f - yy * yy); } }
                     for (int k = 0; k < 4; ++k) { acc0[k] += x[k] * (zz[k] - mu[k]) * rs[k]; acc1[k] += x[k]; }
                 } else if (a.mode == 5) {
                     float zz[4], dy[4], tz[4]; ldv(pz, m, zz); ldv(px2, m, dy); ldv(pz2, m, tz);
@@ -238,7 +239,7 @@ __global__ void colpart_kernel(const int* meta, ColArgs a, float* partial, int m
                     for (int k = 0; k < 4; ++k) { g[k] = dy[k]; tg[k] = x[k]; }
                     if (a.do_tanh) {
                         float y[4], ty[4]; ldv(py, m, y); ldv(py2, m, ty);
-                        for (int k = 0; k < 4; ++k) { const float sq = 1.f - y[k] * y[k]; tg[k] = x[k] * sq - 2.f * y[k] * ty[k] * dy[k]; g[k] = dy[k] * sq; }
+                        for (int k = 0; k < 4; ++k) { const float yy = y[k] * a.yscale, tyy = ty[k] * a.yscale; const float sq = 1.f - yy * yy; tg[k] = x[k] * sq - 2.f * yy * tyy * dy[k]; g[k] = dy[k] * sq; }
                     }
                     for (int k = 0; k < 4; ++k) {
                         const float xh = (zz[k] - mu[k]) * rs[k];
@@ -609,7 +610,7 @@ __global__ void bn_bwd_apply_kernel(const int* meta, const float* dY, long long 
                                     long long ya_ts, const float* X, long long x_ts, const float* stats,
                                     long long st_ts, const float* gamma, long long par_ts, const float* dgamma,
                                     const float* dbeta, long long dg_ts, const unsigned char* inrect,
-                                    long long row_ts, int do_tanh, float* dX, long long dx_ts, int C) {
+                                    long long row_ts, int do_tanh, float* dX, long long dx_ts, int C, float yscale) {
     ROW_PROLOGUE(META_MR)
     float* pdx = dX + (long long)z * dx_ts + (long long)row * C;
     if (!inrect[(long long)z * row_ts + row]) { for (int c = lane * 4; c < C; c += 256) st4(pdx + c, zero4()); return; }
@@ -627,8 +628,9 @@ __global__ void bn_bwd_apply_kernel(const int* meta, const float* dY, long long 
         float dd[4] = {d4.x, d4.y, d4.z, d4.w};
         if (do_tanh) {
             const float4 y4 = ld4(pya + c);
-            dd[0] *= (1.f - y4.x * y4.x); dd[1] *= (1.f - y4.y * y4.y);
-            dd[2] *= (1.f - y4.z * y4.z); dd[3] *= (1.f - y4.w * y4.w);
+            const float y0 = y4.x * yscale, y1 = y4.y * yscale, y2 = y4.z * yscale, y3 = y4.w * yscale;
+            dd[0] *= (1.f - y0 * y0); dd[1] *= (1.f - y1 * y1);
+            dd[2] *= (1.f - y2 * y2); dd[3] *= (1.f - y3 * y3);
         }
         const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ms[4] = {mu.x, mu.y, mu.z, mu.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w};
         const float gs[4] = {g4.x, g4.y, g4.z, g4.w}, dgs[4] = {dg4.x, dg4.y, dg4.z, dg4.w}, dbs[4] = {db4.x, db4.y, db4.z, db4.w};
@@ -662,6 +664,33 @@ __global__ void gather_rows_kernel(const int* meta, int mfield, const float* src
     float* po = out + (long long)z * out_ts + (long long)row * C;
     const float* ps = src + (long long)z * src_ts + (long long)(s < 0 ? 0 : s) * C;
     for (int c = lane * 4; c < C; c += 256) st4(po + c, s < 0 ? zero4() : ld4(ps + c));
+}
+
+// ------------------------------------------------------------------------------------------
+// Dropout (nn.Dropout / F.dropout of SubLayers.py:54,90, modules.py:223,235, Layers.py:133-134) as a
+// counter-based mask: keep(seed, task, row, col) is a pure function (splitmix64 of the element id), so
+// forward, backward and the second-order replay regenerate the same mask without storing it.
+// dst = keep ? src / (1 - p) : 0 on rows < M; dst may alias src.  thr16 = round(p * 65536).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void dropout_kernel(const int* meta, int mfield, const float* src, long long src_ts, float* dst, long long dst_ts,
+                               int C, unsigned seed, unsigned thr16, float scale) {
+    ROW_PROLOGUE(mfield)
+    const float* ps = src + (long long)z * src_ts + (long long)row * C;
+    float* pd = dst + (long long)z * dst_ts + (long long)row * C;
+    const unsigned long long base = ((unsigned long long)seed << 32) ^ ((unsigned long long)z << 24);
+    for (int c = lane * 4; c < C; c += 256) {
+        const unsigned long long h = splitmix64(base + ((unsigned long long)row * (unsigned)C + (unsigned)c) / 4ull);
+        const float4 v = ld4(ps + c);
+        st4(pd + c, make_float4(((h) & 0xFFFFu) >= thr16 ? v.x * scale : 0.f, ((h >> 16) & 0xFFFFu) >= thr16 ? v.y * scale : 0.f,
+                                ((h >> 32) & 0xFFFFu) >= thr16 ? v.z * scale : 0.f, ((h >> 48) & 0xFFFFu) >= thr16 ? v.w * scale : 0.f));
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -183,7 +183,7 @@ __global__ void bn_jvp_apply_kernel(const int* meta, const float* X, long long x
                                     long long tsum_ts, const float* gamma, long long par_ts, const float* tgamma,
                                     const float* tbeta, long long tpar_ts, const float* A, long long a_ts,
                                     const unsigned char* inrect, long long row_ts, int do_tanh, float* tA, long long ta_ts,
-                                    int C) {
+                                    int C, float yscale) {
     ROW_PROLOGUE(META_MR)
     float* po = tA + (long long)z * ta_ts + (long long)row * C;
     if (!inrect[(long long)z * row_ts + row]) { for (int c = lane * 4; c < C; c += 256) st4(po + c, zero4()); return; }
@@ -210,7 +210,7 @@ __global__ void bn_jvp_apply_kernel(const int* meta, const float* X, long long x
             const float xh = (x_[k] - mu_[k]) * rs_[k];
             const float txh = rs_[k] * (t_[k] - q0_[k] * inv_n - xh * q1_[k] * inv_n);
             float ty = tg_[k] * xh + g_[k] * txh + tb_[k];
-            if (do_tanh) ty *= (1.f - a_[k] * a_[k]);
+            if (do_tanh) { const float yy = a_[k] * yscale; ty *= (1.f - yy * yy); }
             o[k] = ty;
         }
         st4(po + c, f4(o[0], o[1], o[2], o[3]));
@@ -230,7 +230,7 @@ __global__ void bn_jvp_bwd_kernel(const int* meta, const float* dY, long long dy
                                   long long par_ts, const float* tgamma, long long tpar_ts, const float* dgamma,
                                   const float* dbeta, long long dg_ts, const float* tA0, const float* tA1, long long tA_ts,
                                   const unsigned char* inrect, long long row_ts, int do_tanh, float* dX, long long dx_ts,
-                                  float* tdX, long long tdx_ts, int C) {
+                                  float* tdX, long long tdx_ts, int C, float yscale) {
     ROW_PROLOGUE(META_MR)
     float* pdx = dX + (long long)z * dx_ts + (long long)row * C;
     float* ptd = tdX + (long long)z * tdx_ts + (long long)row * C;
@@ -261,7 +261,7 @@ __global__ void bn_jvp_bwd_kernel(const int* meta, const float* dY, long long dy
             const float m2 = q1_[k] * inv_n;
             const float txh = r * (tx_[k] - q0_[k] * inv_n - xh * m2);
             float gk = dy_[k], tgk = tgy_[k];
-            if (do_tanh) { const float s = 1.f - a_[k] * a_[k]; tgk = tgy_[k] * s - 2.f * a_[k] * ta_[k] * dy_[k]; gk = dy_[k] * s; }
+            if (do_tanh) { const float yy = a_[k] * yscale, tyy = ta_[k] * yscale; const float s = 1.f - yy * yy; tgk = tgy_[k] * s - 2.f * yy * tyy * dy_[k]; gk = dy_[k] * s; }
             const float core = gk - db_[k] * inv_n - xh * dg_[k] * inv_n;
             o0[k] = g_[k] * r * core;
             o1[k] = r * (tgm_[k] - g_[k] * r * m2) * core + g_[k] * r * (tgk - a1_[k] * inv_n - txh * dg_[k] * inv_n - xh * a0_[k] * inv_n);

@@ -38,7 +38,7 @@ class Engine:
         cfg = _lib.ModelCfg()
         for f in ("d_model", "enc_layers", "dec_layers", "enc_heads", "dec_heads", "d_ff", "k1", "k2", "vp_filter",
                   "vp_kernel", "n_bins", "max_seq_len", "n_mel", "vocab", "n_speaker", "postnet_dim", "postnet_kernel",
-                  "postnet_layers", "pitch_min", "pitch_max", "energy_min", "energy_max"):
+                  "postnet_layers", "pitch_min", "pitch_max", "energy_min", "energy_max", "enc_dropout", "dec_dropout", "vp_dropout"):
             setattr(cfg, f, getattr(dims, f))
         mask = 0
         for m in adapt_modules:
@@ -83,6 +83,10 @@ class Engine:
 
     def set_stream(self, stream_ptr: int):
         self._ck(self.lib.mtts_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_dropout(self, enable: bool, seed: int = 0):
+        """Train-mode dropout on/off (off = parity configuration)."""
+        self._ck(self.lib.mtts_set_dropout(self.h, int(enable), int(seed) & 0xFFFFFFFF))
 
     def synchronize(self):
         self._ck(self.lib.mtts_synchronize(self.h))

@@ -258,3 +258,96 @@ def test_second_order_maml_matches_oracle(emu_lib):
     n = "decoder.layer_stack.1.pos_ffn.w_2.weight"
     assert np.abs(eng.export(n, 1) - fo[n]).max() <= 2e-3 * np.abs(fo[n]).max()
     eng.close()
+
+
+def _loss_and_grads(eng, seed, names, use_fast=False):
+    eng.set_dropout(True, seed)            # resets the pass counter: identical masks on every call
+    eng.forward(0, use_fast=use_fast, train=True)
+    l = float(eng.loss(0)[0, 0])
+    eng.backward(0, use_fast=use_fast, scale=1.0, need_encoder=True)
+    return l, {n: eng.export(n, 2, 0).astype(np.float64) for n in names}
+
+
+def test_dropout_masks_are_replayed_and_gradients_consistent(emu_lib):
+    """Train-mode dropout (SubLayers.py:54,90; modules.py:223,235; Layers.py:133-134): counter-based masks, replayed by
+    backward.  No bit-parity with torch's RNG is possible, so: determinism per seed, sensitivity to the seed, keep-rate, and
+    a central finite-difference check of the analytic gradient with the masks frozen."""
+    dims = tiny_dims()
+    eng = _engine(dims, emu_lib, tasks=1)
+    b0 = synth.make_batch(3, 3, speaker=2, **_kw(dims))
+    eng.set_batches(0, [b0])
+    names = ["decoder.layer_stack.1.pos_ffn.w_2.weight", "variance_adaptor.pitch_predictor.conv_layer.conv1d_2.conv.weight",
+             "postnet.convolutions.1.0.conv.weight", "encoder.layer_stack.0.slf_attn.fc.weight", "mel_linear.weight"]
+    l1, g1 = _loss_and_grads(eng, 7, names)
+    l2, g2 = _loss_and_grads(eng, 7, names)
+    l3, _ = _loss_and_grads(eng, 8, names)
+    assert l1 == l2 and all(np.array_equal(g1[n], g2[n]) for n in names)
+    assert l1 != l3
+    eng.set_dropout(False)
+    eng.forward(0, train=True)
+    l0 = float(eng.loss(0)[0, 0])
+    assert abs(l1 - l0) > 1e-3  # dropout really changes the forward
+    # keep-rate of the last PostNet layer's mask: zeros of mel_post - mel where the un-dropped value is non-zero
+    eng.set_dropout(True, 7)
+    eng.forward(0, train=True)
+    o = eng.outputs(0, 0)
+    resid = o["mel_post"] - o["mel"]
+    frac_zero = float((resid == 0).mean())
+    assert 0.4 < frac_zero < 0.6
+    # finite differences along a random direction, masks frozen by re-seeding
+    base = {n: eng.export(n) for n in names}
+    g = np.random.RandomState(0)
+    dirs = {n: g.standard_normal(base[n].shape).astype(np.float32) for n in names}
+    eps = 2e-4  # small enough to stay on one side of the ReLU / L1 kinks; fp32 loss noise then is ~0.1 in the quotient
+    for n in names:
+        vals = []
+        for sgn in (+1, -1):
+            eng.load_params({n: base[n] + sgn * eps * dirs[n]}, strict=False)
+            vals.append(_loss_and_grads(eng, 7, names)[0])
+        eng.load_params({n: base[n]}, strict=False)
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        an = float((g1[n] * dirs[n]).sum())
+        assert abs(fd - an) <= 0.05 * abs(an) + 0.3, (n, fd, an)
+    eng.close()
+
+
+def test_second_order_with_dropout_replays_inner_step_masks(emu_lib):
+    """HVP with dropout on.  fp32 finite differences of gradients are too noisy for a second derivative, so the check is
+    exact algebra instead: with frozen masks the loss is a smooth function, its Hessian block over the adapted weights is
+    symmetric, hence <u, H v> == <v, H u> for two unrelated directions — which only holds if the tangent forward and the
+    tangent backward regenerate exactly the masks of the primal pass."""
+    dims = tiny_dims()
+    eng = _engine(dims, emu_lib, tasks=1)
+    b0 = synth.make_batch(3, 3, speaker=2, **_kw(dims))
+    eng.set_batches(0, [b0])
+    adapted = [n for n in eng.params if eng.params[n][2]]
+    base = {n: eng.export(n) for n in adapted}
+    g = np.random.RandomState(3)
+
+    def direction_and_hv(perturb):
+        # direction = gradient at (theta + perturb) left in the gradient buffer; H evaluated at theta
+        eng.load_params({n: base[n] + perturb[n] for n in adapted}, strict=False)
+        eng.adapt(0, 0.0, reset=True)
+        _, v = _loss_and_grads(eng, 11, adapted, use_fast=True)
+        eng.load_params(base, strict=False)
+        eng.adapt(0, 0.0, reset=True)
+        eng.set_dropout(True, 11)  # the HVP re-runs the forward: counter reset => same masks as every other pass here
+        eng.hvp_support()
+        return v, {n: eng.export(n, 6, 0).astype(np.float64) for n in adapted}
+
+    zero = {n: np.zeros_like(base[n]) for n in adapted}
+    bump = {n: (0.02 * g.standard_normal(base[n].shape) * np.abs(base[n]).mean()).astype(np.float32) for n in adapted}
+    u, Hu = direction_and_hv(zero)
+    v, Hv = direction_and_hv(bump)
+    uHv = sum(float((u[n] * Hv[n]).sum()) for n in adapted)
+    vHu = sum(float((v[n] * Hu[n]).sum()) for n in adapted)
+    assert abs(uHv - vHu) <= 2e-3 * max(abs(uHv), abs(vHu)), (uHv, vHu)
+    # and the masks matter: without replay (different seed for the HVP) symmetry is lost
+    eng.load_params(base, strict=False)
+    eng.adapt(0, 0.0, reset=True)
+    _loss_and_grads(eng, 11, adapted, use_fast=True)
+    eng.set_dropout(True, 12)
+    eng.hvp_support()
+    Hu_wrong = {n: eng.export(n, 6, 0).astype(np.float64) for n in adapted}
+    assert abs(sum(float((v[n] * Hu_wrong[n]).sum()) for n in adapted) - uHv) > 1e-2 * abs(uHv)
+    eng.close()
