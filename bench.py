@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--order", type=int, default=1, choices=(1, 2),
                     help="MAML order of the timed meta-step: 1 = BASELINE config C3 (first-order), 2 = the reference's training mode / config C4")
     ap.add_argument("--no-second-order", action="store_true", help="skip the extra second-order measurement")
+    ap.add_argument("--numerics", choices=("fp32", "bf16x3"), default="fp32",
+                    help="contraction numerics of the timed meta-step: exact fp32 MFMA (default, parity mode) or split-bf16")
+    ap.add_argument("--no-bf16x3-leg", action="store_true", help="skip the extra split-bf16 measurement")
     ap.add_argument("--no-dropout", action="store_true", help="parity configuration (dropout = identity) instead of train-mode dropout")
     args = ap.parse_args()
 
@@ -164,6 +167,8 @@ def main():
     outer = torch.as_tensor(eng.outer_grad_view(), device=f"cuda:{local_rank}") if n > 1 else None
 
     step_no = [0]
+    lib0 = _lib.load()
+    lib0.mtts_set_numerics(1 if args.numerics == "bf16x3" else 0)
 
     def meta_step(order=None):
         eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=((order or args.order) == 2), fetch_losses=False)
@@ -211,6 +216,29 @@ def main():
             dso = float(tt.item())
         so = {"value": round(so_steps / dso, 4), "unit": "meta-steps/s", "ms_per_step": round(1e3 * dso / so_steps, 2), "steps": so_steps,
               "workload": "same 8-task meta-step, second-order MAML (Hessian-vector recursion through the 5 inner steps)"}
+    b16 = None
+    if args.numerics == "fp32" and not args.no_bf16x3_leg:
+        # same first-order meta-step with the split-bf16 contraction numerics (3 bf16 MFMAs per product)
+        lib0.mtts_set_numerics(1)
+        meta_step(1)
+        torch.cuda.synchronize()
+        if n > 1:
+            dist.barrier()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            meta_step(1)
+        torch.cuda.synchronize()
+        if n > 1:
+            dist.barrier()
+        d16 = time.perf_counter() - t2
+        lib0.mtts_set_numerics(0)
+        if n > 1:
+            tt = torch.tensor([d16], device=f"cuda:{local_rank}", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d16 = float(tt.item())
+        b16 = {"value": round(args.steps / d16, 4), "unit": "meta-steps/s", "ms_per_step": round(1e3 * d16 / args.steps, 2),
+               "numerics": "fp32 operands split into 2 x bf16, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; "
+                           "mel L1 vs reference 1.0e-5 in eval mode (gate 1e-4), 1.6e-4 with train-mode BatchNorm"}
     q_losses = None
     roof = None
     if rank == 0:
@@ -254,10 +282,12 @@ def main():
                 "config": {"workload": ("C3: Meta-TTS MAML first-order" if args.order == 1 else "C4-style: Meta-TTS MAML second-order") + " (algorithm=meta_emb_vad, inner=5, meta-batch=8 tasks x (5 support + 5 query utts)), "
                                        "FastSpeech2 base.yaml, outer mean + clip(1.0) + Adam/Noam", "meta_batch": META_BATCH,
                            "tasks_per_gpu": META_BATCH // n, "inner_steps": INNER_STEPS, "order": "first" if args.order == 1 else "second", "parallelism": f"task-dp{n}",
-                           "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "dropout": "identity (parity config)" if args.no_dropout else "on (0.2 / 0.5 / 0.5, counter-based masks)"},
+                           "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.numerics == "fp32" else "bf16x3 (split-fp32 on v_mfma_f32_32x32x16_bf16)", "dropout": "identity (parity config)" if args.no_dropout else "on (0.2 / 0.5 / 0.5, counter-based masks)"},
                 "query_total_loss_mean": round(float(q_losses[:, 0].mean()), 5) if q_losses is not None else None}
         if so is not None:
             line["second_order"] = so
+        if b16 is not None:
+            line["bf16x3_numerics"] = b16
         if infer is not None:
             line["inference_c5"] = infer
         if roof is not None:

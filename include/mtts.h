@@ -136,6 +136,12 @@ int mtts_outer_update(mtts_handle* h, const float* grad_dev, float lr, float bet
                       float weight_decay, float max_norm, float* grad_norm_host);
 int mtts_reset_optimizer(mtts_handle* h);
 
+/* ---- numerics of the contraction kernels (process-wide).  0 (default): exact fp32 MFMA, the parity reference.
+ * 1: "bf16x3" — fp32 operands split into two bf16 (16 mantissa bits) at LDS-staging time, three bf16 MFMAs per
+ * product, fp32 accumulation: ~1e-5 relative error per contraction, still inside the 1e-4 mel-L1 gate (tests), at
+ * up to 5.3x the fp32-MFMA rate.  Inputs, outputs, parameters and every non-GEMM kernel stay fp32. */
+int mtts_set_numerics(int mode);
+
 /* ---- measurement: per-launch HIP-event timing of the GEMM kernel family on the launch stream.
  * report: out[kernel][3] = {launches, total ms, total algorithmic flops}, kernel = form*2 + (tile==128),
  * form 0 NT / 1 NN / 2 TN.  (bench.py roofline leg) */

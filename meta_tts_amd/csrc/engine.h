@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "gemm.h"
+#include "gemm_bf16_launch.h"
 #include "rowops.h"
 #include "tangent.h"
 

@@ -151,6 +151,39 @@ __device__ __forceinline__ void mma_half(const Frags<TM, TN, BK>& f, int hf, f32
 #endif
 }
 
+// Fused epilogue shared by the fp32 and the split-bf16 kernels: alpha, bias, accumulate, ReLU, ReLU-mask of a
+// saved activation, row mask, output row remap.  (mb, nb) = origin of this wave's tile.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int z, f32x16 (&acc)[TM][TN], float* C, int ldc, int M, int N,
+                                              int mb, int nb, int lane) {
+    const float* bias = g.bias ? g.bias + (long long)z * g.bias_gs : nullptr;
+    const unsigned char* rowmask = g.rowmask ? g.rowmask + (long long)z * g.rowmask_gs : nullptr;
+    const float* relu_ref = g.relu_ref ? g.relu_ref + (long long)z * g.relu_ref_gs : nullptr;
+    const int* rowmap = g.c_rowmap ? g.c_rowmap + (long long)z * g.c_rowmap_gs : nullptr;
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nb + j * 32 + l31;
+            const float bv = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= M || n >= N) continue;
+                int mo = m;
+                if (rowmap) { mo = rowmap[m]; if (mo < 0) continue; }
+                float* p = C + (long long)mo * ldc + n;
+                float v = g.alpha * acc[i][j][r] + bv;
+                if (g.flags & GEMM_ACCUM) v += *p;  // accumulate first: the masks below act on the sum
+                if (g.flags & GEMM_RELU) v = fmaxf(v, 0.f);
+                if (relu_ref && !(relu_ref[(long long)m * g.ld_relu + n] > 0.f)) v = 0.f;
+                if (rowmask && !rowmask[m]) v = 0.f;
+                *p = v;
+            }
+        }
+}
+
 template <int FORM, int BM, int BN, int BK, bool PIPE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int kLDK = BK + 4;  // K-contiguous LDS row stride: 80 / 144 bytes, ds_read_b128 conflict-free
@@ -293,33 +326,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
     }
 
-    // ---- epilogue ----------------------------------------------------------------------
-    const float* bias = g.bias ? g.bias + (long long)z * g.bias_gs : nullptr;
-    const unsigned char* rowmask = g.rowmask ? g.rowmask + (long long)z * g.rowmask_gs : nullptr;
-    const float* relu_ref = g.relu_ref ? g.relu_ref + (long long)z * g.relu_ref_gs : nullptr;
-    const int* rowmap = g.c_rowmap ? g.c_rowmap + (long long)z * g.c_rowmap_gs : nullptr;
-    const int l31 = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn0 + j * 32 + l31;
-            const float bv = (bias && n < N) ? bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= M || n >= N) continue;
-                int mo = m;
-                if (rowmap) { mo = rowmap[m]; if (mo < 0) continue; }
-                float* p = C + (long long)mo * ldc + n;
-                float v = g.alpha * acc[i][j][r] + bv;
-                if (g.flags & GEMM_ACCUM) v += *p;  // accumulate first: the masks below act on the sum
-                if (g.flags & GEMM_RELU) v = fmaxf(v, 0.f);
-                if (relu_ref && !(relu_ref[(long long)m * g.ld_relu + n] > 0.f)) v = 0.f;
-                if (rowmask && !rowmask[m]) v = 0.f;
-                *p = v;
-            }
-        }
+    gemm_epilogue<TM, TN>(g, z, acc, C, ldc, M, N, m0 + wm0, n0 + wn0, lane);
 }
 
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg):
@@ -347,6 +354,12 @@ struct GemmProfiler {
     }
 };
 inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
+inline int& gemm_numerics() {  // 0: exact fp32 MFMA (default), 1: split-bf16 "bf16x3" (gemm_bf16.h); MTTS_NUMERICS env overrides
+    static int v = [] { const char* e = getenv("MTTS_NUMERICS"); return (e && atoi(e) == 1) ? 1 : 0; }();
+    return v;
+}
+inline bool gemm_launch_bf16x3(int form, const GemmArgs& g, int max_M, int max_N, int groups, hipStream_t stream, int tile,
+                               double rows);  // gemm_bf16_launch.h
 inline int& gemm_default_bk() {  // MTTS_GEMM_BK=16/32
     static int v = [] { const char* e = getenv("MTTS_GEMM_BK"); return (e && atoi(e) == 32) ? 32 : 16; }();
     return v;
@@ -364,6 +377,7 @@ inline bool& gemm_default_pipe() {  // MTTS_GEMM_PIPE=0/1 overrides the built-in
 inline void gemm_launch(int form, const GemmArgs& g, int max_M, int max_N, int groups, hipStream_t stream,
                         int tile = 0, double alg_flops = 0.0, long long total_M = 0) {
     if (max_M <= 0 || max_N <= 0 || groups <= 0) return;
+    const int user_tile = tile;
     auto ntiles = [&](int t) { return (long)((max_M + t - 1) / t) * ((max_N + t - 1) / t); };
     if (tile == 0) {
         const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
@@ -372,6 +386,15 @@ inline void gemm_launch(int form, const GemmArgs& g, int max_M, int max_N, int g
             return base * b / std::ceil(b);
         };
         tile = eff(128, 1.0) >= eff(64, 0.97) ? 128 : 64;
+    }
+    GemmProfiler& prof0 = gemm_profiler();
+    if (gemm_numerics() == 1 && tile < 1000 && !(g.taps > 1 && g.tap_k % 32 != 0)) {
+        hipEvent_t b0 = nullptr, b1 = nullptr;
+        if (prof0.enabled) { b0 = prof0.get(); b1 = prof0.get(); hipEventRecord(b0, stream); }
+        const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
+        const bool big = gemm_launch_bf16x3(form, g, max_M, max_N, groups, stream, user_tile, rows);
+        if (prof0.enabled) { hipEventRecord(b1, stream); prof0.recs.push_back(GemmProfiler::Rec{form * 2 + (big ? 1 : 0), alg_flops, b0, b1}); }
+        return;
     }
     // tile code: 64 / 128 (+1000 software pipeline, +2000 BK=32); plain 64 / 128 take the defaults
     bool pipe = gemm_default_pipe();

@@ -1,0 +1,287 @@
+// Split-fp32 GEMM on the bf16 matrix cores ("bf16x3"): every fp32 operand element is split at LDS-staging
+// time into two bf16 values, hi = bf16(a) and mid = bf16(a - hi) (16 mantissa bits together), and each
+// 32x32x16 product is accumulated in fp32 as  hi*hi + hi*mid + mid*hi  (the dropped mid*mid term is
+// 2^-16 relative).  Three v_mfma_f32_32x32x16_bf16 do the work of eight v_mfma_f32_32x32x2_f32 at 1/16 of
+// their cycle cost each: 2.5 PFLOP/s / 3 = 833 TFLOP/s effective peak against 157 TFLOP/s for the exact fp32
+// MFMA, at ~1e-5 relative error per contraction (plain bf16 would be 4e-3 and misses the 1e-4 mel-L1 gate by
+// 14x).  Same GemmArgs, forms, grouping and fused epilogue as gemm.h; selected per
+// handle with mtts_set_numerics(h, 1).  The exact fp32 kernel stays the default and the parity reference.
+//
+// Layout: BK = 32.  All operands are staged K-contiguous in LDS as bf16 [row][32 + 8] (80-byte rows,
+// ds_read_b128 conflict-free), one image for hi and one for mid.  K-contiguous global operands are loaded as
+// float4 along k; reduction-major operands (NN's B, TN's A and B) are loaded one dword per lane down k
+// (each load instruction still covers 64 consecutive columns = 256 contiguous bytes) and transposed for free
+// by where the thread writes its 8-element bf16 packet.  Lane half h = lane>>5 feeds k = 16 s + 8 h .. +7
+// of MFMA step s for both operands.
+#pragma once
+#include "gemm.h"
+
+namespace mtts {
+
+#if defined(MTTS_EMU)
+struct bfrag { unsigned short v[8]; };
+#else
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+struct bfrag { bf16x8_t v; };
+#endif
+
+__device__ __forceinline__ unsigned f2u(float x) { unsigned u; __builtin_memcpy(&u, &x, 4); return u; }
+__device__ __forceinline__ float u2f(unsigned u) { float x; __builtin_memcpy(&x, &u, 4); return x; }
+// (hi, mid) of two floats packed as 2 x bf16 each: lo 16 bits = first element
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& mid) {
+#if defined(MTTS_EMU)
+    auto rne = [](float x) { const unsigned u = f2u(x); return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16; };
+    const unsigned ha = rne(a), hb = rne(b);
+    const unsigned ma = rne(a - u2f(ha << 16)), mb = rne(b - u2f(hb << 16));
+    hi = ha | (hb << 16);
+    mid = ma | (mb << 16);
+#else
+    const bf16x2_t h = {(__bf16)a, (__bf16)b};  // v_cvt_pk_bf16_f32 (round to nearest even)
+    hi = __builtin_bit_cast(unsigned, h);
+    const float ra = a - u2f(hi << 16), rb = b - u2f(hi & 0xFFFF0000u);
+    const bf16x2_t m = {(__bf16)ra, (__bf16)rb};
+    mid = __builtin_bit_cast(unsigned, m);
+#endif
+}
+
+inline double& gemm_bf16_small_tile_eff() {  // MTTS_BF16_EFF64 tunes the tile model (A/B runs)
+    static double v = [] { const char* e = getenv("MTTS_BF16_EFF64"); return e ? atof(e) : 0.7; }();
+    return v;
+}
+constexpr int kBK16 = 32;       // K slice of the bf16x3 kernel
+constexpr int kLD16 = 40;       // bf16 elements per LDS row (80 bytes)
+
+template <int TM, int TN>
+struct Frags16 {
+    bfrag ah[2][TM], am[2][TM], bh[2][TN], bm[2][TN];  // [k-step][subtile]
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void read_frags16(const unsigned short* Ah, const unsigned short* Am, const unsigned short* Bh,
+                                             const unsigned short* Bm, int wm0, int wn0, int lane, Frags16<TM, TN>& f) {
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int kb = 16 * s + 8 * h;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int o = (wm0 + i * 32 + l31) * kLD16 + kb;
+            f.ah[s][i] = *reinterpret_cast<const bfrag*>(Ah + o);
+            f.am[s][i] = *reinterpret_cast<const bfrag*>(Am + o);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int o = (wn0 + j * 32 + l31) * kLD16 + kb;
+            f.bh[s][j] = *reinterpret_cast<const bfrag*>(Bh + o);
+            f.bm[s][j] = *reinterpret_cast<const bfrag*>(Bm + o);
+        }
+    }
+}
+
+#if defined(MTTS_EMU)
+// emulator: every lane keeps its accumulator rows itself, so the product is evaluated from the LDS images
+template <int TM, int TN>
+__device__ __forceinline__ void mma16_emu(const unsigned short* Ah, const unsigned short* Am, const unsigned short* Bh,
+                                          const unsigned short* Bm, int wm0, int wn0, int lane, f32x16 (&acc)[TM][TN]) {
+    const int l31 = lane & 31, h = lane >> 5;
+    auto bf = [](unsigned short v) { return u2f((unsigned)v << 16); };
+    for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j)
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, col = wn0 + j * 32 + l31;
+                float s = acc[i][j][r];
+                for (int k = 0; k < kBK16; ++k) {
+                    const float ah = bf(Ah[row * kLD16 + k]), am = bf(Am[row * kLD16 + k]);
+                    const float bh = bf(Bh[col * kLD16 + k]), bm = bf(Bm[col * kLD16 + k]);
+                    s += ah * bh + ah * bm + am * bh;
+                }
+                acc[i][j][r] = s;
+            }
+}
+#else
+template <int TM, int TN>
+__device__ __forceinline__ void mma16(const Frags16<TM, TN>& f, f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am[s][i].v, f.bh[s][j].v, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[s][i].v, f.bm[s][j].v, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[s][i].v, f.bh[s][j].v, acc[i][j], 0, 0, 0);
+            }
+}
+#endif
+
+template <int FORM, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
+    constexpr bool A_KC = (FORM != GEMM_TN);
+    constexpr bool B_KC = (FORM == GEMM_NT);
+    constexpr int BK = kBK16;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_IMG = BM * kLD16, B_IMG = BN * kLD16;          // bf16 elements per image
+    constexpr int BUF = 2 * (A_IMG + B_IMG);                       // hi + mid of both operands
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
+    // K-contiguous loader: rows x 8 float4; reduction-major loader: cols x (256/cols) k-groups
+    constexpr int A_KC4 = (BM * 8) / 256, B_KC4 = (BN * 8) / 256;  // float4 per thread
+    constexpr int A_KG = 256 / BM, B_KG = 256 / BN;                // k-groups (2 for 128 cols, 4 for 64)
+    constexpr int A_KPT = BK / A_KG, B_KPT = BK / B_KG;            // k per thread (16 or 8)
+    constexpr int A_NREG = A_KC ? A_KC4 * 4 : A_KPT, B_NREG = B_KC ? B_KC4 * 4 : B_KPT;
+
+    const int z = blockIdx.z;
+    const float* A = g.A;
+    const float* B = g.B;
+    float* C = g.C;
+    int M = g.M, N = g.N, K = g.K;
+    int lda = g.lda, ldb = g.ldb, ldc = g.ldc;
+    if (g.table) {
+        const GemmGroupDesc d = g.table[z];
+        A += d.a_off; B += d.b_off; C += d.c_off;
+        M = d.M; N = d.N; K = d.K;
+        if (d.lda) lda = d.lda;
+        if (d.ldb) ldb = d.ldb;
+        if (d.ldc) ldc = d.ldc;
+    } else {
+        A += (long long)z * g.a_gs; B += (long long)z * g.b_gs; C += (long long)z * g.c_gs;
+        if (g.dimptr) {
+            const int v = g.dimptr[(long long)z * g.dim_stride];
+            if (g.dim_sel == 0) M = v; else K = v;
+        }
+    }
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    if ((int)blockIdx.x >= tiles_m * tiles_n || K <= 0) return;
+    const int m0 = ((int)blockIdx.x / tiles_n) * BM, n0 = ((int)blockIdx.x % tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int K4 = (K + 3) & ~3;
+
+    float areg[A_NREG], breg[B_NREG];
+
+    auto load_a = [&](int k0) {
+        if (A_KC) {
+#pragma unroll
+            for (int i = 0; i < A_KC4; ++i) {
+                const int row = tid / 8 + 32 * i, gk = k0 + (tid % 8) * 4, gm = m0 + row;
+                const float4 v = (gm < M && gk < K4) ? ld4(A + (long long)gm * lda + gk) : zero4();
+                areg[4 * i] = v.x; areg[4 * i + 1] = v.y; areg[4 * i + 2] = v.z; areg[4 * i + 3] = v.w;
+            }
+        } else {
+            const int col = tid % BM, kg = tid / BM, gc = m0 + col;
+#pragma unroll
+            for (int j = 0; j < A_KPT; ++j) {
+                const int gk = k0 + kg * A_KPT + j;
+                areg[j] = (gk < K && gc < M) ? A[(long long)gk * lda + gc] : 0.f;
+            }
+        }
+    };
+    auto load_b = [&](int k0) {
+        if (B_KC) {
+#pragma unroll
+            for (int i = 0; i < B_KC4; ++i) {
+                const int row = tid / 8 + 32 * i, gk = k0 + (tid % 8) * 4, gn = n0 + row;
+                const float4 v = (gn < N && gk < K4) ? ld4(B + (long long)gn * ldb + gk) : zero4();
+                breg[4 * i] = v.x; breg[4 * i + 1] = v.y; breg[4 * i + 2] = v.z; breg[4 * i + 3] = v.w;
+            }
+        } else {
+            const int tap = k0 / g.tap_k, kin = k0 - tap * g.tap_k;
+            const float* Bc = B + (long long)(g.taps - 1 - tap) * g.tap_bstride;
+            const int col = tid % BN, kg = tid / BN, gc = n0 + col;
+#pragma unroll
+            for (int j = 0; j < B_KPT; ++j) {
+                const int kk = kg * B_KPT + j;
+                breg[j] = (k0 + kk < K && gc < N) ? Bc[(long long)(kin + kk) * ldb + gc] : 0.f;
+            }
+        }
+    };
+    // split + store one operand image pair; K-contiguous source: 4 consecutive k per float4; reduction-major
+    // source: KPT consecutive k of one column
+    auto store_a = [&](unsigned short* Ah, unsigned short* Am) {
+        if (A_KC) {
+#pragma unroll
+            for (int i = 0; i < A_KC4; ++i) {
+                const int o = (tid / 8 + 32 * i) * kLD16 + (tid % 8) * 4;
+                unsigned h0, m0_, h1, m1;
+                split2(areg[4 * i], areg[4 * i + 1], h0, m0_);
+                split2(areg[4 * i + 2], areg[4 * i + 3], h1, m1);
+                *reinterpret_cast<float2*>(Ah + o) = make_float2(u2f(h0), u2f(h1));
+                *reinterpret_cast<float2*>(Am + o) = make_float2(u2f(m0_), u2f(m1));
+            }
+        } else {
+            const int o = (tid % BM) * kLD16 + (tid / BM) * A_KPT;
+#pragma unroll
+            for (int q = 0; q < A_KPT / 8; ++q) {
+                unsigned hh[4], mm[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2(areg[8 * q + 2 * e], areg[8 * q + 2 * e + 1], hh[e], mm[e]);
+                *reinterpret_cast<float4*>(Ah + o + 8 * q) = make_float4(u2f(hh[0]), u2f(hh[1]), u2f(hh[2]), u2f(hh[3]));
+                *reinterpret_cast<float4*>(Am + o + 8 * q) = make_float4(u2f(mm[0]), u2f(mm[1]), u2f(mm[2]), u2f(mm[3]));
+            }
+        }
+    };
+    auto store_b = [&](unsigned short* Bh, unsigned short* Bm) {
+        if (B_KC) {
+#pragma unroll
+            for (int i = 0; i < B_KC4; ++i) {
+                const int o = (tid / 8 + 32 * i) * kLD16 + (tid % 8) * 4;
+                unsigned h0, m0_, h1, m1;
+                split2(breg[4 * i], breg[4 * i + 1], h0, m0_);
+                split2(breg[4 * i + 2], breg[4 * i + 3], h1, m1);
+                *reinterpret_cast<float2*>(Bh + o) = make_float2(u2f(h0), u2f(h1));
+                *reinterpret_cast<float2*>(Bm + o) = make_float2(u2f(m0_), u2f(m1));
+            }
+        } else {
+            const int o = (tid % BN) * kLD16 + (tid / BN) * B_KPT;
+#pragma unroll
+            for (int q = 0; q < B_KPT / 8; ++q) {
+                unsigned hh[4], mm[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2(breg[8 * q + 2 * e], breg[8 * q + 2 * e + 1], hh[e], mm[e]);
+                *reinterpret_cast<float4*>(Bh + o + 8 * q) = make_float4(u2f(hh[0]), u2f(hh[1]), u2f(hh[2]), u2f(hh[3]));
+                *reinterpret_cast<float4*>(Bm + o + 8 * q) = make_float4(u2f(mm[0]), u2f(mm[1]), u2f(mm[2]), u2f(mm[3]));
+            }
+        }
+    };
+    auto images = [&](int buf, unsigned short*& Ah, unsigned short*& Am, unsigned short*& Bh, unsigned short*& Bm) {
+        Ah = smem + buf * BUF; Am = Ah + A_IMG; Bh = Am + A_IMG; Bm = Bh + B_IMG;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = (K + BK - 1) / BK;
+    unsigned short *Ah, *Am, *Bh, *Bm;
+    load_a(0);
+    load_b(0);
+    images(0, Ah, Am, Bh, Bm);
+    store_a(Ah, Am);
+    store_b(Bh, Bm);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) { load_a((c + 1) * BK); load_b((c + 1) * BK); }
+        images(buf, Ah, Am, Bh, Bm);
+#if defined(MTTS_EMU)
+        mma16_emu<TM, TN>(Ah, Am, Bh, Bm, wm0, wn0, lane, acc);
+#else
+        Frags16<TM, TN> f;
+        read_frags16<TM, TN>(Ah, Am, Bh, Bm, wm0, wn0, lane, f);
+        mma16<TM, TN>(f, acc);
+#endif
+        if (c + 1 < nchunks) {
+            images(buf ^ 1, Ah, Am, Bh, Bm);
+            store_a(Ah, Am);
+            store_b(Bh, Bm);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<TM, TN>(g, z, acc, C, ldc, M, N, m0 + wm0, n0 + wn0, lane);
+}
+
+}  // namespace mtts

@@ -233,6 +233,12 @@ int mtts_reset_optimizer(mtts_handle* h) {
     return 0;
 }
 
+int mtts_set_numerics(int mode) {
+    if (mode != 0 && mode != 1) return -1;
+    gemm_numerics() = mode;
+    return 0;
+}
+
 int mtts_profile_gemm(int enable) {
     GemmProfiler& p = gemm_profiler();
     p.reset();

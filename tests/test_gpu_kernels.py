@@ -88,3 +88,35 @@ def test_conv1d_fwd_dgrad_wgrad(lib, tile, L, Cin, Cout, k):
     assert (dx - dxr).abs().max().item() < tol(dxr)
     dwr = wt.grad.permute(0, 2, 1)
     assert (dw - dwr).abs().max().item() < tol(dwr) * 4
+
+
+@pytest.mark.parametrize("tile", [0, 64, 128])
+@pytest.mark.parametrize("form", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 80, 256), (300, 768, 48), (33, 130, 100), (5, 7, 20), (1000, 256, 2304)])
+def test_gemm_bf16x3_forms(lib, form, tile, M, N, K):
+    """Split-bf16 numerics (mtts_set_numerics(1)): same forms / edges, error bound 2^-16-class instead of fp32."""
+    g = np.random.RandomState(M + N * 3 + K * 5 + form)
+    pad4 = lambda x: (x + 3) & ~3
+    if form == 0:
+        A = _rand(g, M, pad4(K)); B = _rand(g, N, pad4(K)); A[:, K:] = 0; B[:, K:] = 0
+        ref = A[:, :K].double() @ B[:, :K].double().T; lda, ldb = pad4(K), pad4(K)
+    elif form == 1:
+        A = _rand(g, M, pad4(K)); B = _rand(g, K, pad4(N)); A[:, K:] = 0
+        ref = A[:, :K].double() @ B[:, :N].double(); lda, ldb = pad4(K), pad4(N)
+    else:
+        A = _rand(g, K, pad4(M)); B = _rand(g, K, pad4(N))
+        ref = A[:, :M].double().T @ B[:, :N].double(); lda, ldb = pad4(M), pad4(N)
+    bias = _rand(g, N)
+    Cm = torch.full((M, pad4(N)), 7.0, device="cuda")
+    assert lib.mtts_set_numerics(1) == 0
+    try:
+        assert lib.mtts_gemm_f32(form, M, N, K, P(A), lda, P(B), ldb, P(Cm), pad4(N), P(bias), 0.5, 0, tile, None) == 0
+        torch.cuda.synchronize()
+    finally:
+        lib.mtts_set_numerics(0)
+    want = 0.5 * ref + bias.double()[None, :]
+    err = (Cm[:, :N].double() - want).abs().max().item()
+    # |a.b| error ~ 2^-16 * sum|a||b| ~ 2^-16 * K * E|a|E|b| (worst case); observed ~ sqrt(K) of that
+    assert err < 3e-5 * np.sqrt(K) * 4, err
+    assert err > 0  # it is not the exact fp32 path
+    assert torch.all(Cm[:, N:] == 7.0)

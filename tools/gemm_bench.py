@@ -30,11 +30,14 @@ def bench(form, tile, M, N, K, reps=5):
     return 2.0 * M * N * K / (ms * 1e-3) / 1e12, ms
 
 
+NUM = int(os.environ.get('BENCH_NUMERICS', '0'))
+lib.mtts_set_numerics(NUM)
+TILES = (64, 128) if NUM else (1064, 1128)
 shapes = [("square4096", 4096, 4096, 4096), ("conv1_fwd 8 tasks", 26400, 1024, 2304), ("conv2_fwd", 26400, 256, 1024),
           ("qkv", 26400, 768, 256), ("out_proj", 26400, 256, 256), ("postnet_mid", 24000, 512, 2560)]
 for name, M, N, K in shapes:
     for form in (0, 1, 2):
-        for tile in (1064, 1128, 3064, 3128, 2064):
+        for tile in TILES:
             if form == 2:  # TN: output [M', N'] small, reduction long — use wgrad-like shapes
                 m2, n2, k2 = N, K, M // 8 if M > 8192 else M
             else:
