@@ -67,8 +67,25 @@ struct GemmArgs {
     float alpha = 1.f;
     int flags = 0;
     int taps = 1, tap_k = 0x40000000, tap_bstride = 0;  // NN conv dgrad tap walk
+    int swizzle = 0;                                     // XCD-aware workgroup order (set by the launcher)
 };
 
+
+// XCD-aware workgroup order (speed only, never correctness): the dispatcher is observed to place consecutive
+// workgroups round-robin on the 8 XCDs, each with a private L2.  Remap the linear (group, tile) id so that every XCD
+// walks ONE contiguous eighth of the work: with 8 tasks per launch an XCD's L2 then holds a single task's weights and
+// activation panels instead of all eight (HBM/fabric fetch per launch drops; PMC numbers in profiles/).  Bijective for
+// any grid size.  Measured on the C3 meta-step: -3 % (the per-task tile counts differ, so contiguous eighths are unevenly
+// loaded while the kernel is MFMA-bound, not fetch-bound) => off by default (MTTS_XCD_SWIZZLE=1 enables it for A/B runs).
+__device__ __forceinline__ void xcd_swizzle(int enable, int& z, int& bx) {
+    if (!enable) { z = blockIdx.z; bx = blockIdx.x; return; }
+    const unsigned gx = gridDim.x, total = gx * gridDim.z;
+    const unsigned lin = blockIdx.z * gx + blockIdx.x;
+    const unsigned xcd = lin & 7u, k = lin >> 3, q = total >> 3, r = total & 7u;
+    const unsigned nl = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    z = (int)(nl / gx);
+    bx = (int)(nl % gx);
+}
 
 // Register fragments of one BK=16 slice of the wave tile.  A_KC/B_KC: operand tile is [row][kLDK]
 // (K-contiguous: two ds_read_b128 per 32-row subtile) or [k][LD] (reduction-major: ds_read_b32).
@@ -200,7 +217,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int RPP = 256 / KQ;           // K-contiguous rows covered per pass
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
 
-    const int z = blockIdx.z;
+    int z, bxs;
+    xcd_swizzle(g.swizzle, z, bxs);
     const float* A = g.A;
     const float* B = g.B;
     float* C = g.C;
@@ -221,8 +239,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
     }
     const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-    if ((int)blockIdx.x >= tiles_m * tiles_n || K <= 0) return;
-    const int m0 = ((int)blockIdx.x / tiles_n) * BM, n0 = ((int)blockIdx.x % tiles_n) * BN;
+    if (bxs >= tiles_m * tiles_n || K <= 0) return;
+    const int m0 = (bxs / tiles_n) * BM, n0 = (bxs % tiles_n) * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
@@ -354,6 +372,10 @@ struct GemmProfiler {
     }
 };
 inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
+inline int& gemm_xcd_swizzle() {
+    static int v = [] { const char* e = getenv("MTTS_XCD_SWIZZLE"); return (e && atoi(e) == 1) ? 1 : 0; }();
+    return v;
+}
 inline int& gemm_numerics() {  // 0: exact fp32 MFMA (default), 1: split-bf16 "bf16x3" (gemm_bf16.h); MTTS_NUMERICS env overrides
     static int v = [] { const char* e = getenv("MTTS_NUMERICS"); return (e && atoi(e) == 1) ? 1 : 0; }();
     return v;
@@ -374,9 +396,11 @@ inline bool& gemm_default_pipe() {  // MTTS_GEMM_PIPE=0/1 overrides the built-in
 // on 256 CUs take ceil(B/256) rounds; the 64x64 tile quarters the quantum at ~0.97x the per-tile
 // efficiency of 128x128 (software-pipelined variants, measured with tools/gemm_bench.py).  total_M = sum of the groups' row counts
 // (0: max_M * groups).  alg_flops: algorithmic (unpadded) flops of this launch, profiler only.
-inline void gemm_launch(int form, const GemmArgs& g, int max_M, int max_N, int groups, hipStream_t stream,
+inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, int groups, hipStream_t stream,
                         int tile = 0, double alg_flops = 0.0, long long total_M = 0) {
     if (max_M <= 0 || max_N <= 0 || groups <= 0) return;
+    GemmArgs g = g_in;
+    g.swizzle = gemm_xcd_swizzle();
     const int user_tile = tile;
     auto ntiles = [&](int t) { return (long)((max_M + t - 1) / t) * ((max_N + t - 1) / t); };
     if (tile == 0) {

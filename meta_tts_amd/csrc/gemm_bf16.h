@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     constexpr int A_KPT = BK / A_KG, B_KPT = BK / B_KG;            // k per thread (16 or 8)
     constexpr int A_NREG = A_KC ? A_KC4 * 4 : A_KPT, B_NREG = B_KC ? B_KC4 * 4 : B_KPT;
 
-    const int z = blockIdx.z;
+    int z, bxs;
+    xcd_swizzle(g.swizzle, z, bxs);
     const float* A = g.A;
     const float* B = g.B;
     float* C = g.C;
@@ -151,8 +152,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         }
     }
     const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-    if ((int)blockIdx.x >= tiles_m * tiles_n || K <= 0) return;
-    const int m0 = ((int)blockIdx.x / tiles_n) * BM, n0 = ((int)blockIdx.x % tiles_n) * BN;
+    if (bxs >= tiles_m * tiles_n || K <= 0) return;
+    const int m0 = (bxs / tiles_n) * BM, n0 = (bxs % tiles_n) * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
     const int K4 = (K + 3) & ~3;
