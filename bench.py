@@ -125,6 +125,9 @@ def main():
                     help="contraction numerics of the timed meta-step: exact fp32 MFMA (default, parity mode) or split-bf16")
     ap.add_argument("--no-bf16x3-leg", action="store_true", help="skip the extra split-bf16 measurement")
     ap.add_argument("--no-dropout", action="store_true", help="parity configuration (dropout = identity) instead of train-mode dropout")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostic: run ONE process with the task share of rank 0 of this many ranks (no collective) to see the per-rank "
+                         "step time of an N-GPU run on a 1-GPU box; the JSON line is marked emulated and is not a bench result")
     args = ap.parse_args()
 
     import torch
@@ -155,7 +158,8 @@ def main():
     alg = default_algorithm_config()
     trn = default_train_config()["optimizer"]
     mods = alg["adapt"]["modules"]
-    local = list(range(rank * META_BATCH // n, (rank + 1) * META_BATCH // n))
+    part = args.emulate_world if (args.emulate_world and n == 1) else n
+    local = list(range(rank * META_BATCH // part, (rank + 1) * META_BATCH // part))
     tasks = [synth.make_task(j) for j in local]
     max_T = max(max(s[8], q[8]) for s, q in tasks)
     eng = Engine(dims, adapt_modules=mods, max_tasks=len(local), max_B=5, max_S=80, max_T=max_T, device=local_rank)
@@ -292,6 +296,7 @@ def main():
                                        "FastSpeech2 base.yaml, outer mean + clip(1.0) + Adam/Noam", "meta_batch": META_BATCH,
                            "tasks_per_gpu": META_BATCH // n, "inner_steps": INNER_STEPS, "order": "first" if args.order == 1 else "second", "parallelism": f"task-dp{n}",
                            "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.numerics == "fp32" else "bf16x3 (split-fp32 on v_mfma_f32_32x32x16_bf16)", "dropout": "identity (parity config)" if args.no_dropout else "on (0.2 / 0.5 / 0.5, counter-based masks)"},
+                **({"emulated_world": part, "note": "diagnostic: rank-0 share of an emulated multi-rank run, no collective"} if part != n else {}),
                 "query_total_loss_mean": round(float(q_losses[:, 0].mean()), 5) if q_losses is not None else None}
         if so is not None:
             line["second_order"] = so

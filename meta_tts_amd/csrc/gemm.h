@@ -29,6 +29,7 @@
 //    row mask (guard / padded rows), output row remap, accumulate.
 #pragma once
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -68,6 +69,12 @@ struct GemmArgs {
     int flags = 0;
     int taps = 1, tap_k = 0x40000000, tap_bstride = 0;  // NN conv dgrad tap walk
     int swizzle = 0;                                     // XCD-aware workgroup order (set by the launcher)
+    // split-K (set by the launcher for under-filled grids): `splitk` workgroups share one output tile, each reducing a
+    // contiguous run of K-chunks; partial tiles go to `ws`, the last workgroup to arrive (tile counter in `tile_ctr`) sums
+    // them in split order and runs the fused epilogue, so the result does not depend on the arrival order
+    int splitk = 1;
+    float* ws = nullptr;
+    int* tile_ctr = nullptr;
 };
 
 
@@ -201,20 +208,66 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int z, f32x16 (
         }
 }
 
-template <int FORM, int BM, int BN, int BK, bool PIPE>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+// Split-K rendezvous: park this workgroup's partial tile in the workspace; the last of the S workgroups of a tile to
+// arrive reloads all S partials in split order (its own included, so the sum is order-independent) and returns true to
+// run the epilogue; it also re-arms the tile counter for the next launch.
+template <int TM, int TN, int NTH>
+__device__ __forceinline__ bool splitk_combine(const GemmArgs& g, int z, int tile_lin, int split, int S, f32x16 (&acc)[TM][TN]) {
+    constexpr int PART = NTH * 16 * TM * TN;  // floats per partial tile
+    const int tid = threadIdx.x;
+    const long long slot = (long long)z * (gridDim.x / S) + tile_lin;
+    float* base = g.ws + slot * S * PART;
+    float* mine = base + (long long)split * PART;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float4 v;
+                v.x = acc[i][j][4 * r4]; v.y = acc[i][j][4 * r4 + 1]; v.z = acc[i][j][4 * r4 + 2]; v.w = acc[i][j][4 * r4 + 3];
+                st4(mine + (((i * TN + j) * 4 + r4) * NTH + tid) * 4, v);
+            }
+    __threadfence();
+    __shared__ int s_last;
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(g.tile_ctr + slot, 1) == S - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return false;
+    __threadfence();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float4 sum = zero4();
+                for (int sp = 0; sp < S; ++sp) {
+                    const float4 v = ld4(base + (long long)sp * PART + (((i * TN + j) * 4 + r4) * NTH + tid) * 4);
+                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                }
+                acc[i][j][4 * r4] = sum.x; acc[i][j][4 * r4 + 1] = sum.y; acc[i][j][4 * r4 + 2] = sum.z; acc[i][j][4 * r4 + 3] = sum.w;
+            }
+    if (tid == 0) g.tile_ctr[slot] = 0;
+    return true;
+}
+
+// WGM x WGN waves per workgroup (64 threads each); the wave tile is (BM/WGM) x (BN/WGN) = TM x TN MFMA tiles.
+template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int NTH = 64 * WGM * WGN;
     constexpr int kLDK = BK + 4;  // K-contiguous LDS row stride: 80 / 144 bytes, ds_read_b128 conflict-free
     constexpr int KQ = BK / 4;    // float4 per K-contiguous row
     constexpr bool A_KC = (FORM != GEMM_TN);
     constexpr bool B_KC = (FORM == GEMM_NT);
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int LDA_S = A_KC ? kLDK : BM;
     constexpr int LDB_S = B_KC ? kLDK : BN;
     constexpr int A_TILE = A_KC ? BM * kLDK : BK * BM;
     constexpr int B_TILE = B_KC ? BN * kLDK : BK * BN;
-    constexpr int A_LD4 = (BM * KQ) / 256;  // float4 loads per thread (both layouts: BM*BK/4 float4 per tile)
-    constexpr int B_LD4 = (BN * KQ) / 256;
-    constexpr int RPP = 256 / KQ;           // K-contiguous rows covered per pass
+    constexpr int A_LD4 = (BM * KQ) / NTH;  // float4 loads per thread (both layouts: BM*BK/4 float4 per tile)
+    constexpr int B_LD4 = (BN * KQ) / NTH;
+    constexpr int RPP = NTH / KQ;           // K-contiguous rows covered per pass
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
 
     int z, bxs;
@@ -239,11 +292,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
     }
     const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-    if (bxs >= tiles_m * tiles_n || K <= 0) return;
-    const int m0 = (bxs / tiles_n) * BM, n0 = (bxs % tiles_n) * BN;
+    const int S = g.splitk > 1 ? g.splitk : 1;
+    const int tile_lin = bxs / S, split = bxs - tile_lin * S;
+    if (tile_lin >= tiles_m * tiles_n || K <= 0) return;
+    const int m0 = (tile_lin / tiles_n) * BM, n0 = (tile_lin % tiles_n) * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
     const int M4 = (M + 3) & ~3, N4 = (N + 3) & ~3, K4 = (K + 3) & ~3;
 
     float4 areg[A_LD4], breg[B_LD4];
@@ -256,7 +311,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                 const int gm = m0 + row;
                 areg[i] = (gm < M && gk < K4) ? ld4(A + (long long)gm * lda + gk) : zero4();
             } else {
-                const int idx = tid + 256 * i, kk = idx / (BM / 4), c4 = idx % (BM / 4);
+                const int idx = tid + NTH * i, kk = idx / (BM / 4), c4 = idx % (BM / 4);
                 const int gk = k0 + kk, gc = m0 + c4 * 4;
                 areg[i] = (gk < K && gc < M4) ? ld4(A + (long long)gk * lda + gc) : zero4();
             }
@@ -272,7 +327,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                 const int gn = n0 + row;
                 breg[i] = (gn < N && gk < K4) ? ld4(B + (long long)gn * ldb + gk) : zero4();
             } else {
-                const int idx = tid + 256 * i, kk = idx / (BN / 4), c4 = idx % (BN / 4);
+                const int idx = tid + NTH * i, kk = idx / (BN / 4), c4 = idx % (BN / 4);
                 const int gc = n0 + c4 * 4;
                 breg[i] = (k0 + kk < K && gc < N4) ? ld4(Bc + (long long)(kin + kk) * ldb + gc) : zero4();
             }
@@ -284,12 +339,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < A_LD4; ++i) {
             if (A_KC) st4(As + (tid / KQ + RPP * i) * kLDK + (tid % KQ) * 4, areg[i]);
-            else { const int idx = tid + 256 * i; st4(As + (idx / (BM / 4)) * BM + (idx % (BM / 4)) * 4, areg[i]); }
+            else { const int idx = tid + NTH * i; st4(As + (idx / (BM / 4)) * BM + (idx % (BM / 4)) * 4, areg[i]); }
         }
 #pragma unroll
         for (int i = 0; i < B_LD4; ++i) {
             if (B_KC) st4(Bs + (tid / KQ + RPP * i) * kLDK + (tid % KQ) * 4, breg[i]);
-            else { const int idx = tid + 256 * i; st4(Bs + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4, breg[i]); }
+            else { const int idx = tid + NTH * i; st4(Bs + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4, breg[i]); }
         }
     };
 
@@ -301,9 +356,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = (K + BK - 1) / BK;
-    load_a(0);
-    load_b(0);
+    const int nch_all = (K + BK - 1) / BK, cps = (nch_all + S - 1) / S;
+    const int c_lo = split * cps, c_hi = (c_lo + cps < nch_all) ? c_lo + cps : nch_all;
+    const int nchunks = c_hi > c_lo ? c_hi - c_lo : 0;  // this workgroup's run of K-chunks (all of them when S == 1)
+    const int kb0 = c_lo * BK;
+    load_a(kb0);
+    load_b(kb0);
     store_ab(0);
     __syncthreads();
     if (!PIPE) {
@@ -311,7 +369,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         Frags<TM, TN, BK> f;
         for (int c = 0; c < nchunks; ++c) {
             const int buf = c & 1;
-            if (c + 1 < nchunks) { load_a((c + 1) * BK); load_b((c + 1) * BK); }
+            if (c + 1 < nchunks) { load_a(kb0 + (c + 1) * BK); load_b(kb0 + (c + 1) * BK); }
             const float* As = smem + buf * (A_TILE + B_TILE);
             read_frags<TM, TN, BK, A_KC, B_KC, LDA_S, LDB_S>(As, As + A_TILE, wm0, wn0, lane, f);
             mma_half<TM, TN, BK>(f, 0, acc);
@@ -324,12 +382,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         // c+1 are issued between the two MFMA halves of slice c, whose operands already sit in
         // registers — the wave's MFMA stream never waits on LDS or HBM, only on barrier skew.
         Frags<TM, TN, BK> f0, f1;
-        if (nchunks > 1) { load_a(BK); load_b(BK); }
+        if (nchunks > 1) { load_a(kb0 + BK); load_b(kb0 + BK); }
         read_frags<TM, TN, BK, A_KC, B_KC, LDA_S, LDB_S>(smem, smem + A_TILE, wm0, wn0, lane, f0);
         auto step = [&](int c, const Frags<TM, TN, BK>& fc, Frags<TM, TN, BK>& fn) {
             const int nb = (c & 1) ^ 1;
             if (c + 1 < nchunks) store_ab(nb);
-            if (c + 2 < nchunks) { load_a((c + 2) * BK); load_b((c + 2) * BK); }
+            if (c + 2 < nchunks) { load_a(kb0 + (c + 2) * BK); load_b(kb0 + (c + 2) * BK); }
             mma_half<TM, TN, BK>(fc, 0, acc);
             __syncthreads();
             if (c + 1 < nchunks) {
@@ -344,13 +402,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
     }
 
+    if (S > 1 && !splitk_combine<TM, TN, NTH>(g, z, tile_lin, split, S, acc)) return;
     gemm_epilogue<TM, TN>(g, z, acc, C, ldc, M, N, m0 + wm0, n0 + wn0, lane);
 }
 
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg):
 // one record per launch, aggregated per (form, tile) kernel instantiation.
 struct GemmProfiler {
-    struct Rec { int kernel; double flops; hipEvent_t e0, e1; };
+    struct Rec { int kernel; double flops; hipEvent_t e0, e1; int form = 0, tile = 0, N = 0, K = 0, groups = 0, splitk = 1; double rows = 0; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
@@ -363,12 +422,16 @@ struct GemmProfiler {
     // out[kernel][3] = launches, total ms, total algorithmic flops; kernel = form * 2 + (tile == 128)
     void report(double out[6][3]) {
         for (int k = 0; k < 6; ++k) out[k][0] = out[k][1] = out[k][2] = 0.0;
+        FILE* dump = getenv("MTTS_GEMM_DUMP") ? fopen(getenv("MTTS_GEMM_DUMP"), "w") : nullptr;  // per-launch CSV (tools/gemm_sites.py)
+        if (dump) fprintf(dump, "form,tile,N,K,rows,groups,splitk,us,gflop\n");
         for (auto& r : recs) {
             hipEventSynchronize(r.e1);
             float ms = 0.f;
             hipEventElapsedTime(&ms, r.e0, r.e1);
             out[r.kernel][0] += 1.0; out[r.kernel][1] += ms; out[r.kernel][2] += r.flops;
+            if (dump) fprintf(dump, "%d,%d,%d,%d,%.0f,%d,%d,%.2f,%.4f\n", r.form, r.tile, r.N, r.K, r.rows, r.groups, r.splitk, 1e3 * ms, r.flops * 1e-9);
         }
+        if (dump) fclose(dump);
     }
 };
 inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
@@ -388,6 +451,29 @@ inline int& gemm_default_bk() {  // MTTS_GEMM_BK=16/32
 }
 inline bool& gemm_default_pipe() {  // MTTS_GEMM_PIPE=0/1 overrides the built-in default (A/B runs)
     static bool v = [] { const char* e = getenv("MTTS_GEMM_PIPE"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
+
+// Split-K workspace, one per launch stream (GEMMs on different streams may overlap): partial tiles + tile counters.
+struct GemmWorkspace { float* ws = nullptr; int* ctr = nullptr; };
+constexpr long long kSplitWsFloats = 16ll << 20;  // 64 MB of partial tiles
+constexpr int kSplitCtrs = 1 << 16;
+inline GemmWorkspace& gemm_workspace(hipStream_t stream) {
+    static std::vector<std::pair<hipStream_t, GemmWorkspace>> all;
+    for (auto& e : all) if (e.first == stream) return e.second;
+    GemmWorkspace w;
+    if (hipMalloc((void**)&w.ws, kSplitWsFloats * sizeof(float)) != hipSuccess || hipMalloc((void**)&w.ctr, kSplitCtrs * sizeof(int)) != hipSuccess ||
+        hipMemset(w.ctr, 0, kSplitCtrs * sizeof(int)) != hipSuccess) { w.ws = nullptr; w.ctr = nullptr; }
+    all.emplace_back(stream, w);
+    return all.back().second;
+}
+inline int& gemm_splitk_target() {  // workgroups a launch should reach before split-K stops adding more; 0 disables (MTTS_SPLITK_TARGET)
+    static int v = [] { const char* e = getenv("MTTS_SPLITK_TARGET"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+inline int& gemm_splitk_minchunks() {  // K-chunks every split must keep (MTTS_SPLITK_MINCH)
+    static int v = [] { const char* e = getenv("MTTS_SPLITK_MINCH"); return (e && atoi(e) > 0) ? atoi(e) : 16; }();
     return v;
 }
 
@@ -425,7 +511,30 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
     int bk = gemm_default_bk();
     if (tile >= 1000) { pipe = (tile / 1000) & 1; bk = (tile / 2000) ? 32 : 16; tile %= 1000; }
     if (g.taps > 1 && g.tap_k % 32 != 0) bk = 16;  // a K-slice must not straddle two conv taps
-    dim3 block(256), grid((unsigned)ntiles(tile), 1, (unsigned)groups);
+    // split-K for under-filled grids (single-task ranks, the phoneme-side GEMMs, small wgrads): enough workgroups for
+    // ~4 per CU, each still reducing >= 4 K-chunks
+    int S = 1;
+    if (!g.table && gemm_splitk_target() > 0) {
+        const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
+        const long wgs = (long)std::ceil(rows / tile) * ((max_N + tile - 1) / tile);
+        const int nch = (g.K + bk - 1) / bk;
+        S = (int)std::min<long>(std::min<long>(gemm_splitk_target() / std::max<long>(wgs, 1), nch / gemm_splitk_minchunks()), 8);
+        const long long slots = (long long)ntiles(tile) * groups;
+        if (S >= 2 && (slots * S * tile * tile > kSplitWsFloats || slots > kSplitCtrs)) S = 1;
+        if (S >= 2) {
+            GemmWorkspace& w = gemm_workspace(stream);
+            if (w.ws) { g.splitk = S; g.ws = w.ws; g.tile_ctr = w.ctr; } else S = 1;
+        } else S = 1;
+    }
+    // experimental workgroup shapes (tile code 164 / 264 / 364: 64x64 on one wave, 128x64 and 64x128 on two waves — all with
+    // the 64x64 wave tile of the 128x128 kernel), software-pipelined BK=16 only
+    int bm = tile, bn = tile, nth = 256;
+    if (tile == 164) { bm = 64; bn = 64; nth = 64; }
+    if (tile == 264) { bm = 128; bn = 64; nth = 128; }
+    if (tile == 364) { bm = 64; bn = 128; nth = 128; }
+    const long grid_tiles = (long)((max_M + bm - 1) / bm) * ((max_N + bn - 1) / bn);
+    if (tile > 128) S = 1, g.splitk = 1;
+    dim3 block(nth), grid((unsigned)(grid_tiles * S), 1, (unsigned)groups);
     GemmProfiler& prof = gemm_profiler();
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
@@ -436,13 +545,22 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
         else if (pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, true>), grid, block, stream, g); }          \
         else { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, false>), grid, block, stream, g); }                   \
     }
+#define MTTS_GEMM_XCASE(F)                                                                                           \
+    if (form == F && tile == 164) { MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 16, true, 1, 1>), grid, block, stream, g); }   \
+    if (form == F && tile == 264) { MTTS_LAUNCH((gemm_f32_kernel<F, 128, 64, 16, true, 2, 1>), grid, block, stream, g); }  \
+    if (form == F && tile == 364) { MTTS_LAUNCH((gemm_f32_kernel<F, 64, 128, 16, true, 1, 2>), grid, block, stream, g); }
     MTTS_GEMM_CASE(GEMM_NT, 128) MTTS_GEMM_CASE(GEMM_NT, 64)
     MTTS_GEMM_CASE(GEMM_NN, 128) MTTS_GEMM_CASE(GEMM_NN, 64)
     MTTS_GEMM_CASE(GEMM_TN, 128) MTTS_GEMM_CASE(GEMM_TN, 64)
+    MTTS_GEMM_XCASE(GEMM_NT) MTTS_GEMM_XCASE(GEMM_NN) MTTS_GEMM_XCASE(GEMM_TN)
 #undef MTTS_GEMM_CASE
+#undef MTTS_GEMM_XCASE
     if (prof.enabled) {
         hipEventRecord(e1, stream);
-        prof.recs.push_back(GemmProfiler::Rec{form * 2 + (tile == 128 ? 1 : 0), alg_flops, e0, e1});
+        GemmProfiler::Rec rec{form * 2 + (tile == 128 ? 1 : 0), alg_flops, e0, e1};
+        rec.form = form; rec.tile = tile; rec.N = max_N; rec.K = g.K; rec.groups = groups; rec.splitk = S;
+        rec.rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
+        prof.recs.push_back(rec);
     }
 }
 

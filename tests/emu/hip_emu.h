@@ -36,6 +36,7 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
 void emu_syncthreads();
 #define __syncthreads() emu_syncthreads()
+#define __threadfence() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 float emu_wave_sum(float v);
 float emu_wave_max(float v);
 float emu_shfl(float v, int src_lane);
