@@ -31,7 +31,7 @@ META_BATCH = 8
 INNER_STEPS = 5
 INNER_LR = 0.001
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
-KERNEL_NAMES = ["gemm_f32<NT,64>", "gemm_f32<NT,128>", "gemm_f32<NN,64>", "gemm_f32<NN,128>", "gemm_f32<TN,64>", "gemm_f32<TN,128>"]
+KERNEL_NAMES = ["gemm_f32<NT,64>", "gemm_f32<NT,128>", "gemm_f32<NN,64>", "gemm_f32<NN,128>", "gemm_f32<TN,64>", "gemm_f32<TN,128>", "gemm_f32_multi<64>"]
 
 
 def noam_lr(step, d_model=256, warm=4000, anneal=(300000, 400000, 500000), rate=0.3):
@@ -253,10 +253,10 @@ def main():
         lib.mtts_profile_gemm(1)
         eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, fetch_losses=False)
         torch.cuda.synchronize()
-        rep = (C.c_double * 18)()
+        rep = (C.c_double * 21)()
         lib.mtts_profile_report(rep)
         lib.mtts_profile_gemm(0)
-        rows = [(KERNEL_NAMES[k], rep[3 * k], rep[3 * k + 1], rep[3 * k + 2]) for k in range(6)]
+        rows = [(KERNEL_NAMES[k], rep[3 * k], rep[3 * k + 1], rep[3 * k + 2]) for k in range(7)]
         dom = max(rows, key=lambda r: r[2])
         tot_ms = sum(r[2] for r in rows)
         tot_fl = sum(r[3] for r in rows)

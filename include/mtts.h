@@ -143,10 +143,10 @@ int mtts_reset_optimizer(mtts_handle* h);
 int mtts_set_numerics(int mode);
 
 /* ---- measurement: per-launch HIP-event timing of the GEMM kernel family on the launch stream.
- * report: out[kernel][3] = {launches, total ms, total algorithmic flops}, kernel = form*2 + (tile==128),
- * form 0 NT / 1 NN / 2 TN.  (bench.py roofline leg) */
+ * report: out[kernel][3] = {launches, total ms, total algorithmic flops}, 7 kernels: form*2 + (tile==128) with
+ * form 0 NT / 1 NN / 2 TN, and 6 = the multi-problem launch (several independent products in one grid).  (bench.py roofline leg) */
 int mtts_profile_gemm(int enable);
-int mtts_profile_report(double* out18);
+int mtts_profile_report(double* out21);
 
 /* ---- kernel-level entry points (parity tests; dev pointers; stream may be NULL) ----------------
  * form 0: C[M,N] = alpha*A[M,K]*B[N,K]^T + bias   1: C = A[M,K]*B[K,N]   2: C[M,N] = A[K,M]^T*B[K,N]

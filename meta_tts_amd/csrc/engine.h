@@ -161,6 +161,11 @@ public:
     size_t arena_bytes = 0;
 
     struct Pass;
+struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.h)
+    hipStream_t s;
+    explicit GemmBatchScope(hipStream_t st) : s(st) { gemm_batch_begin(); }
+    ~GemmBatchScope() { gemm_batch_end(s); }
+};
     // dropout (off by default: parity runs patch it to identity)
     bool dropout_on = false;
     unsigned drop_base = 0x1234567u, drop_counter = 0;
@@ -889,6 +894,7 @@ public:
         const int groups = (s == SP_P) ? p.n_enc_groups : p.n_dec_groups;
         int mM = L, mN = L;
         if (which == TAB_PV || which == TAB_DV || which == TAB_DQ || which == TAB_DK) mN = dk;
+        g.K = (which == TAB_QK || which == TAB_DP) ? dk : L;  // cost hint for launch batching (the table carries the real K)
         gemm_launch(form, g, mM, mN, groups, stream, 0, 2.0 * ((s == SP_P) ? p.sum_attn_p : p.sum_attn_f) * dk,
                     (s == SP_P) ? p.sumLp : p.sumLf);
     }
@@ -931,31 +937,49 @@ public:
         TS gm = (s == SP_P) ? gPm : gFm;                                   // masked copy feeds the conv branch, g1 the residual
         TS dc = drop(ps, s, g1, gm, d, block_dropout(s), site_base + 1);
         // conv2
-        conv_wgrad(ps, s, dc, d, cfg.k2, b.h, ff, P.w2, P.b2, vm);
-        conv_dgrad(ps, s, dc, d, cfg.k2, W(ps, P.w2), ff, gh, 0, im, b.h);
+        {   // wgrad and dgrad of a layer are independent: one multi-problem launch (gemm.h: gemm_f32_multi_kernel)
+            GemmBatchScope pair(stream);
+            conv_wgrad(ps, s, dc, d, cfg.k2, b.h, ff, P.w2, P.b2, vm);
+            conv_dgrad(ps, s, dc, d, cfg.k2, W(ps, P.w2), ff, gh, 0, im, b.h);
+        }
         // conv1: g1 += dgrad -> dy1
-        conv_wgrad(ps, s, gh, ff, cfg.k1, b.y1, d, P.w1, P.b1, im);
-        conv_dgrad(ps, s, gh, ff, cfg.k1, W(ps, P.w1), d, g1, GEMM_ACCUM, im);
+        {
+            GemmBatchScope pair(stream);
+            conv_wgrad(ps, s, gh, ff, cfg.k1, b.y1, d, P.w1, P.b1, im);
+            conv_dgrad(ps, s, gh, ff, cfg.k1, W(ps, P.w1), d, g1, GEMM_ACCUM, im);
+        }
         // LN1 backward -> g0 = dz1
         ln_bwd(ps, s, g1, b.z1, b.st1, P.ln1g, P.ln1b, vm, g0, d, 0);
         TS da = drop(ps, s, g0, gm, d, block_dropout(s), site_base);
         // fc
-        conv_wgrad(ps, s, da, d, 1, b.O, d, P.wfc, P.bfc, vm);
-        conv_dgrad(ps, s, da, d, 1, W(ps, P.wfc), d, g1, 0, nullptr);  // g1 = dO
+        {
+            GemmBatchScope pair(stream);
+            conv_wgrad(ps, s, da, d, 1, b.O, d, P.wfc, P.bfc, vm);
+            conv_dgrad(ps, s, da, d, 1, W(ps, P.wfc), d, g1, 0, nullptr);  // g1 = dO
+        }
         // attention
         const int groups = (s == SP_P) ? p.n_enc_groups : p.n_dec_groups;
         const int L = (s == SP_P) ? p.enc_maxL : p.dec_maxL;
         const AttnSeq* seqs = (s == SP_P) ? p.enc_seqs : p.dec_seqs;
-        attn_gemm(ps, s, TAB_DP, GEMM_NT, g1.p, d, b.qkv.p, 3 * d, dS.p, 0, 1.f, heads);
-        attn_gemm(ps, s, TAB_DV, GEMM_TN, b.P.p, 0, g1.p, d, gqkv.p, 3 * d, 1.f, heads);
+        {
+            GemmBatchScope pair(stream);
+            attn_gemm(ps, s, TAB_DP, GEMM_NT, g1.p, d, b.qkv.p, 3 * d, dS.p, 0, 1.f, heads);
+            attn_gemm(ps, s, TAB_DV, GEMM_TN, b.P.p, 0, g1.p, d, gqkv.p, 3 * d, 1.f, heads);
+        }
         if (groups > 0 && L > 0)
             MTTS_LAUNCH(softmax_bwd_kernel, dim3((L + 3) / 4, 1, groups), dim3(256), stream, seqs, (const float*)b.P.p, dS.p,
                         1.f / sqrtf((float)dk));
-        attn_gemm(ps, s, TAB_DQ, GEMM_NN, dS.p, 0, b.qkv.p, 3 * d, gqkv.p, 3 * d, 1.f, heads);
-        attn_gemm(ps, s, TAB_DK, GEMM_TN, dS.p, 0, b.qkv.p, 3 * d, gqkv.p, 3 * d, 1.f, heads);
+        {
+            GemmBatchScope pair(stream);
+            attn_gemm(ps, s, TAB_DQ, GEMM_NN, dS.p, 0, b.qkv.p, 3 * d, gqkv.p, 3 * d, 1.f, heads);
+            attn_gemm(ps, s, TAB_DK, GEMM_TN, dS.p, 0, b.qkv.p, 3 * d, gqkv.p, 3 * d, 1.f, heads);
+        }
         // fused q/k/v projection
-        conv_wgrad(ps, s, gqkv, 3 * d, 1, xin, d, P.wqkv, P.bqkv, vm);
-        conv_dgrad(ps, s, gqkv, 3 * d, 1, W(ps, P.wqkv), d, g0, GEMM_ACCUM, nullptr);
+        {
+            GemmBatchScope pair(stream);
+            conv_wgrad(ps, s, gqkv, 3 * d, 1, xin, d, P.wqkv, P.bqkv, vm);
+            conv_dgrad(ps, s, gqkv, 3 * d, 1, W(ps, P.wqkv), d, g0, GEMM_ACCUM, nullptr);
+        }
     }
 
     // =================================================================================
@@ -990,12 +1014,18 @@ public:
                     (const float*)dout.p, dout.ts, (const float*)w.p, w.ts, gPf1.p, gPf1.ts, f);
         drop(ps, SP_P, gPf1, gPf1, f, cfg.vp_dropout, site_base + 1);
         ln_bwd(ps, SP_P, gPf1, b.r2, b.st2, P.l2g, P.l2b, im, gPf2, f, 1);       // gPf2 = d conv2 out
-        conv_wgrad(ps, SP_P, gPf2, f, k, b.n1, f, P.c2w, P.c2b, im);
-        conv_dgrad(ps, SP_P, gPf2, f, k, W(ps, P.c2w), f, gPf1, 0, im);         // gPf1 = d n1
+        {
+            GemmBatchScope pair(stream);
+            conv_wgrad(ps, SP_P, gPf2, f, k, b.n1, f, P.c2w, P.c2b, im);
+            conv_dgrad(ps, SP_P, gPf2, f, k, W(ps, P.c2w), f, gPf1, 0, im);     // gPf1 = d n1
+        }
         drop(ps, SP_P, gPf1, gPf1, f, cfg.vp_dropout, site_base);
         ln_bwd(ps, SP_P, gPf1, b.r1, b.st1, P.l1g, P.l1b, im, gPf2, f, 1);       // gPf2 = d conv1 out
-        conv_wgrad(ps, SP_P, gPf2, f, k, xin, d, P.c1w, P.c1b, im);
-        conv_dgrad(ps, SP_P, gPf2, f, k, W(ps, P.c1w), d, dx, GEMM_ACCUM, im);
+        {
+            GemmBatchScope pair(stream);
+            conv_wgrad(ps, SP_P, gPf2, f, k, xin, d, P.c1w, P.c1b, im);
+            conv_dgrad(ps, SP_P, gPf2, f, k, W(ps, P.c1w), d, dx, GEMM_ACCUM, im);
+        }
     }
 
     // =================================================================================
@@ -1192,6 +1222,7 @@ public:
                         (const float*)gm.p, gm.ts, (const float*)dgm.p, (const float*)dbt.p, dgm.ts,
                         (const unsigned char*)p.r_inrect, row_ts_r, act, dc.p, dc.ts, P.cout, ysc);
             TS xin = (i == 0) ? mel : postB[i - 1].a;
+            GemmBatchScope pair(stream);
             conv_wgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, xin, P.cin, P.w, P.b, p.r_inrect);
             if (i > 0) {
                 conv_dgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, W(ps, P.w), P.cin, gR1, 0, p.r_inrect);
@@ -1211,8 +1242,11 @@ public:
         MTTS_LAUNCH(gather_rows_kernel, row_grid(p.maxMf, nt), dim3(256), stream, (const int*)p.meta, (int)META_MF,
                     (const float*)gRm.p, gRm.ts, (const int*)p.f2r, row_ts_f, gMelF.p, gMelF.ts, nm);
         TS dec_out = cfg.dec_layers ? decB[cfg.dec_layers - 1].y2 : dec_in;
-        conv_wgrad(ps, SP_F, gMelF, nm, 1, dec_out, d, mel_w, -1, nullptr);
-        conv_dgrad(ps, SP_F, gMelF, nm, 1, W(ps, mel_w), d, gF0, 0, nullptr);
+        {
+            GemmBatchScope pair(stream);
+            conv_wgrad(ps, SP_F, gMelF, nm, 1, dec_out, d, mel_w, -1, nullptr);
+            conv_dgrad(ps, SP_F, gMelF, nm, 1, W(ps, mel_w), d, gF0, 0, nullptr);
+        }
         // ---- decoder ----------------------------------------------------------------------
         for (int l = cfg.dec_layers - 1; l >= 0; --l) {
             TS xin = l == 0 ? dec_in : decB[l - 1].y2;

@@ -28,6 +28,7 @@
 //  * fused epilogue: alpha, bias, ReLU, ReLU-mask of a saved activation (dgrad through ReLU),
 //    row mask (guard / padded rows), output row remap, accumulate.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -253,8 +254,17 @@ __device__ __forceinline__ bool splitk_combine(const GemmArgs& g, int z, int til
 }
 
 // WGM x WGN waves per workgroup (64 threads each); the wave tile is (BM/WGM) x (BN/WGN) = TM x TN MFMA tiles.
+template <int FORM, int BM, int BN, int BK>
+struct GemmSmem {
+    static constexpr int kLDK = BK + 4;
+    static constexpr int A_TILE = (FORM != GEMM_TN) ? BM * kLDK : BK * BM;
+    static constexpr int B_TILE = (FORM == GEMM_NT) ? BN * kLDK : BK * BN;
+    static constexpr int FLOATS = 2 * (A_TILE + B_TILE);
+};
+
+// One workgroup's share of one problem: output tile `bxs` (times split) of group `z`.
 template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs, float* smem) {
     constexpr int NTH = 64 * WGM * WGN;
     constexpr int kLDK = BK + 4;  // K-contiguous LDS row stride: 80 / 144 bytes, ds_read_b128 conflict-free
     constexpr int KQ = BK / 4;    // float4 per K-contiguous row
@@ -268,10 +278,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
     constexpr int A_LD4 = (BM * KQ) / NTH;  // float4 loads per thread (both layouts: BM*BK/4 float4 per tile)
     constexpr int B_LD4 = (BN * KQ) / NTH;
     constexpr int RPP = NTH / KQ;           // K-contiguous rows covered per pass
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
-
-    int z, bxs;
-    xcd_swizzle(g.swizzle, z, bxs);
     const float* A = g.A;
     const float* B = g.B;
     float* C = g.C;
@@ -406,6 +412,44 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
     gemm_epilogue<TM, TN>(g, z, acc, C, ldc, M, N, m0 + wm0, n0 + wn0, lane);
 }
 
+template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[GemmSmem<FORM, BM, BN, BK>::FLOATS];
+    int z, bxs;
+    xcd_swizzle(g.swizzle, z, bxs);
+    gemm_f32_body<FORM, BM, BN, BK, PIPE, WGM, WGN>(g, z, bxs, smem);
+}
+
+// Several independent problems (any mix of forms, e.g. the dgrad and the wgrad of one layer) in ONE launch: workgroups
+// [start[p], start[p+1]) of every z-slice belong to problem p.  The chip then never drains between two under-filled or
+// badly quantised grids — the tail of one problem is filled by the next — and it costs no stream / event traffic.
+constexpr int kGemmMultiMax = 6;
+struct GemmMulti {
+    int n = 0;
+    int start[kGemmMultiMax + 1] = {0};
+    int form[kGemmMultiMax] = {0};
+    int groups[kGemmMultiMax] = {0};
+    GemmArgs g[kGemmMultiMax];
+};
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void gemm_f32_multi_kernel(GemmMulti mp) {
+    constexpr int F0 = GemmSmem<GEMM_NT, BM, BN, BK>::FLOATS, F1 = GemmSmem<GEMM_NN, BM, BN, BK>::FLOATS, F2 = GemmSmem<GEMM_TN, BM, BN, BK>::FLOATS;
+    constexpr int FL = F0 > F1 ? (F0 > F2 ? F0 : F2) : (F1 > F2 ? F1 : F2);
+    __shared__ __attribute__((aligned(16))) float smem[FL];
+    // problems are sorted by per-tile cost (longest first) and laid out problem-major over a 1-D grid, so the long tiles
+    // all start in the first dispatch round and the short ones fill the tail
+    int p = 0;
+    int lin = (int)blockIdx.x;
+    while (p + 1 < mp.n && lin >= mp.start[p + 1]) ++p;
+    lin -= mp.start[p];
+    const int tiles = (mp.start[p + 1] - mp.start[p]) / mp.groups[p];
+    const int z = lin / tiles, bx = lin - z * tiles;
+    const int form = mp.form[p];
+    if (form == GEMM_NT) gemm_f32_body<GEMM_NT, BM, BN, BK, true>(mp.g[p], z, bx, smem);
+    else if (form == GEMM_NN) gemm_f32_body<GEMM_NN, BM, BN, BK, true>(mp.g[p], z, bx, smem);
+    else gemm_f32_body<GEMM_TN, BM, BN, BK, true>(mp.g[p], z, bx, smem);
+}
+
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg):
 // one record per launch, aggregated per (form, tile) kernel instantiation.
 struct GemmProfiler {
@@ -419,9 +463,9 @@ struct GemmProfiler {
         return pool[used++];
     }
     void reset() { recs.clear(); used = 0; }
-    // out[kernel][3] = launches, total ms, total algorithmic flops; kernel = form * 2 + (tile == 128)
-    void report(double out[6][3]) {
-        for (int k = 0; k < 6; ++k) out[k][0] = out[k][1] = out[k][2] = 0.0;
+    // out[kernel][3] = launches, total ms, total algorithmic flops; kernel = form * 2 + (tile == 128), 6 = multi-problem launch
+    void report(double out[7][3]) {
+        for (int k = 0; k < 7; ++k) out[k][0] = out[k][1] = out[k][2] = 0.0;
         FILE* dump = getenv("MTTS_GEMM_DUMP") ? fopen(getenv("MTTS_GEMM_DUMP"), "w") : nullptr;  // per-launch CSV (tools/gemm_sites.py)
         if (dump) fprintf(dump, "form,tile,N,K,rows,groups,splitk,us,gflop\n");
         for (auto& r : recs) {
@@ -477,6 +521,20 @@ inline int& gemm_splitk_minchunks() {  // K-chunks every split must keep (MTTS_S
     return v;
 }
 
+// Launch batching: between gemm_batch_begin() and gemm_batch_end() every eligible gemm_launch (auto tile resolving to
+// 64x64, fp32 numerics) is queued instead of launched; gemm_batch_end() issues the queue as ONE gemm_f32_multi_kernel.
+// The caller guarantees the queued problems are mutually independent and that nothing launched before gemm_batch_end()
+// reads their outputs (engine: the wgrad / dgrad pair of a layer, dQ / dK / dV of an attention block).
+struct GemmPending { int form; GemmArgs g; int max_M, max_N, groups; double flops, rows; };
+struct GemmBatch { bool open = false; std::vector<GemmPending> q; };
+inline GemmBatch& gemm_batch() { static GemmBatch b; return b; }
+inline bool& gemm_batch_enabled() {  // MTTS_GEMM_BATCH=0 launches every problem on its own (A/B runs)
+    static bool v = [] { const char* e = getenv("MTTS_GEMM_BATCH"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
+inline void gemm_batch_begin() { if (gemm_batch_enabled()) gemm_batch().open = true; }
+inline void gemm_batch_end(hipStream_t stream);
+
 // Host launcher.  max_M / max_N bound the tile grid over all groups.  tile = 0 picks the tile by a
 // wave-quantisation model: one 4-wave workgroup saturates a CU's four MFMA pipes, so B workgroups
 // on 256 CUs take ceil(B/256) rounds; the 64x64 tile quarters the quantum at ~0.97x the per-tile
@@ -506,10 +564,16 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
         if (prof0.enabled) { hipEventRecord(b1, stream); prof0.recs.push_back(GemmProfiler::Rec{form * 2 + (big ? 1 : 0), alg_flops, b0, b1}); }
         return;
     }
+    if (gemm_batch().open && user_tile == 0 && tile == 64) {
+        gemm_batch().q.push_back(GemmPending{form, g, max_M, max_N, groups, alg_flops, total_M > 0 ? (double)total_M : (double)max_M * groups});
+        if ((int)gemm_batch().q.size() == kGemmMultiMax) { gemm_batch_end(stream); gemm_batch().open = true; }
+        return;
+    }
     // tile code: 64 / 128 (+1000 software pipeline, +2000 BK=32); plain 64 / 128 take the defaults
     bool pipe = gemm_default_pipe();
     int bk = gemm_default_bk();
     if (tile >= 1000) { pipe = (tile / 1000) & 1; bk = (tile / 2000) ? 32 : 16; tile %= 1000; }
+    if (user_tile == 0 && !g.table && g.K >= 1024 && (form == GEMM_NT || form == GEMM_TN)) bk = 32;  // long K-contiguous panels: full 128-B lines per row
     if (g.taps > 1 && g.tap_k % 32 != 0) bk = 16;  // a K-slice must not straddle two conv taps
     // split-K for under-filled grids (single-task ranks, the phoneme-side GEMMs, small wgrads): enough workgroups for
     // ~4 per CU, each still reducing >= 4 K-chunks
@@ -562,6 +626,43 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
         rec.rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
         prof.recs.push_back(rec);
     }
+}
+
+inline void gemm_batch_end(hipStream_t stream) {
+    GemmBatch& b = gemm_batch();
+    b.open = false;
+    if (b.q.empty()) return;
+    if (b.q.size() == 1) {
+        const GemmPending p = b.q[0];
+        b.q.clear();
+        gemm_launch(p.form, p.g, p.max_M, p.max_N, p.groups, stream, 0, p.flops, (long long)p.rows);
+        return;
+    }
+    std::stable_sort(b.q.begin(), b.q.end(), [](const GemmPending& x, const GemmPending& y) { return x.g.K > y.g.K; });
+    GemmMulti mp;
+    mp.n = (int)b.q.size();
+    int max_groups = 0;
+    double flops = 0.0, rows = 0.0;
+    for (int i = 0; i < mp.n; ++i) {
+        const GemmPending& p = b.q[i];
+        mp.form[i] = p.form; mp.groups[i] = p.groups; mp.g[i] = p.g;
+        mp.g[i].swizzle = 0; mp.g[i].splitk = 1;
+        mp.start[i + 1] = mp.start[i] + ((p.max_M + 63) / 64) * ((p.max_N + 63) / 64) * p.groups;
+        max_groups = std::max(max_groups, p.groups);
+        flops += p.flops; rows += p.rows;
+    }
+    GemmProfiler& prof = gemm_profiler();
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
+    dim3 block(256), grid((unsigned)mp.start[mp.n], 1, 1);
+    MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 16>), grid, block, stream, mp);
+    if (prof.enabled) {
+        hipEventRecord(e1, stream);
+        GemmProfiler::Rec rec{6, flops, e0, e1};
+        rec.form = 3; rec.tile = 64; rec.N = mp.n; rec.K = 0; rec.groups = max_groups; rec.splitk = 1; rec.rows = rows;
+        prof.recs.push_back(rec);
+    }
+    b.q.clear();
 }
 
 }  // namespace mtts

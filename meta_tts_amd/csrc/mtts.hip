@@ -246,10 +246,10 @@ int mtts_profile_gemm(int enable) {
     return 0;
 }
 
-int mtts_profile_report(double* out18) {
-    double r[6][3];
+int mtts_profile_report(double* out21) {
+    double r[7][3];
     gemm_profiler().report(r);
-    for (int k = 0; k < 6; ++k) for (int j = 0; j < 3; ++j) out18[k * 3 + j] = r[k][j];
+    for (int k = 0; k < 7; ++k) for (int j = 0; j < 3; ++j) out21[k * 3 + j] = r[k][j];
     return 0;
 }
 
