@@ -590,14 +590,8 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
             if (w.ws) { g.splitk = S; g.ws = w.ws; g.tile_ctr = w.ctr; } else S = 1;
         } else S = 1;
     }
-    // experimental workgroup shapes (tile code 164 / 264 / 364: 64x64 on one wave, 128x64 and 64x128 on two waves — all with
-    // the 64x64 wave tile of the 128x128 kernel), software-pipelined BK=16 only
-    int bm = tile, bn = tile, nth = 256;
-    if (tile == 164) { bm = 64; bn = 64; nth = 64; }
-    if (tile == 264) { bm = 128; bn = 64; nth = 128; }
-    if (tile == 364) { bm = 64; bn = 128; nth = 128; }
-    const long grid_tiles = (long)((max_M + bm - 1) / bm) * ((max_N + bn - 1) / bn);
-    if (tile > 128) S = 1, g.splitk = 1;
+    const int nth = 256;
+    const long grid_tiles = ntiles(tile);
     dim3 block(nth), grid((unsigned)(grid_tiles * S), 1, (unsigned)groups);
     GemmProfiler& prof = gemm_profiler();
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -609,16 +603,10 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
         else if (pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, true>), grid, block, stream, g); }          \
         else { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, false>), grid, block, stream, g); }                   \
     }
-#define MTTS_GEMM_XCASE(F)                                                                                           \
-    if (form == F && tile == 164) { MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 16, true, 1, 1>), grid, block, stream, g); }   \
-    if (form == F && tile == 264) { MTTS_LAUNCH((gemm_f32_kernel<F, 128, 64, 16, true, 2, 1>), grid, block, stream, g); }  \
-    if (form == F && tile == 364) { MTTS_LAUNCH((gemm_f32_kernel<F, 64, 128, 16, true, 1, 2>), grid, block, stream, g); }
     MTTS_GEMM_CASE(GEMM_NT, 128) MTTS_GEMM_CASE(GEMM_NT, 64)
     MTTS_GEMM_CASE(GEMM_NN, 128) MTTS_GEMM_CASE(GEMM_NN, 64)
     MTTS_GEMM_CASE(GEMM_TN, 128) MTTS_GEMM_CASE(GEMM_TN, 64)
-    MTTS_GEMM_XCASE(GEMM_NT) MTTS_GEMM_XCASE(GEMM_NN) MTTS_GEMM_XCASE(GEMM_TN)
 #undef MTTS_GEMM_CASE
-#undef MTTS_GEMM_XCASE
     if (prof.enabled) {
         hipEventRecord(e1, stream);
         GemmProfiler::Rec rec{form * 2 + (tile == 128 ? 1 : 0), alg_flops, e0, e1};
