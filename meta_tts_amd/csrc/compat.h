@@ -23,13 +23,29 @@ constexpr int kWave = 64;  // CDNA wavefront width
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Wavefront reductions on the DPP cross-lane paths (no LDS traffic): quad_perm xor-1 / xor-2, row_half_mirror and
+// row_mirror leave the sum of each 16-lane row in all of its lanes; four v_readlane + scalar adds combine the rows, so the
+// result is wave-uniform.  (__shfl_xor lowers to six dependent ds_bpermute round trips per reduction, which made the row
+// kernels latency- instead of HBM-bound.)
+#if !defined(MTTS_EMU)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #if defined(MTTS_EMU)
     return emu_wave_sum(v);
 #else
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
 #endif
 }
 
@@ -37,9 +53,11 @@ __device__ __forceinline__ float wave_max(float v) {
 #if defined(MTTS_EMU)
     return emu_wave_max(v);
 #else
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 #endif
 }
 

@@ -160,7 +160,8 @@ def main():
         o = model(*b[2:])
         lo = loss_fn(b, o)
     c1.update({"train_mel_post": o[1].numpy(), "train_losses": np.array([float(x) for x in lo], np.float64)})
-    np.savez_compressed(os.path.join(out_dir, "c1_forward.npz"), **c1)
+    if not os.environ.get("MTTS_GOLDEN_ONLY_MAML"):
+        np.savez_compressed(os.path.join(out_dir, "c1_forward.npz"), **c1)
     meta["c1_shapes"] = {"S": int(batch[5]), "T": int(batch[8])}
 
     # ---------------- small padded batch: forward, loss, gradients (train mode) ---------------
@@ -192,13 +193,19 @@ def main():
     with torch.no_grad():
         oe = model(*b[2:])
     small["eval_mel_post"] = oe[1].numpy()
-    np.savez_compressed(os.path.join(out_dir, "small_grad.npz"), **small)
+    if not os.environ.get("MTTS_GOLDEN_ONLY_MAML"):
+        np.savez_compressed(os.path.join(out_dir, "small_grad.npz"), **small)
 
     # ---------------- MAML: 5 inner steps, FO and SO, small task ------------------------------
     from torch.func import functional_call
     alg = cfgs[2]
     modules = alg["adapt"]["modules"]
-    for tag, lr in (("lr1e-3", 0.001), ("lr2e-3", 0.002)):
+    # lr 1e-4: contractive inner loop (losses fall) -> tight parity; 1e-3 / 2e-3: the tiny random model is expansive
+    # there (support loss grows over the steps), kept as loose-tolerance cases
+    only = os.environ.get("MTTS_GOLDEN_ONLY_MAML")  # e.g. "lr1e-4": write only that fixture (the others stay as committed)
+    for tag, lr in (("lr1e-4", 0.0001), ("lr1e-3", 0.001), ("lr2e-3", 0.002)):
+        if only and tag != only:
+            continue
         res = {}
         for order in ("fo", "so"):
             model.train(); reset_bn(model)
@@ -240,6 +247,8 @@ def main():
         res["adapted_names"] = np.array(names)
         np.savez_compressed(os.path.join(out_dir, f"maml_small_{tag}.npz"), **res)
 
+    if os.environ.get("MTTS_GOLDEN_ONLY_MAML"):
+        return
     # ---------------- optimizer / scheduler ---------------------------------------------------
     from lightning.scheduler import get_scheduler
     from lightning.optimizer import get_optimizer

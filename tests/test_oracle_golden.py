@@ -95,7 +95,7 @@ def test_small_batch_losses_grads_and_bn_buffers(golden_dir):
     assert np.abs(oe[1].numpy() - g["eval_mel_post"]).max() < TOL
 
 
-@pytest.mark.parametrize("tag,lr", [("lr1e-3", 0.001), ("lr2e-3", 0.002)])
+@pytest.mark.parametrize("tag,lr", [("lr1e-4", 0.0001), ("lr1e-3", 0.001), ("lr2e-3", 0.002)])
 @pytest.mark.parametrize("order", ["fo", "so"])
 def test_maml_task(golden_dir, tag, lr, order):
     g = _load(golden_dir, f"maml_small_{tag}.npz")
