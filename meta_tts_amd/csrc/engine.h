@@ -852,7 +852,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         const int chunks = (maxM + kRC - 1) / kRC;
         MTTS_LAUNCH(colpart_kernel, dim3((a.C + 127) / 128, chunks, p.tasks), dim3(256), stream, (const int*)p.meta, a, col_partial,
                     col_max_chunks);
-        MTTS_LAUNCH(colfinal_kernel, dim3((a.C + 255) / 256, 1, p.tasks), dim3(256), stream, (const int*)p.meta, a.mfield, a.mode,
+        MTTS_LAUNCH(colfinal_kernel, dim3((a.C + 63) / 64, 1, p.tasks), dim3(256), stream, (const int*)p.meta, a.mfield, a.mode,
                     (const float*)col_partial, col_max_chunks, a.C, out0, out1, out_ts, 1e-5f, a.accumulate);
     }
     void colsum(const Pass& ps, Space s, TS x, int C, const unsigned char* mask, TS roww, TS out) {

@@ -152,7 +152,7 @@ __global__ void layernorm_bwd_kernel(const int* meta, int mfield, const float* d
 //        3  BatchNorm backward sums: out0 = sum dpre*xhat, out1 = sum dpre, dpre = dy*(1-y^2) if tanh,
 //           xhat from per-column stats [mean | rstd]
 // ------------------------------------------------------------------------------------------
-constexpr int kRC = 128;  // rows per chunk
+constexpr int kRC = 32;   // rows per chunk (small chunks: 4 row iterations per thread, ~1000+ workgroups per launch)
 
 struct ColArgs {
     const float* X = nullptr; long long x_ts = 0;      // primary operand [M][C] (dy for modes 1, 3)
@@ -286,24 +286,47 @@ __global__ void colpart_kernel(const int* meta, ColArgs a, float* partial, int m
         }
 }
 
+// 64 columns x 4 chunk lanes per workgroup: lane q folds chunks q, q+4, ... of its column, the four lane results are
+// merged in lane order through LDS (fixed order => run-to-run identical).
 __global__ void colfinal_kernel(const int* meta, int mfield, int mode, const float* partial, int max_chunks, int C,
                                 float* out0, float* out1, long long out_ts, float eps, int accumulate) {
-    const int z = blockIdx.z, c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[3][4][64];
+    const int z = blockIdx.z, cl = (int)threadIdx.x & 63, q = (int)threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool cin = c < C;
     const int M_ = meta[z * META_STRIDE + mfield];
     const int nch = (M_ + kRC - 1) / kRC;
-    const float* p = partial + (long long)z * max_chunks * 3 * C;
+    const float* p = partial + (long long)z * max_chunks * 3 * C + (cin ? c : 0);
     if (mode != 2) {
         float s0 = 0.f, s1 = 0.f;
-        for (int i = 0; i < nch; ++i) { s0 += p[(long long)i * 3 * C + c]; s1 += p[(long long)i * 3 * C + C + c]; }
+        if (cin)
+            for (int i = q; i < nch; i += 4) { s0 += p[(long long)i * 3 * C]; s1 += p[(long long)i * 3 * C + C]; }
+        red[0][q][cl] = s0; red[1][q][cl] = s1;
+        __syncthreads();
+        if (q != 0 || !cin) return;
+        s0 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        s1 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
         if (accumulate) { s0 += out0[(long long)z * out_ts + c]; if (out1) s1 += out1[(long long)z * out_ts + c]; }
         out0[(long long)z * out_ts + c] = s0;
         if (out1) out1[(long long)z * out_ts + c] = s1;
         return;
     }
-    float n = 0.f, mean = 0.f, m2 = 0.f;  // Chan et al. pairwise merge, chunks in order
-    for (int i = 0; i < nch; ++i) {
-        const float nb = p[(long long)i * 3 * C + c], mb = p[(long long)i * 3 * C + C + c], sb = p[(long long)i * 3 * C + 2 * C + c];
+    float n = 0.f, mean = 0.f, m2 = 0.f;  // Chan et al. pairwise merge
+    if (cin)
+        for (int i = q; i < nch; i += 4) {
+            const float nb = p[(long long)i * 3 * C], mb = p[(long long)i * 3 * C + C], sb = p[(long long)i * 3 * C + 2 * C];
+            if (nb <= 0.f) continue;
+            const float nn = n + nb, d = mb - mean;
+            mean += d * nb / nn;
+            m2 += sb + d * d * n * nb / nn;
+            n = nn;
+        }
+    red[0][q][cl] = n; red[1][q][cl] = mean; red[2][q][cl] = m2;
+    __syncthreads();
+    if (q != 0 || !cin) return;
+    n = 0.f; mean = 0.f; m2 = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        const float nb = red[0][i][cl], mb = red[1][i][cl], sb = red[2][i][cl];
         if (nb <= 0.f) continue;
         const float nn = n + nb, d = mb - mean;
         mean += d * nb / nn;
