@@ -66,3 +66,16 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 }  // namespace mtts
+
+// cross-workgroup hand-off primitives (split-K rendezvous in gemm.h)
+#if defined(MTTS_EMU)
+#define MTTS_WAIT_VMEM() ((void)0)
+#define MTTS_FENCE_RELEASE_AGENT() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define MTTS_FENCE_ACQUIRE_AGENT() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define MTTS_ATOMIC_INC_AGENT(p) atomicAdd((p), 1)
+#else
+#define MTTS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define MTTS_FENCE_RELEASE_AGENT() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define MTTS_FENCE_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define MTTS_ATOMIC_INC_AGENT(p) __hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif

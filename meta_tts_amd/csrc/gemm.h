@@ -74,6 +74,7 @@ struct GemmArgs {
     // contiguous run of K-chunks; partial tiles go to `ws`, the last workgroup to arrive (tile counter in `tile_ctr`) sums
     // them in split order and runs the fused epilogue, so the result does not depend on the arrival order
     int splitk = 1;
+    int tiles_pg = 0;  // output tiles per group (workspace slot = group * tiles_pg + tile)
     float* ws = nullptr;
     int* tile_ctr = nullptr;
 };
@@ -216,7 +217,7 @@ template <int TM, int TN, int NTH>
 __device__ __forceinline__ bool splitk_combine(const GemmArgs& g, int z, int tile_lin, int split, int S, f32x16 (&acc)[TM][TN]) {
     constexpr int PART = NTH * 16 * TM * TN;  // floats per partial tile
     const int tid = threadIdx.x;
-    const long long slot = (long long)z * (gridDim.x / S) + tile_lin;
+    const long long slot = (long long)z * g.tiles_pg + tile_lin;
     float* base = g.ws + slot * S * PART;
     float* mine = base + (long long)split * PART;
 #pragma unroll
@@ -229,13 +230,21 @@ __device__ __forceinline__ bool splitk_combine(const GemmArgs& g, int z, int til
                 v.x = acc[i][j][4 * r4]; v.y = acc[i][j][4 * r4 + 1]; v.z = acc[i][j][4 * r4 + 2]; v.w = acc[i][j][4 * r4 + 3];
                 st4(mine + (((i * TN + j) * 4 + r4) * NTH + tid) * 4, v);
             }
-    __threadfence();
+    // hand-off (cdna_hip_programming.md, in-launch split-K): every wave drains its own stores, ONE agent-scope release by
+    // lane 0 publishes the workgroup's slab, a relaxed agent-scope counter elects the reducer, ONE acquire by its lane 0
+    // precedes the slab reads.  (A __threadfence() by all 256 threads on both sides writes back / invalidates the XCD's
+    // L2 hundreds of times per tile and made split-K a net loss.)
     __shared__ int s_last;
+    MTTS_WAIT_VMEM();
     __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(g.tile_ctr + slot, 1) == S - 1) ? 1 : 0;
+    if (tid == 0) {
+        MTTS_FENCE_RELEASE_AGENT();
+        MTTS_WAIT_VMEM();
+        s_last = (MTTS_ATOMIC_INC_AGENT(g.tile_ctr + slot) == S - 1) ? 1 : 0;
+        if (s_last) MTTS_FENCE_ACQUIRE_AGENT();
+    }
     __syncthreads();
     if (!s_last) return false;
-    __threadfence();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -263,7 +272,9 @@ struct GemmSmem {
 };
 
 // One workgroup's share of one problem: output tile `bxs` (times split) of group `z`.
-template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2>
+// ABL (diagnostic builds only, results are wrong): bit 0 drops the in-loop global loads, bit 1 the LDS stores, bit 2 the
+// in-loop fragment reads, bit 3 the barrier — timing the kernel with one stage removed shows what that stage costs.
+template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0>
 __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs, float* smem) {
     constexpr int NTH = 64 * WGM * WGN;
     constexpr int kLDK = BK + 4;  // K-contiguous LDS row stride: 80 / 144 bytes, ds_read_b128 conflict-free
@@ -392,11 +403,11 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
         read_frags<TM, TN, BK, A_KC, B_KC, LDA_S, LDB_S>(smem, smem + A_TILE, wm0, wn0, lane, f0);
         auto step = [&](int c, const Frags<TM, TN, BK>& fc, Frags<TM, TN, BK>& fn) {
             const int nb = (c & 1) ^ 1;
-            if (c + 1 < nchunks) store_ab(nb);
-            if (c + 2 < nchunks) { load_a(kb0 + (c + 2) * BK); load_b(kb0 + (c + 2) * BK); }
+            if (!(ABL & 2) && c + 1 < nchunks) store_ab(nb);
+            if (!(ABL & 1) && c + 2 < nchunks) { load_a(kb0 + (c + 2) * BK); load_b(kb0 + (c + 2) * BK); }
             mma_half<TM, TN, BK>(fc, 0, acc);
-            __syncthreads();
-            if (c + 1 < nchunks) {
+            if (!(ABL & 8)) __syncthreads();
+            if (!(ABL & 4) && c + 1 < nchunks) {
                 const float* As = smem + nb * (A_TILE + B_TILE);
                 read_frags<TM, TN, BK, A_KC, B_KC, LDA_S, LDB_S>(As, As + A_TILE, wm0, wn0, lane, fn);
             }
@@ -412,12 +423,12 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
     gemm_epilogue<TM, TN>(g, z, acc, C, ldc, M, N, m0 + wm0, n0 + wn0, lane);
 }
 
-template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2>
+template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[GemmSmem<FORM, BM, BN, BK>::FLOATS];
     int z, bxs;
     xcd_swizzle(g.swizzle, z, bxs);
-    gemm_f32_body<FORM, BM, BN, BK, PIPE, WGM, WGN>(g, z, bxs, smem);
+    gemm_f32_body<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL>(g, z, bxs, smem);
 }
 
 // Several independent problems (any mix of forms, e.g. the dgrad and the wgrad of one layer) in ONE launch: workgroups
@@ -512,7 +523,7 @@ inline GemmWorkspace& gemm_workspace(hipStream_t stream) {
     return all.back().second;
 }
 inline int& gemm_splitk_target() {  // workgroups a launch should reach before split-K stops adding more; 0 disables (MTTS_SPLITK_TARGET)
-    static int v = [] { const char* e = getenv("MTTS_SPLITK_TARGET"); return e ? atoi(e) : 0; }();
+    static int v = [] { const char* e = getenv("MTTS_SPLITK_TARGET"); return e ? atoi(e) : -1; }();  // -1: batched launches only
     return v;
 }
 
@@ -572,13 +583,15 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
     // tile code: 64 / 128 (+1000 software pipeline, +2000 BK=32); plain 64 / 128 take the defaults
     bool pipe = gemm_default_pipe();
     int bk = gemm_default_bk();
+    const int ablate = tile / 10000;  // diagnostic stage ablation (NT 64x64 pipelined BK=16 only), see gemm_f32_body
+    tile %= 10000;
     if (tile >= 1000) { pipe = (tile / 1000) & 1; bk = (tile / 2000) ? 32 : 16; tile %= 1000; }
     if (user_tile == 0 && !g.table && g.K >= 1024 && (form == GEMM_NT || form == GEMM_TN)) bk = 32;  // long K-contiguous panels: full 128-B lines per row
     if (g.taps > 1 && g.tap_k % 32 != 0) bk = 16;  // a K-slice must not straddle two conv taps
     // split-K for under-filled grids (single-task ranks, the phoneme-side GEMMs, small wgrads): enough workgroups for
     // ~4 per CU, each still reducing >= 4 K-chunks
     int S = 1;
-    if (!g.table && gemm_splitk_target() > 0) {
+    if (!g.table && gemm_splitk_target() > 0) {  // stand-alone launches: opt-in (measured neutral on the model's forward shapes)
         const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
         const long wgs = (long)std::ceil(rows / tile) * ((max_N + tile - 1) / tile);
         const int nch = (g.K + bk - 1) / bk;
@@ -587,7 +600,7 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
         if (S >= 2 && (slots * S * tile * tile > kSplitWsFloats || slots > kSplitCtrs)) S = 1;
         if (S >= 2) {
             GemmWorkspace& w = gemm_workspace(stream);
-            if (w.ws) { g.splitk = S; g.ws = w.ws; g.tile_ctr = w.ctr; } else S = 1;
+            if (w.ws) { g.splitk = S; g.ws = w.ws; g.tile_ctr = w.ctr; g.tiles_pg = (int)ntiles(tile); } else S = 1;
         } else S = 1;
     }
     const int nth = 256;
@@ -603,6 +616,11 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
         else if (pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, true>), grid, block, stream, g); }          \
         else { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, false>), grid, block, stream, g); }                   \
     }
+#if defined(MTTS_GEMM_ABLATION)
+#define MTTS_ABL(A) if (ablate == A && form == GEMM_NT) { MTTS_LAUNCH((gemm_f32_kernel<GEMM_NT, 64, 64, 16, true, 2, 2, A>), grid, block, stream, g); return; }
+    MTTS_ABL(1) MTTS_ABL(2) MTTS_ABL(3) MTTS_ABL(4) MTTS_ABL(7) MTTS_ABL(8) MTTS_ABL(15) MTTS_ABL(6) MTTS_ABL(14)
+#undef MTTS_ABL
+#endif
     MTTS_GEMM_CASE(GEMM_NT, 128) MTTS_GEMM_CASE(GEMM_NT, 64)
     MTTS_GEMM_CASE(GEMM_NN, 128) MTTS_GEMM_CASE(GEMM_NN, 64)
     MTTS_GEMM_CASE(GEMM_TN, 128) MTTS_GEMM_CASE(GEMM_TN, 64)
@@ -631,11 +649,34 @@ inline void gemm_batch_end(hipStream_t stream) {
     mp.n = (int)b.q.size();
     int max_groups = 0;
     double flops = 0.0, rows = 0.0;
+    // split-K for the long chains of an under-filled batch: a tile whose K-loop is longer than a third of the whole
+    // batch's per-CU work would finish last on its own (single-task ranks: the k=9 dgrad tile, 576 slices, beside a
+    // batch that is worth ~590 slices per CU), so it is cut into S workgroups (rendezvous in splitk_combine)
+    double work = 0.0;
+    for (const GemmPending& p : b.q) work += std::ceil(p.rows / 64.0) * ((p.max_N + 63) / 64) * std::max(1, (p.g.K + 15) / 16);
+    const double per_cu = work / 256.0;
+    GemmWorkspace* wsp = nullptr;
+    long long ws_off = 0, ctr_off = 0;
     for (int i = 0; i < mp.n; ++i) {
         const GemmPending& p = b.q[i];
         mp.form[i] = p.form; mp.groups[i] = p.groups; mp.g[i] = p.g;
         mp.g[i].swizzle = 0; mp.g[i].splitk = 1;
-        mp.start[i + 1] = mp.start[i] + ((p.max_M + 63) / 64) * ((p.max_N + 63) / 64) * p.groups;
+        const int tiles = ((p.max_M + 63) / 64) * ((p.max_N + 63) / 64);
+        int S = 1;
+        const int nch = (p.g.K + 15) / 16;
+        if (!p.g.table && gemm_splitk_target() != 0 && nch > per_cu / 3.0) {
+            S = (int)std::min<double>(std::min<double>(std::ceil(nch / std::max(per_cu / 3.0, 1.0)), nch / 16), 8);
+            const long long slots = (long long)tiles * p.groups;
+            if (S >= 2 && ((ws_off + slots * S * 4096) > kSplitWsFloats || ctr_off + slots > kSplitCtrs)) S = 1;
+            if (S >= 2) {
+                if (!wsp) wsp = &gemm_workspace(stream);
+                if (wsp->ws) {
+                    mp.g[i].splitk = S; mp.g[i].tiles_pg = tiles; mp.g[i].ws = wsp->ws + ws_off; mp.g[i].tile_ctr = wsp->ctr + ctr_off;
+                    ws_off += slots * S * 4096; ctr_off += slots;
+                } else S = 1;
+            } else S = 1;
+        }
+        mp.start[i + 1] = mp.start[i] + tiles * S * p.groups;
         max_groups = std::max(max_groups, p.groups);
         flops += p.flops; rows += p.rows;
     }
@@ -643,7 +684,17 @@ inline void gemm_batch_end(hipStream_t stream) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
     dim3 block(256), grid((unsigned)mp.start[mp.n], 1, 1);
-    MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 16>), grid, block, stream, mp);
+    // BK = 32 stages K-contiguous operands in full 128-byte lines (half the load instructions, TA transactions and barriers
+    // per flop); needs every tapped problem's tap length to be a multiple of 32 and pays off only for long K
+    static const int multi_bk = [] { const char* e = getenv("MTTS_MULTI_BK"); return e ? atoi(e) : 0; }();
+    bool bk32 = multi_bk == 32;
+    int maxK = 0;
+    for (int i = 0; i < mp.n; ++i) {
+        if (mp.g[i].taps > 1 && mp.g[i].tap_k % 32 != 0) bk32 = false;
+        maxK = std::max(maxK, mp.g[i].K);
+    }
+    if (bk32 && maxK >= 1024) { MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32>), grid, block, stream, mp); }
+    else { MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 16>), grid, block, stream, mp); }
     if (prof.enabled) {
         hipEventRecord(e1, stream);
         GemmProfiler::Rec rec{6, flops, e0, e1};
