@@ -1257,7 +1257,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         MTTS_LAUNCH(length_regulate_bwd_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (const float*)gF0.p,
                     gF0.ts, (const int*)p.p_first, (const int*)p.p_count, row_ts_p, gP0.p, gP0.ts, d, 0);
         // speaker vector gradient, part 1: every valid frame
-        MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(64), stream, (const int*)p.meta, (const float*)gF0.p,
+        MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(256), stream, (const int*)p.meta, (const float*)gF0.p,
                     gF0.ts, (const int*)p.f_seg_start, (const int*)p.f_seg_len, (long long)cap_B, dspk.p, dspk.ts, d, 0);
         // ---- variance adaptor ---------------------------------------------------------------
         const bool va_needed = true;
@@ -1270,7 +1270,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         site_base = 132; pred_bwd(ps, pitP, pitB, x0, dpred[1], gP0);
         site_base = 128; pred_bwd(ps, durP, durB, x0, dpred[0], gP0);
         // speaker vector gradient, part 2: every position of the phoneme rectangle
-        MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(64), stream, (const int*)p.meta, (const float*)gP0.p,
+        MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(256), stream, (const int*)p.meta, (const float*)gP0.p,
                     gP0.ts, (const int*)p.p_seg_start, (const int*)p.p_seg_len, (long long)cap_B, dspk.p, dspk.ts, d, 1);
         MTTS_LAUNCH(speaker_table_grad_kernel, dim3(cfg.n_speaker, 1, nt), dim3(64), stream, (const int*)p.meta,
                     (const float*)dspk.p, dspk.ts, (const int*)p.spk_ids, (long long)cap_B + 1, cap_B, p.average_spk,
