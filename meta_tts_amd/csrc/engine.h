@@ -28,6 +28,7 @@
 
 #include "gemm.h"
 #include "gemm_bf16_launch.h"
+#include "gemm_glds.h"
 #include "rowops.h"
 #include "tangent.h"
 

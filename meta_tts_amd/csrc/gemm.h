@@ -546,6 +546,17 @@ inline bool& gemm_batch_enabled() {  // MTTS_GEMM_BATCH=0 launches every problem
 inline void gemm_batch_begin() { if (gemm_batch_enabled()) gemm_batch().open = true; }
 inline void gemm_batch_end(hipStream_t stream);
 
+// LDS-DMA kernel family (gemm_glds.h, device builds only).  MTTS_GLDS=0 keeps the register-staged kernels (A/B runs).
+inline bool& gemm_use_glds() {
+    static bool v = [] { const char* e = getenv("MTTS_GLDS"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
+inline bool gemm_glds_ok(const GemmArgs& g) { return !(g.taps > 1 && g.tap_k % 32 != 0); }
+#if !defined(MTTS_EMU)
+inline void gemm_glds_launch(int form, const GemmArgs& g, dim3 grid, hipStream_t stream);
+inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t stream);
+#endif
+
 // Host launcher.  max_M / max_N bound the tile grid over all groups.  tile = 0 picks the tile by a
 // wave-quantisation model: one 4-wave workgroup saturates a CU's four MFMA pipes, so B workgroups
 // on 256 CUs take ceil(B/256) rounds; the 64x64 tile quarters the quantum at ~0.97x the per-tile
@@ -583,6 +594,13 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
     // tile code: 64 / 128 (+1000 software pipeline, +2000 BK=32); plain 64 / 128 take the defaults
     bool pipe = gemm_default_pipe();
     int bk = gemm_default_bk();
+    bool glds = false;
+#if !defined(MTTS_EMU)
+    if (tile == 4064) { glds = gemm_glds_ok(g); tile = 64; }            // explicit request (kernel tests, microbenchmarks)
+    else if (user_tile == 0 && tile == 64) glds = gemm_use_glds() && gemm_glds_ok(g);
+#else
+    if (tile == 4064) tile = 64;
+#endif
     const int ablate = tile / 10000;  // diagnostic stage ablation (NT 64x64 pipelined BK=16 only), see gemm_f32_body
     tile %= 10000;
     if (tile >= 1000) { pipe = (tile / 1000) & 1; bk = (tile / 2000) ? 32 : 16; tile %= 1000; }
@@ -616,6 +634,19 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
         else if (pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, true>), grid, block, stream, g); }          \
         else { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, false>), grid, block, stream, g); }                   \
     }
+#if !defined(MTTS_EMU)
+    if (glds) {
+        gemm_glds_launch(form, g, grid, stream);
+        if (prof.enabled) {
+            hipEventRecord(e1, stream);
+            GemmProfiler::Rec rec{form * 2, alg_flops, e0, e1};
+            rec.form = form; rec.tile = 4064; rec.N = max_N; rec.K = g.K; rec.groups = groups; rec.splitk = S;
+            rec.rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
+            prof.recs.push_back(rec);
+        }
+        return;
+    }
+#endif
 #if defined(MTTS_GEMM_ABLATION)
 #define MTTS_ABL(A) if (ablate == A && form == GEMM_NT) { MTTS_LAUNCH((gemm_f32_kernel<GEMM_NT, 64, 64, 16, true, 2, 2, A>), grid, block, stream, g); return; }
     MTTS_ABL(1) MTTS_ABL(2) MTTS_ABL(3) MTTS_ABL(4) MTTS_ABL(7) MTTS_ABL(8) MTTS_ABL(15) MTTS_ABL(6) MTTS_ABL(14)
@@ -693,6 +724,12 @@ inline void gemm_batch_end(hipStream_t stream) {
         if (mp.g[i].taps > 1 && mp.g[i].tap_k % 32 != 0) bk32 = false;
         maxK = std::max(maxK, mp.g[i].K);
     }
+    bool glds = gemm_use_glds();
+    for (int i = 0; i < mp.n; ++i) glds = glds && gemm_glds_ok(mp.g[i]);
+#if !defined(MTTS_EMU)
+    if (glds) { gemm_glds_multi_launch(mp, grid, stream); }
+    else
+#endif
     if (bk32 && maxK >= 1024) { MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32>), grid, block, stream, mp); }
     else { MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 16>), grid, block, stream, mp); }
     if (prof.enabled) {

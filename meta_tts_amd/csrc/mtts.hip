@@ -255,7 +255,7 @@ int mtts_profile_report(double* out21) {
 
 int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, float alpha, int flags, int tile, void* stream) {
-    if (form < 0 || form > 2 || (tile != 0 && tile % 1000 != 64 && tile % 1000 != 128) || tile % 10000 >= 4000) return -1;
+    if (form < 0 || form > 2 || (tile != 0 && tile != 4064 && ((tile % 1000 != 64 && tile % 1000 != 128) || tile % 10000 >= 4000))) return -1;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.alpha = alpha; g.flags = flags;

@@ -25,7 +25,7 @@ def _rand(g, *shape):
     return torch.from_numpy(g.standard_normal(shape).astype(np.float32)).cuda()
 
 
-@pytest.mark.parametrize("tile", [64, 128, 1064, 1128, 2064, 3064, 3128])
+@pytest.mark.parametrize("tile", [64, 128, 1064, 1128, 2064, 3064, 3128, 4064])
 @pytest.mark.parametrize("form", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 80, 256), (300, 768, 48), (33, 130, 100), (5, 7, 20)])
 def test_gemm_forms(lib, form, tile, M, N, K):
@@ -60,7 +60,7 @@ def test_gemm_forms(lib, form, tile, M, N, K):
     assert (C2[:, :N].double() - want2).abs().max().item() < 2e-5 * max(1.0, want2.abs().max().item())
 
 
-@pytest.mark.parametrize("tile", [0, 64, 128, 1064, 1128, 3064, 3128])
+@pytest.mark.parametrize("tile", [0, 64, 128, 1064, 1128, 3064, 3128, 4064])
 @pytest.mark.parametrize("L,Cin,Cout,k", [(97, 32, 48, 3), (300, 256, 1024, 9), (211, 80, 512, 5), (150, 1024, 256, 1), (64, 512, 80, 5)])
 def test_conv1d_fwd_dgrad_wgrad(lib, tile, L, Cin, Cout, k):
     g = np.random.RandomState(L + Cin + Cout + k)
