@@ -552,6 +552,14 @@ inline bool& gemm_use_glds() {
     return v;
 }
 inline bool gemm_glds_ok(const GemmArgs& g) { return !(g.taps > 1 && g.tap_k % 32 != 0); }
+// Launches up to this many workgroups take the LDS-DMA kernels (latency regime: few workgroups per CU, where the DMA
+// ring's two slices in flight replace the occupancy the register-staged kernel needs; measured +8 % / +14 % on the
+// single-task first- / second-order step), larger ones the register-staged kernels (5 vs 3 workgroups per CU resident:
+// +3 % on the full 8-task step).  MTTS_GLDS_MAX_WGS overrides.
+inline long& gemm_glds_max_wgs() {
+    static long v = [] { const char* e = getenv("MTTS_GLDS_MAX_WGS"); return e ? atol(e) : 768L; }();
+    return v;
+}
 #if !defined(MTTS_EMU)
 inline void gemm_glds_launch(int form, const GemmArgs& g, dim3 grid, hipStream_t stream);
 inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t stream);
@@ -597,7 +605,11 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
     bool glds = false;
 #if !defined(MTTS_EMU)
     if (tile == 4064) { glds = gemm_glds_ok(g); tile = 64; }            // explicit request (kernel tests, microbenchmarks)
-    else if (user_tile == 0 && tile == 64) glds = gemm_use_glds() && gemm_glds_ok(g);
+    else if (user_tile == 0 && tile == 64) {
+        const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
+        const long wgs = (long)std::ceil(rows / 64.0) * ((max_N + 63) / 64);
+        glds = gemm_use_glds() && gemm_glds_ok(g) && wgs <= gemm_glds_max_wgs();
+    }
 #else
     if (tile == 4064) tile = 64;
 #endif
@@ -724,7 +736,9 @@ inline void gemm_batch_end(hipStream_t stream) {
         if (mp.g[i].taps > 1 && mp.g[i].tap_k % 32 != 0) bk32 = false;
         maxK = std::max(maxK, mp.g[i].K);
     }
-    bool glds = gemm_use_glds();
+    double batch_wgs = 0.0;
+    for (const GemmPending& p : b.q) batch_wgs += std::ceil(p.rows / 64.0) * ((p.max_N + 63) / 64);
+    bool glds = gemm_use_glds() && batch_wgs <= (double)gemm_glds_max_wgs();
     for (int i = 0; i < mp.n; ++i) glds = glds && gemm_glds_ok(mp.g[i]);
 #if !defined(MTTS_EMU)
     if (glds) { gemm_glds_multi_launch(mp, grid, stream); }
