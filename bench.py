@@ -263,15 +263,15 @@ def main():
         ach = dom[3] / (dom[2] * 1e-3) / 1e12 if dom[2] > 0 else 0.0
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read in-process, so this is the figure of the
         # committed separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (profiles/).
-        traffic, traffic_src = None, None
+        traffic, traffic_src, mfma_busy = None, None, None
         pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 k = json.load(f)["kernels"].get(dom[0])
             if k:
-                traffic, traffic_src = k["hbm_bytes_per_launch"], "profiles/r01_pmc_hbm.json"
+                traffic, traffic_src, mfma_busy = k.get("hbm_bytes_per_launch"), "profiles/r01_pmc_hbm.json", k.get("mfma_busy_frac")
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "kernel": dom[0],
+                "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "mfma_pipe_busy_frac_pmc": mfma_busy, "kernel": dom[0],
                 "launches": int(dom[1]), "avg_launch_us": round(1e3 * dom[2] / max(dom[1], 1), 2),
                 "alg_gflop_per_launch": round(dom[3] / max(dom[1], 1) / 1e9, 3),
                 "all_gemm": {"ms_per_meta_step": round(tot_ms, 2), "alg_tflop_per_meta_step": round(tot_fl / 1e12, 3),

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Fold rocprofv3 --pmc rocpd databases (one pass per counter group, as the MI355X guide prescribes) into the per-kernel
+JSON that bench.py's roofline leg reads (profiles/rNN_pmc_hbm.json).
+
+usage: pmc_to_json.py OUT.json DB [DB ...]
+Counters used when present: FETCH_SIZE, WRITE_SIZE (KB; gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B/lane
+loads -> doubled), SQ_BUSY_CYCLES, SQ_VALU_MFMA_BUSY_CYCLES (MFMA-pipe busy fraction = MFMA_BUSY / (BUSY * 32 SIMDs per SE),
+both summed over the shader engines)."""
+import collections
+import json
+import re
+import sqlite3
+import sys
+
+FORMS = {"0": "NT", "1": "NN", "2": "TN"}
+
+
+def category(sym):
+    m = re.search(r"gemm_f32_kernelILi(\d)ELi(\d+)E", sym)
+    if m:
+        return f"gemm_f32<{FORMS[m.group(1)]},{m.group(2)}>"
+    m = re.search(r"gemm_glds_kernelILi(\d)E", sym)
+    if m:
+        return f"gemm_f32<{FORMS[m.group(1)]},64>"
+    if "gemm_f32_multi_kernel" in sym or "gemm_glds_multi_kernel" in sym:
+        return "gemm_f32_multi<64>"
+    return None
+
+
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))  # cat -> counter -> [sum, dispatches]
+for path in sys.argv[2:]:
+    c = sqlite3.connect(path)
+    rows = c.execute("""select s.kernel_name, p.name, d.id, sum(e.value) from rocpd_pmc_event e
+        join rocpd_info_pmc p on e.pmc_id = p.id
+        join rocpd_kernel_dispatch d on e.event_id = d.event_id
+        join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by 1, 2, 3""").fetchall()
+    for sym, ctr, _disp, val in rows:
+        cat = category(sym)
+        if cat is None:
+            continue
+        a = acc[cat][ctr]
+        a[0] += val
+        a[1] += 1
+out = {"source": "rocprofv3 --pmc passes (one counter group per pass) over `bench.py --steps 1 --warmup 0` (fp32, dropout on), 1x MI355X",
+       "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B/lane loads -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported; both KB",
+       "kernels": {}}
+for cat, d in sorted(acc.items()):
+    k = {}
+    if "FETCH_SIZE" in d:
+        k["fetch_size_kb_per_launch_raw"] = round(d["FETCH_SIZE"][0] / d["FETCH_SIZE"][1], 1)
+        k["launches_sampled"] = d["FETCH_SIZE"][1]
+    if "WRITE_SIZE" in d:
+        k["write_size_kb_per_launch_raw"] = round(d["WRITE_SIZE"][0] / d["WRITE_SIZE"][1], 1)
+    if "fetch_size_kb_per_launch_raw" in k and "write_size_kb_per_launch_raw" in k:
+        k["hbm_bytes_per_launch"] = int(1024 * (2 * k["fetch_size_kb_per_launch_raw"] + k["write_size_kb_per_launch_raw"]))
+    if "SQ_BUSY_CYCLES" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["SQ_BUSY_CYCLES"][0] > 0:
+        k["mfma_busy_frac"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (32.0 * d["SQ_BUSY_CYCLES"][0]), 4)
+    out["kernels"][cat] = k
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+print(json.dumps(out["kernels"], indent=1))
