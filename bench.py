@@ -74,13 +74,15 @@ def cpu_baseline(dims, mods, budget_s=25.0):
 
 
 def inference_leg(dims, mods, device, iters=5):
-    """BASELINE config 5 without the vocoder (MelGAN is not built): 5-shot speaker adaptation (5 first-order inner steps
+    """BASELINE config 5: 5-shot speaker adaptation (5 first-order inner steps
     on the 5 support utterances of task 0) followed by free-running synthesis (predicted durations) of the 5 query texts
-    with the adapted weights in train mode, as the reference's test loop does (base_adaptor.py:170-189).  The random-init
+    with the adapted weights in train mode, as the reference's test loop does (base_adaptor.py:170-189), then the MelGAN
+    generator on the synthesised mels (lightning/utils.py:16-30; synthetic generator weights).  The random-init
     duration predictor emits ~0 frames, so its output bias is set to ln(8) (about 7 frames per phoneme, LibriTTS-like)."""
     import torch
     from meta_tts_amd import synth
     from meta_tts_amd.engine import Engine
+    from meta_tts_amd.vocoder import MelGAN
     sup, qry = synth.make_task(0)
     params = synth.make_params(dims, 0)
     params["variance_adaptor.duration_predictor.linear_layer.bias"][:] = np.log(8.0)
@@ -89,8 +91,11 @@ def inference_leg(dims, mods, device, iters=5):
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.load_params(params)
     eng.set_batches(0, [sup])
+    voc = MelGAN(max_B=5, max_T=1000, device=device)
+    voc.set_stream(torch.cuda.current_stream().cuda_stream)
     res = {}
-    for name, with_adapt in (("adapt5_plus_synthesis", True), ("synthesis_only", False)):
+    for name, with_adapt, with_voc in (("adapt5_plus_synthesis_plus_vocoder", True, True), ("synthesis_plus_vocoder", False, True),
+                                       ("adapt5_plus_synthesis", True, False), ("synthesis_only", False, False)):
         frames = 0
         for it in range(iters + 1):
             if it == 1:
@@ -99,14 +104,22 @@ def inference_leg(dims, mods, device, iters=5):
                 eng.adapt(INNER_STEPS, INNER_LR, reset=True, fetch_losses=False)
             eng.set_batches(1, [qry[:6]], spk_from=[sup], average_spk=True)
             eng.synthesize(1, use_fast=True, train=True)
-            d, mel_lens, tcap = eng.durations(1, 0)
+            if with_voc:
+                o = eng.outputs(1, 0)
+                mel_lens = o["mel_lens"]
+                wav = voc.infer(np.ascontiguousarray(o["mel_post"].transpose(0, 2, 1)), 32768.0, lengths=[int(l) * 256 for l in mel_lens])
+            else:
+                d, mel_lens, tcap = eng.durations(1, 0)
             frames += int(mel_lens.sum())
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         res[name] = {"mels_per_sec": round(frames / dt, 1), "ms_per_iter": round(1e3 * dt / iters, 2), "frames_per_iter": frames // iters,
-                     "rtf_acoustic_only": round(dt / (frames * 256 / 22050.0), 5)}
+                     "rtf": round(dt / (frames * 256 / 22050.0), 5)}
     eng.close()
-    res["note"] = "acoustic model only (no vocoder); 5 query utterances per iteration; host->device batch upload and the one duration read-back are inside the timed loop"
+    voc.close()
+    res["note"] = ("5 query utterances per iteration; host->device batch upload, the duration read-back and (vocoder legs) the mel download, "
+                   "waveform download and int16 conversion on the host are inside the timed loop; MelGAN generator with synthetic weights "
+                   "(~90 MFLOP per mel frame)")
     return res
 
 

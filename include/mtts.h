@@ -158,6 +158,30 @@ int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const 
 int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* x_or_dy, const float* w_or_x, float* out,
                     const float* bias, int tile, void* hip_stream);
 
+/* ---- MelGAN generator: mel -> waveform --------------------------------------------
+ * Replaces `LightningMelGAN.inverse / infer`, lightning/utils.py:8-30 (vocoder.mel2wav of torch.hub
+ * "descriptinc/melgan-neurips"; the generator is an un-vendored dependency: architecture of that hub entry, weights
+ * supplied by the caller).  Tensors (weight-norm already folded, see meta_tts_amd/vocoder.py):
+ *   conv_in.w [C0][7][n_mel], conv_in.b [C0];  up{s}.w [r][C_out][2*C_in] (phase-major polyphase image of the
+ *   ConvTranspose1d), up{s}.b;  res{s}.{j}.w1 [C][3][C], .b1, .w2 [C][C], .b2, .ws [C][C], .bs;  conv_out.w [7][C_last],
+ *   conv_out.b [1];  C0 = ngf << n_ratios.
+ * infer: mel [B][T_max][n_mel] (host), mel_lens[b] frames valid, every value multiplied by mel_scale (the reference
+ * passes mel / ln 10) -> wav [B][T_max * hop] floats in (-1, 1), the first mel_lens[b] * hop samples of a row written.
+ * infer_device: same with device pointers (no copies, no synchronisation; runs on the vocoder's stream). */
+typedef struct mtts_vocoder mtts_vocoder;
+int mtts_vocoder_create(int n_mel, int ngf, int n_res, const int* ratios, int n_ratios, int device, int max_B, int max_T,
+                        mtts_vocoder** out);
+void mtts_vocoder_destroy(mtts_vocoder* h);
+const char* mtts_vocoder_last_error(mtts_vocoder* h);
+int mtts_vocoder_set_stream(mtts_vocoder* h, void* hip_stream);
+int mtts_vocoder_hop(mtts_vocoder* h);
+int mtts_vocoder_param_count(mtts_vocoder* h);
+int mtts_vocoder_param_info(mtts_vocoder* h, int index, char* name, int name_cap, int64_t* numel);
+int mtts_vocoder_load(mtts_vocoder* h, const char* name, const float* data, int64_t numel);
+int mtts_vocoder_infer(mtts_vocoder* h, const float* mel, int B, int T_max, const int* mel_lens, float mel_scale, float* wav);
+int mtts_vocoder_infer_device(mtts_vocoder* h, const float* mel_dev, int B, int T_max, const int* mel_lens, float mel_scale,
+                              float* wav_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,17 @@ EXPORTS = {
                                 C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "mtts_conv1d_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_void_p]),
+    "mtts_vocoder_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_void_p)]),
+    "mtts_vocoder_destroy": (None, [C.c_void_p]),
+    "mtts_vocoder_last_error": (C.c_char_p, [C.c_void_p]),
+    "mtts_vocoder_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mtts_vocoder_hop": (C.c_int, [C.c_void_p]),
+    "mtts_vocoder_param_count": (C.c_int, [C.c_void_p]),
+    "mtts_vocoder_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64)]),
+    "mtts_vocoder_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "mtts_vocoder_infer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
+    "mtts_vocoder_infer_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
 }
 
 _cache = {}

@@ -39,7 +39,7 @@
 namespace mtts {
 
 enum GemmForm { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
-enum GemmFlags { GEMM_RELU = 1, GEMM_ACCUM = 2 };
+enum GemmFlags { GEMM_RELU = 1, GEMM_ACCUM = 2, GEMM_LRELU = 4 };  // LRELU: v < 0 -> act_slope * v (MelGAN generator)
 
 struct GemmGroupDesc {
     long long a_off, b_off, c_off;  // element offsets added to A / B / C
@@ -55,7 +55,7 @@ struct GemmArgs {
     int lda = 0, ldb = 0, ldc = 0;
     int M = 0, N = 0, K = 0;
     const int* dimptr = nullptr;  // per-group override of M (dim_sel 0) or K (dim_sel 2)
-    int dim_stride = 1, dim_sel = 0;
+    int dim_stride = 1, dim_sel = 0, dim_mult = 1;  // value used = dimptr[group * dim_stride] * dim_mult
     const GemmGroupDesc* table = nullptr;  // TABLE mode: per-group offsets and sizes
     const float* bias = nullptr;
     long long bias_gs = 0;
@@ -67,6 +67,7 @@ struct GemmArgs {
     const int* c_rowmap = nullptr;  // output row remap, < 0 -> row dropped
     long long c_rowmap_gs = 0;
     float alpha = 1.f;
+    float act_slope = 0.2f;
     int flags = 0;
     int taps = 1, tap_k = 0x40000000, tap_bstride = 0;  // NN conv dgrad tap walk
     int swizzle = 0;                                     // XCD-aware workgroup order (set by the launcher)
@@ -203,6 +204,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int z, f32x16 (
                 float v = g.alpha * acc[i][j][r] + bv;
                 if (g.flags & GEMM_ACCUM) v += *p;  // accumulate first: the masks below act on the sum
                 if (g.flags & GEMM_RELU) v = fmaxf(v, 0.f);
+                if (g.flags & GEMM_LRELU) v = v > 0.f ? v : g.act_slope * v;
                 if (relu_ref && !(relu_ref[(long long)m * g.ld_relu + n] > 0.f)) v = 0.f;
                 if (rowmask && !rowmask[m]) v = 0.f;
                 *p = v;
@@ -304,7 +306,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
     } else {
         A += (long long)z * g.a_gs; B += (long long)z * g.b_gs; C += (long long)z * g.c_gs;
         if (g.dimptr) {
-            const int v = g.dimptr[(long long)z * g.dim_stride];
+            const int v = g.dimptr[(long long)z * g.dim_stride] * g.dim_mult;
             if (g.dim_sel == 0) M = v; else K = v;
         }
     }

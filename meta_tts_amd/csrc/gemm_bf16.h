@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     } else {
         A += (long long)z * g.a_gs; B += (long long)z * g.b_gs; C += (long long)z * g.c_gs;
         if (g.dimptr) {
-            const int v = g.dimptr[(long long)z * g.dim_stride];
+            const int v = g.dimptr[(long long)z * g.dim_stride] * g.dim_mult;
             if (g.dim_sel == 0) M = v; else K = v;
         }
     }

@@ -57,7 +57,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
     } else {
         A += (long long)z * g.a_gs; B += (long long)z * g.b_gs; C += (long long)z * g.c_gs;
         if (g.dimptr) {
-            const int v = g.dimptr[(long long)z * g.dim_stride];
+            const int v = g.dimptr[(long long)z * g.dim_stride] * g.dim_mult;
             if (g.dim_sel == 0) M = v; else K = v;
         }
     }

@@ -4,6 +4,7 @@
 #include "../../include/mtts.h"
 
 #include "engine.h"
+#include "vocoder.h"
 
 using namespace mtts;
 
@@ -17,6 +18,10 @@ struct mtts_handle {
 };
 
 static std::string g_create_error;
+
+struct mtts_vocoder {
+    Vocoder v;
+};
 
 extern "C" {
 
@@ -282,6 +287,44 @@ int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* a, c
         gemm_launch(GEMM_TN, g, Cout, k * Cin, 1, (hipStream_t)stream, tile);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---- MelGAN generator (vocoder.h; reference call site lightning/utils.py:8-30) ----------------------------
+int mtts_vocoder_create(int n_mel, int ngf, int n_res, const int* ratios, int n_ratios, int device, int max_B, int max_T,
+                        mtts_vocoder** out) {
+    if (!out || !ratios || n_ratios < 1 || n_ratios > 8) { g_create_error = "bad arguments"; return -1; }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed (no MI355X visible?)"; return -1; }
+    mtts_vocoder* h = new mtts_vocoder();
+    VocoderCfg c;
+    c.n_mel = n_mel; c.ngf = ngf; c.n_res = n_res; c.n_ratios = n_ratios;
+    for (int i = 0; i < n_ratios; ++i) c.ratios[i] = ratios[i];
+    if (h->v.init(c, max_B, max_T) != 0) { g_create_error = h->v.last_error; h->v.destroy(); delete h; return -1; }
+    *out = h;
+    return 0;
+}
+void mtts_vocoder_destroy(mtts_vocoder* h) {
+    if (!h) return;
+    hipDeviceSynchronize();
+    h->v.destroy();
+    delete h;
+}
+const char* mtts_vocoder_last_error(mtts_vocoder* h) { return h ? h->v.last_error.c_str() : g_create_error.c_str(); }
+int mtts_vocoder_set_stream(mtts_vocoder* h, void* s) { h->v.stream = (hipStream_t)s; return 0; }
+int mtts_vocoder_hop(mtts_vocoder* h) { return h->v.hop; }
+int mtts_vocoder_param_count(mtts_vocoder* h) { return (int)h->v.tensors.size(); }
+int mtts_vocoder_param_info(mtts_vocoder* h, int i, char* name, int cap, int64_t* numel) {
+    if (i < 0 || i >= (int)h->v.tensors.size()) return -1;
+    snprintf(name, cap, "%s", h->v.tensors[i].name.c_str());
+    *numel = h->v.tensors[i].numel;
+    return 0;
+}
+int mtts_vocoder_load(mtts_vocoder* h, const char* name, const float* data, int64_t numel) { return h->v.load(name, data, numel); }
+int mtts_vocoder_infer(mtts_vocoder* h, const float* mel, int B, int T_max, const int* mel_lens, float mel_scale, float* wav) {
+    return h->v.infer_host(mel, B, T_max, mel_lens, mel_scale, wav);
+}
+int mtts_vocoder_infer_device(mtts_vocoder* h, const float* mel_dev, int B, int T_max, const int* mel_lens, float mel_scale,
+                              float* wav_dev) {
+    return h->v.run(mel_dev, B, T_max, mel_lens, mel_scale, wav_dev, (long long)T_max * h->v.hop);
 }
 
 }  // extern "C"

@@ -5,7 +5,7 @@ import collections
 import csv
 import sys
 
-FORMS = ["NT", "NN", "TN"]
+FORMS = ["NT", "NN", "TN", "multi"]
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for r in csv.DictReader(open(sys.argv[1])):
     key = (FORMS[int(r["form"])], int(r["tile"]), int(r["N"]), int(r["K"]), int(float(r["rows"])), int(r["groups"]), int(r["splitk"]))
@@ -16,4 +16,4 @@ print(f"total GEMM time {tot / 1e3:.2f} ms, {sum(a[2] for a in agg.values()) / 1
 print("| form | tile | N | K | rows | groups | splitK | launches | total us | avg us | TFLOP/s | % |")
 print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print(f"| {k[0]} | {k[1]} | {k[2]} | {k[3]} | {k[4]} | {k[5]} | {k[6]} | {a[0]} | {a[1]:.0f} | {a[1] / a[0]:.1f} | {a[2] / a[1] * 1e-3 if a[1] else 0:.1f} | {100 * a[1] / tot:.1f} |")
+    print(f"| {k[0]} | {k[1]} | {k[2]} | {k[3]} | {k[4]} | {k[5]} | {k[6]} | {a[0]} | {a[1]:.0f} | {a[1] / a[0]:.1f} | {a[2] / a[1] * 1e3 if a[1] else 0:.1f} | {100 * a[1] / tot:.1f} |")
