@@ -123,6 +123,49 @@ def inference_leg(dims, mods, device, iters=5):
     return res
 
 
+def baseline_c2_leg(dims, device, noam_lr, trn, iters=8):
+    """BASELINE config 2: multi-task baseline (algorithm=baseline: no inner loop, baseline.py:25-36) on ONE synthetic
+    LibriTTS-shaped batch of 16 utterances — forward + backward + clip + Adam per step, dropout on.  Timed in the exact
+    fp32 mode (the parity numerics) and in the config's own bf16-operand mode; the bf16 line carries its mel L1 against the
+    fp32 forward of the same weights (eval mode) so the precision cost is visible next to the speed."""
+    import torch
+    from meta_tts_amd import _lib, synth
+    from meta_tts_amd.engine import Engine
+    lib = _lib.load()
+    batch = synth.make_batch(0, 16)
+    eng = Engine(dims, adapt_modules=(), max_tasks=1, max_B=16, max_S=80, max_T=int(batch[8]), device=device)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.load_params(synth.make_params(dims, 0))
+    eng.set_batches(0, [batch])
+    frames = int(np.asarray(batch[7]).sum())
+    lens = np.asarray(batch[7])
+    evals = {}
+    for mode in (0, 2):  # eval-mode forwards of the untouched weights / BatchNorm buffers, before any training step
+        lib.mtts_set_numerics(mode)
+        eng.forward(0, train=False)
+        evals[mode] = eng.outputs(0, 0)["mel_post"]
+    res = {"workload": "C2: algorithm=baseline, batch 16 (sum T = %d frames), fwd + bwd + clip + Adam" % frames}
+    for name, mode in (("fp32", 0), ("bf16", 2)):
+        lib.mtts_set_numerics(mode)
+        eng.load_params(synth.make_params(dims, 0))
+        eng.reset_optimizer()
+        l1 = float(np.mean([np.abs(evals[mode][b, :lens[b]] - evals[0][b, :lens[b]]).mean() for b in range(16)]))
+        eng.set_dropout(True, 99)
+        for it in range(iters + 2):
+            if it == 2:
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            eng.plain_grad(0, 1.0, fetch_losses=False)
+            eng.outer_update(lr=noam_lr(it, dims.d_model, trn["warm_up_step"], trn["anneal_steps"], trn["anneal_rate"]), betas=tuple(trn["betas"]),
+                             eps=trn["eps"], weight_decay=trn["weight_decay"], max_norm=trn["grad_clip_thresh"])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        res[name] = {"steps_per_sec": round(1.0 / dt, 3), "ms_per_step": round(1e3 * dt, 2), "frames_per_sec": round(frames / dt, 1),
+                     "mel_l1_vs_fp32_eval": l1}
+    lib.mtts_set_numerics(0)
+    eng.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +174,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-inference", action="store_true")
+    ap.add_argument("--no-baseline-c2", action="store_true", help="skip the extra C2 (multi-task baseline, batch 16, fp32 + bf16) measurement")
     ap.add_argument("--order", type=int, default=1, choices=(1, 2),
                     help="MAML order of the timed meta-step: 1 = BASELINE config C3 (first-order), 2 = the reference's training mode / config C4")
     ap.add_argument("--no-second-order", action="store_true", help="skip the extra second-order measurement")
@@ -297,6 +341,9 @@ def main():
     infer = None
     if rank == 0 and n == 1 and not args.no_inference:
         infer = inference_leg(dims, mods, local_rank)
+    c2 = None
+    if rank == 0 and n == 1 and not args.no_baseline_c2:
+        c2 = baseline_c2_leg(dims, local_rank, noam_lr, trn)
     if n > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -317,6 +364,8 @@ def main():
             line["bf16x3_numerics"] = b16
         if infer is not None:
             line["inference_c5"] = infer
+        if c2 is not None:
+            line["baseline_c2"] = c2
         if roof is not None:
             line["roofline"] = roof
         if cpu is not None:

@@ -81,7 +81,7 @@ __device__ __forceinline__ void read_frags16(const unsigned short* Ah, const uns
 
 #if defined(MTTS_EMU)
 // emulator: every lane keeps its accumulator rows itself, so the product is evaluated from the LDS images
-template <int TM, int TN>
+template <int TM, int TN, int TERMS>
 __device__ __forceinline__ void mma16_emu(const unsigned short* Ah, const unsigned short* Am, const unsigned short* Bh,
                                           const unsigned short* Bm, int wm0, int wn0, int lane, f32x16 (&acc)[TM][TN]) {
     const int l31 = lane & 31, h = lane >> 5;
@@ -94,13 +94,15 @@ __device__ __forceinline__ void mma16_emu(const unsigned short* Ah, const unsign
                 for (int k = 0; k < kBK16; ++k) {
                     const float ah = bf(Ah[row * kLD16 + k]), am = bf(Am[row * kLD16 + k]);
                     const float bh = bf(Bh[col * kLD16 + k]), bm = bf(Bm[col * kLD16 + k]);
-                    s += ah * bh + ah * bm + am * bh;
+                    s += TERMS == 3 ? ah * bh + ah * bm + am * bh : ah * bh;
                 }
                 acc[i][j][r] = s;
             }
 }
 #else
-template <int TM, int TN>
+// TERMS = 3: hi*hi + hi*mid + mid*hi ("bf16x3", ~fp32 accuracy); TERMS = 1: hi*hi only = plain bf16 operands with fp32
+// accumulation (BASELINE config C2's numerics; misses the 1e-4 mel gate by an order of magnitude)
+template <int TM, int TN, int TERMS>
 __device__ __forceinline__ void mma16(const Frags16<TM, TN>& f, f32x16 (&acc)[TM][TN]) {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -108,14 +110,16 @@ __device__ __forceinline__ void mma16(const Frags16<TM, TN>& f, f32x16 (&acc)[TM
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am[s][i].v, f.bh[s][j].v, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[s][i].v, f.bm[s][j].v, acc[i][j], 0, 0, 0);
+                if (TERMS == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.am[s][i].v, f.bh[s][j].v, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[s][i].v, f.bm[s][j].v, acc[i][j], 0, 0, 0);
+                }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[s][i].v, f.bh[s][j].v, acc[i][j], 0, 0, 0);
             }
 }
 #endif
 
-template <int FORM, int BM, int BN>
+template <int FORM, int BM, int BN, int TERMS = 3>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     constexpr bool A_KC = (FORM != GEMM_TN);
     constexpr bool B_KC = (FORM == GEMM_NT);
@@ -269,11 +273,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         if (c + 1 < nchunks) { load_a((c + 1) * BK); load_b((c + 1) * BK); }
         images(buf, Ah, Am, Bh, Bm);
 #if defined(MTTS_EMU)
-        mma16_emu<TM, TN>(Ah, Am, Bh, Bm, wm0, wn0, lane, acc);
+        mma16_emu<TM, TN, TERMS>(Ah, Am, Bh, Bm, wm0, wn0, lane, acc);
 #else
         Frags16<TM, TN> f;
         read_frags16<TM, TN>(Ah, Am, Bh, Bm, wm0, wn0, lane, f);
-        mma16<TM, TN>(f, acc);
+        mma16<TM, TN, TERMS>(f, acc);
 #endif
         if (c + 1 < nchunks) {
             images(buf ^ 1, Ah, Am, Bh, Bm);

@@ -239,7 +239,7 @@ int mtts_reset_optimizer(mtts_handle* h) {
 }
 
 int mtts_set_numerics(int mode) {
-    if (mode != 0 && mode != 1) return -1;
+    if (mode < 0 || mode > 2) return -1;
     gemm_numerics() = mode;
     return 0;
 }

@@ -219,6 +219,42 @@ def test_full_size_properties_meta_step():
     eng.close()
 
 
+def test_c2_baseline_batch16_vs_oracle():
+    """BASELINE config 2 (algorithm=baseline, one batch of 16 LibriTTS-shaped utterances, full-size model): the 6 losses
+    and sampled parameter gradients of one plain step against the oracle; then the same step in the config's bf16-operand
+    numerics (mode 2): finite, and within bf16 distance of the fp32 result."""
+    from meta_tts_amd import _lib
+    batch = synth.make_batch(0, 16)
+    eng = _engine(1, 16, 80, int(batch[8]))
+    eng.set_batches(0, [batch])
+    q = eng.plain_grad(0, 1.0)
+    p = torch_params(DIMS, requires_grad=True)
+    tb = O.to_torch_batch(batch)
+    preds = O.fs2_forward(p, torch_buffers(DIMS), *tb[2:], n_head=heads(DIMS), max_seq_len=DIMS.max_seq_len, training=True)
+    ls = O.fs2_loss(tb, preds)
+    np.testing.assert_allclose(q[0], [float(x) for x in ls], rtol=1e-4)
+    check = ["mel_linear.weight", "decoder.layer_stack.5.pos_ffn.w_2.weight", "encoder.layer_stack.0.slf_attn.w_qs.weight",
+             "variance_adaptor.duration_predictor.conv_layer.conv1d_1.conv.weight", "postnet.convolutions.4.0.conv.weight"]
+    gs = torch.autograd.grad(ls[0], [p[n] for n in check])
+    fp32 = {}
+    for n, x in zip(check, gs):
+        got = eng.export(n, 1)
+        fp32[n] = got
+        assert np.abs(got - x.numpy()).max() <= 3e-3 * np.abs(x.numpy()).max() + 1e-7, n
+    lib = _lib.load()
+    try:
+        lib.mtts_set_numerics(2)
+        q2 = eng.plain_grad(0, 1.0)
+        assert np.all(np.isfinite(q2))
+        np.testing.assert_allclose(q2[0], q[0], rtol=3e-2)
+        for n in check:
+            got = eng.export(n, 1)
+            assert np.isfinite(got).all() and np.abs(got - fp32[n]).max() <= 0.25 * np.abs(fp32[n]).max(), n
+    finally:
+        lib.mtts_set_numerics(0)
+    eng.close()
+
+
 def test_bf16x3_numerics_mode_stays_inside_the_gate(golden_dir):
     """Optional throughput numerics (mtts_set_numerics(1), csrc/gemm_bf16.h): fp32 operands split into two bf16, three bf16
     MFMAs per product.  It must stay inside the north-star gate on the reference fixture in eval mode (mel L1 <= 1e-4;
