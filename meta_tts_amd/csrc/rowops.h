@@ -52,50 +52,78 @@ __global__ void embed_pos_kernel(const int* meta, int mfield, float* out, long l
 // y = mask ? LayerNorm(a (+ res)) : 0   (SubLayers.py:55,91 post-LN; modules.py:222,234)
 // z_out (optional) receives a + res; stats = (mean, rstd) per row.  C <= 1024.
 // ------------------------------------------------------------------------------------------
+// Two rows per wavefront (8 per workgroup): all loads of both rows are in flight before the first reduction — these
+// launches are only a couple of wave "rounds" long, so what matters is the number of serialised memory round trips per
+// wave (was: mask -> rows -> stats), not bandwidth.
+#define ROW2_PROLOGUE(Mfield)                                                                   \
+    const int z = blockIdx.z;                                                                   \
+    const int M_ = meta[z * META_STRIDE + (Mfield)];                                            \
+    const int lane = (int)threadIdx.x & 63;                                                     \
+    const int row0 = blockIdx.x * 8 + ((int)threadIdx.x >> 6) * 2;                              \
+    if (row0 >= M_) return;                                                                     \
+    const int rows_[2] = {row0, row0 + 1 < M_ ? row0 + 1 : row0};                               \
+    const bool live1 = row0 + 1 < M_;
+
+inline dim3 row2_grid(int max_rows, int tasks) { return dim3((unsigned)((max_rows + 7) / 8), 1, (unsigned)tasks); }
+
 __global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a, long long a_ts, const float* res,
                                      long long res_ts, const float* gamma, const float* beta, long long par_ts,
                                      const unsigned char* mask, long long mask_ts, float* z_out, long long z_ts,
                                      float* y, long long y_ts, float* stats, long long st_ts, int C, float eps) {
-    ROW_PROLOGUE(mfield)
-    const float* pa = a + (long long)z * a_ts + (long long)row * C;
-    const float* pr = res ? res + (long long)z * res_ts + (long long)row * C : nullptr;
-    float4 v[4];
-    float s = 0.f;
-    int n = 0;
-    for (int c = lane * 4; c < C; c += 256, ++n) {
-        float4 x = ld4(pa + c);
-        if (pr) { const float4 r4 = ld4(pr + c); x = make_float4(x.x + r4.x, x.y + r4.y, x.z + r4.z, x.w + r4.w); }
-        v[n] = x;
-        s += (x.x + x.y) + (x.z + x.w);
+    ROW2_PROLOGUE(mfield)
+    float4 v[2][4];
+    float s[2] = {0.f, 0.f};
+    bool keep[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = rows_[q];
+        const float* pa = a + (long long)z * a_ts + (long long)row * C;
+        const float* pr = res ? res + (long long)z * res_ts + (long long)row * C : nullptr;
+        keep[q] = mask ? (mask[(long long)z * mask_ts + row] != 0) : true;
+        int n = 0;
+        for (int c = lane * 4; c < C; c += 256, ++n) {
+            float4 x = ld4(pa + c);
+            if (pr) { const float4 r4 = ld4(pr + c); x = make_float4(x.x + r4.x, x.y + r4.y, x.z + r4.z, x.w + r4.w); }
+            v[q][n] = x;
+            s[q] += (x.x + x.y) + (x.z + x.w);
+        }
     }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
-    for (int i = 0; i < n; ++i) {
-        const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
-        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    const int nv = (C - lane * 4 + 255) / 256 > 0 ? (C - lane * 4 + 255) / 256 : 0;  // float4 this lane holds per row
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        mean[q] = wave_sum(s[q]) / (float)C;
+        float t = 0.f;
+        for (int i = 0; i < nv; ++i) {
+            const float dx = v[q][i].x - mean[q], dy = v[q][i].y - mean[q], dz = v[q][i].z - mean[q], dw = v[q][i].w - mean[q];
+            t += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        rstd[q] = rsqrtf(wave_sum(t) / (float)C + eps);
     }
-    const float var = wave_sum(q) / (float)C;
-    const float rstd = rsqrtf(var + eps);
-    const bool keep = mask ? (mask[(long long)z * mask_ts + row] != 0) : true;
     const float* g = gamma + (long long)z * par_ts;
     const float* b = beta + (long long)z * par_ts;
-    float* py = y + (long long)z * y_ts + (long long)row * C;
-    float* pz = z_out ? z_out + (long long)z * z_ts + (long long)row * C : nullptr;
-    int i = 0;
-    for (int c = lane * 4; c < C; c += 256, ++i) {
-        if (pz) st4(pz + c, v[i]);
-        float4 o = zero4();
-        if (keep) {
-            const float4 g4 = ld4(g + c), b4 = ld4(b + c);
-            o = make_float4((v[i].x - mean) * rstd * g4.x + b4.x, (v[i].y - mean) * rstd * g4.y + b4.y,
-                            (v[i].z - mean) * rstd * g4.z + b4.z, (v[i].w - mean) * rstd * g4.w + b4.w);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (q == 1 && !live1) break;
+        const int row = rows_[q];
+        float* py = y + (long long)z * y_ts + (long long)row * C;
+        float* pz = z_out ? z_out + (long long)z * z_ts + (long long)row * C : nullptr;
+        int i = 0;
+        for (int c = lane * 4; c < C; c += 256, ++i) {
+            if (pz) st4(pz + c, v[q][i]);
+            float4 o = zero4();
+            if (keep[q]) {
+                const float4 g4 = ld4(g + c), b4 = ld4(b + c);
+                o = make_float4((v[q][i].x - mean[q]) * rstd[q] * g4.x + b4.x, (v[q][i].y - mean[q]) * rstd[q] * g4.y + b4.y,
+                                (v[q][i].z - mean[q]) * rstd[q] * g4.z + b4.z, (v[q][i].w - mean[q]) * rstd[q] * g4.w + b4.w);
+            }
+            st4(py + c, o);
         }
-        st4(py + c, o);
-    }
-    if (lane == 0) {
-        float* st = stats + (long long)z * st_ts + (long long)row * 2;
-        st[0] = mean;
-        st[1] = rstd;
+        if (lane == 0) {
+            float* st = stats + (long long)z * st_ts + (long long)row * 2;
+            st[0] = mean[q];
+            st[1] = rstd[q];
+        }
     }
 }
 
@@ -105,38 +133,47 @@ __global__ void layernorm_bwd_kernel(const int* meta, int mfield, const float* d
                                      long long z_ts, const float* stats, long long st_ts, const float* gamma,
                                      long long par_ts, const unsigned char* mask, long long mask_ts, float* dz,
                                      long long dz_ts, int C, int relu_on_z) {
-    ROW_PROLOGUE(mfield)
-    float* pd = dz + (long long)z * dz_ts + (long long)row * C;
-    const bool keep = mask ? (mask[(long long)z * mask_ts + row] != 0) : true;
-    if (!keep) {
-        for (int c = lane * 4; c < C; c += 256) st4(pd + c, zero4());
-        return;
-    }
-    const float* pdy = dy + (long long)z * dy_ts + (long long)row * C;
-    const float* pz = zin + (long long)z * z_ts + (long long)row * C;
-    const float* st = stats + (long long)z * st_ts + (long long)row * 2;
-    const float mean = st[0], rstd = st[1];
+    ROW2_PROLOGUE(mfield)
     const float* g = gamma + (long long)z * par_ts;
-    float4 gv[4], xh[4];
-    float s1 = 0.f, s2 = 0.f;
-    int n = 0;
-    for (int c = lane * 4; c < C; c += 256, ++n) {
-        const float4 d = ld4(pdy + c), x = ld4(pz + c), g4 = ld4(g + c);
-        gv[n] = make_float4(d.x * g4.x, d.y * g4.y, d.z * g4.z, d.w * g4.w);
-        xh[n] = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
-        s1 += (gv[n].x + gv[n].y) + (gv[n].z + gv[n].w);
-        s2 += (gv[n].x * xh[n].x + gv[n].y * xh[n].y) + (gv[n].z * xh[n].z + gv[n].w * xh[n].w);
-    }
-    const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
-    int i = 0;
-    for (int c = lane * 4; c < C; c += 256, ++i) {
-        float4 o = make_float4(rstd * (gv[i].x - m1 - xh[i].x * m2), rstd * (gv[i].y - m1 - xh[i].y * m2),
-                               rstd * (gv[i].z - m1 - xh[i].z * m2), rstd * (gv[i].w - m1 - xh[i].w * m2));
-        if (relu_on_z) {  // z is a ReLU output: pass the gradient only where the pre-activation was > 0
-            const float4 x = ld4(pz + c);
-            o = make_float4(x.x > 0.f ? o.x : 0.f, x.y > 0.f ? o.y : 0.f, x.z > 0.f ? o.z : 0.f, x.w > 0.f ? o.w : 0.f);
+    float4 gv[2][4], xh[2][4];
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rstd[2];
+    bool keep[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = rows_[q];
+        keep[q] = mask ? (mask[(long long)z * mask_ts + row] != 0) : true;
+        const float* pdy = dy + (long long)z * dy_ts + (long long)row * C;
+        const float* pz = zin + (long long)z * z_ts + (long long)row * C;
+        const float* st = stats + (long long)z * st_ts + (long long)row * 2;
+        const float mean = st[0];
+        rstd[q] = st[1];
+        int n = 0;
+        for (int c = lane * 4; c < C; c += 256, ++n) {
+            const float4 d = ld4(pdy + c), x = ld4(pz + c), g4 = ld4(g + c);
+            gv[q][n] = make_float4(d.x * g4.x, d.y * g4.y, d.z * g4.z, d.w * g4.w);
+            xh[q][n] = make_float4((x.x - mean) * rstd[q], (x.y - mean) * rstd[q], (x.z - mean) * rstd[q], (x.w - mean) * rstd[q]);
+            s1[q] += (gv[q][n].x + gv[q][n].y) + (gv[q][n].z + gv[q][n].w);
+            s2[q] += (gv[q][n].x * xh[q][n].x + gv[q][n].y * xh[q][n].y) + (gv[q][n].z * xh[q][n].z + gv[q][n].w * xh[q][n].w);
         }
-        st4(pd + c, o);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float m1 = wave_sum(s1[q]) / (float)C, m2 = wave_sum(s2[q]) / (float)C;
+        if (q == 1 && !live1) break;
+        const int row = rows_[q];
+        float* pd = dz + (long long)z * dz_ts + (long long)row * C;
+        const float* pz = zin + (long long)z * z_ts + (long long)row * C;
+        int i = 0;
+        for (int c = lane * 4; c < C; c += 256, ++i) {
+            float4 o = make_float4(rstd[q] * (gv[q][i].x - m1 - xh[q][i].x * m2), rstd[q] * (gv[q][i].y - m1 - xh[q][i].y * m2),
+                                   rstd[q] * (gv[q][i].z - m1 - xh[q][i].z * m2), rstd[q] * (gv[q][i].w - m1 - xh[q][i].w * m2));
+            if (relu_on_z) {  // z is a ReLU output: pass the gradient only where the pre-activation was > 0
+                const float4 x = ld4(pz + c);
+                o = make_float4(x.x > 0.f ? o.x : 0.f, x.y > 0.f ? o.y : 0.f, x.z > 0.f ? o.z : 0.f, x.w > 0.f ? o.w : 0.f);
+            }
+            if (!keep[q]) o = zero4();
+            st4(pd + c, o);
+        }
     }
 }
 
