@@ -284,3 +284,32 @@ def test_bf16x3_numerics_mode_stays_inside_the_gate(golden_dir):
         eng.close()
     finally:
         lib.mtts_set_numerics(0)
+
+
+def test_outer_gradient_buffer_is_shared_with_torch_and_all_reduces():
+    """The multi-GPU path (bench.py --gpus N, systems.Trainer): the flat outer-gradient buffer is handed to torch zero-copy
+    (__cuda_array_interface__) and summed with one RCCL all_reduce.  One GPU here: world_size-1 NCCL group."""
+    import torch.distributed as dist
+    sup = synth.make_batch(21, 3, speaker=9, **SMALL)
+    qry = synth.make_batch(22, 3, speaker=9, **SMALL)
+    eng = _engine(1, 3, 16, 96)
+    eng.set_batches(0, [sup])
+    eng.set_batches(1, [qry], spk_from=[sup], average_spk=True)
+    eng.meta_grad(1, 1e-4, 1.0, fetch_losses=False)
+    eng.synchronize()
+    outer = torch.as_tensor(eng.outer_grad_view(), device="cuda:0")
+    assert outer.dtype == torch.float32 and outer.numel() >= 35_000_000
+    g = eng.export("mel_linear.weight", 1)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        outer.mul_(0.5)                      # torch writes are the engine's buffer
+        dist.all_reduce(outer, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    np.testing.assert_allclose(eng.export("mel_linear.weight", 1), 0.5 * g, rtol=1e-6, atol=1e-12)
+    norm = eng.outer_update(lr=1e-3, fetch_norm=True)
+    assert np.isfinite(norm) and norm > 0
+    eng.close()
