@@ -155,6 +155,8 @@ public:
     TS gPm, gFm;  // dropout-masked copies of a LayerNorm input gradient
     TS gP0, gP1, gPqkv, gPh, gPf1, gPf2, gF0, gF1, gFqkv, gFh, dSp, dSf, gR0, gR1, gRm, gRp, gMelF, dspk, dpred[3];
     float *loss_partial = nullptr, *losses = nullptr, *col_partial = nullptr;
+    int* col_ctr = nullptr;                       // arrival counters of the fused column reduction (zero between launches)
+    static constexpr int kColCtrPerTask = 8;      // 128-column groups per task (C <= 1024)
     int col_max_chunks = 0;
     long long S_ts_p = 0, S_ts_f = 0;
 
@@ -380,6 +382,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (int i = 0; i < 3; ++i) dpred[i] = rows(capMp, 1);
         col_max_chunks = (std::max(capMp, capMf) + kRC - 1) / kRC;
         col_partial = (float*)take((size_t)cap_tasks * col_max_chunks * 3 * 1024 * sizeof(float));
+        col_ctr = (int*)take((size_t)cap_tasks * kColCtrPerTask * sizeof(int));
         loss_partial = (float*)take((size_t)cap_tasks * kLossBlocks * 5 * sizeof(float));
         losses = (float*)take((size_t)cap_tasks * 6 * sizeof(float));
         // plans
@@ -851,6 +854,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // two-stage deterministic column reduction (rowops.h colpart/colfinal)
     void colreduce(const Plan& p, ColArgs a, float* out0, float* out1, long long out_ts, int maxM) {
         const int chunks = (maxM + kRC - 1) / kRC;
+        // single-launch variant (last-arriving workgroup folds): measured SLOWER (+10 % on the whole meta-step) — its agent-scope
+        // release / acquire writes back and invalidates an L2 that the neighbouring GEMMs keep full of dirty lines; opt-in only
+        static const bool fused = [] { const char* e = getenv("MTTS_COL_FUSED"); return e ? atoi(e) != 0 : false; }();
+        if (fused && col_ctr && (a.C + 127) / 128 <= kColCtrPerTask) {
+            MTTS_LAUNCH(colreduce_kernel, dim3((a.C + 127) / 128, chunks, p.tasks), dim3(256), stream, (const int*)p.meta, a, col_partial,
+                        col_max_chunks, col_ctr, out0, out1, out_ts, 1e-5f);
+            return;
+        }
         MTTS_LAUNCH(colpart_kernel, dim3((a.C + 127) / 128, chunks, p.tasks), dim3(256), stream, (const int*)p.meta, a, col_partial,
                     col_max_chunks);
         MTTS_LAUNCH(colfinal_kernel, dim3((a.C + 63) / 64, 1, p.tasks), dim3(256), stream, (const int*)p.meta, a.mfield, a.mode,

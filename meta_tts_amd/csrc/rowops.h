@@ -209,7 +209,7 @@ struct ColArgs {
     int C = 0, mode = 0, do_tanh = 0, mfield = 0, accumulate = 0;
 };
 
-__global__ void colpart_kernel(const int* meta, ColArgs a, float* partial, int max_chunks) {
+__device__ __forceinline__ void colpart_body(const int* meta, const ColArgs& a, float* partial, int max_chunks) {
     __shared__ __attribute__((aligned(16))) float red[3][8][132];
     const int z = blockIdx.z, chunk = blockIdx.y;
     const int M_ = meta[z * META_STRIDE + a.mfield];
@@ -325,11 +325,12 @@ __global__ void colpart_kernel(const int* meta, ColArgs a, float* partial, int m
 
 // 64 columns x 4 chunk lanes per workgroup: lane q folds chunks q, q+4, ... of its column, the four lane results are
 // merged in lane order through LDS (fixed order => run-to-run identical).
-__global__ void colfinal_kernel(const int* meta, int mfield, int mode, const float* partial, int max_chunks, int C,
-                                float* out0, float* out1, long long out_ts, float eps, int accumulate) {
+__device__ __forceinline__ void colfinal_fold(const int* meta, int mfield, int mode, const float* partial, int max_chunks, int C,
+                                              float* out0, float* out1, long long out_ts, float eps, int accumulate, int c_base) {
     __shared__ float red[3][4][64];
+    __syncthreads();  // the fold may run twice per workgroup (fused tail): red is reused
     const int z = blockIdx.z, cl = (int)threadIdx.x & 63, q = (int)threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    const int c = c_base + cl;
     const bool cin = c < C;
     const int M_ = meta[z * META_STRIDE + mfield];
     const int nch = (M_ + kRC - 1) / kRC;
@@ -374,6 +375,40 @@ __global__ void colfinal_kernel(const int* meta, int mfield, int mode, const flo
     so[c] = mean;
     so[C + c] = rsqrtf(m2 / n + eps);
     so[2 * C + c] = m2 / fmaxf(n - 1.f, 1.f);
+}
+
+__global__ void colpart_kernel(const int* meta, ColArgs a, float* partial, int max_chunks) { colpart_body(meta, a, partial, max_chunks); }
+
+__global__ void colfinal_kernel(const int* meta, int mfield, int mode, const float* partial, int max_chunks, int C,
+                                float* out0, float* out1, long long out_ts, float eps, int accumulate) {
+    colfinal_fold(meta, mfield, mode, partial, max_chunks, C, out0, out1, out_ts, eps, accumulate, blockIdx.x * 64);
+}
+
+// Both stages in one launch: every (task, 128-column group) keeps an arrival counter; the last row-chunk workgroup to
+// publish its partials (one agent-scope release / acquire pair, as in the split-K GEMM) folds the chunks of its 128
+// columns in chunk order.  Same arithmetic and order as colpart + colfinal, one launch fewer per reduction (the row kernels
+// of a single-task rank are launch-latency bound).
+__global__ void colreduce_kernel(const int* meta, ColArgs a, float* partial, int max_chunks, int* ctr, float* out0, float* out1,
+                                 long long out_ts, float eps) {
+    const int z = blockIdx.z;
+    const int M_ = meta[z * META_STRIDE + a.mfield];
+    if ((int)blockIdx.y * kRC >= M_) return;       // dead chunk: not counted
+    colpart_body(meta, a, partial, max_chunks);
+    __shared__ int s_last;
+    MTTS_WAIT_VMEM();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        MTTS_FENCE_RELEASE_AGENT();
+        MTTS_WAIT_VMEM();
+        int* cnt = ctr + z * gridDim.x + blockIdx.x;
+        const int nch = (M_ + kRC - 1) / kRC;
+        s_last = (MTTS_ATOMIC_INC_AGENT(cnt) == nch - 1) ? 1 : 0;
+        if (s_last) { MTTS_FENCE_ACQUIRE_AGENT(); *cnt = 0; }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    colfinal_fold(meta, a.mfield, a.mode, partial, max_chunks, a.C, out0, out1, out_ts, eps, a.accumulate, blockIdx.x * 128);
+    colfinal_fold(meta, a.mfield, a.mode, partial, max_chunks, a.C, out0, out1, out_ts, eps, a.accumulate, blockIdx.x * 128 + 64);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -582,9 +617,9 @@ __global__ void segsum_rows_kernel(const int* meta, const float* X, long long x_
 // padding_idx of src_word_emb, Models.py:56-58) are written as zero, so no memset is needed.
 __global__ void table_grad_kernel(const int* meta, int mfield, const float* dx, long long dx_ts, const int* idx,
                                   long long idx_ts, int skip_row, float* dtable, long long dt_ts, int C) {
-    // 64 threads: the index list is matched 64 entries at a time (one compare per lane, flags through LDS), hits are
-    // then accumulated in ascending row order — same summation order as a serial scan, ~60x fewer dependent loads
-    __shared__ int hit[64];
+    // 64 threads: the index list is matched 64 entries at a time (one compare per lane); the 64 match bits are gathered
+    // with four exact 16-bit wavefront sums and the hits are then accumulated in ascending row order — the summation
+    // order of a serial scan, with a loop per HIT instead of per entry
     const int z = blockIdx.z, v = blockIdx.x, lane = (int)threadIdx.x;
     const int M_ = meta[z * META_STRIDE + mfield];
     const int* pi = idx + (long long)z * idx_ts;
@@ -596,15 +631,20 @@ __global__ void table_grad_kernel(const int* meta, int mfield, const float* dx, 
     if (v != skip_row)
         for (int base = 0; base < M_; base += 64) {
             const int m = base + lane;
-            hit[lane] = (m < M_ && pi[m] == v) ? 1 : 0;
-            __syncthreads();
-            for (int j = 0; j < 64; ++j)
-                if (hit[j]) {
-                    const float* row = pd + (long long)(base + j) * C;
+            const bool hit = m < M_ && pi[m] == v;
+            unsigned long long bits = 0;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) { const int c = lane + 64 * k; if (c < C) s[k] += row[c]; }
-                }
-            __syncthreads();
+            for (int part = 0; part < 4; ++part) {
+                const float w = (hit && (lane >> 4) == part) ? (float)(1u << (lane & 15)) : 0.f;
+                bits |= (unsigned long long)(unsigned)wave_sum(w) << (16 * part);
+            }
+            while (bits) {
+                const int j = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                const float* row = pd + (long long)(base + j) * C;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { const int c = lane + 64 * k; if (c < C) s[k] += row[c]; }
+            }
         }
 #pragma unroll
     for (int k = 0; k < 16; ++k) { const int c = lane + 64 * k; if (c < C) po[c] = s[k]; }
