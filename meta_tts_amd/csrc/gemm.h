@@ -700,6 +700,9 @@ inline void gemm_batch_end(hipStream_t stream) {
     double work = 0.0;
     for (const GemmPending& p : b.q) work += std::ceil(p.rows / 64.0) * ((p.max_N + 63) / 64) * std::max(1, (p.g.K + 15) / 16);
     const double per_cu = work / 256.0;
+    double batch_wgs = 0.0;
+    for (const GemmPending& p : b.q) batch_wgs += std::ceil(p.rows / 64.0) * ((p.max_N + 63) / 64);
+    const bool small_batch = batch_wgs <= (double)gemm_glds_max_wgs();  // latency regime: split-K and the LDS-DMA kernels apply
     GemmWorkspace* wsp = nullptr;
     long long ws_off = 0, ctr_off = 0;
     for (int i = 0; i < mp.n; ++i) {
@@ -709,7 +712,7 @@ inline void gemm_batch_end(hipStream_t stream) {
         const int tiles = ((p.max_M + 63) / 64) * ((p.max_N + 63) / 64);
         int S = 1;
         const int nch = (p.g.K + 15) / 16;
-        if (!p.g.table && gemm_splitk_target() != 0 && nch > per_cu / 3.0) {
+        if (small_batch && !p.g.table && gemm_splitk_target() != 0 && nch > per_cu / 3.0) {
             S = (int)std::min<double>(std::min<double>(std::ceil(nch / std::max(per_cu / 3.0, 1.0)), nch / 16), 8);
             const long long slots = (long long)tiles * p.groups;
             if (S >= 2 && ((ws_off + slots * S * 4096) > kSplitWsFloats || ctr_off + slots > kSplitCtrs)) S = 1;
@@ -738,9 +741,7 @@ inline void gemm_batch_end(hipStream_t stream) {
         if (mp.g[i].taps > 1 && mp.g[i].tap_k % 32 != 0) bk32 = false;
         maxK = std::max(maxK, mp.g[i].K);
     }
-    double batch_wgs = 0.0;
-    for (const GemmPending& p : b.q) batch_wgs += std::ceil(p.rows / 64.0) * ((p.max_N + 63) / 64);
-    bool glds = gemm_use_glds() && batch_wgs <= (double)gemm_glds_max_wgs();
+    bool glds = gemm_use_glds() && small_batch;
     for (int i = 0; i < mp.n; ++i) glds = glds && gemm_glds_ok(mp.g[i]);
 #if !defined(MTTS_EMU)
     if (glds) { gemm_glds_multi_launch(mp, grid, stream); }
