@@ -54,6 +54,54 @@ def reprocess(data: Sequence[dict], idxs: Sequence[int]):
             pad_1D([np.asarray(d["duration"]) for d in pick]).astype(np.int64))
 
 
+def split_reprocess(batch, idxs):
+    """lightning/collate.py:63-127 (table-speaker path): the sub-batch `idxs` of a collated 12-tuple, re-cropped to its own
+    maximum lengths (phoneme- or frame-level pitch / energy detected by their padded width, as the reference does)."""
+    ids, raw, spk, texts, tlens, tmax, mels, mlens, mmax, pit, ene, dur = batch
+    idxs = np.asarray(idxs)
+    A = lambda x: np.asarray(x)
+    tl, ml = A(tlens)[idxs], A(mlens)[idxs]
+    st, sm = int(tl.max()), int(ml.max())
+    crop = lambda x: A(x)[idxs][:, :st] if A(x).shape[1] == int(tmax) else A(x)[idxs][:, :sm]
+    return ([ids[i] for i in idxs], [raw[i] for i in idxs], A(spk)[idxs], A(texts)[idxs][:, :st], tl, st,
+            A(mels)[idxs][:, :sm], ml, sm, crop(pit), crop(ene), A(dur)[idxs][:, :st])
+
+
+class Task:
+    """lightning/systems/utils.py:80-117: iterate a task's support set in mini-batches (drop_last), e.g. batch_size = 1 for
+    the 1-shot test mode (base_adaptor.py:139-147).  shuffle uses its own RandomState."""
+
+    def __init__(self, sup_data, qry_data, batch_size=None, shuffle=True, seed=0):
+        self.sup_data, self.qry_data, self.batch_size, self.shuffle = sup_data, qry_data, batch_size, shuffle
+        self.rng = np.random.RandomState(seed)
+        self.reset_iterator()
+
+    def reset_iterator(self):
+        n = len(self.sup_data[0])
+        order = self.rng.permutation(n) if self.shuffle else np.arange(n)
+        bs = self.batch_size or n
+        self._batches = [order[i:i + bs] for i in range(0, n - bs + 1, bs)]
+        self._pos = 0
+
+    def next_batch(self):
+        if self._pos >= len(self._batches):
+            self.reset_iterator()
+        idxs = self._batches[self._pos]
+        self._pos += 1
+        return split_reprocess(self.sup_data, idxs)
+
+    def __iter__(self):
+        self.reset_iterator()
+        return self
+
+    def __next__(self):
+        if self._pos >= len(self._batches):
+            raise StopIteration
+        idxs = self._batches[self._pos]
+        self._pos += 1
+        return split_reprocess(self.sup_data, idxs)
+
+
 class SpeakerTaskCollate:
     """lightning/collate.py:146-196."""
 

@@ -150,7 +150,11 @@ class BaseAdaptorSystem(System):
     def test_step(self, batch, batch_idx):
         self._on_meta_batch_start(batch)
         if self.algorithm_config["adapt"]["test"].get("1-shot", False):
-            raise NotImplementedError("1-shot test mode (base_adaptor.py:139-147) is a later row (SURVEY.md 8(f).2)")
+            # base_adaptor.py:139-147: adapt on every single support utterance in turn, same query set
+            from .data import Task
+            qry_batch = batch[0][1][0]
+            return [self._test_step([([sup_batch], [qry_batch])], batch_idx)
+                    for sup_batch in Task(sup_data=batch[0][0][0], qry_data=qry_batch, batch_size=1, shuffle=False)]
         return [self._test_step(batch, batch_idx)]
 
 

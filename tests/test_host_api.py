@@ -171,3 +171,32 @@ def test_few_shot_test_step_matches_oracle(cfgs, emu_lib):
         with torch.no_grad():
             lq = O.fs2_loss(tq, O.fs2_forward(cur, buf, ts[2], *tq[3:], training=True, average_spk_emb=True, **kw))
         np.testing.assert_allclose([float(x) for x in out[f"step_{chunk}"]["recon"]["losses"]], [float(x) for x in lq], rtol=2e-4)
+
+
+def test_one_shot_test_mode_adapts_on_each_support_utterance(cfgs, emu_lib):
+    """base_adaptor.py:139-147 — `adapt.test.1-shot`: one _test_step per single support utterance (Task batch_size 1,
+    no shuffle), all against the same query set; each equals a plain test_step on that 1-utterance support set."""
+    from meta_tts_amd.data import split_reprocess
+    pre, mod, trn, alg = cfgs
+    alg["adapt"]["train"]["steps"] = 1
+    alg["adapt"]["test"]["steps"] = 1
+    alg["adapt"]["test"]["saving_steps"] = []
+    alg["adapt"]["test"]["1-shot"] = True
+    sysm = _system((pre, mod, trn, alg), emu_lib)
+    dims = sysm.model.dims
+    prm = synth.make_params(dims, 0)
+    prm["variance_adaptor.duration_predictor.linear_layer.bias"][:] = np.log(3.0)   # random init predicts 0 frames
+    sysm.engine.load_params(prm)
+    sup = synth.make_batch(5, 3, speaker=2, vocab=dims.vocab, **_kw(dims.n_mel))
+    qry = synth.make_batch(6, 2, speaker=2, vocab=dims.vocab, **_kw(dims.n_mel))
+    outs = sysm.test_step([([sup], [qry])], 0)
+    assert len(outs) == 3 and all(set(o) == {"_batch", "step_0", "step_1"} for o in outs)
+    alg["adapt"]["test"]["1-shot"] = False
+    for i, o in enumerate(outs):
+        one = split_reprocess(sup, [i])
+        assert one[3].shape == (1, int(sup[4][i])) and one[6].shape == (1, int(sup[7][i]), dims.n_mel) and one[0] == [sup[0][i]]
+        ref = sysm.test_step([([one], [qry])], 0)[0]
+        np.testing.assert_allclose([float(x) for x in o["step_1"]["recon"]["losses"]],
+                                   [float(x) for x in ref["step_1"]["recon"]["losses"]], rtol=1e-6)
+    l = [[float(x) for x in o["step_1"]["recon"]["losses"]] for o in outs]
+    assert l[0] != l[1] and l[1] != l[2]      # different support utterances give different adapted models
