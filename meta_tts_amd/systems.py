@@ -104,16 +104,19 @@ class BaseAdaptorSystem(System):
     def meta_learn_tasks(self, tasks: Sequence[tuple], train: bool = True, total_tasks: Optional[int] = None):
         """adapt + meta_learn (base_adaptor.py:100-124) for all local tasks in one grouped pass.
         tasks: [(sup12, qry12), ...].  Leaves sum_t dL_q,t/dtheta / total_tasks in the outer-gradient buffer;
-        returns (query losses [n][6], support losses [steps][n][6])."""
-        if train and self.algorithm_config.get("_second_order", False):
-            raise NotImplementedError("second-order MAML")
+        returns (query losses [n][6], support losses [steps][n][6]).
+        MAML order: the reference hard-wires `first_order = not train` (base_adaptor.py:107), i.e. second-order in training;
+        `adapt.first_order: true|false` in the algorithm config (an extension key, absent in the reference's YAMLs) overrides
+        it — BASELINE config C3 is the first-order variant."""
+        fo = self.algorithm_config["adapt"].get("first_order")
+        second_order = bool(train) if fo is None else (not fo)
         sup = [t[0] for t in tasks]
         qry = [t[1] for t in tasks]
         self.engine.set_batches(0, sup)
         self.engine.set_batches(1, qry, spk_from=sup, average_spk=True)
         scale = 1.0 / (total_tasks or (len(tasks) * self.world_size))
         steps = min(self.adaptation_steps, self.test_adaptation_steps)
-        return self.engine.meta_grad(steps, self.adaptation_lr, scale)
+        return self.engine.meta_grad(steps, self.adaptation_lr, scale, second_order=second_order)
 
 
     # -- few-shot test loop (base_adaptor.py:136-189) ---------------------------------------------

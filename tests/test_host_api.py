@@ -200,3 +200,34 @@ def test_one_shot_test_mode_adapts_on_each_support_utterance(cfgs, emu_lib):
                                    [float(x) for x in ref["step_1"]["recon"]["losses"]], rtol=1e-6)
     l = [[float(x) for x in o["step_1"]["recon"]["losses"]] for o in outs]
     assert l[0] != l[1] and l[1] != l[2]      # different support utterances give different adapted models
+
+
+def test_meta_system_trains_second_order_like_the_reference(cfgs, emu_lib):
+    """base_adaptor.py:107 `first_order = not train`: MetaSystem's training step differentiates THROUGH the inner steps
+    unless `adapt.first_order` says otherwise; both variants against the oracle's outer gradient."""
+    pre, mod, trn, alg = cfgs
+    alg["adapt"]["train"]["steps"] = 2
+    alg["adapt"]["task"]["lr"] = 0.001
+    got = {}
+    for fo in (None, True):
+        if fo is None:
+            alg["adapt"].pop("first_order", None)
+        else:
+            alg["adapt"]["first_order"] = fo
+        sysm = _system((pre, mod, trn, alg), emu_lib)
+        dims = sysm.model.dims
+        sup = synth.make_batch(5, 3, speaker=2, vocab=dims.vocab, **_kw(dims.n_mel))
+        qry = synth.make_batch(6, 2, speaker=2, vocab=dims.vocab, **_kw(dims.n_mel))
+        sysm.training_step([([sup], [qry])], 0)
+        got[fo] = {n: sysm.engine.export(n, 1) for n in ("mel_linear.weight", "encoder.layer_stack.0.slf_attn.fc.weight")}
+    for fo, second in ((None, True), (True, False)):
+        prm = {k: torch.from_numpy(v.copy()) for k, v in synth.make_params(dims, 0).items()}
+        for k, v in prm.items():
+            if not k.endswith(("position_enc", "pitch_bins", "energy_bins")):
+                v.requires_grad_(True)
+        ql, _, _, _ = O.maml_task(prm, torch_buffers(dims), O.to_torch_batch(sup), O.to_torch_batch(qry), steps=2, lr=0.001,
+                                  second_order=second, modules=alg["adapt"]["modules"], n_head=heads(dims), max_seq_len=dims.max_seq_len)
+        for n, x in got[fo].items():
+            ref = torch.autograd.grad(ql[0], prm[n], retain_graph=True)[0].numpy()
+            assert np.abs(x - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, (fo, n)
+    assert np.abs(got[None]["encoder.layer_stack.0.slf_attn.fc.weight"] - got[True]["encoder.layer_stack.0.slf_attn.fc.weight"]).max() > 0
