@@ -351,7 +351,7 @@ def main():
         ms = 1e3 * dt / args.steps
         line = {"metric": "meta-steps/sec (8-task meta-batch, 5 inner steps)", "value": round(args.steps / dt, 4), "unit": "meta-steps/s",
                 "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
-                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.numerics == "fp32" else "bf16x3 (split f32, fp32 accumulate)", "data": "synthetic",
                 "config": {"workload": ("C3: Meta-TTS MAML first-order" if args.order == 1 else "C4-style: Meta-TTS MAML second-order") + " (algorithm=meta_emb_vad, inner=5, meta-batch=8 tasks x (5 support + 5 query utts)), "
                                        "FastSpeech2 base.yaml, outer mean + clip(1.0) + Adam/Noam", "meta_batch": META_BATCH,
                            "tasks_per_gpu": META_BATCH // n, "inner_steps": INNER_STEPS, "order": "first" if args.order == 1 else "second", "parallelism": f"task-dp{n}",
