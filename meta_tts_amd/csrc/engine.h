@@ -109,6 +109,7 @@ public:
         std::vector<long long> texts, src_lens, mel_lens, durations;
         std::vector<float> pitches, energies;
         const float* mels = nullptr;
+        std::vector<float> mels_keep;  // own copy, only when T_max > max_seq_len (the plan may be rebuilt untruncated, see retarget)
         std::vector<int> spk_ids;
     };
     struct Plan {
@@ -117,6 +118,7 @@ public:
         int maxMp = 0, maxMf = 0, maxMr = 0, maxB = 0, enc_maxL = 0, dec_maxL = 0, n_enc_groups = 0, n_dec_groups = 0;
         int average_spk = 0;
         bool has_targets = false, frames_ready = false;
+        bool over_max = false, truncated = true;  // some T_max > max_seq_len / frames beyond it dropped in the current row spaces
         unsigned drop_seed = 0;  // seed of the last train-mode forward on this plan (backward replays it)
         std::vector<TaskIn> in;
         double sum_nP = 0, sum_nF = 0, sum_attn_p = 0, sum_attn_f = 0;
@@ -615,9 +617,24 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         if (any_tf && any_fr) { set_error("cannot mix teacher-forced and free-running batches in one slot"); return -1; }
         p.has_targets = any_tf;
+        p.over_max = false;
+        for (auto& in : p.in)
+            if (in.has_targets && in.T_max > cfg.max_seq_len) {   // rare: keep the targets so the plan can be rebuilt (retarget)
+                p.over_max = true;
+                in.mels_keep.assign(in.mels, in.mels + (size_t)in.B * in.T_max * cfg.n_mel);
+            }
         const int rc = build_plan(slot, any_tf, true);
-        for (auto& in : p.in) in.mels = nullptr;  // caller memory: valid during this call only
+        for (auto& in : p.in) in.mels = in.mels_keep.empty() ? nullptr : in.mels_keep.data();  // caller memory is only borrowed
         return rc;
+    }
+
+    // The reference's Decoder drops frames beyond max_seq_len in training mode only; in eval mode it extends the sinusoid
+    // table instead (transformer/Models.py:145-162).  Teacher-forced plans are built truncated (training is the hot path);
+    // an eval-mode forward of a batch longer than max_seq_len rebuilds the row spaces untruncated, and back.
+    int retarget(int slot, bool train) {
+        Plan& p = plans[slot];
+        if (!p.over_max || !p.has_targets || p.truncated == train) return 0;
+        return build_plan(slot, true, train);
     }
 
     // (Re)build the row spaces of plan `slot` from p.in.  with_frames: durations / mel_lens are known.
@@ -629,6 +646,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         p.hMp.assign(tasks, 0); p.hMf.assign(tasks, 0); p.hMr.assign(tasks, 0);
         p.maxMp = p.maxMf = p.maxMr = p.maxB = p.enc_maxL = p.dec_maxL = 0;
         p.frames_ready = with_frames;
+        p.truncated = truncate;
         p.sum_nP = p.sum_nF = p.sum_attn_p = p.sum_attn_f = 0;
         p.sumMp = p.sumMf = p.sumMr = p.sumLp = p.sumLf = 0;
         std::vector<int> meta((size_t)tasks * META_STRIDE, 0);

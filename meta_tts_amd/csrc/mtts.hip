@@ -135,6 +135,7 @@ int mtts_set_batches(mtts_handle* h, int slot, int n_tasks, const mtts_batch* ba
 int mtts_forward(mtts_handle* h, int slot, int use_fast, int train) {
     Engine& e = h->eng;
     if (slot < 0 || slot > 1 || e.plans[slot].tasks < 1) { e.set_error("plan not set"); return -1; }
+    if (e.plans[slot].has_targets && e.retarget(slot, train != 0)) return -1;
     Engine::Pass ps{&e.plans[slot], use_fast != 0, train != 0};
     return e.forward(ps);
 }
@@ -161,6 +162,7 @@ int mtts_get_durations(mtts_handle* h, int slot, int task, float* d_rounded, int
 int mtts_adapt(mtts_handle* h, int steps, float inner_lr, int reset, float* sup_losses_host) {
     Engine& e = h->eng;
     if (steps < 0 || steps > h->sup_losses_cap) { e.set_error("too many inner steps"); return -1; }
+    if (e.plans[0].tasks > 0 && e.retarget(0, true)) return -1;
     if (e.adapt(steps, inner_lr, reset != 0, h->sup_losses_dev)) return -1;
     return copy_losses(e, h->sup_losses_dev, sup_losses_host, steps * e.plans[0].tasks * 6);
 }
@@ -208,6 +210,7 @@ int mtts_meta_grad(mtts_handle* h, int steps, float inner_lr, float grad_scale, 
                    float* sup_losses_host) {
     Engine& e = h->eng;
     if (steps < 0 || steps > h->sup_losses_cap) { e.set_error("too many inner steps"); return -1; }
+    for (int sl = 0; sl < 2; ++sl) if (e.plans[sl].tasks > 0 && e.retarget(sl, true)) return -1;
     if (second_order ? e.meta_grad_so(steps, inner_lr, grad_scale, e.losses, h->sup_losses_dev)
                      : e.meta_grad(steps, inner_lr, grad_scale, e.losses, h->sup_losses_dev)) return -1;
     if (copy_losses(e, e.losses, qry_losses_host, e.plans[1].tasks * 6)) return -1;
@@ -219,6 +222,7 @@ int mtts_hvp_support(mtts_handle* h) { return h->eng.hvp_support(); }
 int mtts_plain_grad(mtts_handle* h, int slot, float grad_scale, float* losses_host) {
     Engine& e = h->eng;
     if (slot < 0 || slot > 1) { e.set_error("bad slot"); return -1; }
+    if (e.plans[slot].tasks > 0 && e.retarget(slot, true)) return -1;
     if (e.plain_grad(slot, grad_scale, e.losses)) return -1;
     return copy_losses(e, e.losses, losses_host, e.plans[slot].tasks * 6);
 }
