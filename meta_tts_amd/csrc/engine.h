@@ -811,6 +811,15 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         return dst;
     }
     float block_dropout(Space s) const { return s == SP_P ? cfg.enc_dropout : cfg.dec_dropout; }
+    // the same mask stream as drop(), for kernels that apply the dropout in passing (LayerNorm fwd / bwd)
+    DropSpec drop_spec(const Pass& ps, float prob, int site) const {
+        DropSpec d;
+        if (!drop_active(ps) || prob <= 0.f) return d;
+        d.seed = ps.pl->drop_seed * 0x9E3779B1u + (unsigned)site * 0x85EBCA6Bu + 0xC2B2AE35u;
+        d.thr16 = (unsigned)std::lround((double)prob * 65536.0);
+        d.scale = 1.f / (1.f - prob);
+        return d;
+    }
 
     // row-space GEMM over all tasks: C[M,N] (+)= op(A, B); M (or the reduction length for TN) is
     // the task's row count
@@ -893,16 +902,16 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         colreduce(p, a, out.p, nullptr, out.ts, maxM(p, s));
     }
     void ln_fwd(const Pass& ps, Space s, TS a, TS res, long long g_off, long long b_off, const unsigned char* mask,
-                TS zout, TS y, TS st, int C) {
+                TS zout, TS y, TS st, int C, DropSpec din = DropSpec(), DropSpec dout = DropSpec()) {
         const Plan& p = *ps.pl;
         TS gm = W(ps, g_off), bt = W(ps, b_off);
         MTTS_LAUNCH(layernorm_fwd_kernel, row2_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
                     (const float*)a.p, a.ts, (const float*)res.p, res.ts, (const float*)gm.p, (const float*)bt.p, gm.ts, mask,
-                    row_ts(s), zout.p, zout.ts, y.p, y.ts, st.p, st.ts, C, 1e-5f);
+                    row_ts(s), zout.p, zout.ts, y.p, y.ts, st.p, st.ts, C, 1e-5f, din, dout);
     }
     // dz = LayerNorm backward (masked); parameter grads into the per-task grad buffer
     void ln_bwd(const Pass& ps, Space s, TS dy, TS z, TS st, long long g_off, long long b_off, const unsigned char* mask,
-                TS dz, int C, int relu_on_z) {
+                TS dz, int C, int relu_on_z, TS dz_drop = TS{nullptr, 0}, DropSpec dd = DropSpec()) {
         const Plan& p = *ps.pl;
         TS gm = W(ps, g_off);
         TS gg = Gd(g_off), gb = Gd(b_off);
@@ -912,7 +921,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         colreduce(p, a, gg.p, gb.p, gg.ts, maxM(p, s));
         MTTS_LAUNCH(layernorm_bwd_kernel, row2_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
                     (const float*)dy.p, dy.ts, (const float*)z.p, z.ts, (const float*)st.p, st.ts, (const float*)gm.p, gm.ts,
-                    mask, row_ts(s), dz.p, dz.ts, C, relu_on_z);
+                    mask, row_ts(s), dz.p, dz.ts, C, relu_on_z, dd.thr16 ? dz_drop.p : nullptr, dz_drop.ts, dd);
     }
     void attn_gemm(const Pass& ps, Space s, int which, int form, const float* A, int lda, const float* B, int ldb,
                    float* C, int ldc, float alpha, int heads, int flags = 0) {
@@ -947,12 +956,12 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             MTTS_LAUNCH(softmax_fwd_kernel, dim3((L + 3) / 4, 1, groups), dim3(256), stream, seqs, b.P.p);
         attn_gemm(ps, s, TAB_PV, GEMM_NN, b.P.p, 0, b.qkv.p, 3 * d, b.O.p, d, 1.f, heads);
         conv_fwd(ps, s, b.O, d, 1, W(ps, P.wfc), W(ps, P.bfc), d, b.z1, 0, nullptr);
-        drop(ps, s, b.z1, b.z1, d, block_dropout(s), site_base);          // self.dropout(self.fc(output)), SubLayers.py:54
-        ln_fwd(ps, s, b.z1, xin, P.ln1g, P.ln1b, vm, b.z1, b.y1, b.st1, d);
+        // self.dropout(self.fc(output)) + residual -> LayerNorm (SubLayers.py:54-55): the dropout rides in the LayerNorm kernel
+        ln_fwd(ps, s, b.z1, xin, P.ln1g, P.ln1b, vm, b.z1, b.y1, b.st1, d, drop_spec(ps, block_dropout(s), site_base));
         conv_fwd(ps, s, b.y1, d, cfg.k1, W(ps, P.w1), W(ps, P.b1), cfg.d_ff, b.h, GEMM_RELU, im);
         conv_fwd(ps, s, b.h, cfg.d_ff, cfg.k2, W(ps, P.w2), W(ps, P.b2), d, b.z2, 0, nullptr);
-        drop(ps, s, b.z2, b.z2, d, block_dropout(s), site_base + 1);      // self.dropout(output), SubLayers.py:90
-        ln_fwd(ps, s, b.z2, b.y1, P.ln2g, P.ln2b, vm, b.z2, b.y2, b.st2, d);
+        // self.dropout(output) + residual -> LayerNorm (SubLayers.py:90-91)
+        ln_fwd(ps, s, b.z2, b.y1, P.ln2g, P.ln2b, vm, b.z2, b.y2, b.st2, d, drop_spec(ps, block_dropout(s), site_base + 1));
     }
 
     // g0 holds dL/dy2 on entry and dL/dx on exit; g1, gqkv, gh, dS are scratch
@@ -963,9 +972,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         const unsigned char* vm = valid_mask(p, s);
         const unsigned char* im = inrect_mask(p, s);
         // LN2 (+ row mask) backward -> g1 = dz2
-        ln_bwd(ps, s, g0, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0);
         TS gm = (s == SP_P) ? gPm : gFm;                                   // masked copy feeds the conv branch, g1 the residual
-        TS dc = drop(ps, s, g1, gm, d, block_dropout(s), site_base + 1);
+        const DropSpec dd2 = drop_spec(ps, block_dropout(s), site_base + 1);
+        ln_bwd(ps, s, g0, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0, gm, dd2);
+        TS dc = dd2.thr16 ? gm : g1;
         // conv2
         {   // wgrad and dgrad of a layer are independent: one multi-problem launch (gemm.h: gemm_f32_multi_kernel)
             GemmBatchScope pair(stream);
@@ -979,8 +989,9 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             conv_dgrad(ps, s, gh, ff, cfg.k1, W(ps, P.w1), d, g1, GEMM_ACCUM, im);
         }
         // LN1 backward -> g0 = dz1
-        ln_bwd(ps, s, g1, b.z1, b.st1, P.ln1g, P.ln1b, vm, g0, d, 0);
-        TS da = drop(ps, s, g0, gm, d, block_dropout(s), site_base);
+        const DropSpec dd1 = drop_spec(ps, block_dropout(s), site_base);
+        ln_bwd(ps, s, g1, b.z1, b.st1, P.ln1g, P.ln1b, vm, g0, d, 0, gm, dd1);
+        TS da = dd1.thr16 ? gm : g0;
         // fc
         {
             GemmBatchScope pair(stream);
@@ -1021,11 +1032,9 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         const unsigned char* im = p.p_inrect;
         TS none{nullptr, 0};
         conv_fwd(ps, SP_P, xin, d, k, W(ps, P.c1w), W(ps, P.c1b), f, b.r1, GEMM_RELU, im);
-        ln_fwd(ps, SP_P, b.r1, none, P.l1g, P.l1b, im, none, b.n1, b.st1, f);
-        drop(ps, SP_P, b.n1, b.n1, f, cfg.vp_dropout, site_base);
+        ln_fwd(ps, SP_P, b.r1, none, P.l1g, P.l1b, im, none, b.n1, b.st1, f, DropSpec(), drop_spec(ps, cfg.vp_dropout, site_base));
         conv_fwd(ps, SP_P, b.n1, f, k, W(ps, P.c2w), W(ps, P.c2b), f, b.r2, GEMM_RELU, im);
-        ln_fwd(ps, SP_P, b.r2, none, P.l2g, P.l2b, im, none, b.n2, b.st2, f);
-        drop(ps, SP_P, b.n2, b.n2, f, cfg.vp_dropout, site_base + 1);
+        ln_fwd(ps, SP_P, b.r2, none, P.l2g, P.l2b, im, none, b.n2, b.st2, f, DropSpec(), drop_spec(ps, cfg.vp_dropout, site_base + 1));
         TS w = W(ps, P.lw), bb = W(ps, P.lb);
         MTTS_LAUNCH(rowdot_kernel, row_grid(p.maxMp, p.tasks), dim3(256), stream, (const int*)p.meta, (int)META_MP,
                     (const float*)b.n2.p, b.n2.ts, (const float*)w.p, (const float*)bb.p, w.ts, (const unsigned char*)p.p_valid,

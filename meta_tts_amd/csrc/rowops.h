@@ -52,6 +52,22 @@ __global__ void embed_pos_kernel(const int* meta, int mfield, float* out, long l
 // y = mask ? LayerNorm(a (+ res)) : 0   (SubLayers.py:55,91 post-LN; modules.py:222,234)
 // z_out (optional) receives a + res; stats = (mean, rstd) per row.  C <= 1024.
 // ------------------------------------------------------------------------------------------
+// counter-based dropout mask shared by dropout_kernel and the LayerNorm kernels that apply it in passing: keep bits of
+// the four elements (row, c .. c+3) of task z = 16-bit fields of splitmix64(seed, z, element id / 4)
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+struct DropSpec { unsigned seed = 0, thr16 = 0; float scale = 1.f; };  // thr16 == 0: off
+__device__ __forceinline__ float4 drop4(const DropSpec& d, int z, int row, int C, int c, float4 v) {
+    const unsigned long long base = ((unsigned long long)d.seed << 32) ^ ((unsigned long long)z << 24);
+    const unsigned long long h = splitmix64(base + ((unsigned long long)row * (unsigned)C + (unsigned)c) / 4ull);
+    return make_float4(((h) & 0xFFFFu) >= d.thr16 ? v.x * d.scale : 0.f, ((h >> 16) & 0xFFFFu) >= d.thr16 ? v.y * d.scale : 0.f,
+                       ((h >> 32) & 0xFFFFu) >= d.thr16 ? v.z * d.scale : 0.f, ((h >> 48) & 0xFFFFu) >= d.thr16 ? v.w * d.scale : 0.f);
+}
+
 // Two rows per wavefront (8 per workgroup): all loads of both rows are in flight before the first reduction — these
 // launches are only a couple of wave "rounds" long, so what matters is the number of serialised memory round trips per
 // wave (was: mask -> rows -> stats), not bandwidth.
@@ -69,7 +85,10 @@ inline dim3 row2_grid(int max_rows, int tasks) { return dim3((unsigned)((max_row
 __global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a, long long a_ts, const float* res,
                                      long long res_ts, const float* gamma, const float* beta, long long par_ts,
                                      const unsigned char* mask, long long mask_ts, float* z_out, long long z_ts,
-                                     float* y, long long y_ts, float* stats, long long st_ts, int C, float eps) {
+                                     float* y, long long y_ts, float* stats, long long st_ts, int C, float eps,
+                                     DropSpec din, DropSpec dout) {
+    // din: dropout applied to `a` before the residual add (self.dropout(sublayer(x)) + residual, SubLayers.py:54-55,90-91);
+    // dout: dropout applied to the normalised output (LayerNorm -> Dropout of the variance predictors, modules.py:222-235)
     ROW2_PROLOGUE(mfield)
     float4 v[2][4];
     float s[2] = {0.f, 0.f};
@@ -83,6 +102,7 @@ __global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a
         int n = 0;
         for (int c = lane * 4; c < C; c += 256, ++n) {
             float4 x = ld4(pa + c);
+            if (din.thr16) x = drop4(din, z, row, C, c, x);
             if (pr) { const float4 r4 = ld4(pr + c); x = make_float4(x.x + r4.x, x.y + r4.y, x.z + r4.z, x.w + r4.w); }
             v[q][n] = x;
             s[q] += (x.x + x.y) + (x.z + x.w);
@@ -116,6 +136,7 @@ __global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a
                 const float4 g4 = ld4(g + c), b4 = ld4(b + c);
                 o = make_float4((v[q][i].x - mean[q]) * rstd[q] * g4.x + b4.x, (v[q][i].y - mean[q]) * rstd[q] * g4.y + b4.y,
                                 (v[q][i].z - mean[q]) * rstd[q] * g4.z + b4.z, (v[q][i].w - mean[q]) * rstd[q] * g4.w + b4.w);
+                if (dout.thr16) o = drop4(dout, z, row, C, c, o);
             }
             st4(py + c, o);
         }
@@ -132,7 +153,9 @@ __global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a
 __global__ void layernorm_bwd_kernel(const int* meta, int mfield, const float* dy, long long dy_ts, const float* zin,
                                      long long z_ts, const float* stats, long long st_ts, const float* gamma,
                                      long long par_ts, const unsigned char* mask, long long mask_ts, float* dz,
-                                     long long dz_ts, int C, int relu_on_z) {
+                                     long long dz_ts, int C, int relu_on_z, float* dz_drop, long long dzd_ts, DropSpec dd) {
+    // dz_drop (optional): dropout(dz) with the mask of the forward site — the gradient entering the dropped branch, while dz
+    // itself continues along the residual path
     ROW2_PROLOGUE(mfield)
     const float* g = gamma + (long long)z * par_ts;
     float4 gv[2][4], xh[2][4];
@@ -173,6 +196,7 @@ __global__ void layernorm_bwd_kernel(const int* meta, int mfield, const float* d
             }
             if (!keep[q]) o = zero4();
             st4(pd + c, o);
+            if (dz_drop) st4(dz_drop + (long long)z * dzd_ts + (long long)row * C + c, drop4(dd, z, row, C, c, o));
         }
     }
 }
@@ -638,12 +662,27 @@ __global__ void table_grad_kernel(const int* meta, int mfield, const float* dx, 
                 const float w = (hit && (lane >> 4) == part) ? (float)(1u << (lane & 15)) : 0.f;
                 bits |= (unsigned long long)(unsigned)wave_sum(w) << (16 * part);
             }
+            // hits four at a time: the loads of four rows are in flight together, the adds keep the ascending row order
+            // (a padding bucket collects ~100 rows per task; one dependent load per hit made that workgroup the kernel's tail)
             while (bits) {
-                const int j = __builtin_ctzll(bits);
-                bits &= bits - 1;
-                const float* row = pd + (long long)(base + j) * C;
+                const float* row[4];
+                int nh = 0;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) { const int c = lane + 64 * k; if (c < C) s[k] += row[c]; }
+                for (int q = 0; q < 4; ++q) {
+                    row[q] = pd;
+                    if (bits) { row[q] = pd + (long long)(base + __builtin_ctzll(bits)) * C; bits &= bits - 1; nh = q + 1; }
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int c = lane + 64 * k;
+                    if (c < C) {
+                        const float v0 = row[0][c], v1 = row[1][c], v2 = row[2][c], v3 = row[3][c];
+                        s[k] += v0;
+                        if (nh > 1) s[k] += v1;
+                        if (nh > 2) s[k] += v2;
+                        if (nh > 3) s[k] += v3;
+                    }
+                }
             }
         }
 #pragma unroll
@@ -799,13 +838,6 @@ __global__ void gather_rows_kernel(const int* meta, int mfield, const float* src
 // forward, backward and the second-order replay regenerate the same mask without storing it.
 // dst = keep ? src / (1 - p) : 0 on rows < M; dst may alias src.  thr16 = round(p * 65536).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-
 __global__ void dropout_kernel(const int* meta, int mfield, const float* src, long long src_ts, float* dst, long long dst_ts,
                                int C, unsigned seed, unsigned thr16, float scale) {
     ROW_PROLOGUE(mfield)
