@@ -442,11 +442,28 @@ __global__ void colreduce_kernel(const int* meta, ColArgs a, float* partial, int
 // ------------------------------------------------------------------------------------------
 struct AttnSeq { long long s_off; int L, ldS; };
 
+// One wavefront per row, the row lives in registers (L <= 1024: 16 values per lane) between the single read and the single
+// write; longer rows (eval mode beyond max_seq_len) take the streaming path.
 __global__ void softmax_fwd_kernel(const AttnSeq* seqs, float* S) {
     const AttnSeq q = seqs[blockIdx.z];
     const int row = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
     if (row >= q.L) return;
     float* p = S + q.s_off + (long long)row * q.ldS;
+    if (q.L <= 1024) {
+        float v[16];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int c = lane + 64 * k; v[k] = c < q.L ? p[c] : -3.0e38f; mx = fmaxf(mx, v[k]); }
+        mx = wave_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int c = lane + 64 * k; v[k] = c < q.L ? expf(v[k] - mx) : 0.f; s += v[k]; }
+        s = wave_sum(s);
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int c = lane + 64 * k; if (c < q.ldS) p[c] = v[k] * inv; }
+        return;
+    }
     float mx = -3.0e38f;
     for (int c = lane; c < q.L; c += 64) mx = fmaxf(mx, p[c]);
     mx = wave_max(mx);
@@ -464,6 +481,21 @@ __global__ void softmax_bwd_kernel(const AttnSeq* seqs, const float* P, float* d
     if (row >= q.L) return;
     const float* p = P + q.s_off + (long long)row * q.ldS;
     float* d = dP + q.s_off + (long long)row * q.ldS;
+    if (q.L <= 1024) {
+        float pv[16], dv[16];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int c = lane + 64 * k;
+            pv[k] = c < q.L ? p[c] : 0.f;
+            dv[k] = c < q.L ? d[c] : 0.f;
+            s += dv[k] * pv[k];
+        }
+        s = wave_sum(s);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int c = lane + 64 * k; if (c < q.ldS) d[c] = alpha * pv[k] * (dv[k] - s); }
+        return;
+    }
     float s = 0.f;
     for (int c = lane; c < q.L; c += 64) s += d[c] * p[c];
     s = wave_sum(s);
