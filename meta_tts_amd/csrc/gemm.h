@@ -70,7 +70,7 @@ struct GemmArgs {
     float act_slope = 0.2f;
     int flags = 0;
     int taps = 1, tap_k = 0x40000000, tap_bstride = 0;  // NN conv dgrad tap walk
-    int swizzle = 0;                                     // XCD-aware workgroup order (set by the launcher)
+    int swizzle = 0;                                     // XCD-aware tile order (xcd_group_remap; set by the launcher)
     // split-K (set by the launcher for under-filled grids): `splitk` workgroups share one output tile, each reducing a
     // contiguous run of K-chunks; partial tiles go to `ws`, the last workgroup to arrive (tile counter in `tile_ctr`) sums
     // them in split order and runs the fused epilogue, so the result does not depend on the arrival order
@@ -81,20 +81,23 @@ struct GemmArgs {
 };
 
 
-// XCD-aware workgroup order (speed only, never correctness): the dispatcher is observed to place consecutive
-// workgroups round-robin on the 8 XCDs, each with a private L2.  Remap the linear (group, tile) id so that every XCD
-// walks ONE contiguous eighth of the work: with 8 tasks per launch an XCD's L2 then holds a single task's weights and
-// activation panels instead of all eight (HBM/fabric fetch per launch drops; PMC numbers in profiles/).  Bijective for
-// any grid size.  Measured on the C3 meta-step: -3 % (the per-task tile counts differ, so contiguous eighths are unevenly
-// loaded while the kernel is MFMA-bound, not fetch-bound) => off by default (MTTS_XCD_SWIZZLE=1 enables it for A/B runs).
-__device__ __forceinline__ void xcd_swizzle(int enable, int& z, int& bx) {
-    if (!enable) { z = blockIdx.z; bx = blockIdx.x; return; }
-    const unsigned gx = gridDim.x, total = gx * gridDim.z;
-    const unsigned lin = blockIdx.z * gx + blockIdx.x;
-    const unsigned xcd = lin & 7u, k = lin >> 3, q = total >> 3, r = total & 7u;
-    const unsigned nl = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    z = (int)(nl / gx);
-    bx = (int)(nl % gx);
+// XCD-aware tile order (speed only, never correctness).  The dispatcher deals consecutive workgroups round-robin to the 8
+// XCDs, each with a private 4 MB L2, so with the natural order the n-tiles of one m-tile — which read the same A panel —
+// land on 8 different L2s.  Within every run of 8*G workgroup slots the G slots of residue r (mod 8) are mapped to G
+// consecutive tiles instead: with G = tiles_n (x split-K factor) one m-tile's n-tiles share an XCD while every XCD still
+// receives every eighth workgroup — no imbalance (a contiguous eighth of the grid per XCD measured -3 % on the ragged
+// 8-task launches).  PMC: L2-miss traffic of the multi-problem launches 454 -> 286 MB per launch; time neutral (the kernels
+// are MFMA-, not fetch-bound).  MTTS_XCD_GROUP=0 restores the natural order.
+__device__ __forceinline__ int xcd_group_size(int tiles_n, int splitk) {
+    const int G = tiles_n * (splitk > 1 ? splitk : 1);
+    return G < 64 ? G : 64;
+}
+__device__ __forceinline__ int xcd_group_remap(int lin, int total, int G) {
+    if (G <= 1) return lin;
+    const int run = 8 * G, blk = lin / run;
+    if ((blk + 1) * run > total) return lin;  // ragged last run: natural order
+    const int r = lin - blk * run;
+    return blk * run + (r & 7) * G + (r >> 3);
 }
 
 // Register fragments of one BK=16 slice of the wave tile.  A_KC/B_KC: operand tile is [row][kLDK]
@@ -428,8 +431,9 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
 template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[GemmSmem<FORM, BM, BN, BK>::FLOATS];
-    int z, bxs;
-    xcd_swizzle(g.swizzle, z, bxs);
+    const int z = blockIdx.z;
+    int bxs = blockIdx.x;
+    if (g.swizzle) bxs = xcd_group_remap(bxs, (int)gridDim.x, xcd_group_size((g.N + BN - 1) / BN, g.splitk));
     gemm_f32_body<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL>(g, z, bxs, smem);
 }
 
@@ -442,21 +446,31 @@ struct GemmMulti {
     int start[kGemmMultiMax + 1] = {0};
     int form[kGemmMultiMax] = {0};
     int groups[kGemmMultiMax] = {0};
+    int xcd_group[kGemmMultiMax] = {0};  // > 1: this many consecutive tile slots share an XCD (gemm_multi_locate)
     GemmArgs g[kGemmMultiMax];
 };
+
+// Problem / group / tile of a workgroup of a multi-problem launch.  Problems are sorted by per-tile cost (longest first) and
+// laid out problem-major over a 1-D grid, so the long tiles all start in the first dispatch round and the short ones fill
+// the tail; within a problem the tile order is XCD-grouped (xcd_group_remap).
+__device__ __forceinline__ void gemm_multi_locate(const GemmMulti& mp, int& p, int& z, int& bx) {
+    p = 0;
+    int lin = (int)blockIdx.x;
+    while (p + 1 < mp.n && lin >= mp.start[p + 1]) ++p;
+    lin -= mp.start[p];
+    const int total = mp.start[p + 1] - mp.start[p];
+    lin = xcd_group_remap(lin, total, mp.xcd_group[p]);
+    const int tiles = total / mp.groups[p];
+    z = lin / tiles;
+    bx = lin - z * tiles;
+}
 template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_multi_kernel(GemmMulti mp) {
     constexpr int F0 = GemmSmem<GEMM_NT, BM, BN, BK>::FLOATS, F1 = GemmSmem<GEMM_NN, BM, BN, BK>::FLOATS, F2 = GemmSmem<GEMM_TN, BM, BN, BK>::FLOATS;
     constexpr int FL = F0 > F1 ? (F0 > F2 ? F0 : F2) : (F1 > F2 ? F1 : F2);
     __shared__ __attribute__((aligned(16))) float smem[FL];
-    // problems are sorted by per-tile cost (longest first) and laid out problem-major over a 1-D grid, so the long tiles
-    // all start in the first dispatch round and the short ones fill the tail
-    int p = 0;
-    int lin = (int)blockIdx.x;
-    while (p + 1 < mp.n && lin >= mp.start[p + 1]) ++p;
-    lin -= mp.start[p];
-    const int tiles = (mp.start[p + 1] - mp.start[p]) / mp.groups[p];
-    const int z = lin / tiles, bx = lin - z * tiles;
+    int p, z, bx;
+    gemm_multi_locate(mp, p, z, bx);
     const int form = mp.form[p];
     if (form == GEMM_NT) gemm_f32_body<GEMM_NT, BM, BN, BK, true>(mp.g[p], z, bx, smem);
     else if (form == GEMM_NN) gemm_f32_body<GEMM_NN, BM, BN, BK, true>(mp.g[p], z, bx, smem);
@@ -493,7 +507,7 @@ struct GemmProfiler {
 };
 inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
 inline int& gemm_xcd_swizzle() {
-    static int v = [] { const char* e = getenv("MTTS_XCD_SWIZZLE"); return (e && atoi(e) == 1) ? 1 : 0; }();
+    static int v = [] { const char* e = getenv("MTTS_XCD_GROUP"); return e ? (atoi(e) != 0) : 1; }();
     return v;
 }
 inline int& gemm_numerics() {  // 0: exact fp32 MFMA (default), 1: split-bf16 "bf16x3", 2: plain bf16 operands (gemm_bf16.h); MTTS_NUMERICS env overrides
@@ -724,6 +738,7 @@ inline void gemm_batch_end(hipStream_t stream) {
                 } else S = 1;
             } else S = 1;
         }
+        mp.xcd_group[i] = gemm_xcd_swizzle() ? std::min(((p.max_N + 63) / 64) * S, 64) : 0;
         mp.start[i + 1] = mp.start[i] + tiles * S * p.groups;
         max_groups = std::max(max_groups, p.groups);
         flops += p.flops; rows += p.rows;

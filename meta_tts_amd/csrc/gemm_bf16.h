@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     constexpr int A_KPT = BK / A_KG, B_KPT = BK / B_KG;            // k per thread (16 or 8)
     constexpr int A_NREG = A_KC ? A_KC4 * 4 : A_KPT, B_NREG = B_KC ? B_KC4 * 4 : B_KPT;
 
-    int z, bxs;
-    xcd_swizzle(g.swizzle, z, bxs);
+    const int z = blockIdx.z;
+    const int bxs = blockIdx.x;
     const float* A = g.A;
     const float* B = g.B;
     float* C = g.C;

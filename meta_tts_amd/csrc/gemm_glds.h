@@ -226,17 +226,15 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
 template <int FORM>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[kGldsSmemFloats];
-    gemm_glds_body<FORM>(g, blockIdx.z, blockIdx.x, smem);
+    int bx = blockIdx.x;
+    if (g.swizzle) bx = xcd_group_remap(bx, (int)gridDim.x, xcd_group_size((g.N + 63) / 64, g.splitk));
+    gemm_glds_body<FORM>(g, blockIdx.z, bx, smem);
 }
 
 __global__ __launch_bounds__(256) void gemm_glds_multi_kernel(GemmMulti mp) {
     __shared__ __attribute__((aligned(16))) float smem[kGldsSmemFloats];
-    int p = 0;
-    int lin = (int)blockIdx.x;
-    while (p + 1 < mp.n && lin >= mp.start[p + 1]) ++p;
-    lin -= mp.start[p];
-    const int tiles = (mp.start[p + 1] - mp.start[p]) / mp.groups[p];
-    const int z = lin / tiles, bx = lin - z * tiles;
+    int p, z, bx;
+    gemm_multi_locate(mp, p, z, bx);
     const int form = mp.form[p];
     if (form == GEMM_NT) gemm_glds_body<GEMM_NT>(mp.g[p], z, bx, smem);
     else if (form == GEMM_NN) gemm_glds_body<GEMM_NN>(mp.g[p], z, bx, smem);
