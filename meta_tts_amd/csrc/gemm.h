@@ -582,7 +582,7 @@ inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t s
 #endif
 
 // Host launcher.  max_M / max_N bound the tile grid over all groups.  tile = 0 picks the tile by a
-// wave-quantisation model: one 4-wave workgroup saturates a CU's four MFMA pipes, so B workgroups
+// wave-quantisation model (128x128 rated 0.85x the 64x64 tile, measured on the model shapes; MTTS_TILE128_EFF): one 4-wave workgroup saturates a CU's four MFMA pipes, so B workgroups
 // on 256 CUs take ceil(B/256) rounds; the 64x64 tile quarters the quantum at ~0.97x the per-tile
 // efficiency of 128x128 (software-pipelined variants, measured with tools/gemm_bench.py).  total_M = sum of the groups' row counts
 // (0: max_M * groups).  alg_flops: algorithmic (unpadded) flops of this launch, profiler only.
@@ -599,7 +599,8 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
             const double b = std::ceil(rows / t) * ((max_N + t - 1) / t) / 256.0;
             return base * b / std::ceil(b);
         };
-        tile = eff(128, 1.0) >= eff(64, 0.97) ? 128 : 64;
+        static const double eff128 = [] { const char* e = getenv("MTTS_TILE128_EFF"); return e ? atof(e) : 0.85; }();
+        tile = eff(128, eff128) >= eff(64, 1.0) ? 128 : 64;
     }
     GemmProfiler& prof0 = gemm_profiler();
     if (gemm_numerics() >= 1 && tile < 1000 && !(g.taps > 1 && g.tap_k % 32 != 0)) {
