@@ -694,14 +694,24 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
     }
 }
 
+inline bool batch_full_regime(const std::vector<GemmPending>& q) {  // more workgroups than the latency regime's limit
+    double wgs = 0.0;
+    for (const GemmPending& p : q) wgs += std::ceil(p.rows / 64.0) * ((p.max_N + 63) / 64);
+    return wgs > (double)gemm_glds_max_wgs();
+}
 inline void gemm_batch_end(hipStream_t stream) {
     GemmBatch& b = gemm_batch();
     b.open = false;
     if (b.q.empty()) return;
-    if (b.q.size() == 1) {
-        const GemmPending p = b.q[0];
+    // pairs whose dgrad has a short K-loop (K <= 256: fc, conv2) measured ~10 % SLOWER batched than back to back — their
+    // many 16-slice tiles gain nothing from a shared grid and lose the stand-alone kernels' higher occupancy
+    static const int min_k = [] { const char* e = getenv("MTTS_BATCH_MIN_K"); return e ? atoi(e) : 512; }();
+    bool solo = b.q.size() == 1;
+    for (const GemmPending& p : b.q) if (!p.g.table && p.g.K < min_k && batch_full_regime(b.q)) solo = true;
+    if (solo) {
+        const std::vector<GemmPending> q = b.q;
         b.q.clear();
-        gemm_launch(p.form, p.g, p.max_M, p.max_N, p.groups, stream, 0, p.flops, (long long)p.rows);
+        for (const GemmPending& p : q) gemm_launch(p.form, p.g, p.max_M, p.max_N, p.groups, stream, 0, p.flops, (long long)p.rows);
         return;
     }
     std::stable_sort(b.q.begin(), b.q.end(), [](const GemmPending& x, const GemmPending& y) { return x.g.K > y.g.K; });
