@@ -123,6 +123,27 @@ def inference_leg(dims, mods, device, iters=5):
     return res
 
 
+def mel_l1_leg(dims, device):
+    """The metric's third component: mel L1 of this path against the REFERENCE model's output on config C1 (one LibriTTS-shaped
+    utterance, S = 80, T = 555), from the committed fixture tests/golden/c1_forward.npz (produced by importing the reference,
+    tests/golden/make_golden.py).  Eval mode and train mode (BatchNorm batch statistics); gate 1e-4 (BASELINE north_star)."""
+    from meta_tts_amd import synth
+    from meta_tts_amd.engine import Engine
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "c1_forward.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    eng = Engine(dims, adapt_modules=[], max_tasks=1, max_B=1, max_S=80, max_T=555, device=device)
+    eng.load_params(synth.make_params(dims, 0))
+    eng.set_batches(0, [synth.make_batch(0, 1)])
+    out = {"gate": 1e-4, "config": "C1 (1 utterance, S=80, T=555, fp32)", "source": "tests/golden/c1_forward.npz (reference model output)"}
+    for train, key, name in ((False, "mel_post", "eval"), (True, "train_mel_post", "train_mode_batchnorm")):
+        eng.forward(0, train=train)
+        out[name] = float(np.abs(eng.outputs(0, 0)["mel_post"] - g[key]).mean())
+    eng.close()
+    return out
+
+
 def baseline_c2_leg(dims, device, noam_lr, trn, iters=8):
     """BASELINE config 2: multi-task baseline (algorithm=baseline: no inner loop, baseline.py:25-36) on ONE synthetic
     LibriTTS-shaped batch of 16 utterances — forward + backward + clip + Adam per step, dropout on.  Timed in the exact
@@ -341,6 +362,7 @@ def main():
     infer = None
     if rank == 0 and n == 1 and not args.no_inference:
         infer = inference_leg(dims, mods, local_rank)
+    mel_l1 = mel_l1_leg(dims, local_rank) if (rank == 0 and n == 1 and args.numerics == "fp32") else None
     c2 = None
     if rank == 0 and n == 1 and not args.no_baseline_c2:
         c2 = baseline_c2_leg(dims, local_rank, noam_lr, trn)
@@ -362,6 +384,8 @@ def main():
             line["second_order"] = so
         if b16 is not None:
             line["bf16x3_numerics"] = b16
+        if mel_l1 is not None:
+            line["mel_l1_vs_reference"] = mel_l1
         if infer is not None:
             line["inference_c5"] = infer
         if c2 is not None:
