@@ -19,6 +19,15 @@ struct mtts_handle {
 
 static std::string g_create_error;
 
+// Launches are asynchronous: a rejected launch (bad configuration, out of resources) only shows up in hipGetLastError().
+// Every compute entry point ends here so such a failure is reported as an error, never as silently stale results.
+static int launched(Engine& e, int rc) {
+    if (rc) return rc;
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) { e.set_error(std::string("kernel launch failed: ") + hipGetErrorString(err)); return -1; }
+    return 0;
+}
+
 struct mtts_vocoder {
     Vocoder v;
 };
@@ -137,14 +146,14 @@ int mtts_forward(mtts_handle* h, int slot, int use_fast, int train) {
     if (slot < 0 || slot > 1 || e.plans[slot].tasks < 1) { e.set_error("plan not set"); return -1; }
     if (e.plans[slot].has_targets && e.retarget(slot, train != 0)) return -1;
     Engine::Pass ps{&e.plans[slot], use_fast != 0, train != 0};
-    return e.forward(ps);
+    return launched(e, e.forward(ps));
 }
 
 int mtts_synthesize(mtts_handle* h, int slot, int use_fast, int train, float p_control, float e_control, float d_control) {
     Engine& e = h->eng;
     if (slot < 0 || slot > 1 || e.plans[slot].tasks < 1) { e.set_error("plan not set"); return -1; }
     Engine::Pass ps{&e.plans[slot], use_fast != 0, train != 0, p_control, e_control, d_control};
-    return e.forward(ps);
+    return launched(e, e.forward(ps));
 }
 
 int mtts_get_durations(mtts_handle* h, int slot, int task, float* d_rounded, int64_t* mel_lens, int* t_cap) {
@@ -163,7 +172,7 @@ int mtts_adapt(mtts_handle* h, int steps, float inner_lr, int reset, float* sup_
     Engine& e = h->eng;
     if (steps < 0 || steps > h->sup_losses_cap) { e.set_error("too many inner steps"); return -1; }
     if (e.plans[0].tasks > 0 && e.retarget(0, true)) return -1;
-    if (e.adapt(steps, inner_lr, reset != 0, h->sup_losses_dev)) return -1;
+    if (launched(e, e.adapt(steps, inner_lr, reset != 0, h->sup_losses_dev))) return -1;
     return copy_losses(e, h->sup_losses_dev, sup_losses_host, steps * e.plans[0].tasks * 6);
 }
 
@@ -195,7 +204,7 @@ int mtts_loss(mtts_handle* h, int slot, float* losses_host) {
     Engine& e = h->eng;
     if (slot < 0 || slot > 1 || e.plans[slot].tasks < 1) { e.set_error("plan not set"); return -1; }
     Engine::Pass ps{&e.plans[slot], false, true};
-    if (e.loss(ps, e.losses)) return -1;
+    if (launched(e, e.loss(ps, e.losses))) return -1;
     return copy_losses(e, e.losses, losses_host, e.plans[slot].tasks * 6);
 }
 
@@ -203,7 +212,7 @@ int mtts_backward(mtts_handle* h, int slot, int use_fast, float scale, int need_
     Engine& e = h->eng;
     if (slot < 0 || slot > 1 || e.plans[slot].tasks < 1) { e.set_error("plan not set"); return -1; }
     Engine::Pass ps{&e.plans[slot], use_fast != 0, true};
-    return e.backward(ps, scale, need_encoder != 0);
+    return launched(e, e.backward(ps, scale, need_encoder != 0));
 }
 
 int mtts_meta_grad(mtts_handle* h, int steps, float inner_lr, float grad_scale, int second_order, float* qry_losses_host,
@@ -211,19 +220,19 @@ int mtts_meta_grad(mtts_handle* h, int steps, float inner_lr, float grad_scale, 
     Engine& e = h->eng;
     if (steps < 0 || steps > h->sup_losses_cap) { e.set_error("too many inner steps"); return -1; }
     for (int sl = 0; sl < 2; ++sl) if (e.plans[sl].tasks > 0 && e.retarget(sl, true)) return -1;
-    if (second_order ? e.meta_grad_so(steps, inner_lr, grad_scale, e.losses, h->sup_losses_dev)
-                     : e.meta_grad(steps, inner_lr, grad_scale, e.losses, h->sup_losses_dev)) return -1;
+    if (launched(e, second_order ? e.meta_grad_so(steps, inner_lr, grad_scale, e.losses, h->sup_losses_dev)
+                                 : e.meta_grad(steps, inner_lr, grad_scale, e.losses, h->sup_losses_dev))) return -1;
     if (copy_losses(e, e.losses, qry_losses_host, e.plans[1].tasks * 6)) return -1;
     return copy_losses(e, h->sup_losses_dev, sup_losses_host, steps * e.plans[0].tasks * 6);
 }
 
-int mtts_hvp_support(mtts_handle* h) { return h->eng.hvp_support(); }
+int mtts_hvp_support(mtts_handle* h) { return launched(h->eng, h->eng.hvp_support()); }
 
 int mtts_plain_grad(mtts_handle* h, int slot, float grad_scale, float* losses_host) {
     Engine& e = h->eng;
     if (slot < 0 || slot > 1) { e.set_error("bad slot"); return -1; }
     if (e.plans[slot].tasks > 0 && e.retarget(slot, true)) return -1;
-    if (e.plain_grad(slot, grad_scale, e.losses)) return -1;
+    if (launched(e, e.plain_grad(slot, grad_scale, e.losses))) return -1;
     return copy_losses(e, e.losses, losses_host, e.plans[slot].tasks * 6);
 }
 
@@ -231,7 +240,7 @@ float* mtts_outer_grad_ptr(mtts_handle* h) { return h->eng.outer; }
 
 int mtts_outer_update(mtts_handle* h, const float* grad_dev, float lr, float b1, float b2, float eps, float wd, float max_norm,
                       float* norm_host) {
-    return h->eng.outer_update(grad_dev ? grad_dev : h->eng.outer, lr, b1, b2, eps, wd, max_norm, norm_host);
+    return launched(h->eng, h->eng.outer_update(grad_dev ? grad_dev : h->eng.outer, lr, b1, b2, eps, wd, max_norm, norm_host));
 }
 
 int mtts_reset_optimizer(mtts_handle* h) {
