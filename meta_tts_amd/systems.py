@@ -150,6 +150,17 @@ class BaseAdaptorSystem(System):
                 outputs[f"step_{ft_step}"]["synth"] = {"output": self._forward_learner(sup_batch, qry_batch, True, True, False)}
         return outputs
 
+    def on_test_start(self):
+        """system.py:194-212: with `adapt.test.avg_train_spk_emb` (LibriTTS, table embedding) the last 39 speaker rows — the
+        unseen test speakers — start from the mean of the first 247 (train-clean-100) rows."""
+        a = self.algorithm_config["adapt"]
+        if a["speaker_emb"] != "table":
+            return
+        if self.preprocess_config["dataset"] == "LibriTTS" and a["test"].get("avg_train_spk_emb", False):
+            w = self.engine.export("speaker_emb.model.weight")
+            w[-39:] = w[:247].mean(axis=0)
+            self.engine.load_params({"speaker_emb.model.weight": w}, strict=False)
+
     def test_step(self, batch, batch_idx):
         self._on_meta_batch_start(batch)
         if self.algorithm_config["adapt"]["test"].get("1-shot", False):

@@ -231,3 +231,31 @@ def test_meta_system_trains_second_order_like_the_reference(cfgs, emu_lib):
             ref = torch.autograd.grad(ql[0], prm[n], retain_graph=True)[0].numpy()
             assert np.abs(x - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, (fo, n)
     assert np.abs(got[None]["encoder.layer_stack.0.slf_attn.fc.weight"] - got[True]["encoder.layer_stack.0.slf_attn.fc.weight"]).max() > 0
+
+
+def test_on_test_start_avg_train_spk_emb(cfgs, emu_lib, tmp_path):
+    """system.py:194-212: the 39 unseen LibriTTS test speakers start from the mean of the 247 train-clean-100 rows."""
+    import json
+    from meta_tts_amd.config import SYNTH_STATS
+    pre, mod, trn, alg = cfgs
+    with open(tmp_path / "speakers.json", "w") as f:
+        json.dump({f"s{i}": i for i in range(300)}, f)
+    with open(tmp_path / "stats.json", "w") as f:
+        json.dump(SYNTH_STATS, f)
+    pre = dict(pre)
+    pre["path"] = {"preprocessed_path": str(tmp_path)}
+    pre["dataset"] = "LibriTTS"
+    alg["adapt"]["test"]["avg_train_spk_emb"] = True
+    sysm = _system((pre, mod, trn, alg), emu_lib)
+    assert sysm.model.dims.n_speaker == 300
+    g = np.random.RandomState(0)
+    w = g.standard_normal((300, sysm.model.dims.d_model)).astype(np.float32)
+    sysm.engine.load_params({"speaker_emb.model.weight": w}, strict=False)
+    sysm.on_test_start()
+    after = sysm.engine.export("speaker_emb.model.weight")
+    np.testing.assert_array_equal(after[:-39], w[:-39])
+    np.testing.assert_allclose(after[-39:], np.broadcast_to(w[:247].mean(axis=0), (39, w.shape[1])), rtol=1e-6, atol=1e-7)
+    alg["adapt"]["test"]["avg_train_spk_emb"] = False
+    sysm.engine.load_params({"speaker_emb.model.weight": w}, strict=False)
+    sysm.on_test_start()
+    np.testing.assert_array_equal(sysm.engine.export("speaker_emb.model.weight"), w)
