@@ -355,6 +355,22 @@ def main():
                 "all_gemm": {"ms_per_meta_step": round(tot_ms, 2), "alg_tflop_per_meta_step": round(tot_fl / 1e12, 3),
                              "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
                              "per_kernel": {r[0]: {"launches": int(r[1]), "ms": round(r[2], 2), "tflop": round(r[3] / 1e12, 3)} for r in rows}}}
+    hbm = None
+    if rank == 0 and n == 1 and not args.no_roofline:
+        # the HBM-bound tail of the step, reported as achieved GB/s against the 8 TB/s HBM3E peak: fused clip + Adam
+        # (grad-norm reduction + update: 32 B per parameter) timed on its own with events on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            eng.outer_update(lr=1e-9, betas=tuple(trn["betas"]), eps=trn["eps"], weight_decay=trn["weight_decay"], max_norm=trn["grad_clip_thresh"])
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / reps
+        nbytes = 32.0 * eng.n_total
+        hbm = {"clip_adam": {"us": round(us, 1), "gbytes": round(nbytes / 1e9, 3), "achieved_GBps": round(nbytes / (us * 1e-6) / 1e9, 1), "peak_GBps": 8000.0,
+                             "frac": round(nbytes / (us * 1e-6) / 8e12, 3),
+                             "bytes_model": "per parameter: 4 (grad, norm pass) + 4 (grad) + 12 (theta, m, v read) + 12 (written)"}}
     cpu = None
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(dims, mods)
@@ -392,6 +408,8 @@ def main():
             line["baseline_c2"] = c2
         if roof is not None:
             line["roofline"] = roof
+        if hbm is not None:
+            line["hbm_bound_kernels"] = hbm
         if cpu is not None:
             line["cpu_baseline"] = cpu
             line["speedup_vs_cpu_baseline"] = round((args.steps / dt) / cpu["value"], 1)
