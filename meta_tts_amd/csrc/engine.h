@@ -874,6 +874,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         TS gw = Gd(w_off);
         g.C = gw.p; g.c_gs = gw.ts; g.ldc = k * cin;
         g.M = cout; g.N = k * cin;
+        g.K = maxM(p, s);  // upper bound of the per-task reduction length (the kernel reads the exact one through dimptr)
         g.flags = flags;
         gemm_launch(GEMM_TN, g, cout, k * cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, (long long)cout * p.tasks);
         if (b_off >= 0) colsum(ps, s, dy, cout, bias_mask, TS{nullptr, 0}, Gd(b_off));
