@@ -719,8 +719,8 @@ inline void gemm_batch_end(hipStream_t stream) {
     mp.n = (int)b.q.size();
     int max_groups = 0;
     double flops = 0.0, rows = 0.0;
-    // split-K for the long chains of an under-filled batch: a tile whose K-loop is longer than a third of the whole
-    // batch's per-CU work would finish last on its own (single-task ranks: the k=9 dgrad tile, 576 slices, beside a
+    // split-K for the long chains of an under-filled batch: a tile whose K-loop is longer than two thirds (1 / MTTS_SPLIT_RATIO,
+    // swept: 1.25-1.5 best) of the whole batch's per-CU work would finish last on its own (single-task ranks: the k=9 dgrad tile, 576 slices, beside a
     // batch that is worth ~590 slices per CU), so it is cut into S workgroups (rendezvous in splitk_combine)
     double work = 0.0;
     for (const GemmPending& p : b.q) work += std::ceil(p.rows / 64.0) * ((p.max_N + 63) / 64) * std::max(1, (p.g.K + 15) / 16);
@@ -737,8 +737,9 @@ inline void gemm_batch_end(hipStream_t stream) {
         const int tiles = ((p.max_M + 63) / 64) * ((p.max_N + 63) / 64);
         int S = 1;
         const int nch = (p.g.K + 15) / 16;
-        if (small_batch && !p.g.table && gemm_splitk_target() != 0 && nch > per_cu / 3.0) {
-            S = (int)std::min<double>(std::min<double>(std::ceil(nch / std::max(per_cu / 3.0, 1.0)), nch / 16), 8);
+        static const double ratio = [] { const char* e = getenv("MTTS_SPLIT_RATIO"); return e ? atof(e) : 1.5; }();
+        if (small_batch && !p.g.table && gemm_splitk_target() != 0 && nch > per_cu / ratio) {
+            S = (int)std::min<double>(std::min<double>(std::ceil(nch / std::max(per_cu / ratio, 1.0)), nch / 16), 8);
             const long long slots = (long long)tiles * p.groups;
             if (S >= 2 && ((ws_off + slots * S * 4096) > kSplitWsFloats || ctr_off + slots > kSplitCtrs)) S = 1;
             if (S >= 2) {
