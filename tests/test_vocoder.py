@@ -88,3 +88,26 @@ def test_full_generator_on_gpu_vs_oracle():
     wav2 = voc.mel2wav(mel, lens, mel_scale=1.0 / math.log(10.0))
     assert np.array_equal(wav, wav2)   # run-to-run identical
     voc.close()
+
+
+@pytest.mark.gpu
+def test_device_pointer_entry_matches_host_entry():
+    """mtts_vocoder_infer_device: mel and waveform stay in HBM (torch tensors only provide the memory)."""
+    import ctypes as C
+    import torch
+    sd = V.synthetic_state_dict(0)
+    voc = V.MelGAN(sd, max_B=2, max_T=64)
+    mel = _mel(4, 2, 48, 80)
+    lens = np.array([48, 31], np.int32)
+    ref = voc.mel2wav(mel, lens, mel_scale=0.5)
+    voc.set_stream(torch.cuda.current_stream().cuda_stream)
+    x = torch.from_numpy(np.ascontiguousarray(mel.transpose(0, 2, 1))).cuda()      # [B][T][n_mel]
+    wav = torch.zeros(2, 48 * voc.hop, device="cuda")
+    rc = voc.lib.mtts_vocoder_infer_device(voc.h, C.c_void_p(x.data_ptr()), 2, 48, lens.ctypes.data_as(C.c_void_p), C.c_float(0.5),
+                                           C.c_void_p(wav.data_ptr()))
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = wav.cpu().numpy()
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1, :31 * voc.hop], ref[1, :31 * voc.hop])
+    voc.close()
