@@ -105,6 +105,9 @@ int mtts_synthesize(mtts_handle* h, int slot, int use_fast_weights, int train_mo
 int mtts_get_durations(mtts_handle* h, int slot, int task, float* d_rounded, int64_t* mel_lens, int* t_cap);
 /* copy the outputs of task `task` to host: mel, mel_post [B][T_cap][n_mel] (T_cap = min(T_max, max_seq_len));
  * p, e, logd [B][S_max].  Any pointer may be NULL. */
+/* device view of the last forward's mel (postnet = 0) or mel_post (1) of one task: utterance b, frame t, channel c at
+ * mel_dev[b * utt_stride + t * n_mel + c], t < t_cap.  Valid until the next set_batches / forward on that slot. */
+int mtts_get_mel_device(mtts_handle* h, int slot, int task, int postnet, const float** mel_dev, int* t_cap, int64_t* utt_stride);
 int mtts_get_outputs(mtts_handle* h, int slot, int task, float* mel, float* mel_post, float* p, float* e, float* logd);
 int mtts_loss(mtts_handle* h, int slot, float* losses_host /* [n_tasks][6]: total, mel, postnet, pitch, energy, duration */);
 /* gradient of scale * total loss w.r.t. every parameter of the touched modules -> per-task gradient */
@@ -169,7 +172,9 @@ int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* x_or
  *   conv_out.b [1];  C0 = ngf << n_ratios.
  * infer: mel [B][T_max][n_mel] (host), mel_lens[b] frames valid, every value multiplied by mel_scale (the reference
  * passes mel / ln 10) -> wav [B][T_max * hop] floats in (-1, 1), the first mel_lens[b] * hop samples of a row written.
- * infer_device: same with device pointers (no copies, no synchronisation; runs on the vocoder's stream). */
+ * infer_device: same with device pointers (no copies, no synchronisation; runs on the vocoder's stream); mel_utt_stride =
+ * floats between consecutive utterances of mel_dev (0: T_max * n_mel) so that the engine's own mel buffer can be fed as it
+ * is (mtts_get_mel_device). */
 typedef struct mtts_vocoder mtts_vocoder;
 int mtts_vocoder_create(int n_mel, int ngf, int n_res, const int* ratios, int n_ratios, int device, int max_B, int max_T,
                         mtts_vocoder** out);
@@ -181,8 +186,8 @@ int mtts_vocoder_param_count(mtts_vocoder* h);
 int mtts_vocoder_param_info(mtts_vocoder* h, int index, char* name, int name_cap, int64_t* numel);
 int mtts_vocoder_load(mtts_vocoder* h, const char* name, const float* data, int64_t numel);
 int mtts_vocoder_infer(mtts_vocoder* h, const float* mel, int B, int T_max, const int* mel_lens, float mel_scale, float* wav);
-int mtts_vocoder_infer_device(mtts_vocoder* h, const float* mel_dev, int B, int T_max, const int* mel_lens, float mel_scale,
-                              float* wav_dev);
+int mtts_vocoder_infer_device(mtts_vocoder* h, const float* mel_dev, int64_t mel_utt_stride, int B, int T_max, const int* mel_lens,
+                              float mel_scale, float* wav_dev);
 
 #ifdef __cplusplus
 }

@@ -81,7 +81,8 @@ EXPORTS = {
     "mtts_vocoder_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64)]),
     "mtts_vocoder_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     "mtts_vocoder_infer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
-    "mtts_vocoder_infer_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
+    "mtts_vocoder_infer_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
+    "mtts_get_mel_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
 }
 
 _cache = {}

@@ -194,6 +194,19 @@ int mtts_get_outputs(mtts_handle* h, int slot, int task, float* mel, float* mel_
     return 0;
 }
 
+int mtts_get_mel_device(mtts_handle* h, int slot, int task, int postnet, const float** mel_dev, int* t_cap, int64_t* utt_stride) {
+    Engine& e = h->eng;
+    if (slot < 0 || slot > 1 || task < 0 || task >= e.plans[slot].tasks || !mel_dev) { e.set_error("bad slot/task"); return -1; }
+    const Engine::Plan& pl = e.plans[slot];
+    if (!pl.frames_ready) { e.set_error("no mel yet (run mtts_forward / mtts_synthesize first)"); return -1; }
+    const int T = pl.hTcap[task], nm = e.cfg.n_mel;
+    const auto& buf = postnet ? e.mel_post : e.mel;
+    *mel_dev = buf.p + task * buf.ts + (long long)G * nm;      // row(b, t) = G + b * (T + G) + t
+    if (t_cap) *t_cap = T;
+    if (utt_stride) *utt_stride = (int64_t)(T + G) * nm;
+    return 0;
+}
+
 static int copy_losses_impl(Engine& e, const float* dev, float* host, int n) {
     if (!host) return 0;
     if (hipStreamSynchronize(e.stream) != hipSuccess) return -1;
@@ -335,9 +348,9 @@ int mtts_vocoder_load(mtts_vocoder* h, const char* name, const float* data, int6
 int mtts_vocoder_infer(mtts_vocoder* h, const float* mel, int B, int T_max, const int* mel_lens, float mel_scale, float* wav) {
     return h->v.infer_host(mel, B, T_max, mel_lens, mel_scale, wav);
 }
-int mtts_vocoder_infer_device(mtts_vocoder* h, const float* mel_dev, int B, int T_max, const int* mel_lens, float mel_scale,
-                              float* wav_dev) {
-    return h->v.run(mel_dev, B, T_max, mel_lens, mel_scale, wav_dev, (long long)T_max * h->v.hop);
+int mtts_vocoder_infer_device(mtts_vocoder* h, const float* mel_dev, int64_t mel_utt_stride, int B, int T_max, const int* mel_lens,
+                              float mel_scale, float* wav_dev) {
+    return h->v.run(mel_dev, B, T_max, mel_lens, mel_scale, wav_dev, (long long)T_max * h->v.hop, (long long)mel_utt_stride);
 }
 
 }  // extern "C"

@@ -177,7 +177,8 @@ public:
     }
 
     // mel: device pointer [B][T_max][n_mel] (row-major, already scaled as the caller wants); wav: device [B][T_max * hop]
-    int run(const float* mel, int B, int T_max, const int* lens_host, float mel_scale, float* wav, long long wav_gs) {
+    // mel_gs: floats between consecutive utterances of `mel` (0: T_max * n_mel, i.e. a dense [B][T_max][n_mel] array)
+    int run(const float* mel, int B, int T_max, const int* lens_host, float mel_scale, float* wav, long long wav_gs, long long mel_gs = 0) {
         if (B < 1 || B > cap_B || T_max < 4 || T_max > cap_T) { set_error("vocoder batch exceeds capacity"); return -1; }
         for (int b = 0; b < B; ++b) if (lens_host[b] < 4 || lens_host[b] > T_max) { set_error("mel length out of range (need 4 <= len <= T_max)"); return -1; }
         VOC_CHECK(hipMemcpyAsync(lens_dev, lens_host, B * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -185,7 +186,7 @@ public:
         // conv_in: reflection pad 3 of the scaled mel, k=7 conv
         {
             MTTS_LAUNCH(pad_act_kernel, dim3((unsigned)((T_max + 6 + 3) / 4), 1, (unsigned)B), dim3(256), stream, (const int*)lens_dev, 1, mel,
-                        (long long)T_max * nm, arena + b_pad.off, b_pad.gs, nm, 3, 1.f, mel_scale, 1);
+                        mel_gs > 0 ? mel_gs : (long long)T_max * nm, arena + b_pad.off, b_pad.gs, nm, 3, 1.f, mel_scale, 1);
             gemm(arena + b_pad.off, b_pad.gs, nm, params + find("conv_in.w"), 7 * nm, 7 * nm, params + find("conv_in.b"), arena + b_x[0].off,
                  b_x[0].gs, ch(0), ch(0), B, T_max, 1, 0);
         }

@@ -198,6 +198,13 @@ class Engine:
         o["d_rounded"], o["mel_lens"] = d_rounded, mel_lens
         return o
 
+    def mel_device(self, slot: int = 0, task: int = 0, postnet: bool = True):
+        """(device pointer, T_cap, floats between utterances) of the last forward's mel / mel_post of one task — lets the
+        vocoder consume the synthesis in HBM (mtts_vocoder_infer_device) without a host round trip."""
+        ptr, t_cap, stride = C.c_void_p(), C.c_int(), C.c_int64()
+        self._ck(self.lib.mtts_get_mel_device(self.h, slot, task, int(postnet), C.byref(ptr), C.byref(t_cap), C.byref(stride)))
+        return int(ptr.value), int(t_cap.value), int(stride.value)
+
     def adapt(self, steps: int, inner_lr: float, reset: bool = True, fetch_losses: bool = True):
         if fetch_losses:
             s = np.empty((steps, self.n_tasks[0], 6), np.float32)

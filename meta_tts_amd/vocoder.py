@@ -148,6 +148,14 @@ class MelGAN:
             raise MttsError(self.lib.mtts_vocoder_last_error(self.h).decode())
         return wav
 
+    def mel2wav_device(self, mel_ptr: int, utt_stride: int, B: int, T: int, lengths, wav_ptr: int, mel_scale: float = 1.0):
+        """Device-to-device: mel at `mel_ptr` laid out [B][..][n_mel] with `utt_stride` floats between utterances (e.g.
+        Engine.mel_device()), waveform written to `wav_ptr` as [B][T * hop] floats; asynchronous on the vocoder's stream."""
+        lens = np.ascontiguousarray(lengths, np.int32)
+        if self.lib.mtts_vocoder_infer_device(self.h, C.c_void_p(mel_ptr), C.c_int64(utt_stride), B, T, lens.ctypes.data_as(C.c_void_p),
+                                              C.c_float(mel_scale), C.c_void_p(wav_ptr)) != 0:
+            raise MttsError(self.lib.mtts_vocoder_last_error(self.h).decode())
+
     def inverse(self, mel):                      # lightning/utils.py:16-18
         return self.mel2wav(mel)
 

@@ -103,7 +103,7 @@ def test_device_pointer_entry_matches_host_entry():
     voc.set_stream(torch.cuda.current_stream().cuda_stream)
     x = torch.from_numpy(np.ascontiguousarray(mel.transpose(0, 2, 1))).cuda()      # [B][T][n_mel]
     wav = torch.zeros(2, 48 * voc.hop, device="cuda")
-    rc = voc.lib.mtts_vocoder_infer_device(voc.h, C.c_void_p(x.data_ptr()), 2, 48, lens.ctypes.data_as(C.c_void_p), C.c_float(0.5),
+    rc = voc.lib.mtts_vocoder_infer_device(voc.h, C.c_void_p(x.data_ptr()), 0, 2, 48, lens.ctypes.data_as(C.c_void_p), C.c_float(0.5),
                                            C.c_void_p(wav.data_ptr()))
     assert rc == 0
     torch.cuda.synchronize()
@@ -111,3 +111,32 @@ def test_device_pointer_entry_matches_host_entry():
     np.testing.assert_array_equal(got[0], ref[0])
     np.testing.assert_array_equal(got[1, :31 * voc.hop], ref[1, :31 * voc.hop])
     voc.close()
+
+
+@pytest.mark.gpu
+def test_engine_mel_feeds_the_vocoder_in_hbm():
+    """mtts_get_mel_device -> mtts_vocoder_infer_device: the synthesised mel_post never leaves the GPU; same waveform as
+    downloading it and using the host entry."""
+    import torch
+    from meta_tts_amd import synth
+    from meta_tts_amd.config import ModelDims
+    from meta_tts_amd.engine import Engine
+    dims = ModelDims()
+    b = synth.make_batch(3, 2, speaker=4, s_range=(10, 20), d_range=(2, 6), first_len=16)
+    eng = Engine(dims, adapt_modules=[], max_tasks=1, max_B=2, max_S=20, max_T=int(b[8]))
+    eng.load_params(synth.make_params(dims, 0))
+    eng.set_batches(0, [b])
+    eng.forward(0, train=False)
+    out = eng.outputs(0, 0)
+    lens = np.asarray(b[7], np.int32)
+    voc = V.MelGAN(max_B=2, max_T=int(b[8]))
+    ref = voc.mel2wav(np.ascontiguousarray(out["mel_post"].transpose(0, 2, 1)), lens, mel_scale=0.4)
+    ptr, tcap, stride = eng.mel_device(0, 0, postnet=True)
+    assert tcap == int(b[8]) and stride > tcap * dims.n_mel
+    wav = torch.zeros(2, tcap * voc.hop, device="cuda")
+    voc.mel2wav_device(ptr, stride, 2, tcap, lens, wav.data_ptr(), mel_scale=0.4)
+    torch.cuda.synchronize()
+    got = wav.cpu().numpy()
+    for i in range(2):
+        np.testing.assert_array_equal(got[i, :lens[i] * voc.hop], ref[i, :lens[i] * voc.hop])
+    voc.close(); eng.close()
