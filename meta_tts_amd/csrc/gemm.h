@@ -70,6 +70,10 @@ struct GemmArgs {
     float act_slope = 0.2f;
     int flags = 0;
     int taps = 1, tap_k = 0x40000000, tap_bstride = 0;  // NN conv dgrad tap walk
+    // dilated taps of a K-contiguous A operand (NT / NN): k = tap * a_tap_k + kin reads row m + tap * a_tap_rows — a dilated
+    // Conv1d as ONE implicit GEMM (K = taps * C_in) instead of one accumulate pass per tap (vocoder.h).  K-slices must not
+    // straddle taps: a_tap_k % 32 == 0.
+    int a_tap_k = 0x40000000, a_tap_rows = 0;
     int swizzle = 0;                                     // XCD-aware tile order (xcd_group_remap; set by the launcher)
     // split-K (set by the launcher for under-filled grids): `splitk` workgroups share one output tile, each reducing a
     // contiguous run of K-chunks; partial tiles go to `ws`, the last workgroup to arrive (tile counter in `tile_ctr`) sums
@@ -331,7 +335,8 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
             if (A_KC) {
                 const int row = tid / KQ + RPP * i, gk = k0 + (tid % KQ) * 4;
                 const int gm = m0 + row;
-                areg[i] = (gm < M && gk < K4) ? ld4(A + (long long)gm * lda + gk) : zero4();
+                const int atap = k0 / g.a_tap_k;   // 0 unless the operand has dilated taps
+                areg[i] = (gm < M && gk < K4) ? ld4(A + ((long long)gm + (long long)atap * g.a_tap_rows) * lda + (gk - atap * g.a_tap_k)) : zero4();
             } else {
                 const int idx = tid + NTH * i, kk = idx / (BM / 4), c4 = idx % (BM / 4);
                 const int gk = k0 + kk, gc = m0 + c4 * 4;
@@ -603,7 +608,7 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
         tile = eff(128, eff128) >= eff(64, 1.0) ? 128 : 64;
     }
     GemmProfiler& prof0 = gemm_profiler();
-    if (gemm_numerics() >= 1 && tile < 1000 && !(g.taps > 1 && g.tap_k % 32 != 0)) {
+    if (gemm_numerics() >= 1 && tile < 1000 && !(g.taps > 1 && g.tap_k % 32 != 0) && g.a_tap_rows == 0) {  // (the split-bf16 kernels have no dilated-tap walk)
         hipEvent_t b0 = nullptr, b1 = nullptr;
         if (prof0.enabled) { b0 = prof0.get(); b1 = prof0.get(); hipEventRecord(b0, stream); }
         const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;

@@ -114,7 +114,8 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
         float* Bs = As + kGldsTile;
         if (is_full(c)) {
             const unsigned sa = lds_base + (unsigned)(st * kGldsStage) * 4u, sb = sa + (unsigned)kGldsTile * 4u;
-            const float* Ab = A_KC ? A + k0 : A + (long long)k0 * lda;
+            const int atap = A_KC ? k0 / g.a_tap_k : 0;   // dilated taps of a K-contiguous A operand (gemm.h)
+            const float* Ab = A_KC ? A + (long long)atap * g.a_tap_rows * lda + (k0 - atap * g.a_tap_k) : A + (long long)k0 * lda;
             const float* Bb;
             if (B_KC) Bb = B + k0;
             else {
@@ -136,7 +137,8 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
                     if (A_KC) {
                         const int r = idx >> 3, pos = idx & 7, kq = pos ^ ((r >> 1) & 7), gk = k0 + 4 * kq;
                         if (m0 + r < M) {
-                            const float* p = A + (long long)(m0 + r) * lda + gk;
+                            const int atap = k0 / g.a_tap_k;
+                            const float* p = A + ((long long)(m0 + r) + (long long)atap * g.a_tap_rows) * lda + (gk - atap * g.a_tap_k);
                             if (gk + 3 < K) v = ld4(p);
                             else { if (gk < K) v.x = p[0]; if (gk + 1 < K) v.y = p[1]; if (gk + 2 < K) v.z = p[2]; }
                         }

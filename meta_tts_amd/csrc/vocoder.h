@@ -15,7 +15,8 @@
 // MI355X mapping: activations are channels-last row matrices [time][C] per utterance (group = utterance, per-group row
 // count through GemmArgs::dimptr), so
 //   * Conv1d k (dilation 1) is the implicit GEMM over overlapping rows of engine.h (K = k*C_in, A rows contiguous);
-//   * a dilated k=3 conv is three accumulate-GEMMs over row-shifted views (K = C_in each);
+//   * a dilated k=3 conv is ONE implicit GEMM too: the K-loop walks the taps and shifts the A row by the dilation
+//     (GemmArgs::a_tap_k / a_tap_rows; channel counts that are not a multiple of 32 fall back to three accumulate passes);
 //   * ConvTranspose1d (k = 2r, stride r) is r polyphase GEMMs: output o = q*r + ph - p reads exactly x[q-1] and x[q]
 //     -> A row = the contiguous pair [x[q-1] | x[q]] (K = 2*C_in), B = the phase's [C_out][2*C_in] weight image, C rows
 //     interleaved through ldc = r*C_out; the r phases are independent and go out as multi-problem launches;
@@ -161,8 +162,9 @@ public:
 
     // one grouped GEMM: C[z][M_z, N] (+)= A[z][M_z, K] * W[N, K]^T + bias; M_z = lens[z] * len_mult
     void gemm(const float* A, long long a_gs, int lda, const float* W, int ldb, int K, const float* bias, float* C, long long c_gs,
-              int ldc, int N, int B, int max_rows, int len_mult, int flags) {
+              int ldc, int N, int B, int max_rows, int len_mult, int flags, int a_tap_k = 0, int a_tap_rows = 0) {
         GemmArgs g;
+        if (a_tap_k > 0) { g.a_tap_k = a_tap_k; g.a_tap_rows = a_tap_rows; }
         g.A = A; g.a_gs = a_gs; g.lda = lda;
         g.B = W; g.b_gs = 0; g.ldb = ldb;
         g.C = C; g.c_gs = c_gs; g.ldc = ldc;
@@ -218,6 +220,10 @@ public:
                 float* h = arena + b_h.off;
                 if (d == 1) {
                     gemm(arena + b_pad.off, b_pad.gs, cout, w1, 3 * cout, 3 * cout, params + find(pre + ".b1"), h, b_h.gs, cout, cout, B, rows, mult, GEMM_LRELU);
+                } else if (cout % 32 == 0) {
+                    // dilated taps inside the K-loop: k = t * C + c reads row m + t * d
+                    gemm(arena + b_pad.off, b_pad.gs, cout, w1, 3 * cout, 3 * cout, params + find(pre + ".b1"), h, b_h.gs, cout, cout, B, rows, mult,
+                         GEMM_LRELU, cout, d);
                 } else {
                     for (int t = 0; t < 3; ++t)
                         gemm(arena + b_pad.off + (long long)t * d * cout, b_pad.gs, cout, w1 + (long long)t * cout, 3 * cout, cout,
