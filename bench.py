@@ -43,19 +43,80 @@ def noam_lr(step, d_model=256, warm=4000, anneal=(300000, 400000, 500000), rate=
     return d_model ** -0.5 * lr
 
 
+def spawn_command(n_gpus, argv, port=None):
+    """The command `bench.py --gpus N` re-executes itself under when it was started as ONE process: one rank per GPU through
+    torch.distributed.run, rendezvous on 127.0.0.1 (the reference's launcher, pl.Trainer(strategy="ddp"), main.py:30-38, also
+    spawns its own ranks)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_self_launch(args):
+    """--gpus N > 1 without a launcher (WORLD_SIZE unset): spawn the N ranks and relay rank 0's JSON line.  Returns the child's
+    exit code, or None when this process is itself a rank (or N == 1)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL between the ranks
+    return subprocess.call(spawn_command(args.gpus, sys.argv[1:]), env=env)
+
+
+def spawn_selftest(args):
+    """CPU-only check of the launch plumbing (tests/test_bench_spawn.py): every rank joins a gloo group, one all_reduce, rank 0
+    prints a line whose n_gpus is the group's real size.  No engine, no timing — not a bench result."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"refusing to report: {world} rank(s) running but --gpus {args.gpus}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.ones(4) * (rank + 1)
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"selftest": "spawn", "n_gpus": world, "allreduce_sum": float(t[0]), "tasks_per_rank": META_BATCH // world}))
+
+
 def cpu_baseline(dims, mods, budget_s=25.0):
     """Oracle (oracle/fs2_oracle.py) on the host cores: whole first-order tasks of the same workload until
     ~budget_s of CPU time is spent; meta-steps/s = 1 / (8 * mean task time)."""
     import torch
     from meta_tts_amd import synth
     from oracle import fs2_oracle as O
-    cores = torch.get_num_threads()
+    host_cores = os.cpu_count() or torch.get_num_threads()
     params = {k: torch.from_numpy(v.copy()) for k, v in synth.make_params(dims, 0).items()}
     for k, v in params.items():
         if not k.endswith(("position_enc", "pitch_bins", "energy_bins")):
             v.requires_grad_(True)
     buffers = {k: torch.from_numpy(v.copy()) for k, v in synth.make_buffers(dims).items()}
     names = [k for k, v in params.items() if v.requires_grad]
+    # intra-op thread sweep on ONE inner step (support forward + backward of task 0): torch's default (= every hardware thread)
+    # is not the fastest setting for these GEMM sizes; the whole-task timing below runs at the best count found
+    sup0, qry0 = synth.make_task(0)
+    tb0 = O.to_torch_batch(sup0)
+    sweep = {}
+    for nthr in sorted({t for t in (8, 16, 32, 64, 128, host_cores) if t <= host_cores}):
+        torch.set_num_threads(nthr)
+        best = None
+        for rep in range(2):
+            t0 = time.perf_counter()
+            lo = O.fs2_loss(tb0, O.fs2_forward(params, buffers, *tb0[2:], n_head=(dims.enc_heads, dims.dec_heads), training=True))
+            torch.autograd.grad(lo[0], [params[n] for n in names], allow_unused=True)
+            dt1 = time.perf_counter() - t0
+            best = dt1 if best is None else min(best, dt1)
+        sweep[nthr] = round(best, 3)
+    cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
     times = []
     t_all = time.perf_counter()
     j = 0
@@ -69,8 +130,9 @@ def cpu_baseline(dims, mods, budget_s=25.0):
         j += 1
     mean_t = float(np.mean(times))
     return {"value": 1.0 / (META_BATCH * mean_t), "unit": "meta-steps/s", "cores": int(cores), "kind": "port",
-            "sample": f"{len(times)} of {META_BATCH} tasks (5 inner steps + query fwd/bwd each, first-order, fp32 torch-CPU oracle); "
-                      f"{mean_t:.2f} s/task, clip+Adam excluded (<1%)"}
+            "host_cores": int(host_cores), "thread_sweep_s_per_inner_step": {str(k): v for k, v in sweep.items()},
+            "sample": f"{len(times)} of {META_BATCH} tasks (5 inner steps + query fwd/bwd each, first-order, fp32 torch-CPU oracle) at the best of the "
+                      f"swept intra-op thread counts ({cores}); {mean_t:.2f} s/task, clip+Adam excluded (<1%)"}
 
 
 def inference_leg(dims, mods, device, iters=5):
@@ -154,9 +216,8 @@ def baseline_c2_leg(dims, device, noam_lr, trn, iters=8):
     fp32 mode (the parity numerics) and in the config's own bf16-operand mode; the bf16 line carries its mel L1 against the
     fp32 forward of the same weights (eval mode) so the precision cost is visible next to the speed."""
     import torch
-    from meta_tts_amd import _lib, synth
+    from meta_tts_amd import synth
     from meta_tts_amd.engine import Engine
-    lib = _lib.load()
     batch = synth.make_batch(0, 16)
     eng = Engine(dims, adapt_modules=(), max_tasks=1, max_B=16, max_S=80, max_T=int(batch[8]), device=device)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -166,12 +227,12 @@ def baseline_c2_leg(dims, device, noam_lr, trn, iters=8):
     lens = np.asarray(batch[7])
     evals = {}
     for mode in (0, 2):  # eval-mode forwards of the untouched weights / BatchNorm buffers, before any training step
-        lib.mtts_set_numerics(mode)
+        eng.set_numerics(mode)
         eng.forward(0, train=False)
         evals[mode] = eng.outputs(0, 0)["mel_post"]
     res = {"workload": "C2: algorithm=baseline, batch 16 (sum T = %d frames), fwd + bwd + clip + Adam" % frames}
     for name, mode in (("fp32", 0), ("bf16", 2)):
-        lib.mtts_set_numerics(mode)
+        eng.set_numerics(mode)
         eng.load_params(synth.make_params(dims, 0))
         eng.reset_optimizer()
         l1 = float(np.mean([np.abs(evals[mode][b, :lens[b]] - evals[0][b, :lens[b]]).mean() for b in range(16)]))
@@ -186,9 +247,51 @@ def baseline_c2_leg(dims, device, noam_lr, trn, iters=8):
         dt = (time.perf_counter() - t0) / iters
         res[name] = {"steps_per_sec": round(1.0 / dt, 3), "ms_per_step": round(1e3 * dt, 2), "frames_per_sec": round(frames / dt, 1),
                      "mel_l1_vs_fp32_eval": l1}
-    lib.mtts_set_numerics(0)
     eng.close()
     return res
+
+
+def gemm_profile(eng, run):
+    """Run `run()` once with every GEMM launch of this handle timed by HIP events on its stream; rows of
+    (kernel, launches, ms, algorithmic flops, algorithmic bytes)."""
+    import torch
+    eng.profile_gemm(True)
+    run()
+    torch.cuda.synchronize()
+    rep = eng.profile_report()
+    eng.profile_gemm(False)
+    return [(KERNEL_NAMES[k], rep[k][0], rep[k][1], rep[k][2], rep[k][3]) for k in range(7)]
+
+
+def roofline_of(rows, pmc_key=None):
+    dom = max(rows, key=lambda r: r[2])
+    tot_ms = sum(r[2] for r in rows)
+    tot_fl = sum(r[3] for r in rows)
+    ach = dom[3] / (dom[2] * 1e-3) / 1e12 if dom[2] > 0 else 0.0
+    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read in-process, so this is the figure of the
+    # committed separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (profiles/).
+    traffic, traffic_src, mfma_busy = None, None, None
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("r02_pmc_hbm.json", "r01_pmc_hbm.json"):
+        pmc_path = os.path.join(here, "profiles", name)
+        if pmc_key is not None and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                k = json.load(f).get(pmc_key, {}).get(dom[0])
+            if k:
+                traffic, traffic_src, mfma_busy = k.get("hbm_bytes_per_launch"), "profiles/" + name, k.get("mfma_busy_frac")
+                break
+    launches = max(dom[1], 1)
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+            "alg_bytes_per_launch": round(dom[4] / launches), "traffic_over_alg_bytes": round(traffic / (dom[4] / launches), 2) if (traffic and dom[4] > 0) else None,
+            "mfma_pipe_busy_frac_pmc": mfma_busy, "kernel": dom[0],
+            "launches": int(dom[1]), "avg_launch_us": round(1e3 * dom[2] / launches, 2),
+            "alg_gflop_per_launch": round(dom[3] / launches / 1e9, 3),
+            "all_gemm": {"ms_per_meta_step": round(tot_ms, 2), "alg_tflop_per_meta_step": round(tot_fl / 1e12, 3),
+                         "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
+                         "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4) if tot_ms > 0 else 0.0,
+                         "per_kernel": {r[0]: {"launches": int(r[1]), "ms": round(r[2], 2), "tflop": round(r[3] / 1e12, 3),
+                                               "alg_gbytes": round(r[4] / 1e9, 3)} for r in rows}}}
 
 
 def main():
@@ -207,30 +310,44 @@ def main():
                     help="contraction numerics of the timed meta-step: exact fp32 MFMA (default, parity mode) or split-bf16")
     ap.add_argument("--no-bf16x3-leg", action="store_true", help="skip the extra split-bf16 measurement")
     ap.add_argument("--no-dropout", action="store_true", help="parity configuration (dropout = identity) instead of train-mode dropout")
+    ap.add_argument("--resident-batches", action="store_true",
+                    help="upload the batches once before the timed region instead of every step (round-1 behaviour; the default re-ingests the "
+                         "host batches inside every timed step, as training does)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic: run ONE process with the task share of rank 0 of this many ranks (no collective) to see the per-rank "
                          "step time of an N-GPU run on a 1-GPU box; the JSON line is marked emulated and is not a bench result")
+    ap.add_argument("--selftest-spawn", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    rc = maybe_self_launch(args)
+    if rc is not None:
+        raise SystemExit(rc)
+    if args.selftest_spawn:
+        return spawn_selftest(args)
 
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
-    from meta_tts_amd import _lib, synth
+    from meta_tts_amd import synth
     from meta_tts_amd.config import ModelDims, default_algorithm_config, default_train_config
     from meta_tts_amd.engine import Engine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if world != args.gpus:  # never print an n_gpus that is not what was asked for
+        raise SystemExit(f"bench.py: {world} rank(s) running but --gpus {args.gpus} requested")
     n = world
     assert META_BATCH % n == 0, "the 8-task meta-batch must split evenly over the ranks"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if torch.cuda.device_count() < n:
+        raise SystemExit(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     if n > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=n)
+        assert dist.get_world_size() == n
     if rank == 0:
         ge.build_device()
     if n > 1:
@@ -248,80 +365,81 @@ def main():
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.load_params(synth.make_params(dims, 0))
     eng.set_dropout(not args.no_dropout, 1234 + rank)  # train-mode dropout as in the reference's inner/outer loop (per-rank stream)
-    eng.set_batches(0, [t[0] for t in tasks])
-    eng.set_batches(1, [t[1] for t in tasks], spk_from=[t[0] for t in tasks], average_spk=True)
+    sup_b, qry_b = [t[0] for t in tasks], [t[1] for t in tasks]
+
+    def ingest():
+        eng.set_batches(0, sup_b)
+        eng.set_batches(1, qry_b, spk_from=sup_b, average_spk=True)
+
+    ingest()
     outer = torch.as_tensor(eng.outer_grad_view(), device=f"cuda:{local_rank}") if n > 1 else None
 
     step_no = [0]
-    lib0 = _lib.load()
-    lib0.mtts_set_numerics(1 if args.numerics == "bf16x3" else 0)
+    eng.set_numerics(1 if args.numerics == "bf16x3" else 0)
+    ar_events = []
 
-    def meta_step(order=None):
+    def meta_step(order=None, timed_ar=False):
+        if not args.resident_batches:
+            ingest()  # host 12-tuples -> HBM + row-space plans, every step (what PL's batch transfer + collate hand-off cost)
         eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=((order or args.order) == 2), fetch_losses=False)
         if n > 1:
+            if timed_ar:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.all_reduce(outer, op=dist.ReduceOp.SUM)
+            if timed_ar:
+                e1.record()
+                ar_events.append((e0, e1))
         eng.outer_update(lr=noam_lr(step_no[0], dims.d_model, trn["warm_up_step"], trn["anneal_steps"], trn["anneal_rate"]),
                          betas=tuple(trn["betas"]), eps=trn["eps"], weight_decay=trn["weight_decay"],
                          max_norm=trn["grad_clip_thresh"])
         step_no[0] += 1
 
+    def timed(k, order=None, timed_ar=False):
+        torch.cuda.synchronize()
+        if n > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            meta_step(order, timed_ar)
+        torch.cuda.synchronize()
+        if n > 1:
+            dist.barrier()
+        d = time.perf_counter() - t0
+        if n > 1:
+            tt = torch.tensor([d], device=f"cuda:{local_rank}", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = float(tt.item())
+        return d
+
     for _ in range(args.warmup):
         meta_step()
+    dt = timed(args.steps, timed_ar=True)
+    ar_ms = None
+    if ar_events:
+        ar_ms = float(np.mean([a.elapsed_time(b) for a, b in ar_events]))  # events on the stream RCCL was enqueued on (torch's current stream)
+    # cost of the per-step ingestion alone (host -> HBM + plans), for the record
     torch.cuda.synchronize()
-    if n > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        meta_step()
+    t_in = time.perf_counter()
+    for _ in range(3):
+        ingest()
     torch.cuda.synchronize()
-    if n > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if n > 1:
-        tt = torch.tensor([dt], device=f"cuda:{local_rank}", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    ingest_ms = 1e3 * (time.perf_counter() - t_in) / 3
     so = None
     if args.order == 1 and not args.no_second_order:
         # the same meta-step in the reference's training mode (second-order, config C4 per-GPU work), all ranks
         meta_step(2)
-        torch.cuda.synchronize()
-        if n > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
         so_steps = max(1, min(args.steps, 3))
-        for _ in range(so_steps):
-            meta_step(2)
-        torch.cuda.synchronize()
-        if n > 1:
-            dist.barrier()
-        dso = time.perf_counter() - t1
-        if n > 1:
-            tt = torch.tensor([dso], device=f"cuda:{local_rank}", dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dso = float(tt.item())
+        dso = timed(so_steps, 2)
         so = {"value": round(so_steps / dso, 4), "unit": "meta-steps/s", "ms_per_step": round(1e3 * dso / so_steps, 2), "steps": so_steps,
               "workload": "same 8-task meta-step, second-order MAML (Hessian-vector recursion through the 5 inner steps)"}
     b16 = None
     if args.numerics == "fp32" and not args.no_bf16x3_leg:
         # same first-order meta-step with the split-bf16 contraction numerics (3 bf16 MFMAs per product)
-        lib0.mtts_set_numerics(1)
+        eng.set_numerics(1)
         meta_step(1)
-        torch.cuda.synchronize()
-        if n > 1:
-            dist.barrier()
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            meta_step(1)
-        torch.cuda.synchronize()
-        if n > 1:
-            dist.barrier()
-        d16 = time.perf_counter() - t2
-        lib0.mtts_set_numerics(0)
-        if n > 1:
-            tt = torch.tensor([d16], device=f"cuda:{local_rank}", dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            d16 = float(tt.item())
+        d16 = timed(args.steps, 1)
+        eng.set_numerics(0)
         b16 = {"value": round(args.steps / d16, 4), "unit": "meta-steps/s", "ms_per_step": round(1e3 * d16 / args.steps, 2),
                "numerics": "fp32 operands split into 2 x bf16, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; "
                            "mel L1 vs reference 1.0e-5 in eval mode (gate 1e-4), 1.6e-4 with train-mode BatchNorm"}
@@ -330,35 +448,15 @@ def main():
     if rank == 0:
         q_losses, _ = eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, fetch_losses=True)
     if rank == 0 and n == 1 and not args.no_roofline:
-        lib = _lib.load()
-        import ctypes as C
-        lib.mtts_profile_gemm(1)
-        eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, fetch_losses=False)
-        torch.cuda.synchronize()
-        rep = (C.c_double * 21)()
-        lib.mtts_profile_report(rep)
-        lib.mtts_profile_gemm(0)
-        rows = [(KERNEL_NAMES[k], rep[3 * k], rep[3 * k + 1], rep[3 * k + 2]) for k in range(7)]
-        dom = max(rows, key=lambda r: r[2])
-        tot_ms = sum(r[2] for r in rows)
-        tot_fl = sum(r[3] for r in rows)
-        ach = dom[3] / (dom[2] * 1e-3) / 1e12 if dom[2] > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read in-process, so this is the figure of the
-        # committed separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (profiles/).
-        traffic, traffic_src, mfma_busy = None, None, None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm.json")
-        if os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                k = json.load(f)["kernels"].get(dom[0])
-            if k:
-                traffic, traffic_src, mfma_busy = k.get("hbm_bytes_per_launch"), "profiles/r01_pmc_hbm.json", k.get("mfma_busy_frac")
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "mfma_pipe_busy_frac_pmc": mfma_busy, "kernel": dom[0],
-                "launches": int(dom[1]), "avg_launch_us": round(1e3 * dom[2] / max(dom[1], 1), 2),
-                "alg_gflop_per_launch": round(dom[3] / max(dom[1], 1) / 1e9, 3),
-                "all_gemm": {"ms_per_meta_step": round(tot_ms, 2), "alg_tflop_per_meta_step": round(tot_fl / 1e12, 3),
-                             "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
-                             "per_kernel": {r[0]: {"launches": int(r[1]), "ms": round(r[2], 2), "tflop": round(r[3] / 1e12, 3)} for r in rows}}}
+        rows = gemm_profile(eng, lambda: eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=(args.order == 2), fetch_losses=False))
+        roof = roofline_of(rows, "kernels")
+        if so is not None:
+            rows2 = gemm_profile(eng, lambda: eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=True, fetch_losses=False))
+            r2 = roofline_of(rows2, "kernels_second_order")
+            so["roofline"] = {k: r2[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launches", "avg_launch_us", "alg_gflop_per_launch",
+                                                 "alg_bytes_per_launch", "traffic", "traffic_source")}
+            so["roofline"]["all_gemm"] = {k: r2["all_gemm"][k] for k in ("ms_per_meta_step", "alg_tflop_per_meta_step", "achieved", "frac")}
+            so["whole_step_tflops"] = round(r2["all_gemm"]["alg_tflop_per_meta_step"] / (so["ms_per_step"] * 1e-3), 2)
     hbm = None
     if rank == 0 and n == 1 and not args.no_roofline:
         # the HBM-bound tail of the step, reported as achieved GB/s against the 8 TB/s HBM3E peak: fused clip + Adam
@@ -397,8 +495,12 @@ def main():
                 "config": {"workload": ("C3: Meta-TTS MAML first-order" if args.order == 1 else "C4-style: Meta-TTS MAML second-order") + " (algorithm=meta_emb_vad, inner=5, meta-batch=8 tasks x (5 support + 5 query utts)), "
                                        "FastSpeech2 base.yaml, outer mean + clip(1.0) + Adam/Noam", "meta_batch": META_BATCH,
                            "tasks_per_gpu": META_BATCH // n, "inner_steps": INNER_STEPS, "order": "first" if args.order == 1 else "second", "parallelism": f"task-dp{n}",
-                           "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.numerics == "fp32" else "bf16x3 (split-fp32 on v_mfma_f32_32x32x16_bf16)", "dropout": "identity (parity config)" if args.no_dropout else "on (0.2 / 0.5 / 0.5, counter-based masks)"},
+                           "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.numerics == "fp32" else "bf16x3 (split-fp32 on v_mfma_f32_32x32x16_bf16)", "dropout": "identity (parity config)" if args.no_dropout else "on (0.2 / 0.5 / 0.5, counter-based masks)",
+                           "batch_ingestion": "resident (uploaded once before the timed region)" if args.resident_batches else "inside every timed step (host 12-tuples -> HBM + plans)"},
                 **({"emulated_world": part, "note": "diagnostic: rank-0 share of an emulated multi-rank run, no collective"} if part != n else {}),
+                "batch_ingest_ms_per_step": round(ingest_ms, 3),
+                "rccl_ranks": n if n > 1 else None, "allreduce_ms_per_step": round(ar_ms, 3) if ar_ms is not None else None,
+                "allreduce_payload_mbytes": round(4e-6 * eng.n_total, 1) if n > 1 else None,
                 "query_total_loss_mean": round(float(q_losses[:, 0].mean()), 5) if q_losses is not None else None}
         if so is not None:
             line["second_order"] = so

@@ -9,7 +9,9 @@
  * mtts_create for the stated capacities; no allocation afterwards).  All work is enqueued on the
  * handle's HIP stream (mtts_set_stream) and is asynchronous w.r.t. the host unless a function
  * copies results to a host pointer, in which case it synchronises that stream.  A handle must not
- * be used from two host threads at once.  "host" pointers are host memory, "dev" pointers device.
+ * be used from two host threads at once, but DIFFERENT handles share no mutable state (launch queue,
+ * profiler, split-K workspace and numerics mode are per handle) and may be driven from different host
+ * threads concurrently.  "host" pointers are host memory, "dev" pointers device.
  */
 #ifndef MTTS_H
 #define MTTS_H
@@ -139,23 +141,25 @@ int mtts_outer_update(mtts_handle* h, const float* grad_dev, float lr, float bet
                       float weight_decay, float max_norm, float* grad_norm_host);
 int mtts_reset_optimizer(mtts_handle* h);
 
-/* ---- numerics of the contraction kernels (process-wide).  0 (default): exact fp32 MFMA, the parity reference.
+/* ---- numerics of the contraction kernels of this handle.  0 (default): exact fp32 MFMA, the parity reference.
  * 1: "bf16x3" — fp32 operands split into two bf16 (16 mantissa bits) at LDS-staging time, three bf16 MFMAs per
  * product, fp32 accumulation: ~1e-5 relative error per contraction, still inside the 1e-4 mel-L1 gate (tests), at
  * up to 5.3x the fp32-MFMA rate.  2: plain bf16 operands (one bf16 MFMA per product, fp32 accumulation) — the numerics of
  * BASELINE config C2; outside the 1e-4 gate, throughput mode only.  Inputs, outputs, parameters and every non-GEMM
  * kernel stay fp32. */
-int mtts_set_numerics(int mode);
+int mtts_set_numerics(mtts_handle* h, int mode);
 
-/* ---- measurement: per-launch HIP-event timing of the GEMM kernel family on the launch stream.
- * report: out[kernel][3] = {launches, total ms, total algorithmic flops}, 7 kernels: form*2 + (tile==128) with
- * form 0 NT / 1 NN / 2 TN, and 6 = the multi-problem launch (several independent products in one grid).  (bench.py roofline leg) */
-int mtts_profile_gemm(int enable);
-int mtts_profile_report(double* out21);
+/* ---- measurement: per-launch HIP-event timing of this handle's GEMM launches on its stream.
+ * report: out[kernel][4] = {launches, total ms, total algorithmic flops, total algorithmic bytes (every operand and the output
+ * moved once, fp32)}, 7 kernels: form*2 + (tile==128) with form 0 NT / 1 NN / 2 TN, and 6 = the multi-problem launch
+ * (several independent products in one grid).  (bench.py roofline leg) */
+int mtts_profile_gemm(mtts_handle* h, int enable);
+int mtts_profile_report(mtts_handle* h, double* out28);
 
 /* ---- kernel-level entry points (parity tests; dev pointers; stream may be NULL) ----------------
  * form 0: C[M,N] = alpha*A[M,K]*B[N,K]^T + bias   1: C = A[M,K]*B[K,N]   2: C[M,N] = A[K,M]^T*B[K,N]
- * flags bit0 ReLU, bit1 accumulate; tile 0 (auto) / 64 / 128, +1000 = software-pipelined variant */
+ * flags bit0 ReLU, bit1 accumulate, bits 8-9 contraction numerics of this call (0 fp32, 1 bf16x3, 2 bf16);
+ * tile 0 (auto) / 64 / 128, +1000 = software-pipelined variant */
 int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, float alpha, int flags, int tile, void* hip_stream);
 /* Conv1d over one zero-guarded sequence, channels-last: x [L][Cin] with >= k/2 zero rows before and

@@ -108,6 +108,7 @@ public:
         bool has_targets = false;
         std::vector<long long> texts, src_lens, mel_lens, durations;
         std::vector<float> pitches, energies;
+        std::vector<float> d_rounded;  // free-running only: clamp(round(exp(logd) - 1) * d_control, 0) as the reference returns it (not truncated)
         const float* mels = nullptr;
         std::vector<float> mels_keep;  // own copy, only when T_max > max_seq_len (the plan may be rebuilt untruncated, see retarget)
         std::vector<int> spk_ids;
@@ -166,10 +167,12 @@ public:
     size_t arena_bytes = 0;
 
     struct Pass;
+    GemmCtx gx;  // this handle's launcher state: batching queue, profiler, split-K workspace, numerics mode (gemm.h)
 struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.h)
+    GemmCtx& cx;
     hipStream_t s;
-    explicit GemmBatchScope(hipStream_t st) : s(st) { gemm_batch_begin(); }
-    ~GemmBatchScope() { gemm_batch_end(s); }
+    GemmBatchScope(GemmCtx& c, hipStream_t st) : cx(c), s(st) { gemm_batch_begin(cx); }
+    ~GemmBatchScope() { gemm_batch_end(cx, s); }
 };
     // dropout (off by default: parity runs patch it to identity)
     bool dropout_on = false;
@@ -439,6 +442,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         HIP_CHECK(hipMemset(outer, 0, n_total * sizeof(float)));
         HIP_CHECK(hipMemset(grad, 0, (size_t)n_total * cap_tasks * sizeof(float)));
         fast_cur = fast; grad_dst = grad;
+        if (gx.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace)"); return -1; }
         HIP_CHECK(hipMalloc((void**)&norm_partial, 1024 * sizeof(float)));
         HIP_CHECK(hipMalloc((void**)&norm_out, 4 * sizeof(float)));
         // frozen tables: sinusoid positions (Models.py:10-30, float64 math), linear bins
@@ -500,6 +504,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             if (p) hipFree(p);
         for (float* p : bn_rm) hipFree(p);
         for (float* p : bn_rv) hipFree(p);
+        gx.release();
         if (arena) hipFree(arena);
         if (arena_so) hipFree(arena_so);
         if (hv) hipFree(hv);
@@ -597,6 +602,11 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             in.src_lens.assign(b.src_lens, b.src_lens + b.B);
             for (int i = 0; i < b.B; ++i)
                 if (in.src_lens[i] < 1 || in.src_lens[i] > b.S_max) { set_error("src_len out of range"); return -1; }
+            for (int i = 0; i < b.B; ++i)  // phoneme ids index the embedding table on the device: reject what nn.Embedding would
+                for (long long s2 = 0; s2 < in.src_lens[i]; ++s2) {
+                    const long long tk = in.texts[(size_t)i * b.S_max + s2];
+                    if (tk < 0 || tk >= cfg.vocab) { set_error("phoneme token id out of range"); return -1; }
+                }
             if (in.has_targets) {
                 if (b.T_max < 1 || b.T_max > cap_T) { set_error("batch exceeds engine capacity (T_max)"); return -1; }
                 in.pitches.assign(b.pitches, b.pitches + BS);
@@ -845,7 +855,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         g.flags = flags;
         g.rowmask = rowmask; g.rowmask_gs = row_ts(s);
         if (relu_ref.p) { g.relu_ref = relu_ref.p; g.relu_ref_gs = relu_ref.ts; g.ld_relu = cout; }
-        gemm_launch(GEMM_NT, g, maxM(p, s), cout, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s));
+        gemm_launch(gx, GEMM_NT, g, maxM(p, s), cout, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s),
+                    4.0 * (alg_rows(p, s) * (cin + cout) + (double)p.tasks * cout * k * cin));
     }
     // dX[M,Cin] (+)= sum_taps dY[M +- tap, Cout] * W  (conv dgrad over the same [Cout][k][Cin] image)
     void conv_dgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS w, int cin, TS dx, int flags,
@@ -861,7 +872,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         g.flags = flags;
         g.rowmask = rowmask; g.rowmask_gs = row_ts(s);
         if (relu_ref.p) { g.relu_ref = relu_ref.p; g.relu_ref_gs = relu_ref.ts; g.ld_relu = cin; }
-        gemm_launch(GEMM_NN, g, maxM(p, s), cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s));
+        gemm_launch(gx, GEMM_NN, g, maxM(p, s), cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s),
+                    4.0 * (alg_rows(p, s) * (cin + cout) + (double)p.tasks * cout * k * cin));
     }
     // dW[Cout][k*Cin] = dY^T * conv_k(X), db = colsum(dY)
     void conv_wgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS x, int cin, long long w_off, long long b_off,
@@ -876,7 +888,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         g.M = cout; g.N = k * cin;
         g.K = maxM(p, s);  // upper bound of the per-task reduction length (the kernel reads the exact one through dimptr)
         g.flags = flags;
-        gemm_launch(GEMM_TN, g, cout, k * cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, (long long)cout * p.tasks);
+        gemm_launch(gx, GEMM_TN, g, cout, k * cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, (long long)cout * p.tasks,
+                    4.0 * (alg_rows(p, s) * (cin + cout) + (double)p.tasks * cout * k * cin));
         if (b_off >= 0) colsum(ps, s, dy, cout, bias_mask, TS{nullptr, 0}, Gd(b_off));
     }
     // two-stage deterministic column reduction (rowops.h colpart/colfinal)
@@ -935,8 +948,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         int mM = L, mN = L;
         if (which == TAB_PV || which == TAB_DV || which == TAB_DQ || which == TAB_DK) mN = dk;
         g.K = (which == TAB_QK || which == TAB_DP) ? dk : L;  // cost hint for launch batching (the table carries the real K)
-        gemm_launch(form, g, mM, mN, groups, stream, 0, 2.0 * ((s == SP_P) ? p.sum_attn_p : p.sum_attn_f) * dk,
-                    (s == SP_P) ? p.sumLp : p.sumLf);
+        // per (sequence, head): two L x dk operands and one L x L matrix, each moved once
+        const double sumL2 = (s == SP_P) ? p.sum_attn_p : p.sum_attn_f, sumL = (double)((s == SP_P) ? p.sumLp : p.sumLf);
+        gemm_launch(gx, form, g, mM, mN, groups, stream, 0, 2.0 * sumL2 * dk, (s == SP_P) ? p.sumLp : p.sumLf,
+                    4.0 * (sumL2 + 2.0 * sumL * dk));
     }
 
     // =================================================================================
@@ -979,13 +994,13 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         TS dc = dd2.thr16 ? gm : g1;
         // conv2
         {   // wgrad and dgrad of a layer are independent: one multi-problem launch (gemm.h: gemm_f32_multi_kernel)
-            GemmBatchScope pair(stream);
+            GemmBatchScope pair(gx, stream);
             conv_wgrad(ps, s, dc, d, cfg.k2, b.h, ff, P.w2, P.b2, vm);
             conv_dgrad(ps, s, dc, d, cfg.k2, W(ps, P.w2), ff, gh, 0, im, b.h);
         }
         // conv1: g1 += dgrad -> dy1
         {
-            GemmBatchScope pair(stream);
+            GemmBatchScope pair(gx, stream);
             conv_wgrad(ps, s, gh, ff, cfg.k1, b.y1, d, P.w1, P.b1, im);
             conv_dgrad(ps, s, gh, ff, cfg.k1, W(ps, P.w1), d, g1, GEMM_ACCUM, im);
         }
@@ -995,7 +1010,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         TS da = dd1.thr16 ? gm : g0;
         // fc
         {
-            GemmBatchScope pair(stream);
+            GemmBatchScope pair(gx, stream);
             conv_wgrad(ps, s, da, d, 1, b.O, d, P.wfc, P.bfc, vm);
             conv_dgrad(ps, s, da, d, 1, W(ps, P.wfc), d, g1, 0, nullptr);  // g1 = dO
         }
@@ -1004,7 +1019,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         const int L = (s == SP_P) ? p.enc_maxL : p.dec_maxL;
         const AttnSeq* seqs = (s == SP_P) ? p.enc_seqs : p.dec_seqs;
         {
-            GemmBatchScope pair(stream);
+            GemmBatchScope pair(gx, stream);
             attn_gemm(ps, s, TAB_DP, GEMM_NT, g1.p, d, b.qkv.p, 3 * d, dS.p, 0, 1.f, heads);
             attn_gemm(ps, s, TAB_DV, GEMM_TN, b.P.p, 0, g1.p, d, gqkv.p, 3 * d, 1.f, heads);
         }
@@ -1012,13 +1027,13 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             MTTS_LAUNCH(softmax_bwd_kernel, dim3((L + 3) / 4, 1, groups), dim3(256), stream, seqs, (const float*)b.P.p, dS.p,
                         1.f / sqrtf((float)dk));
         {
-            GemmBatchScope pair(stream);
+            GemmBatchScope pair(gx, stream);
             attn_gemm(ps, s, TAB_DQ, GEMM_NN, dS.p, 0, b.qkv.p, 3 * d, gqkv.p, 3 * d, 1.f, heads);
             attn_gemm(ps, s, TAB_DK, GEMM_TN, dS.p, 0, b.qkv.p, 3 * d, gqkv.p, 3 * d, 1.f, heads);
         }
         // fused q/k/v projection
         {
-            GemmBatchScope pair(stream);
+            GemmBatchScope pair(gx, stream);
             conv_wgrad(ps, s, gqkv, 3 * d, 1, xin, d, P.wqkv, P.bqkv, vm);
             conv_dgrad(ps, s, gqkv, 3 * d, 1, W(ps, P.wqkv), d, g0, GEMM_ACCUM, nullptr);
         }
@@ -1055,14 +1070,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         drop(ps, SP_P, gPf1, gPf1, f, cfg.vp_dropout, site_base + 1);
         ln_bwd(ps, SP_P, gPf1, b.r2, b.st2, P.l2g, P.l2b, im, gPf2, f, 1);       // gPf2 = d conv2 out
         {
-            GemmBatchScope pair(stream);
+            GemmBatchScope pair(gx, stream);
             conv_wgrad(ps, SP_P, gPf2, f, k, b.n1, f, P.c2w, P.c2b, im);
             conv_dgrad(ps, SP_P, gPf2, f, k, W(ps, P.c2w), f, gPf1, 0, im);     // gPf1 = d n1
         }
         drop(ps, SP_P, gPf1, gPf1, f, cfg.vp_dropout, site_base);
         ln_bwd(ps, SP_P, gPf1, b.r1, b.st1, P.l1g, P.l1b, im, gPf2, f, 1);       // gPf2 = d conv1 out
         {
-            GemmBatchScope pair(stream);
+            GemmBatchScope pair(gx, stream);
             conv_wgrad(ps, SP_P, gPf2, f, k, xin, d, P.c1w, P.c1b, im);
             conv_dgrad(ps, SP_P, gPf2, f, k, W(ps, P.c1w), d, dx, GEMM_ACCUM, im);
         }
@@ -1129,7 +1144,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             g.N = cfg.n_mel; g.K = d;
             g.bias = b.p; g.bias_gs = b.ts;
             g.c_rowmap = p.f2r; g.c_rowmap_gs = row_ts_f;
-            gemm_launch(GEMM_NT, g, p.maxMf, cfg.n_mel, nt, stream, 0, 2.0 * p.sum_nF * cfg.n_mel * d, p.sumMf);
+            gemm_launch(gx, GEMM_NT, g, p.maxMf, cfg.n_mel, nt, stream, 0, 2.0 * p.sum_nF * cfg.n_mel * d, p.sumMf,
+                        4.0 * (p.sum_nF * (d + cfg.n_mel) + (double)nt * cfg.n_mel * d));
             MTTS_LAUNCH(fill_padded_rows_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, mel.p, mel.ts,
                         (const float*)b.p, b.ts, (const unsigned char*)p.r_inrect, (const unsigned char*)p.r_valid, row_ts_r,
                         cfg.n_mel);
@@ -1185,6 +1201,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             std::vector<float> dr(p.hMp[t]);
             HIP_CHECK(hipMemcpy(dr.data(), d_rounded.p + (long long)t * d_rounded.ts, dr.size() * sizeof(float), hipMemcpyDeviceToHost));
             in.durations.assign((size_t)in.B * in.S, 0);
+            in.d_rounded.assign((size_t)in.B * in.S, 0.f);
             in.mel_lens.assign(in.B, 0);
             long long tmax = 0;
             for (int i = 0; i < in.B; ++i) {
@@ -1192,6 +1209,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                 for (int s2 = 0; s2 < in.S; ++s2) {
                     const long long dd = std::max<long long>((long long)dr[G + i * (in.S + G) + s2], 0);  // max(int(expand_size), 0)
                     in.durations[(size_t)i * in.S + s2] = dd;
+                    in.d_rounded[(size_t)i * in.S + s2] = dr[G + i * (in.S + G) + s2];
                     tot += dd;
                 }
                 in.mel_lens[i] = tot;
@@ -1262,7 +1280,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                         (const float*)gm.p, gm.ts, (const float*)dgm.p, (const float*)dbt.p, dgm.ts,
                         (const unsigned char*)p.r_inrect, row_ts_r, act, dc.p, dc.ts, P.cout, ysc);
             TS xin = (i == 0) ? mel : postB[i - 1].a;
-            GemmBatchScope pair(stream);
+            GemmBatchScope pair(gx, stream);
             conv_wgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, xin, P.cin, P.w, P.b, p.r_inrect);
             if (i > 0) {
                 conv_dgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, W(ps, P.w), P.cin, gR1, 0, p.r_inrect);
@@ -1283,7 +1301,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                     (const float*)gRm.p, gRm.ts, (const int*)p.f2r, row_ts_f, gMelF.p, gMelF.ts, nm);
         TS dec_out = cfg.dec_layers ? decB[cfg.dec_layers - 1].y2 : dec_in;
         {
-            GemmBatchScope pair(stream);
+            GemmBatchScope pair(gx, stream);
             conv_wgrad(ps, SP_F, gMelF, nm, 1, dec_out, d, mel_w, -1, nullptr);
             conv_dgrad(ps, SP_F, gMelF, nm, 1, W(ps, mel_w), d, gF0, 0, nullptr);
         }
@@ -1332,6 +1350,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // =================================================================================
     // MAML (base_adaptor.py:98-124) and the outer update
     // =================================================================================
+    // the inner-loop backward must reach the encoder when adapt.modules lists it (config/algorithm/dev.yaml does)
+    bool encoder_adapted() const { return (cfg.adapt_mask >> MOD_ENCODER) & 1; }
     static unsigned blocks_for(long long n4) { return (unsigned)std::min<long long>(std::max<long long>((n4 + 255) / 256, 1), 4096); }
 
     // One meta-gradient: `steps` inner SGD steps on plan 0 (support), query pass on plan 1 with the
@@ -1351,7 +1371,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (int s = 0; s < steps; ++s) {
             if (forward(ps)) return -1;
             if (sup_losses_out && loss(ps, sup_losses_out + (long long)s * nt * 6)) return -1;
-            if (backward(ps, 1.f, false)) return -1;
+            if (backward(ps, 1.f, encoder_adapted())) return -1;
             if (n_adapt > 0)
                 MTTS_LAUNCH(sgd_update_kernel, dim3(blocks_for(n_adapt / 4), 1, nt), dim3(256), stream, fast,
                             (const float*)(grad + adapt_start), n_adapt / 4, inner_lr, n_adapt, n_total);
@@ -1378,7 +1398,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (int s2 = 0; s2 < steps; ++s2) {
             if (forward(ps)) return -1;
             if (sup_losses_out && loss(ps, sup_losses_out + (long long)s2 * nt * 6)) return -1;
-            if (backward(ps, 1.f, false)) return -1;
+            if (backward(ps, 1.f, encoder_adapted())) return -1;
             if (n_adapt > 0)
                 MTTS_LAUNCH(sgd_update_kernel, dim3(blocks_for(n_adapt / 4), 1, nt), dim3(256), stream, fast,
                             (const float*)(grad + adapt_start), n_adapt / 4, inner_lr, n_adapt, n_total);

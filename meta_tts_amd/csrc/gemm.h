@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void gemm_f32_multi_kernel(GemmMulti mp) {
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg):
 // one record per launch, aggregated per (form, tile) kernel instantiation.
 struct GemmProfiler {
-    struct Rec { int kernel; double flops; hipEvent_t e0, e1; int form = 0, tile = 0, N = 0, K = 0, groups = 0, splitk = 1; double rows = 0; };
+    struct Rec { int kernel; double flops; hipEvent_t e0, e1; int form = 0, tile = 0, N = 0, K = 0, groups = 0, splitk = 1; double rows = 0, bytes = 0; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
@@ -495,28 +495,28 @@ struct GemmProfiler {
         return pool[used++];
     }
     void reset() { recs.clear(); used = 0; }
-    // out[kernel][3] = launches, total ms, total algorithmic flops; kernel = form * 2 + (tile == 128), 6 = multi-problem launch
-    void report(double out[7][3]) {
-        for (int k = 0; k < 7; ++k) out[k][0] = out[k][1] = out[k][2] = 0.0;
+    void destroy() { for (hipEvent_t e : pool) hipEventDestroy(e); pool.clear(); recs.clear(); used = 0; }
+    // out[kernel][4] = launches, total ms, total algorithmic flops, total algorithmic bytes; kernel = form * 2 + (tile == 128), 6 = multi-problem launch
+    void report(double out[7][4]) {
+        for (int k = 0; k < 7; ++k) out[k][0] = out[k][1] = out[k][2] = out[k][3] = 0.0;
         FILE* dump = getenv("MTTS_GEMM_DUMP") ? fopen(getenv("MTTS_GEMM_DUMP"), "w") : nullptr;  // per-launch CSV (tools/gemm_sites.py)
         if (dump) fprintf(dump, "form,tile,N,K,rows,groups,splitk,us,gflop\n");
         for (auto& r : recs) {
             hipEventSynchronize(r.e1);
             float ms = 0.f;
             hipEventElapsedTime(&ms, r.e0, r.e1);
-            out[r.kernel][0] += 1.0; out[r.kernel][1] += ms; out[r.kernel][2] += r.flops;
+            out[r.kernel][0] += 1.0; out[r.kernel][1] += ms; out[r.kernel][2] += r.flops; out[r.kernel][3] += r.bytes;
             if (dump) fprintf(dump, "%d,%d,%d,%d,%.0f,%d,%d,%.2f,%.4f\n", r.form, r.tile, r.N, r.K, r.rows, r.groups, r.splitk, 1e3 * ms, r.flops * 1e-9);
         }
         if (dump) fclose(dump);
     }
 };
-inline GemmProfiler& gemm_profiler() { static GemmProfiler p; return p; }
 inline int& gemm_xcd_swizzle() {
     static int v = [] { const char* e = getenv("MTTS_XCD_GROUP"); return e ? (atoi(e) != 0) : 1; }();
     return v;
 }
-inline int& gemm_numerics() {  // 0: exact fp32 MFMA (default), 1: split-bf16 "bf16x3", 2: plain bf16 operands (gemm_bf16.h); MTTS_NUMERICS env overrides
-    static int v = [] { const char* e = getenv("MTTS_NUMERICS"); return (e && atoi(e) >= 1 && atoi(e) <= 2) ? atoi(e) : 0; }();
+inline int gemm_numerics_default() {  // 0: exact fp32 MFMA (default), 1: split-bf16 "bf16x3", 2: plain bf16 operands (gemm_bf16.h); MTTS_NUMERICS sets the initial mode of every context
+    static const int v = [] { const char* e = getenv("MTTS_NUMERICS"); return (e && atoi(e) >= 1 && atoi(e) <= 2) ? atoi(e) : 0; }();
     return v;
 }
 inline bool gemm_launch_bf16x3(int form, const GemmArgs& g, int max_M, int max_N, int groups, hipStream_t stream, int tile,
@@ -530,19 +530,10 @@ inline bool& gemm_default_pipe() {  // MTTS_GEMM_PIPE=0/1 overrides the built-in
     return v;
 }
 
-// Split-K workspace, one per launch stream (GEMMs on different streams may overlap): partial tiles + tile counters.
+// Split-K workspace (partial tiles + tile counters): owned by a GemmCtx, allocated once by its owner's create.
 struct GemmWorkspace { float* ws = nullptr; int* ctr = nullptr; };
 constexpr long long kSplitWsFloats = 16ll << 20;  // 64 MB of partial tiles
 constexpr int kSplitCtrs = 1 << 16;
-inline GemmWorkspace& gemm_workspace(hipStream_t stream) {
-    static std::vector<std::pair<hipStream_t, GemmWorkspace>> all;
-    for (auto& e : all) if (e.first == stream) return e.second;
-    GemmWorkspace w;
-    if (hipMalloc((void**)&w.ws, kSplitWsFloats * sizeof(float)) != hipSuccess || hipMalloc((void**)&w.ctr, kSplitCtrs * sizeof(int)) != hipSuccess ||
-        hipMemset(w.ctr, 0, kSplitCtrs * sizeof(int)) != hipSuccess) { w.ws = nullptr; w.ctr = nullptr; }
-    all.emplace_back(stream, w);
-    return all.back().second;
-}
 inline int& gemm_splitk_target() {  // workgroups a launch should reach before split-K stops adding more; 0 disables (MTTS_SPLITK_TARGET)
     static int v = [] { const char* e = getenv("MTTS_SPLITK_TARGET"); return e ? atoi(e) : -1; }();  // -1: batched launches only
     return v;
@@ -557,15 +548,36 @@ inline int& gemm_splitk_minchunks() {  // K-chunks every split must keep (MTTS_S
 // 64x64, fp32 numerics) is queued instead of launched; gemm_batch_end() issues the queue as ONE gemm_f32_multi_kernel.
 // The caller guarantees the queued problems are mutually independent and that nothing launched before gemm_batch_end()
 // reads their outputs (engine: the wgrad / dgrad pair of a layer, dQ / dK / dV of an attention block).
-struct GemmPending { int form; GemmArgs g; int max_M, max_N, groups; double flops, rows; };
+struct GemmPending { int form; GemmArgs g; int max_M, max_N, groups; double flops, rows, bytes; };
 struct GemmBatch { bool open = false; std::vector<GemmPending> q; };
-inline GemmBatch& gemm_batch() { static GemmBatch b; return b; }
 inline bool& gemm_batch_enabled() {  // MTTS_GEMM_BATCH=0 launches every problem on its own (A/B runs)
     static bool v = [] { const char* e = getenv("MTTS_GEMM_BATCH"); return e ? atoi(e) != 0 : true; }();
     return v;
 }
-inline void gemm_batch_begin() { if (gemm_batch_enabled()) gemm_batch().open = true; }
-inline void gemm_batch_end(hipStream_t stream);
+
+// Every piece of MUTABLE launcher state — the launch-batching queue, the per-launch profiler, the split-K workspace and the
+// contraction numerics mode — lives in a context owned by one handle (Engine / Vocoder), so two handles on two host threads
+// share nothing (include/mtts.h conventions).  The workspace is allocated by the owner's create, never lazily.
+struct GemmCtx {
+    GemmBatch batch;
+    GemmProfiler prof;
+    GemmWorkspace wsp;
+    int numerics = gemm_numerics_default();
+    int alloc_workspace() {
+        if (wsp.ws) return 0;
+        if (hipMalloc((void**)&wsp.ws, kSplitWsFloats * sizeof(float)) != hipSuccess || hipMalloc((void**)&wsp.ctr, kSplitCtrs * sizeof(int)) != hipSuccess ||
+            hipMemset(wsp.ctr, 0, kSplitCtrs * sizeof(int)) != hipSuccess) { release(); return -1; }
+        return 0;
+    }
+    void release() {
+        if (wsp.ws) hipFree(wsp.ws);
+        if (wsp.ctr) hipFree(wsp.ctr);
+        wsp.ws = nullptr; wsp.ctr = nullptr;
+        prof.destroy();
+    }
+};
+inline void gemm_batch_begin(GemmCtx& cx) { if (gemm_batch_enabled()) cx.batch.open = true; }
+inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream);
 
 // LDS-DMA kernel family (gemm_glds.h, device builds only).  MTTS_GLDS=0 keeps the register-staged kernels (A/B runs).
 inline bool& gemm_use_glds() {
@@ -591,8 +603,8 @@ inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t s
 // on 256 CUs take ceil(B/256) rounds; the 64x64 tile quarters the quantum at ~0.97x the per-tile
 // efficiency of 128x128 (software-pipelined variants, measured with tools/gemm_bench.py).  total_M = sum of the groups' row counts
 // (0: max_M * groups).  alg_flops: algorithmic (unpadded) flops of this launch, profiler only.
-inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, int groups, hipStream_t stream,
-                        int tile = 0, double alg_flops = 0.0, long long total_M = 0) {
+inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, int max_N, int groups, hipStream_t stream,
+                        int tile = 0, double alg_flops = 0.0, long long total_M = 0, double alg_bytes = 0.0) {
     if (max_M <= 0 || max_N <= 0 || groups <= 0) return;
     GemmArgs g = g_in;
     g.swizzle = gemm_xcd_swizzle();
@@ -607,18 +619,18 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
         static const double eff128 = [] { const char* e = getenv("MTTS_TILE128_EFF"); return e ? atof(e) : 0.85; }();
         tile = eff(128, eff128) >= eff(64, 1.0) ? 128 : 64;
     }
-    GemmProfiler& prof0 = gemm_profiler();
-    if (gemm_numerics() >= 1 && tile < 1000 && !(g.taps > 1 && g.tap_k % 32 != 0) && g.a_tap_rows == 0) {  // (the split-bf16 kernels have no dilated-tap walk)
+    GemmProfiler& prof0 = cx.prof;
+    if (cx.numerics >= 1 && tile < 1000 && !(g.taps > 1 && g.tap_k % 32 != 0) && g.a_tap_rows == 0) {  // (the split-bf16 kernels have no dilated-tap walk)
         hipEvent_t b0 = nullptr, b1 = nullptr;
         if (prof0.enabled) { b0 = prof0.get(); b1 = prof0.get(); hipEventRecord(b0, stream); }
         const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
-        const bool big = gemm_launch_bf16x3(form, g, max_M, max_N, groups, stream, user_tile, rows, gemm_numerics() == 1 ? 3 : 1);
-        if (prof0.enabled) { hipEventRecord(b1, stream); prof0.recs.push_back(GemmProfiler::Rec{form * 2 + (big ? 1 : 0), alg_flops, b0, b1}); }
+        const bool big = gemm_launch_bf16x3(form, g, max_M, max_N, groups, stream, user_tile, rows, cx.numerics == 1 ? 3 : 1);
+        if (prof0.enabled) { hipEventRecord(b1, stream); GemmProfiler::Rec rec{form * 2 + (big ? 1 : 0), alg_flops, b0, b1}; rec.bytes = alg_bytes; prof0.recs.push_back(rec); }
         return;
     }
-    if (gemm_batch().open && user_tile == 0 && tile == 64) {
-        gemm_batch().q.push_back(GemmPending{form, g, max_M, max_N, groups, alg_flops, total_M > 0 ? (double)total_M : (double)max_M * groups});
-        if ((int)gemm_batch().q.size() == kGemmMultiMax) { gemm_batch_end(stream); gemm_batch().open = true; }
+    if (cx.batch.open && user_tile == 0 && tile == 64) {
+        cx.batch.q.push_back(GemmPending{form, g, max_M, max_N, groups, alg_flops, total_M > 0 ? (double)total_M : (double)max_M * groups, alg_bytes});
+        if ((int)cx.batch.q.size() == kGemmMultiMax) { gemm_batch_end(cx, stream); cx.batch.open = true; }
         return;
     }
     // tile code: 64 / 128 (+1000 software pipeline, +2000 BK=32); plain 64 / 128 take the defaults
@@ -651,14 +663,14 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
         const long long slots = (long long)ntiles(tile) * groups;
         if (S >= 2 && (slots * S * tile * tile > kSplitWsFloats || slots > kSplitCtrs)) S = 1;
         if (S >= 2) {
-            GemmWorkspace& w = gemm_workspace(stream);
+            GemmWorkspace& w = cx.wsp;
             if (w.ws) { g.splitk = S; g.ws = w.ws; g.tile_ctr = w.ctr; g.tiles_pg = (int)ntiles(tile); } else S = 1;
         } else S = 1;
     }
     const int nth = 256;
     const long grid_tiles = ntiles(tile);
     dim3 block(nth), grid((unsigned)(grid_tiles * S), 1, (unsigned)groups);
-    GemmProfiler& prof = gemm_profiler();
+    GemmProfiler& prof = cx.prof;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
 #define MTTS_GEMM_CASE(F, T)                                                                              \
@@ -676,6 +688,7 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
             GemmProfiler::Rec rec{form * 2, alg_flops, e0, e1};
             rec.form = form; rec.tile = 4064; rec.N = max_N; rec.K = g.K; rec.groups = groups; rec.splitk = S;
             rec.rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
+            rec.bytes = alg_bytes;
             prof.recs.push_back(rec);
         }
         return;
@@ -695,6 +708,7 @@ inline void gemm_launch(int form, const GemmArgs& g_in, int max_M, int max_N, in
         GemmProfiler::Rec rec{form * 2 + (tile == 128 ? 1 : 0), alg_flops, e0, e1};
         rec.form = form; rec.tile = tile; rec.N = max_N; rec.K = g.K; rec.groups = groups; rec.splitk = S;
         rec.rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
+        rec.bytes = alg_bytes;
         prof.recs.push_back(rec);
     }
 }
@@ -704,8 +718,8 @@ inline bool batch_full_regime(const std::vector<GemmPending>& q) {  // more work
     for (const GemmPending& p : q) wgs += std::ceil(p.rows / 64.0) * ((p.max_N + 63) / 64);
     return wgs > (double)gemm_glds_max_wgs();
 }
-inline void gemm_batch_end(hipStream_t stream) {
-    GemmBatch& b = gemm_batch();
+inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
+    GemmBatch& b = cx.batch;
     b.open = false;
     if (b.q.empty()) return;
     // pairs whose dgrad has a short K-loop (K <= 256: fc, conv2) measured ~10 % SLOWER batched than back to back — their
@@ -716,14 +730,14 @@ inline void gemm_batch_end(hipStream_t stream) {
     if (solo) {
         const std::vector<GemmPending> q = b.q;
         b.q.clear();
-        for (const GemmPending& p : q) gemm_launch(p.form, p.g, p.max_M, p.max_N, p.groups, stream, 0, p.flops, (long long)p.rows);
+        for (const GemmPending& p : q) gemm_launch(cx, p.form, p.g, p.max_M, p.max_N, p.groups, stream, 0, p.flops, (long long)p.rows, p.bytes);
         return;
     }
     std::stable_sort(b.q.begin(), b.q.end(), [](const GemmPending& x, const GemmPending& y) { return x.g.K > y.g.K; });
     GemmMulti mp;
     mp.n = (int)b.q.size();
     int max_groups = 0;
-    double flops = 0.0, rows = 0.0;
+    double flops = 0.0, rows = 0.0, bytes = 0.0;
     // split-K for the long chains of an under-filled batch: a tile whose K-loop is longer than two thirds (1 / MTTS_SPLIT_RATIO,
     // swept: 1.25-1.5 best) of the whole batch's per-CU work would finish last on its own (single-task ranks: the k=9 dgrad tile, 576 slices, beside a
     // batch that is worth ~590 slices per CU), so it is cut into S workgroups (rendezvous in splitk_combine)
@@ -748,7 +762,7 @@ inline void gemm_batch_end(hipStream_t stream) {
             const long long slots = (long long)tiles * p.groups;
             if (S >= 2 && ((ws_off + slots * S * 4096) > kSplitWsFloats || ctr_off + slots > kSplitCtrs)) S = 1;
             if (S >= 2) {
-                if (!wsp) wsp = &gemm_workspace(stream);
+                if (!wsp) wsp = &cx.wsp;
                 if (wsp->ws) {
                     mp.g[i].splitk = S; mp.g[i].tiles_pg = tiles; mp.g[i].ws = wsp->ws + ws_off; mp.g[i].tile_ctr = wsp->ctr + ctr_off;
                     ws_off += slots * S * 4096; ctr_off += slots;
@@ -758,9 +772,9 @@ inline void gemm_batch_end(hipStream_t stream) {
         mp.xcd_group[i] = gemm_xcd_swizzle() ? std::min(((p.max_N + 63) / 64) * S, 64) : 0;
         mp.start[i + 1] = mp.start[i] + tiles * S * p.groups;
         max_groups = std::max(max_groups, p.groups);
-        flops += p.flops; rows += p.rows;
+        flops += p.flops; rows += p.rows; bytes += p.bytes;
     }
-    GemmProfiler& prof = gemm_profiler();
+    GemmProfiler& prof = cx.prof;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
     dim3 block(256), grid((unsigned)mp.start[mp.n], 1, 1);
@@ -784,7 +798,7 @@ inline void gemm_batch_end(hipStream_t stream) {
     if (prof.enabled) {
         hipEventRecord(e1, stream);
         GemmProfiler::Rec rec{6, flops, e0, e1};
-        rec.form = 3; rec.tile = 64; rec.N = mp.n; rec.K = 0; rec.groups = max_groups; rec.splitk = 1; rec.rows = rows;
+        rec.form = 3; rec.tile = 64; rec.N = mp.n; rec.K = 0; rec.groups = max_groups; rec.splitk = 1; rec.rows = rows; rec.bytes = bytes;
         prof.recs.push_back(rec);
     }
     b.q.clear();

@@ -162,7 +162,7 @@ int mtts_get_durations(mtts_handle* h, int slot, int task, float* d_rounded, int
     const Engine::Plan& pl = e.plans[slot];
     if (!pl.frames_ready) { e.set_error("durations are not known yet (run mtts_forward / mtts_synthesize first)"); return -1; }
     const Engine::TaskIn& in = pl.in[task];
-    if (d_rounded) for (size_t i = 0; i < in.durations.size(); ++i) d_rounded[i] = (float)in.durations[i];
+    if (d_rounded) for (size_t i = 0; i < in.durations.size(); ++i) d_rounded[i] = in.d_rounded.size() == in.durations.size() ? in.d_rounded[i] : (float)in.durations[i];
     if (mel_lens) for (int i = 0; i < in.B; ++i) mel_lens[i] = std::min<long long>(in.mel_lens[i], pl.hTcap[task]);
     if (t_cap) *t_cap = pl.hTcap[task];
     return 0;
@@ -264,33 +264,44 @@ int mtts_reset_optimizer(mtts_handle* h) {
     return 0;
 }
 
-int mtts_set_numerics(int mode) {
-    if (mode < 0 || mode > 2) return -1;
-    gemm_numerics() = mode;
+int mtts_set_numerics(mtts_handle* h, int mode) {
+    if (!h) return -1;
+    if (mode < 0 || mode > 2) { h->eng.set_error("numerics mode must be 0, 1 or 2"); return -1; }
+    h->eng.gx.numerics = mode;
     return 0;
 }
 
-int mtts_profile_gemm(int enable) {
-    GemmProfiler& p = gemm_profiler();
+int mtts_profile_gemm(mtts_handle* h, int enable) {
+    if (!h) return -1;
+    GemmProfiler& p = h->eng.gx.prof;
     p.reset();
     p.enabled = enable != 0;
     return 0;
 }
 
-int mtts_profile_report(double* out21) {
-    double r[7][3];
-    gemm_profiler().report(r);
-    for (int k = 0; k < 7; ++k) for (int j = 0; j < 3; ++j) out21[k * 3 + j] = r[k][j];
+int mtts_profile_report(mtts_handle* h, double* out28) {
+    if (!h || !out28) return -1;
+    double r[7][4];
+    h->eng.gx.prof.report(r);
+    for (int k = 0; k < 7; ++k) for (int j = 0; j < 4; ++j) out28[k * 4 + j] = r[k][j];
     return 0;
 }
+
+// launcher state of the handle-less kernel-level entry points: one context per host thread, no split-K workspace (stand-alone
+// launches never split), fp32 numerics unless MTTS_NUMERICS says otherwise
+static GemmCtx& kernel_ctx() { static thread_local GemmCtx cx; return cx; }
 
 int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, float alpha, int flags, int tile, void* stream) {
     if (form < 0 || form > 2 || (tile != 0 && tile != 4064 && ((tile % 1000 != 64 && tile % 1000 != 128) || tile % 10000 >= 4000))) return -1;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
-    g.bias = bias; g.alpha = alpha; g.flags = flags;
-    gemm_launch(form, g, M, N, 1, (hipStream_t)stream, tile);
+    g.bias = bias; g.alpha = alpha; g.flags = flags & 0xff;
+    GemmCtx& cx = kernel_ctx();
+    cx.numerics = (flags >> 8) & 3;
+    if (cx.numerics > 2) return -1;
+    gemm_launch(cx, form, g, M, N, 1, (hipStream_t)stream, tile);
+    cx.numerics = gemm_numerics_default();
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -302,15 +313,15 @@ int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* a, c
     if (mode == 0) {         // y[L][Cout] = conv(x) + bias
         g.A = a - (long long)pad * Cin; g.lda = Cin; g.B = b; g.ldb = k * Cin; g.C = out; g.ldc = Cout;
         g.M = L; g.N = Cout; g.K = k * Cin; g.bias = bias;
-        gemm_launch(GEMM_NT, g, L, Cout, 1, (hipStream_t)stream, tile);
+        gemm_launch(kernel_ctx(), GEMM_NT, g, L, Cout, 1, (hipStream_t)stream, tile);
     } else if (mode == 1) {  // dx[L][Cin] = dgrad(dy [L][Cout], w)
         g.A = a - (long long)pad * Cout; g.lda = Cout; g.B = b; g.ldb = k * Cin; g.C = out; g.ldc = Cin;
         g.M = L; g.N = Cin; g.K = k * Cout; g.taps = k; g.tap_k = Cout; g.tap_bstride = Cin;
-        gemm_launch(GEMM_NN, g, L, Cin, 1, (hipStream_t)stream, tile);
+        gemm_launch(kernel_ctx(), GEMM_NN, g, L, Cin, 1, (hipStream_t)stream, tile);
     } else {                 // dw[Cout][k*Cin] = dy^T conv-rows(x)
         g.A = a; g.lda = Cout; g.B = b - (long long)pad * Cin; g.ldb = Cin; g.C = out; g.ldc = k * Cin;
         g.M = Cout; g.N = k * Cin; g.K = L;
-        gemm_launch(GEMM_TN, g, Cout, k * Cin, 1, (hipStream_t)stream, tile);
+        gemm_launch(kernel_ctx(), GEMM_TN, g, Cout, k * Cin, 1, (hipStream_t)stream, tile);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

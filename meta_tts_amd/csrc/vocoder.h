@@ -99,6 +99,7 @@ public:
     int hop = 1;
     // per-stage scratch (element offsets into the arena, per-utterance strides)
     struct Buf { long long off, gs; };
+    GemmCtx gx;  // this handle's launcher state (gemm.h); fp32 numerics always
     Buf b_x[2], b_pad, b_h;
 
     void set_error(const std::string& s) { last_error = s; }
@@ -127,6 +128,8 @@ public:
             }
         }
         add("conv_out.w", 7LL * ch(cfg.n_ratios)); add("conv_out.b", 1);
+        gx.numerics = 0;
+        if (gx.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace)"); return -1; }
         VOC_CHECK(hipMalloc((void**)&params, (size_t)n_params * sizeof(float)));
         VOC_CHECK(hipMemset(params, 0, (size_t)n_params * sizeof(float)));
         // activations: rows x channels is largest where rows*C peaks; size every buffer for the worst stage (+ pad rows)
@@ -148,6 +151,7 @@ public:
     void destroy() {
         for (void* p : {(void*)params, (void*)arena, (void*)lens_dev, (void*)mel_dev, (void*)wav_dev}) if (p) hipFree(p);
         params = arena = mel_dev = wav_dev = nullptr; lens_dev = nullptr;
+        gx.release();
     }
     int load(const char* name, const float* host, long long numel) {
         for (auto& t : tensors)
@@ -171,7 +175,7 @@ public:
         g.M = max_rows; g.N = N; g.K = K;
         g.dimptr = lens_dev; g.dim_stride = 1; g.dim_sel = 0; g.dim_mult = len_mult;
         g.bias = bias; g.flags = flags; g.act_slope = 0.2f;
-        gemm_launch(GEMM_NT, g, max_rows, N, B, stream, 0, 2.0 * max_rows * B * (double)N * K, 0);
+        gemm_launch(gx, GEMM_NT, g, max_rows, N, B, stream, 0, 2.0 * max_rows * B * (double)N * K, 0);
     }
     void pad_act(const Buf& src, const Buf& dst, int B, int max_rows, int len_mult, int C, int d, float slope, float scale, int reflect) {
         MTTS_LAUNCH(pad_act_kernel, dim3((unsigned)((max_rows + 2 * d + 3) / 4), 1, (unsigned)B), dim3(256), stream, (const int*)lens_dev,
@@ -202,13 +206,13 @@ public:
             const float* bias = params + find("up" + std::to_string(s) + ".b");
             float* out = arena + b_x[cur ^ 1].off;
             const long long out_gs = b_x[cur ^ 1].gs;
-            gemm_batch_begin();
+            gemm_batch_begin(gx);
             for (int ph = 0; ph < r; ++ph) {
                 const int q0 = ph >= p ? 0 : 1;
                 gemm(arena + b_pad.off + (long long)q0 * cin, b_pad.gs, cin, W + (long long)ph * cout * 2 * cin, 2 * cin, 2 * cin, bias,
                      out + (long long)(q0 * r + ph - p) * cout, out_gs, r * cout, cout, B, rows_in, mult, 0);
             }
-            gemm_batch_end(stream);
+            gemm_batch_end(gx, stream);
             cur ^= 1; mult *= r;
             const int rows = T_max * mult;
             int d = 1;

@@ -123,8 +123,10 @@ def make_param(name: str, shape: Tuple[int, ...], seed: int = 0) -> np.ndarray:
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
-def make_params(dims: ModelDims, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
-    """All parameters (trainable and frozen) under reference names."""
+def make_params(dims: ModelDims, seed: int = 0, weight_scale: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """All parameters (trainable and frozen) under reference names.  ``weight_scale`` multiplies every Linear / Conv1d
+    weight matrix (not the embedding tables, gains or biases): 0.5 gives a model on which five inner SGD steps at the
+    reference's lr = 1e-3 are contractive (tests/golden maml_small_lr1e-3_scaled.npz)."""
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     for name, (shape, trainable) in param_spec(dims).items():
         if name.endswith("position_enc"):
@@ -136,6 +138,8 @@ def make_params(dims: ModelDims, seed: int = 0) -> "OrderedDict[str, np.ndarray]
             out[name] = np.linspace(dims.energy_min, dims.energy_max, dims.n_bins - 1).astype(np.float32)
         else:
             out[name] = make_param(name, shape, seed)
+            if weight_scale != 1.0 and len(shape) >= 2 and "emb" not in name:
+                out[name] *= np.float32(weight_scale)
     out["encoder.src_word_emb.weight"][0] = 0.0  # padding_idx=0 row (transformer/Models.py:56-58)
     return out
 

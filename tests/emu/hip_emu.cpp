@@ -185,7 +185,9 @@ struct Pool {
         }
     }
     explicit Pool(int n) { for (int i = 0; i < n; ++i) threads.emplace_back([this] { loop(); }); }
+    std::mutex launch_mu;  // one kernel at a time (host threads driving different handles queue up, like on one GPU)
     void launch(dim3 g, dim3 b, const std::function<void()>& f) {
+        std::lock_guard<std::mutex> one(launch_mu);
         std::unique_lock<std::mutex> lk(mu);
         grid = g; block = b; body = &f;
         nblocks = (long)g.x * g.y * g.z;

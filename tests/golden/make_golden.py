@@ -134,6 +134,92 @@ def head(g):
 
 SMALL = dict(s_range=(6, 13), d_range=(1, 7), first_len=12)
 
+def load_synth_params(model, dims, weight_scale=1.0, edit=None):
+    params = synth.make_params(dims, seed=0, weight_scale=weight_scale)
+    if edit:
+        edit(params)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in params.items():
+            sd[k].copy_(torch.from_numpy(v))
+    model.load_state_dict(sd)
+
+
+def maml_fixture(model, loss_fn, modules, lr):
+    """5 inner steps on the SMALL task with the reference model, first- and second-order (MAML rule restated over
+    functional_call: learn2learn is not installed)."""
+    from torch.func import functional_call
+    res = {}
+    for order in ("fo", "so"):
+        model.train(); reset_bn(model)
+        sup = tb(synth.make_batch(21, 3, speaker=9, **SMALL))
+        qry = tb(synth.make_batch(22, 3, speaker=9, **SMALL))
+        named = dict(model.named_parameters())
+        frozen = ("position_enc", "pitch_bins", "energy_bins")
+        names = [k for k in named if k.split(".")[0] in modules and not k.endswith(frozen)]
+        fast = {k: named[k] for k in names}
+        sup_losses = []
+        for _ in range(5):
+            preds = functional_call(model, fast, sup[2:])
+            l = loss_fn(sup, preds)
+            sup_losses.append([float(x) for x in l])
+            gr = torch.autograd.grad(l[0], [fast[k] for k in names], create_graph=(order == "so"))
+            fast = {k: fast[k] - lr * g_ for k, g_ in zip(names, gr)}
+        # query pass: support speaker ids, mean speaker embedding (base_adaptor.py:66-67,122)
+        spk_w = fast["speaker_emb.model.weight"]
+        mean_row = spk_w[sup[2]].mean(dim=0, keepdim=True)
+        # the table path with a single-speaker task: mean of identical rows == that row, so the
+        # reference module can be called with the support ids directly (same batch size)
+        preds = functional_call(model, fast, (sup[2],) + qry[3:])
+        ql = loss_fn(qry, preds)
+        ps = [p for n, p in model.named_parameters() if p.requires_grad]
+        pn = [n for n, p in model.named_parameters() if p.requires_grad]
+        og = torch.autograd.grad(ql[0], ps, allow_unused=True)
+        og = {n: (g_ if g_ is not None else torch.zeros_like(p)) for n, g_, p in zip(pn, og, ps)}
+        res[f"{order}_sup_losses"] = np.array(sup_losses, np.float64)
+        res[f"{order}_qry_losses"] = np.array([float(x) for x in ql], np.float64)
+        res[f"{order}_delta_norms"] = np.array(
+            [float((fast[k] - named[k]).detach().double().norm()) for k in names], np.float64)
+        res[f"{order}_outer_names"] = np.array(pn)
+        res[f"{order}_outer_norms"] = np.array([float(v.double().norm()) for v in og.values()], np.float64)
+        for n in FULL_GRADS:
+            res[f"{order}_grad::" + n] = head(og[n])
+        res[f"{order}_grad::speaker_row"] = og["speaker_emb.model.weight"][9].numpy()
+        res[f"{order}_qry_mel_post"] = preds[1].detach().numpy()
+        res[f"{order}_mean_row_check"] = (mean_row - spk_w[9]).abs().max().detach().numpy()
+    res["adapted_names"] = np.array(names)
+    return res
+
+
+def c5_edit(params):
+    """The random-init duration predictor emits ~0 frames; bias ln(8) and a damped weight give LibriTTS-like durations
+    (about 7 frames per phoneme) — the same edit bench.py's inference leg applies."""
+    params["variance_adaptor.duration_predictor.linear_layer.bias"][:] = np.log(8.0)
+    params["variance_adaptor.duration_predictor.linear_layer.weight"] *= 0.25
+
+
+def c5_fixture(model, dims):
+    """BASELINE config 5, synthesis half: free-running forward (modules.py:132-137,150-158) of the C1 utterance and of a
+    padded 3-utterance batch with the duration predictor of c5_edit, eval mode and train mode (the reference synthesises
+    with the adapted clone left in .train(), base_adaptor.py:170-189), with p/e/d controls != 1."""
+    load_synth_params(model, dims, edit=c5_edit)
+    out = {}
+    cases = (("c1", synth.make_batch(0, 1), (1.0, 1.0, 1.0)), ("b3", synth.make_batch(7, 3, speaker=11), (1.2, 0.8, 0.9)))
+    for tag, batch, (pc, ec, dc) in cases:
+        b = tb(batch)
+        for mode in ("eval", "train"):
+            model.train(mode == "train"); reset_bn(model)
+            with torch.no_grad():
+                fr = model(*b[2:6], p_control=pc, e_control=ec, d_control=dc)
+            k = f"{tag}_{mode}_"
+            out[k + "mel_post"] = fr[1].numpy(); out[k + "mel"] = fr[0].numpy()
+            out[k + "p"] = fr[2].numpy(); out[k + "e"] = fr[3].numpy(); out[k + "logd"] = fr[4].numpy()
+            out[k + "d_rounded"] = fr[5].numpy(); out[k + "mel_len"] = fr[9].numpy()
+        out[tag + "_controls"] = np.array([pc, ec, dc], np.float64)
+    load_synth_params(model, dims)
+    return out
+
+
 
 def main():
     torch.manual_seed(0)
@@ -160,7 +246,7 @@ def main():
         o = model(*b[2:])
         lo = loss_fn(b, o)
     c1.update({"train_mel_post": o[1].numpy(), "train_losses": np.array([float(x) for x in lo], np.float64)})
-    if not os.environ.get("MTTS_GOLDEN_ONLY_MAML"):
+    if not (os.environ.get("MTTS_GOLDEN_ONLY_MAML") or os.environ.get("MTTS_GOLDEN_ONLY_C5")):
         np.savez_compressed(os.path.join(out_dir, "c1_forward.npz"), **c1)
     meta["c1_shapes"] = {"S": int(batch[5]), "T": int(batch[8])}
 
@@ -193,59 +279,30 @@ def main():
     with torch.no_grad():
         oe = model(*b[2:])
     small["eval_mel_post"] = oe[1].numpy()
-    if not os.environ.get("MTTS_GOLDEN_ONLY_MAML"):
+    if not (os.environ.get("MTTS_GOLDEN_ONLY_MAML") or os.environ.get("MTTS_GOLDEN_ONLY_C5")):
         np.savez_compressed(os.path.join(out_dir, "small_grad.npz"), **small)
 
+    # ---------------- C5: free-running synthesis with realistic predicted durations --------------
+    if os.environ.get("MTTS_GOLDEN_ONLY_C5") or not os.environ.get("MTTS_GOLDEN_ONLY_MAML"):
+        np.savez_compressed(os.path.join(out_dir, "c5_synth.npz"), **c5_fixture(model, dims))
+        if os.environ.get("MTTS_GOLDEN_ONLY_C5"):
+            return
+
     # ---------------- MAML: 5 inner steps, FO and SO, small task ------------------------------
-    from torch.func import functional_call
     alg = cfgs[2]
     modules = alg["adapt"]["modules"]
     # lr 1e-4: contractive inner loop (losses fall) -> tight parity; 1e-3 / 2e-3: the tiny random model is expansive
-    # there (support loss grows over the steps), kept as loose-tolerance cases
+    # there (support loss grows over the steps), kept as loose-tolerance cases; "lr1e-3_scaled": the reference's own inner
+    # lr on weights scaled by 0.5 (synth.make_params(weight_scale=0.5)), where the five steps are contractive
+    # (7.5 -> 3.8), so the reference configuration is pinned tightly too
     only = os.environ.get("MTTS_GOLDEN_ONLY_MAML")  # e.g. "lr1e-4": write only that fixture (the others stay as committed)
-    for tag, lr in (("lr1e-4", 0.0001), ("lr1e-3", 0.001), ("lr2e-3", 0.002)):
+    for tag, lr, wscale in (("lr1e-4", 0.0001, 1.0), ("lr1e-3", 0.001, 1.0), ("lr2e-3", 0.002, 1.0), ("lr1e-3_scaled", 0.001, 0.5)):
         if only and tag != only:
             continue
-        res = {}
-        for order in ("fo", "so"):
-            model.train(); reset_bn(model)
-            sup = tb(synth.make_batch(21, 3, speaker=9, **SMALL))
-            qry = tb(synth.make_batch(22, 3, speaker=9, **SMALL))
-            named = dict(model.named_parameters())
-            frozen = ("position_enc", "pitch_bins", "energy_bins")
-            names = [k for k in named if k.split(".")[0] in modules and not k.endswith(frozen)]
-            fast = {k: named[k] for k in names}
-            sup_losses = []
-            for _ in range(5):
-                preds = functional_call(model, fast, sup[2:])
-                l = loss_fn(sup, preds)
-                sup_losses.append([float(x) for x in l])
-                gr = torch.autograd.grad(l[0], [fast[k] for k in names], create_graph=(order == "so"))
-                fast = {k: fast[k] - lr * g_ for k, g_ in zip(names, gr)}
-            # query pass: support speaker ids, mean speaker embedding (base_adaptor.py:66-67,122)
-            spk_w = fast["speaker_emb.model.weight"]
-            mean_row = spk_w[sup[2]].mean(dim=0, keepdim=True)
-            # the table path with a single-speaker task: mean of identical rows == that row, so the
-            # reference module can be called with the support ids directly (same batch size)
-            preds = functional_call(model, fast, (sup[2],) + qry[3:])
-            ql = loss_fn(qry, preds)
-            ps = [p for n, p in model.named_parameters() if p.requires_grad]
-            pn = [n for n, p in model.named_parameters() if p.requires_grad]
-            og = torch.autograd.grad(ql[0], ps, allow_unused=True)
-            og = {n: (g_ if g_ is not None else torch.zeros_like(p)) for n, g_, p in zip(pn, og, ps)}
-            res[f"{order}_sup_losses"] = np.array(sup_losses, np.float64)
-            res[f"{order}_qry_losses"] = np.array([float(x) for x in ql], np.float64)
-            res[f"{order}_delta_norms"] = np.array(
-                [float((fast[k] - named[k]).detach().double().norm()) for k in names], np.float64)
-            res[f"{order}_outer_names"] = np.array(pn)
-            res[f"{order}_outer_norms"] = np.array([float(v.double().norm()) for v in og.values()], np.float64)
-            for n in FULL_GRADS:
-                res[f"{order}_grad::" + n] = head(og[n])
-            res[f"{order}_grad::speaker_row"] = og["speaker_emb.model.weight"][9].numpy()
-            res[f"{order}_qry_mel_post"] = preds[1].detach().numpy()
-            res[f"{order}_mean_row_check"] = (mean_row - spk_w[9]).abs().max().detach().numpy()
-        res["adapted_names"] = np.array(names)
+        load_synth_params(model, dims, weight_scale=wscale)
+        res = maml_fixture(model, loss_fn, modules, lr)
         np.savez_compressed(os.path.join(out_dir, f"maml_small_{tag}.npz"), **res)
+    load_synth_params(model, dims)
 
     if os.environ.get("MTTS_GOLDEN_ONLY_MAML"):
         return

@@ -16,8 +16,18 @@ from oracle import fs2_oracle as O  # noqa: E402
 SMALL = dict(s_range=(6, 13), d_range=(1, 7), first_len=12)
 
 
-def torch_params(dims, seed=0, requires_grad=False):
-    p = {k: torch.from_numpy(v.copy()) for k, v in synth.make_params(dims, seed).items()}
+def c5_edit(params):
+    """Duration predictor giving LibriTTS-like durations at random init (tests/golden/make_golden.py: c5_edit; bench.py)."""
+    params["variance_adaptor.duration_predictor.linear_layer.bias"][:] = np.log(8.0)
+    params["variance_adaptor.duration_predictor.linear_layer.weight"] *= 0.25
+    return params
+
+
+def torch_params(dims, seed=0, requires_grad=False, weight_scale=1.0, edit=None):
+    np_params = synth.make_params(dims, seed, weight_scale=weight_scale)
+    if edit:
+        edit(np_params)
+    p = {k: torch.from_numpy(v.copy()) for k, v in np_params.items()}
     if requires_grad:
         frozen = ("position_enc", "pitch_bins", "energy_bins")
         for k, v in p.items():

@@ -351,3 +351,80 @@ def test_second_order_with_dropout_replays_inner_step_masks(emu_lib):
     Hu_wrong = {n: eng.export(n, 6, 0).astype(np.float64) for n in adapted}
     assert abs(sum(float((v[n] * Hu_wrong[n]).sum()) for n in adapted) - uHv) > 1e-2 * abs(uHv)
     eng.close()
+
+
+def test_adapted_encoder_moves_in_the_inner_loop(emu_lib):
+    """config/algorithm/dev.yaml lists `encoder` in adapt.modules: the inner-loop backward must reach the encoder so its
+    fast weights (incl. the phoneme table) move, as learn2learn's adapt does for every cloned module (utils.py:17-77)."""
+    dims = tiny_dims()
+    mods = ["encoder", "decoder"]
+    eng = _engine(dims, emu_lib, tasks=1, mods=mods)
+    sup = synth.make_batch(30, 2, speaker=3, **_kw(dims)); qry = synth.make_batch(31, 2, speaker=3, **_kw(dims))
+    eng.set_batches(0, [sup]); eng.set_batches(1, [qry], spk_from=[sup], average_spk=True)
+    q, s = eng.meta_grad(2, 0.05, 1.0)
+    p = torch_params(dims, requires_grad=True)
+    ql, sl, fast, _ = O.maml_task(p, torch_buffers(dims), O.to_torch_batch(sup), O.to_torch_batch(qry), steps=2, lr=0.05,
+                                  second_order=False, modules=mods, n_head=heads(dims), max_seq_len=dims.max_seq_len)
+    np.testing.assert_allclose(q[0], [float(x) for x in ql], rtol=1e-4)
+    np.testing.assert_allclose(s[:, 0, 0], [float(l[0]) for l in sl], rtol=1e-4)
+    moved = 0.0
+    for n in O.adapted_names(p, mods):
+        ref = fast[n].detach().numpy()
+        got = eng.export(n, 3, 0)
+        assert np.abs(got - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-3), n
+        if n.startswith("encoder."):
+            moved += float(np.abs(got - eng.export(n, 0)).sum())
+    assert moved > 1e-3  # the encoder's fast weights really left theta
+    for n in ("encoder.layer_stack.0.pos_ffn.w_1.weight", "encoder.src_word_emb.weight", "mel_linear.weight"):
+        g = torch.autograd.grad(ql[0], p[n], retain_graph=True)[0].numpy()
+        assert np.abs(eng.export(n, 1) - g).max() <= 2e-3 * np.abs(g).max() + 2e-7, n
+    # the same through mtts_adapt (few-shot test loop)
+    eng.adapt(2, 0.05, reset=True)
+    n = "encoder.layer_stack.0.slf_attn.fc.weight"
+    assert np.abs(eng.export(n, 3, 0) - fast[n].detach().numpy()).max() <= 2e-5 * np.abs(fast[n].detach().numpy()).max()
+    with pytest.raises(Exception):
+        eng.meta_grad(2, 0.05, 1.0, second_order=True)  # rejected loudly, not silently wrong
+    eng.close()
+
+
+def test_out_of_range_token_ids_are_rejected(emu_lib):
+    dims = tiny_dims()
+    eng = _engine(dims, emu_lib, tasks=1)
+    b = list(synth.make_batch(3, 2, speaker=2, **_kw(dims)))
+    for bad in (dims.vocab, -1):
+        t = b[3].copy(); t[0, 0] = bad
+        with pytest.raises(Exception, match="token"):
+            eng.set_batches(0, [tuple(b[:3]) + (t,) + tuple(b[4:])])
+    t = b[3].copy(); t[1, int(b[4][1]):] = 10 ** 6   # padding positions are never read
+    eng.set_batches(0, [tuple(b[:3]) + (t,) + tuple(b[4:])])
+    eng.close()
+
+
+def test_two_handles_on_two_host_threads_do_not_interfere(emu_lib):
+    """include/mtts.h conventions: different handles share no mutable state (launch-batching queue, profiler, split-K
+    workspace, numerics mode are per handle), so two host threads may drive two handles at once — results must equal the
+    single-threaded ones bit for bit."""
+    import threading
+    dims = tiny_dims()
+    jobs = [(3, 2, 0.01), (4, 5, 0.02)]
+
+    def run(seed, spk, lr, out, key):
+        eng = _engine(dims, emu_lib, tasks=1)
+        sup = synth.make_batch(seed, 3, speaker=spk, **_kw(dims)); qry = synth.make_batch(seed + 10, 2, speaker=spk, **_kw(dims))
+        for _ in range(2):
+            eng.set_batches(0, [sup]); eng.set_batches(1, [qry], spk_from=[sup], average_spk=True)
+            q, s = eng.meta_grad(2, lr, 1.0)
+        out[key] = (q.copy(), s.copy(), eng.export("decoder.layer_stack.1.pos_ffn.w_1.weight", 1), eng.export("mel_linear.weight", 1))
+        eng.close()
+
+    serial, threaded = {}, {}
+    for i, (seed, spk, lr) in enumerate(jobs):
+        run(seed, spk, lr, serial, i)
+    ts = [threading.Thread(target=run, args=(seed, spk, lr, threaded, i)) for i, (seed, spk, lr) in enumerate(jobs)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(len(jobs)):
+        for a, b in zip(serial[i], threaded[i]):
+            np.testing.assert_array_equal(a, b)

@@ -94,7 +94,7 @@ def test_conv1d_fwd_dgrad_wgrad(lib, tile, L, Cin, Cout, k):
 @pytest.mark.parametrize("form", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 80, 256), (300, 768, 48), (33, 130, 100), (5, 7, 20), (1000, 256, 2304)])
 def test_gemm_bf16x3_forms(lib, form, tile, M, N, K):
-    """Split-bf16 numerics (mtts_set_numerics(1)): same forms / edges, error bound 2^-16-class instead of fp32."""
+    """Split-bf16 numerics (numerics mode 1): same forms / edges, error bound 2^-16-class instead of fp32."""
     g = np.random.RandomState(M + N * 3 + K * 5 + form)
     pad4 = lambda x: (x + 3) & ~3
     if form == 0:
@@ -108,12 +108,8 @@ def test_gemm_bf16x3_forms(lib, form, tile, M, N, K):
         ref = A[:, :M].double().T @ B[:, :N].double(); lda, ldb = pad4(M), pad4(N)
     bias = _rand(g, N)
     Cm = torch.full((M, pad4(N)), 7.0, device="cuda")
-    assert lib.mtts_set_numerics(1) == 0
-    try:
-        assert lib.mtts_gemm_f32(form, M, N, K, P(A), lda, P(B), ldb, P(Cm), pad4(N), P(bias), 0.5, 0, tile, None) == 0
-        torch.cuda.synchronize()
-    finally:
-        lib.mtts_set_numerics(0)
+    assert lib.mtts_gemm_f32(form, M, N, K, P(A), lda, P(B), ldb, P(Cm), pad4(N), P(bias), 0.5, 1 << 8, tile, None) == 0  # flags bits 8-9: numerics 1
+    torch.cuda.synchronize()
     want = 0.5 * ref + bias.double()[None, :]
     err = (Cm[:, :N].double() - want).abs().max().item()
     # |a.b| error ~ 2^-16 * sum|a||b| ~ 2^-16 * K * E|a|E|b| (worst case); observed ~ sqrt(K) of that

@@ -40,6 +40,28 @@ def test_c1_forward_eval_and_free_running(golden_dir, params):
     assert np.abs(fr[1].numpy() - g["fr_mel_post"]).max() < TOL
 
 
+def test_c5_free_running_synthesis(golden_dir):
+    """BASELINE config 5, synthesis half (modules.py:132-137,150-158): predicted durations of LibriTTS-like size, p/e/d
+    controls, eval mode and train mode (the adapted clone stays in .train(), base_adaptor.py:170-189)."""
+    from oracle_util import c5_edit
+    g = _load(golden_dir, "c5_synth.npz")
+    p = torch_params(DIMS, edit=c5_edit)
+    for tag, batch in (("c1", synth.make_batch(0, 1)), ("b3", synth.make_batch(7, 3, speaker=11))):
+        b = O.to_torch_batch(batch)
+        pc, ec, dc = (float(x) for x in g[tag + "_controls"])
+        for mode in ("eval", "train"):
+            with torch.no_grad():
+                fr = O.fs2_forward(p, torch_buffers(DIMS), *b[2:6], p_control=pc, e_control=ec, d_control=dc, n_head=heads(DIMS),
+                                   training=(mode == "train"))
+            k = f"{tag}_{mode}_"
+            np.testing.assert_array_equal(fr[5].numpy(), g[k + "d_rounded"])
+            np.testing.assert_array_equal(fr[9].numpy(), g[k + "mel_len"])
+            assert int(fr[9].max()) > 200  # really a LibriTTS-sized synthesis, not the 6 frames of the raw random init
+            for name, i in (("mel", 0), ("mel_post", 1), ("p", 2), ("e", 3), ("logd", 4)):
+                assert np.abs(fr[i].numpy() - g[k + name]).max() < (TOL if mode == "eval" else 2e-4), (k, name)
+            assert np.abs(fr[1].numpy() - g[k + "mel_post"]).mean() < 2e-5
+
+
 def test_c1_forward_train_mode_batchnorm(golden_dir, params):
     g = _load(golden_dir, "c1_forward.npz")
     b = O.to_torch_batch(synth.make_batch(0, 1))
@@ -95,11 +117,11 @@ def test_small_batch_losses_grads_and_bn_buffers(golden_dir):
     assert np.abs(oe[1].numpy() - g["eval_mel_post"]).max() < TOL
 
 
-@pytest.mark.parametrize("tag,lr", [("lr1e-4", 0.0001), ("lr1e-3", 0.001), ("lr2e-3", 0.002)])
+@pytest.mark.parametrize("tag,lr", [("lr1e-4", 0.0001), ("lr1e-3", 0.001), ("lr2e-3", 0.002), ("lr1e-3_scaled", 0.001)])
 @pytest.mark.parametrize("order", ["fo", "so"])
 def test_maml_task(golden_dir, tag, lr, order):
     g = _load(golden_dir, f"maml_small_{tag}.npz")
-    p = torch_params(DIMS, requires_grad=True)
+    p = torch_params(DIMS, requires_grad=True, weight_scale=0.5 if tag.endswith("scaled") else 1.0)
     sup = O.to_torch_batch(synth.make_batch(21, 3, speaker=9, **SMALL))
     qry = O.to_torch_batch(synth.make_batch(22, 3, speaker=9, **SMALL))
     modules = default_algorithm_config()["adapt"]["modules"]

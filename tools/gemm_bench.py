@@ -30,8 +30,7 @@ def bench(form, tile, M, N, K, reps=5):
     return 2.0 * M * N * K / (ms * 1e-3) / 1e12, ms
 
 
-NUM = int(os.environ.get('BENCH_NUMERICS', '0'))
-lib.mtts_set_numerics(NUM)
+NUM = int(os.environ.get('BENCH_NUMERICS', '0'))  # passed per call in flags bits 8-9
 TILES = (64, 128) if NUM else tuple(int(t) for t in os.environ.get('BENCH_TILES', '1064,1128').split(','))
 shapes = [("square4096", 4096, 4096, 4096), ("conv1_fwd 8 tasks", 17047, 1024, 2304), ("conv1_dgrad", 17047, 256, 9216), ("conv2_fwd", 17047, 256, 1024),
           ("qkv", 17047, 768, 256), ("out_proj", 17047, 256, 256), ("postnet_mid", 22132, 512, 2560), ("dec 1 task", 2100, 256, 1024)]
