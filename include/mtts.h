@@ -87,6 +87,12 @@ int mtts_set_optimizer_step(mtts_handle* h, int64_t step);
 int mtts_set_bn_buffers(mtts_handle* h, int layer, const float* mean_host, const float* var_host, int64_t tracked);
 int mtts_get_bn_buffers(mtts_handle* h, int layer, float* mean_host, float* var_host, int64_t* tracked);
 
+/* variance_adaptor.pitch_bins / energy_bins (frozen nn.Parameters, modules.py:57-71; n = n_bins - 1 boundaries each).  mtts_create
+ * builds them from the cfg's stats.json min/max; a checkpoint trained on another corpus carries its own (system.py corpus-mismatch
+ * branch), which the host layer installs here.  Either pointer may be NULL. */
+int mtts_set_bins(mtts_handle* h, const float* pitch_bins_host, const float* energy_bins_host, int n);
+int mtts_get_bins(mtts_handle* h, float* pitch_bins_host, float* energy_bins_host, int n);
+
 /* ---- batches: slot 0 = support (or a plain batch), slot 1 = query.  `spk_from`/`average_spk`
  * reproduce forward_learner(..., sup_batch[2], *qry_batch[3:], average_spk_emb=True)
  * (lightning/systems/base_adaptor.py:64-70,122) --------------------------------------------------- */

@@ -49,6 +49,8 @@ EXPORTS = {
     "mtts_export_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "mtts_set_bn_buffers": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
     "mtts_get_bn_buffers": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "mtts_set_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mtts_get_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mtts_set_batches": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Batch), C.POINTER(Batch), C.c_int]),
     "mtts_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mtts_synthesize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float]),

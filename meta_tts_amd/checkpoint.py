@@ -1,6 +1,8 @@
 """Checkpoint layout compatible with the reference's PyTorch-Lightning files:
 ``{"state_dict": {"model.<name>": tensor, "learner.module.<name>": same tensor, ...}, "global_step": int,
-"optimizer_states": [...]}`` written with plain ``torch.save``.  ``load_checkpoint`` applies the loader
+"optimizer_states": [torch Adam state_dict], "lr_schedulers": [LambdaLR state_dict], "epoch": int}``
+written with plain ``torch.save`` — the optimizer / scheduler entries are exactly what ``optimizer.load_state_dict`` /
+``scheduler.load_state_dict`` of the reference accept (params indexed in ``model.parameters()`` order, torch layouts).  ``load_checkpoint`` applies the loader
 surgery of lightning/systems/system.py:115-192 (old ``model.speaker_emb.weight`` key, 326 <-> 2390 speaker
 tables, unknown keys dropped, optimizer state discarded when anything changed)."""
 from __future__ import annotations
@@ -10,15 +12,55 @@ from typing import Dict
 import numpy as np
 
 
+def _param_order(system):
+    """``model.parameters()`` order of the reference FastSpeech2 (= its state_dict order minus the BatchNorm buffers), frozen
+    nn.Parameters included: torch's Adam indexes its state by position in this list (lightning/optimizer.py:9-15 passes
+    ``model.parameters()``); the four frozen tables (position_enc x2, pitch_bins, energy_bins) sit in the param group but never
+    receive a gradient, so they have no state entry."""
+    from . import synth
+    return [(n, trainable) for n, (_, trainable) in synth.param_spec(system.model.dims).items()]
+
+
+def optimizer_state_dict(system) -> Dict:
+    """``torch.optim.Adam.state_dict()`` of the reference's optimizer, filled from the engine's moments."""
+    import torch
+    from .systems import noam_lr
+    eng, o = system.engine, system.train_config["optimizer"]
+    init_lr = float(system.model.dims.d_model ** -0.5)
+    steps = int(eng_adam_steps(system))
+    state = {}
+    order = _param_order(system)
+    if steps > 0:
+        for i, (n, trainable) in enumerate(order):
+            if trainable:
+                state[i] = {"step": torch.tensor(float(steps)), "exp_avg": torch.from_numpy(eng.export(n, 4)),
+                            "exp_avg_sq": torch.from_numpy(eng.export(n, 5))}
+    group = {"lr": noam_lr(system.global_step, system.model.dims.d_model, system.train_config), "betas": tuple(o["betas"]), "eps": o["eps"],
+             "weight_decay": o["weight_decay"], "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+             "differentiable": False, "fused": None, "initial_lr": init_lr, "params": list(range(len(order)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def eng_adam_steps(system) -> int:
+    return int(getattr(system, "adam_steps", system.global_step))
+
+
+def scheduler_state_dict(system) -> Dict:
+    """``LambdaLR.state_dict()`` (lightning/scheduler.py:25-28): a function lambda is stored as None."""
+    from .systems import noam_lr
+    init_lr = float(system.model.dims.d_model ** -0.5)
+    return {"base_lrs": [init_lr], "last_epoch": int(system.global_step), "_step_count": int(system.global_step) + 1,
+            "_get_lr_called_within_step": False, "_last_lr": [noam_lr(system.global_step, system.model.dims.d_model, system.train_config)],
+            "lr_lambdas": [None]}
+
+
 def save_checkpoint(system, path: str):
     import torch
     sd = {k: (torch.tensor(v.item()) if np.ndim(v) == 0 else torch.from_numpy(np.ascontiguousarray(v)))
           for k, v in system.state_dict().items()}
-    eng = system.engine
-    opt = {"step": int(system.global_step),
-           "exp_avg": {n: torch.from_numpy(eng.export(n, 4)) for n in eng.params},
-           "exp_avg_sq": {n: torch.from_numpy(eng.export(n, 5)) for n in eng.params}}
-    torch.save({"state_dict": sd, "global_step": int(system.global_step), "optimizer_states": [opt],
+    torch.save({"epoch": int(getattr(system, "current_epoch", 0)), "global_step": int(system.global_step),
+                "pytorch-lightning_version": "1.x (written by meta_tts_amd)", "state_dict": sd,
+                "optimizer_states": [optimizer_state_dict(system)], "lr_schedulers": [scheduler_state_dict(system)],
                 "hyper_parameters": {"algorithm_config": system.algorithm_config, "model_config": system.model_config}}, path)
 
 
@@ -74,9 +116,28 @@ def load_checkpoint(system, path: str, strict: bool = False):
     if changed:
         ckpt.pop("optimizer_states", None)  # system.py:191-192
     opt = (ckpt.get("optimizer_states") or [None])[0]
-    if opt and "exp_avg" in opt:
-        for n in system.engine.params:
-            system.engine.import_state(n, 4, opt["exp_avg"][n].numpy())
-            system.engine.import_state(n, 5, opt["exp_avg_sq"][n].numpy())
-        system.engine.set_optimizer_step(int(opt.get("step", system.global_step)))
+    system.adam_steps = 0
+    if opt:
+        if "state" in opt and "param_groups" in opt:   # torch.optim.Adam.state_dict(), what Lightning writes
+            order = _param_order(system)
+            if len(opt["param_groups"][0]["params"]) != len(order):
+                raise ValueError(f"optimizer state covers {len(opt['param_groups'][0]['params'])} parameters, the model has {len(order)}")
+            step = 0
+            for i, (n, trainable) in enumerate(order):
+                st = opt["state"].get(i)
+                if st is None:
+                    continue
+                if not trainable:
+                    raise ValueError(f"optimizer state for the frozen parameter {n}")
+                system.engine.import_state(n, 4, np.asarray(st["exp_avg"]))
+                system.engine.import_state(n, 5, np.asarray(st["exp_avg_sq"]))
+                step = max(step, int(float(st["step"])))
+            system.engine.set_optimizer_step(step)
+            system.adam_steps = step
+        else:
+            import warnings
+            warnings.warn("unrecognised optimizer_states layout: Adam moments reset (the step count restarts the bias correction)")
+            system.engine.reset_optimizer()
+    else:
+        system.engine.reset_optimizer()  # system.py:191-192 drops the optimizer state when the loader changed anything
     return changes

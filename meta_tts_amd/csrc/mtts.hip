@@ -125,6 +125,25 @@ int mtts_get_bn_buffers(mtts_handle* h, int layer, float* mean, float* var, int6
     return 0;
 }
 
+int mtts_set_bins(mtts_handle* h, const float* pb, const float* eb, int n) {
+    Engine& e = h->eng;
+    if (n != e.cfg.n_bins - 1) { e.set_error("bin count must be n_bins - 1"); return -1; }
+    for (const float* b : {pb, eb})
+        if (b) for (int i = 1; i < n; ++i) if (!(b[i] >= b[i - 1])) { e.set_error("bin boundaries must be non-decreasing"); return -1; }
+    if (hipStreamSynchronize(e.stream) != hipSuccess) return -1;
+    if (pb && hipMemcpy(e.pitch_bins, pb, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (eb && hipMemcpy(e.energy_bins, eb, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    return 0;
+}
+int mtts_get_bins(mtts_handle* h, float* pb, float* eb, int n) {
+    Engine& e = h->eng;
+    if (n != e.cfg.n_bins - 1) { e.set_error("bin count must be n_bins - 1"); return -1; }
+    if (hipStreamSynchronize(e.stream) != hipSuccess) return -1;
+    if (pb && hipMemcpy(pb, e.pitch_bins, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (eb && hipMemcpy(eb, e.energy_bins, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return 0;
+}
+
 static HostBatch to_host_batch(const mtts_batch& b) {
     HostBatch o;
     o.B = b.B; o.S_max = b.S_max; o.T_max = b.T_max;

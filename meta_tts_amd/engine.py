@@ -56,6 +56,8 @@ class Engine:
         self._keep: List = []
         self.n_tasks = [0, 0]
         self.batch_shapes = [[], []]
+        self.epoch = 0  # bumped whenever a batch plan or the (single, shared) activation workspace is replaced: stale-Predictions guard (model.py)
+        self.device = device
         # parameter table
         self.params: Dict[str, tuple] = {}
         name = C.c_char_p(); ndim = C.c_int(); shape = (C.c_int * 4)(); off = C.c_int64(); ad = C.c_int()
@@ -147,6 +149,22 @@ class Engine:
         self._ck(self.lib.mtts_get_bn_buffers(self.h, layer, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), C.byref(t)))
         return m, v, int(t.value)
 
+    def set_bins(self, pitch_bins=None, energy_bins=None):
+        nb = self.dims.n_bins - 1
+        pb = _arr(pitch_bins, np.float32) if pitch_bins is not None else None
+        eb = _arr(energy_bins, np.float32) if energy_bins is not None else None
+        for a in (pb, eb):
+            if a is not None and a.shape != (nb,):
+                raise MttsError(f"bins must have shape ({nb},)")
+        self._ck(self.lib.mtts_set_bins(self.h, pb.ctypes.data_as(C.c_void_p) if pb is not None else None,
+                                        eb.ctypes.data_as(C.c_void_p) if eb is not None else None, nb))
+
+    def get_bins(self):
+        nb = self.dims.n_bins - 1
+        pb, eb = np.empty(nb, np.float32), np.empty(nb, np.float32)
+        self._ck(self.lib.mtts_get_bins(self.h, pb.ctypes.data_as(C.c_void_p), eb.ctypes.data_as(C.c_void_p), nb))
+        return pb, eb
+
     # ---- batches -----------------------------------------------------------------
     def _cbatch(self, b, keep):
         """12-tuple (collate.py:47-60) of numpy arrays / torch CPU tensors -> mtts_batch.  A tuple whose
@@ -182,15 +200,18 @@ class Engine:
         if spk_from is not None:
             sarr = (_lib.Batch * n)(*[self._cbatch(b, keep) for b in spk_from])
         self._ck(self.lib.mtts_set_batches(self.h, slot, n, arr, sarr, int(average_spk)))
+        self.epoch += 1
         self.n_tasks[slot] = n
         self.batch_shapes[slot] = [(int(np.shape(b[3])[0]), int(b[5])) for b in batches]
 
     # ---- compute -----------------------------------------------------------------
     def forward(self, slot: int = 0, use_fast: bool = False, train: bool = False):
+        self.epoch += 1
         self._ck(self.lib.mtts_forward(self.h, slot, int(use_fast), int(train)))
 
     def synthesize(self, slot: int = 0, use_fast: bool = False, train: bool = False, p_control: float = 1.0,
                    e_control: float = 1.0, d_control: float = 1.0):
+        self.epoch += 1
         self._ck(self.lib.mtts_synthesize(self.h, slot, int(use_fast), int(train), p_control, e_control, d_control))
 
     def durations(self, slot: int = 0, task: int = 0):
@@ -219,6 +240,7 @@ class Engine:
         return int(ptr.value), int(t_cap.value), int(stride.value)
 
     def adapt(self, steps: int, inner_lr: float, reset: bool = True, fetch_losses: bool = True):
+        self.epoch += 1
         if fetch_losses:
             s = np.empty((steps, self.n_tasks[0], 6), np.float32)
             self._ck(self.lib.mtts_adapt(self.h, steps, inner_lr, int(reset), s.ctypes.data_as(C.c_void_p)))
@@ -235,6 +257,7 @@ class Engine:
         self._ck(self.lib.mtts_backward(self.h, slot, int(use_fast), float(scale), int(need_encoder)))
 
     def meta_grad(self, steps: int, inner_lr: float, grad_scale: float, second_order: bool = False, fetch_losses: bool = True):
+        self.epoch += 1
         nt = self.n_tasks[0]
         if fetch_losses:
             q = np.empty((nt, 6), np.float32)
@@ -250,6 +273,7 @@ class Engine:
         self._ck(self.lib.mtts_hvp_support(self.h))
 
     def plain_grad(self, slot: int = 0, grad_scale: float = 1.0, fetch_losses: bool = True):
+        self.epoch += 1
         if fetch_losses:
             q = np.empty((self.n_tasks[slot], 6), np.float32)
             self._ck(self.lib.mtts_plain_grad(self.h, slot, grad_scale, q.ctypes.data_as(C.c_void_p)))

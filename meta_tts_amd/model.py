@@ -24,6 +24,7 @@ class Predictions(tuple):
     engine: Engine
     slot: int
     task: int
+    epoch: int  # Engine.epoch when these predictions were produced; the loss refuses to run once the engine has moved on
 
 
 def _read_preprocessed(preprocess_config) -> tuple:
@@ -71,9 +72,9 @@ class FastSpeech2:
 
     def state_dict(self) -> Dict[str, np.ndarray]:
         sd = dict(self.engine.state_dict())
-        frozen = synth.make_params(self.dims, 0)
-        for k in ("encoder.position_enc", "decoder.position_enc", "variance_adaptor.pitch_bins", "variance_adaptor.energy_bins"):
-            sd[k] = frozen[k]
+        pos = synth.sinusoid_table(self.dims.max_seq_len + 1, self.dims.d_model)[None]
+        sd["encoder.position_enc"], sd["decoder.position_enc"] = pos, pos.copy()
+        sd["variance_adaptor.pitch_bins"], sd["variance_adaptor.energy_bins"] = self.engine.get_bins()  # what the engine really quantises with
         for i in range(self.dims.postnet_layers):
             m, v, t = self.engine.get_bn_buffers(i)
             sd[f"postnet.convolutions.{i}.1.running_mean"] = m
@@ -84,6 +85,11 @@ class FastSpeech2:
     def load_state_dict(self, sd: Dict[str, np.ndarray], strict: bool = True):
         sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()}
         self.engine.load_params(sd, strict=strict)
+        # frozen nn.Parameters that torch restores from the checkpoint (modules.py:57-71): a checkpoint trained on another
+        # corpus carries that corpus' pitch / energy quantisation (system.py corpus-mismatch branch)
+        pb, eb = sd.get("variance_adaptor.pitch_bins"), sd.get("variance_adaptor.energy_bins")
+        if pb is not None or eb is not None:
+            self.engine.set_bins(pb, eb)
         for i in range(self.dims.postnet_layers):
             km, kv, kt = (f"postnet.convolutions.{i}.1.{s}" for s in ("running_mean", "running_var", "num_batches_tracked"))
             if km in sd and kv in sd:
@@ -120,7 +126,7 @@ class FastSpeech2:
         d_rounded = torch.as_tensor(np.asarray(batch[11])) if batch[11] is not None else torch.from_numpy(o["d_rounded"])
         p = Predictions((torch.from_numpy(o["mel"]), torch.from_numpy(o["mel_post"]), torch.from_numpy(o["p"]),
                          torch.from_numpy(o["e"]), torch.from_numpy(o["logd"]), d_rounded, src_masks, mel_masks, src_lens, mel_lens))
-        p.engine, p.slot, p.task = self.engine, slot, task
+        p.engine, p.slot, p.task, p.epoch = self.engine, slot, task, self.engine.epoch
         return p
 
 
@@ -136,6 +142,9 @@ class FastSpeech2Loss:
         import torch
         if not isinstance(predictions, Predictions):
             raise MttsError("FastSpeech2Loss needs the Predictions object returned by FastSpeech2.forward")
+        if predictions.engine.epoch != predictions.epoch:
+            raise MttsError("stale Predictions: the engine has run another batch / forward since these were produced "
+                            "(the loss is evaluated on the activations resident in HBM)")
         vals = predictions.engine.loss(predictions.slot)[predictions.task]
         return tuple(torch.tensor(float(v)) for v in vals)
 

@@ -45,6 +45,7 @@ class System:
         self.loss_func = FastSpeech2Loss(preprocess_config, model_config)
         self.engine = self.model.engine
         self.global_step = 0
+        self.adam_steps = 0  # optimizer.step() calls since the moments were (re)initialised: Adam's bias-correction count
         self.world_size = 1
 
     # system.py:53-56
@@ -70,6 +71,7 @@ class System:
         self.engine.outer_update(lr=lr, betas=tuple(o["betas"]), eps=o["eps"], weight_decay=o["weight_decay"],
                                  max_norm=o["grad_clip_thresh"], grad_ptr=grad_ptr)
         self.global_step += 1
+        self.adam_steps += 1
         return lr
 
     # checkpoint surface (system.py:115-192 loader surgery lives in checkpoint.py)
@@ -221,13 +223,19 @@ class Trainer:
         self.group = process_group
         self.system.world_size = self.dist.get_world_size(self.group) if self.dist else 1
         self.outer = outer_grad_tensor  # torch view of engine.outer_grad_ptr() (zero copy on GPU)
+        if self.dist is not None and self.dist.get_backend(self.group) == "nccl":
+            # RCCL orders its collective after torch's CURRENT stream of the engine's device: put the engine's launches on that
+            # stream so the all-reduce sees the finished outer gradient and the clip + Adam after it sees the reduced one
+            import torch
+            dev = self.system.engine.device
+            self.system.engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 
     def _allreduce(self):
         if self.dist is None or self.system.world_size == 1:
             return
         if self.outer is None:
             import torch
-            self.outer = torch.as_tensor(self.system.engine.outer_grad_view(), device="cuda")
+            self.outer = torch.as_tensor(self.system.engine.outer_grad_view(), device=f"cuda:{self.system.engine.device}")
         self.dist.all_reduce(self.outer, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def meta_step(self, local_tasks: Sequence[tuple], total_tasks: int):

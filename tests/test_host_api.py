@@ -99,6 +99,65 @@ def test_meta_training_step_and_checkpoint_roundtrip(cfgs, emu_lib, tmp_path):
     np.testing.assert_array_equal(sysm.engine.export("mel_linear.weight"), other.engine.export("mel_linear.weight"))
 
 
+def test_checkpoint_optimizer_state_is_torch_adam_layout(cfgs, emu_lib, tmp_path):
+    """the file must be resumable by the reference — `optimizer.load_state_dict(ckpt["optimizer_states"][0])` on
+    torch.optim.Adam over model.parameters() (lightning/optimizer.py:9-15) and LambdaLR.load_state_dict — and a checkpoint
+    written by torch's Adam must resume here with the moments AND the bias-correction step count."""
+    from meta_tts_amd.systems import noam_lr as host_noam
+    sysm = _system(cfgs, emu_lib)
+    dims = sysm.model.dims
+    trn = cfgs[2]
+    sup = synth.make_batch(5, 3, speaker=2, vocab=dims.vocab, **_kw(dims.n_mel))
+    qry = synth.make_batch(6, 2, speaker=2, vocab=dims.vocab, **_kw(dims.n_mel))
+    for step in range(2):
+        sysm.training_step([([sup], [qry])], step)
+        sysm.optimizer_step()
+    path = str(tmp_path / "a.ckpt")
+    checkpoint.save_checkpoint(sysm, path)
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert {"epoch", "global_step", "state_dict", "optimizer_states", "lr_schedulers"} <= set(raw)
+    # --- the reference side: a torch Adam over parameters in model.parameters() order accepts the state -------------------
+    spec = synth.param_spec(dims)
+    tparams = [torch.nn.Parameter(raw["state_dict"]["model." + n].clone(), requires_grad=tr) for n, (_, tr) in spec.items()]
+    o = trn["optimizer"]
+    opt = torch.optim.Adam(tparams, lr=dims.d_model ** -0.5, betas=o["betas"], eps=o["eps"], weight_decay=o["weight_decay"])
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: host_noam(s, dims.d_model, trn) / dims.d_model ** -0.5)
+    opt.load_state_dict(raw["optimizer_states"][0])
+    sch.load_state_dict(raw["lr_schedulers"][0])
+    assert sch.last_epoch == 2 and abs(sch.get_last_lr()[0] - host_noam(2, dims.d_model, trn)) < 1e-12
+    names = list(spec)
+    i = names.index("mel_linear.weight")
+    st = opt.state[tparams[i]]
+    assert float(st["step"]) == 2.0
+    np.testing.assert_array_equal(st["exp_avg"].numpy(), sysm.engine.export("mel_linear.weight", 4))
+    assert names.index("encoder.position_enc") not in raw["optimizer_states"][0]["state"]  # frozen: in the group, no state
+    # --- third step on both sides from the same gradient: torch Adam (after clip) == the engine's fused clip + Adam --------
+    sysm.training_step([([sup], [qry])], 2)
+    grads = {n: sysm.engine.export(n, 1) for n, (_, tr) in spec.items() if tr}
+    for p_, (n, (_, tr)) in zip(tparams, spec.items()):
+        p_.grad = torch.from_numpy(grads[n].copy()) if tr else None
+    torch.nn.utils.clip_grad_norm_([p_ for p_ in tparams if p_.requires_grad], o["grad_clip_thresh"])
+    opt.step(); sch.step()
+    sysm.optimizer_step()
+    for n in ("mel_linear.weight", "decoder.layer_stack.1.pos_ffn.w_1.weight", "postnet.convolutions.0.1.weight"):
+        np.testing.assert_allclose(sysm.engine.export(n), tparams[names.index(n)].detach().numpy(), rtol=2e-5, atol=2e-7)
+    # --- and back: a checkpoint whose optimizer state was written by torch resumes here ----------------------------------
+    raw["optimizer_states"] = [opt.state_dict()]
+    raw["lr_schedulers"] = [sch.state_dict()]
+    raw["global_step"] = 3
+    raw["state_dict"] = {k: (torch.tensor(v.item()) if np.ndim(v) == 0 else torch.from_numpy(np.ascontiguousarray(v))) for k, v in sysm.state_dict().items()}
+    path2 = str(tmp_path / "b.ckpt")
+    torch.save(raw, path2)
+    other = _system(cfgs, emu_lib)
+    checkpoint.load_checkpoint(other, path2)
+    assert other.global_step == 3 and other.adam_steps == 3
+    np.testing.assert_allclose(other.engine.export("mel_linear.weight", 5), opt.state[tparams[i]]["exp_avg_sq"].numpy(), rtol=1e-6)
+    for s_ in (sysm, other):
+        s_.training_step([([sup], [qry])], 3)
+        s_.optimizer_step()
+    np.testing.assert_allclose(other.engine.export("mel_linear.weight"), sysm.engine.export("mel_linear.weight"), rtol=1e-6, atol=1e-8)
+
+
 def test_loader_surgery_old_key_and_speaker_table():
     """system.py:122-148: rename model.speaker_emb.weight; 326-row table -> 2390-row table keeps rows [:247] and [-79:]."""
     g = np.random.RandomState(0)
@@ -259,3 +318,35 @@ def test_on_test_start_avg_train_spk_emb(cfgs, emu_lib, tmp_path):
     sysm.engine.load_params({"speaker_emb.model.weight": w}, strict=False)
     sysm.on_test_start()
     np.testing.assert_array_equal(sysm.engine.export("speaker_emb.model.weight"), w)
+
+
+def test_bins_follow_the_checkpoint_and_stale_predictions_are_refused(cfgs, emu_lib):
+    """pitch / energy bins are frozen nn.Parameters the reference restores from the checkpoint
+    (modules.py:57-71) — a cross-corpus checkpoint must change the quantisation; and FastSpeech2Loss must not silently
+    evaluate somebody else's activations."""
+    from meta_tts_amd.engine import MttsError
+    sysm = _system(cfgs, emu_lib)
+    dims = sysm.model.dims
+    b = synth.make_batch(3, 2, speaker=4, vocab=dims.vocab, **_kw(dims.n_mel))
+    tb = tuple(torch.from_numpy(x) if isinstance(x, np.ndarray) else x for x in b)
+    sd = sysm.model.state_dict()
+    np.testing.assert_allclose(sd["variance_adaptor.pitch_bins"], np.linspace(dims.pitch_min, dims.pitch_max, dims.n_bins - 1), rtol=1e-6)
+    loss0, out0 = sysm.common_step(tb, 0, train=False)
+    # a checkpoint from a corpus with a different pitch range
+    sd2 = dict(sd)
+    sd2["variance_adaptor.pitch_bins"] = np.linspace(-0.5, 0.5, dims.n_bins - 1).astype(np.float32)
+    sysm.model.load_state_dict(sd2)
+    np.testing.assert_array_equal(sysm.model.state_dict()["variance_adaptor.pitch_bins"], sd2["variance_adaptor.pitch_bins"])
+    loss1, out1 = sysm.common_step(tb, 0, train=False)
+    prm = {k: torch.from_numpy(np.asarray(v).copy()) for k, v in sd2.items() if "running" not in k and "num_batches" not in k}
+    ob = O.to_torch_batch(b)
+    with torch.no_grad():
+        o = O.fs2_forward(prm, torch_buffers(dims), *ob[2:], n_head=heads(dims), max_seq_len=dims.max_seq_len, training=False)
+    assert (out1[1] - o[1]).abs().max() < 5e-5           # the engine quantises with the checkpoint's bins
+    assert (out1[1] - out0[1]).abs().max() > 1e-3        # ... which is not what the local stats.json would give
+    with pytest.raises(MttsError, match="non-decreasing"):
+        sysm.engine.set_bins(pitch_bins=np.linspace(1, -1, dims.n_bins - 1))
+    # stale predictions: out0 was produced two forwards ago
+    with pytest.raises(MttsError, match="stale"):
+        sysm.loss_func(tb, out0)
+    assert len(sysm.loss_func(tb, out1)) == 6
