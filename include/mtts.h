@@ -173,6 +173,30 @@ int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const 
 int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* x_or_dy, const float* w_or_x, float* out,
                     const float* bias, int tile, void* hip_stream);
 
+/* ---- kernel-level entry points of the HBM-bound (non-GEMM) kernels, so each can be parity-tested alone (dev pointers; rows are
+ * dense [rows][C] fp32 matrices, C % 4 == 0, C <= 1024; `ws` = caller-allocated device scratch of mtts_kernel_ws_bytes(rows, n_mat)
+ * bytes; nothing is allocated inside; asynchronous on `stream` apart from a <= 64-byte descriptor upload) -------------------
+ * layernorm: transformer/SubLayers.py:55,91 + modules.py:222-235 (eps 1e-5): z = a + res (res may be NULL; z may be NULL),
+ *   y = LN(z) * gamma + beta on rows with mask != 0 (mask NULL: all), 0 elsewhere; stats[row] = (mean, rstd).  bwd: dz, dgamma, dbeta.
+ * softmax / sdpa: transformer/Modules.py:14-25 for n_mat independent (sequence, head) pairs of length L; S, P are
+ *   [n_mat][L][ldS], ldS = (L + 3) & ~3; q, k, v, o are [n_mat][L][dk].  softmax_bwd turns dP into dS = alpha * P o (dP - rowsum(dP o P)) in place.
+ * batchnorm: PostNet BatchNorm1d in training mode over the rows with inrect != 0 (transformer/Layers.py:129-137), optional tanh;
+ *   stats [3C] = mean | rstd | unbiased var.  bwd takes n_in = number of such rows.
+ * table_grad: nn.Embedding backward, dtable [V][C] fully written, rows summed in ascending order, skip_row (padding_idx) stays 0. */
+int64_t mtts_kernel_ws_bytes(int rows, int n_mat);
+int mtts_layernorm_fwd(int rows, int C, const float* a, const float* res, const float* gamma, const float* beta, const unsigned char* mask,
+                       float* z, float* y, float* stats, void* ws, void* hip_stream);
+int mtts_layernorm_bwd(int rows, int C, const float* dy, const float* z, const float* stats, const float* gamma, const unsigned char* mask,
+                       float* dz, float* dgamma, float* dbeta, void* ws, void* hip_stream);
+int mtts_softmax_fwd(int n_mat, int L, float* S, void* ws, void* hip_stream);
+int mtts_softmax_bwd(int n_mat, int L, const float* P, float* dP, float alpha, void* ws, void* hip_stream);
+int mtts_sdpa_fwd(int n_mat, int L, int dk, const float* q, const float* k, const float* v, float* P, float* o, void* ws, void* hip_stream);
+int mtts_batchnorm_fwd(int rows, int C, const float* x, const unsigned char* inrect, const float* gamma, const float* beta, int do_tanh,
+                       float* stats, float* y, void* ws, void* hip_stream);
+int mtts_batchnorm_bwd(int rows, int n_in, int C, const float* dy, const float* y, const float* x, const float* stats, const unsigned char* inrect,
+                       const float* gamma, int do_tanh, float* dx, float* dgamma, float* dbeta, void* ws, void* hip_stream);
+int mtts_table_grad(int rows, int C, int V, const float* dx, const int* idx, int skip_row, float* dtable, void* ws, void* hip_stream);
+
 /* ---- MelGAN generator: mel -> waveform --------------------------------------------
  * Replaces `LightningMelGAN.inverse / infer`, lightning/utils.py:8-30 (vocoder.mel2wav of torch.hub
  * "descriptinc/melgan-neurips"; the generator is an un-vendored dependency: architecture of that hub entry, weights

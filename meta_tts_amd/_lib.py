@@ -73,6 +73,17 @@ EXPORTS = {
                                 C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "mtts_conv1d_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_void_p]),
+    "mtts_kernel_ws_bytes": (C.c_int64, [C.c_int, C.c_int]),
+    "mtts_layernorm_fwd": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 10),
+    "mtts_layernorm_bwd": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 10),
+    "mtts_softmax_fwd": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtts_softmax_bwd": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "mtts_sdpa_fwd": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7),
+    "mtts_batchnorm_fwd": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "mtts_batchnorm_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtts_table_grad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_vocoder_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]),
     "mtts_vocoder_destroy": (None, [C.c_void_p]),

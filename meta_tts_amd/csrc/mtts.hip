@@ -345,6 +345,8 @@ int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* a, c
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+#include "kernel_api.inc"
+
 // ---- MelGAN generator (vocoder.h; reference call site lightning/utils.py:8-30) ----------------------------
 int mtts_vocoder_create(int n_mel, int ngf, int n_res, const int* ratios, int n_ratios, int device, int max_B, int max_T,
                         mtts_vocoder** out) {
