@@ -102,6 +102,14 @@ class Task:
         return split_reprocess(self.sup_data, idxs)
 
 
+def get_single_collate(sort: bool = True):
+    """lightning/collate.py:130-143 (BaselineDataModule): one plain batch, longest text first when `sort`."""
+    def collate_fn(data):
+        idx = np.argsort(-np.array([d["text"].shape[0] for d in data])) if sort else np.arange(len(data))
+        return reprocess(data, idx)
+    return collate_fn
+
+
 class SpeakerTaskCollate:
     """lightning/collate.py:146-196."""
 

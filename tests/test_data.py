@@ -9,34 +9,18 @@ import __graft_entry__ as ge
 from meta_tts_amd import data as D
 from oracle_util import tiny_dims
 
-SPEAKERS = {"spkA": 12, "spkB": 9, "spkC": 3}
+from data_tree import PHONES, SPEAKERS, write_tree as _write_tree
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "collate.npz")
 
 
-def _write_tree(root, n_mel=32, vocab=40):
-    g = np.random.RandomState(0)
-    for kind in ("mel", "pitch", "energy", "duration"):
-        os.makedirs(os.path.join(root, kind))
-    lines = []
-    for spk, n in SPEAKERS.items():
-        for u in range(n):
-            base = f"{spk}_utt{u:02d}"
-            S = int(g.randint(5, 13))
-            dur = g.randint(1, 6, size=S)
-            T = int(dur.sum())
-            np.save(os.path.join(root, "mel", f"{spk}-mel-{base}.npy"), g.standard_normal((T, n_mel)).astype(np.float32))
-            np.save(os.path.join(root, "pitch", f"{spk}-pitch-{base}.npy"), g.standard_normal(S))
-            np.save(os.path.join(root, "energy", f"{spk}-energy-{base}.npy"), g.standard_normal(S).astype(np.float32))
-            np.save(os.path.join(root, "duration", f"{spk}-duration-{base}.npy"), dur)
-            phones = " ".join(str(int(x)) for x in g.randint(1, vocab, size=S))
-            lines.append(f"{base}|{spk}|{{{phones}}}|raw text of {base}")
-    with open(os.path.join(root, "train.txt"), "w") as f:
-        f.write("\n".join(lines) + "\n")
-    with open(os.path.join(root, "speakers.json"), "w") as f:
-        json.dump({s: i + 3 for i, s in enumerate(SPEAKERS)}, f)
+def _phone_ids(line_text):
+    """Stand-in front-end for tests that do not use the golden: position in PHONES + 1."""
+    return [PHONES.index(p) + 1 for p in line_text.strip("{}").split()]
 
 
 def _dataset(root):
-    return D.ConcatDataset([D.FeatureDataset(root, "train.txt", lambda t: [int(x) for x in t.strip("{}").split()])])
+    return D.ConcatDataset([D.FeatureDataset(root, "train.txt", _phone_ids)])
 
 
 def test_reader_and_reprocess_layout(tmp_path):
@@ -104,3 +88,42 @@ def test_train_stream_feeds_the_engine(tmp_path):
     q, s = eng.meta_grad(1, 1e-3, 1.0)
     assert np.all(np.isfinite(q)) and np.all(np.isfinite(s))
     eng.close()
+
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# exact parity with the reference's reader + collate (tests/golden/collate.npz, made by importing dataset.py and
+# lightning/collate.py in the build container): values AND dtypes of every element of the 12-tuples
+# ---------------------------------------------------------------------------------------------------------------------
+def _check(prefix, got, g):
+    ids, raw, spk, texts, tlens, tmax, mels, mlens, mmax, pit, ene, dur = got
+    assert list(ids) == [str(x) for x in g[prefix + "ids"]]
+    assert list(raw) == [str(x) for x in g[prefix + "raw"]]
+    for k, v in (("spk", spk), ("texts", texts), ("tlens", tlens), ("mels", mels), ("mlens", mlens), ("pit", pit), ("ene", ene), ("dur", dur)):
+        a = np.asarray(v)
+        np.testing.assert_array_equal(a, g[prefix + k], err_msg=prefix + k)
+        assert str(a.dtype) == str(g[prefix + k + "_dtype"]), (prefix + k, a.dtype, g[prefix + k + "_dtype"])
+    assert int(tmax) == int(g[prefix + "tmax"]) and int(mmax) == int(g[prefix + "mmax"])
+
+
+def test_collate_matches_reference_golden_exactly(tmp_path):
+    g = np.load(GOLDEN, allow_pickle=False)
+    lines = _write_tree(str(tmp_path))
+    # the reference's text front-end (text/__init__.py, out of scope) is replaced by its recorded output per line
+    ids_of = {ln.split("|")[2]: g[f"text_{i}"].tolist() for i, ln in enumerate(lines)}
+    ds = D.FeatureDataset(str(tmp_path), "train.txt", lambda t: ids_of[t])
+    assert len(ds) == int(g["n"])
+    samples = [ds[i] for i in range(len(ds))]
+    for i, s in enumerate(samples):
+        assert s["speaker"] == int(g[f"speaker_{i}"])
+    _check("re_", D.reprocess(samples, [2, 0, 13, 22]), g)
+    _check("single_", D.get_single_collate(sort=True)([samples[i] for i in (5, 1, 9, 20, 14)]), g)
+    task = [samples[i] for i in (12, 15, 13, 19, 17, 14)]
+    for sort in (False, True):
+        sup, qry = D.SpeakerTaskCollate().meta_collate_fn(task, shots=3, queries=3, sort=sort, split=True)
+        assert len(sup) == 1 and len(qry) == 1
+        _check(f"meta{int(sort)}_sup_", sup[0], g)
+        _check(f"meta{int(sort)}_qry_", qry[0], g)
+    whole = D.SpeakerTaskCollate().meta_collate_fn(task, shots=3, queries=3, sort=False, split=False)
+    _check("nosplit_", whole[0], g)
+    _check("sub_", D.split_reprocess(whole[0], [4, 1]), g)

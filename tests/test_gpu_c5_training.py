@@ -324,3 +324,41 @@ def test_maml_at_reference_inner_lr_contractive_fixture(golden_dir, order):
         ref = g[key]
         assert np.abs(got - ref).max() <= 5e-3 * max(1e-3, np.abs(ref).max()), key
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f1: episodes sampled and collated by meta_tts_amd.data from a feature tree on disk -> the real engine -> oracle
+# ---------------------------------------------------------------------------------------------------------------------
+def test_feature_tree_episodes_through_the_engine_vs_oracle(tmp_path):
+    """dataset.py + collate.py path (tests/test_data.py pins it to the reference's output exactly) feeding the HIP engine: a
+    val-style fixed 1-way 3-shot task read from .npy files, one second-order meta-gradient, against the oracle on the very same
+    12-tuples."""
+    from data_tree import PHONES, write_tree
+    from meta_tts_amd import data as D
+    from oracle_util import tiny_dims
+    write_tree(str(tmp_path))
+    dims = tiny_dims()                       # n_mel 32 = the tree's mel width, vocab 40 > len(PHONES)
+    ds = D.ConcatDataset([D.FeatureDataset(str(tmp_path), "train.txt", lambda t: [PHONES.index(p) + 1 for p in t.strip("{}").split()])])
+    tasks = D.few_shot_task_dataset(ds, ways=1, shots=3, queries=2, n_tasks_per_label=1, seed=4)
+    assert len(tasks) == 2                   # spkA and spkB have >= 5 utterances
+    mods = ["speaker_emb", "variance_adaptor", "decoder", "mel_linear", "postnet"]
+    eng = Engine(dims, adapt_modules=mods, max_tasks=2, max_B=3, max_S=16, max_T=96)
+    eng.load_params(synth.make_params(dims, 0))
+    eps = [tasks[i] for i in range(2)]
+    sup = [e[0][0] for e in eps]; qry = [e[1][0] for e in eps]
+    eng.set_batches(0, sup)
+    eng.set_batches(1, qry, spk_from=sup, average_spk=True)
+    q, s = eng.meta_grad(2, 0.01, 0.5, second_order=True)
+    tot = {}
+    check = ["mel_linear.weight", "decoder.layer_stack.1.pos_ffn.w_1.weight", "encoder.layer_stack.0.slf_attn.fc.weight", "speaker_emb.model.weight"]
+    for j in range(2):
+        p = torch_params(dims, requires_grad=True)
+        ql, sl, _, _ = O.maml_task(p, torch_buffers(dims), O.to_torch_batch(sup[j]), O.to_torch_batch(qry[j]), steps=2, lr=0.01,
+                                   second_order=True, modules=mods, n_head=heads(dims), max_seq_len=dims.max_seq_len)
+        np.testing.assert_allclose(q[j], [float(x) for x in ql], rtol=2e-4)
+        gs = torch.autograd.grad(ql[0], [p[n] for n in check])
+        for n, x in zip(check, gs):
+            tot[n] = tot.get(n, 0) + 0.5 * x.numpy()
+    for n in check:
+        assert np.abs(eng.export(n, 1) - tot[n]).max() <= 3e-3 * np.abs(tot[n]).max() + 1e-7, n
+    eng.close()
