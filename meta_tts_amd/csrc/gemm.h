@@ -798,7 +798,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     if (prof.enabled) {
         hipEventRecord(e1, stream);
         GemmProfiler::Rec rec{6, flops, e0, e1};
-        rec.form = 3; rec.tile = 64; rec.N = mp.n; rec.K = 0; rec.groups = max_groups; rec.splitk = 1; rec.rows = rows; rec.bytes = bytes;
+        rec.form = 3; rec.tile = glds ? 4064 : 64; rec.N = mp.n; rec.K = maxK; rec.groups = mp.start[mp.n]; rec.splitk = 1; rec.rows = rows; rec.bytes = bytes;  // multi: N = problems, K = longest K, groups = workgroups
         prof.recs.push_back(rec);
     }
     b.q.clear();

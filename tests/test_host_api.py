@@ -350,3 +350,66 @@ def test_bins_follow_the_checkpoint_and_stale_predictions_are_refused(cfgs, emu_
     with pytest.raises(MttsError, match="stale"):
         sysm.loss_func(tb, out0)
     assert len(sysm.loss_func(tb, out1)) == 6
+
+
+def test_test_stage_result_layout_matches_reference_saver(cfgs, emu_lib, tmp_path):
+    """saver.py:130-178 / :203-213 + callbacks/utils.py:55-141: the result tree `evaluation/` globs
+    (`audio/Testing/step_<S>/<task>/<id>.recon.wav`, `...FTstep_<k>.synth.wav`, `csv/Testing/step_<S>/<task>.csv`), with the CSV
+    bytes equal to what pandas writes for the same values (the reference's `DataFrame.to_csv`)."""
+    pd = pytest.importorskip("pandas")
+    from scipy.io import wavfile
+    from meta_tts_amd.saver import CSV_COLUMNS, Saver, loss2dict
+    pre, mod, trn, alg = cfgs
+    alg["adapt"]["train"]["steps"] = 2
+    alg["adapt"]["test"]["steps"] = 4
+    alg["adapt"]["test"]["saving_steps"] = [4]
+    alg["adapt"]["task"]["lr"] = 0.01
+    sysm = _system((pre, mod, trn, alg), emu_lib)
+    dims = sysm.model.dims
+    prm = synth.make_params(dims, 0)
+    prm["variance_adaptor.duration_predictor.linear_layer.bias"][:] = 1.2   # a few predicted frames at random init
+    sysm.model.load_state_dict(prm)
+    sup = synth.make_batch(5, 3, speaker=2, vocab=dims.vocab, **_kw(dims.n_mel))
+    qry = synth.make_batch(6, 2, speaker=2, vocab=dims.vocab, **_kw(dims.n_mel))
+    batch = [([sup], [qry])]
+    sysm.test_global_step = 100000
+    outs = sysm.test_step(batch, 0)
+
+    class StubVocoder:   # LightningMelGAN.infer contract (lightning/utils.py:20-30): list of int16 arrays cropped to `lengths`
+        def infer(self, mels, max_wav_value, lengths=None):
+            return [(np.tanh(m.mean(axis=0)).repeat(256)[:l] * 0.5 * max_wav_value).astype("int16") for m, l in zip(mels, lengths)]
+
+    sq = {f"{'-'.join(sup[0])}.{'-'.join(qry[0])}": "test_007"}
+    sv = Saver(pre, str(tmp_path / "log"), str(tmp_path / "result"))
+    paths = sv.on_test_batch_end(outs, batch, sq, sysm.test_global_step, sysm.adaptation_steps, sysm.test_adaptation_steps, StubVocoder())
+    root = tmp_path / "result"
+    csv_path = root / "csv" / "Testing" / "step_100000" / "test_007.csv"
+    assert paths == [str(csv_path)]
+    # pandas on the same loss values, exactly as saver.py:174-175 does
+    rows = [{"Step": k, **loss2dict(outs[0][f"step_{k}"]["recon"]["losses"])} for k in (0, 2, 4)]
+    ref = tmp_path / "ref.csv"
+    pd.DataFrame(rows, columns=["Step"] + CSV_COLUMNS).set_index("Step").to_csv(ref, mode="a", header=True, index=True)
+    assert csv_path.read_bytes() == ref.read_bytes()
+    adir = root / "audio" / "Testing" / "step_100000" / "test_007"
+    names = sorted(os.listdir(adir))
+    want = sorted([f"{i}.recon.wav" for i in qry[0]] + [f"{i}.step_100000-FTstep_{k}.synth.wav" for i in qry[0] for k in (0, 4)])
+    assert names == want
+    rate, wav = wavfile.read(adir / f"{qry[0][0]}.recon.wav")
+    assert rate == 22050 and wav.dtype == np.int16 and len(wav) == int(qry[7][0]) * 256
+    rate, wav = wavfile.read(adir / f"{qry[0][0]}.step_100000-FTstep_4.synth.wav")
+    assert len(wav) == int(outs[0]["step_4"]["synth"]["output"][9][0]) * 256
+    assert (root / "figure" / "Testing" / "step_100000" / "test_007").is_dir()
+    # validation CSV: one appended row per pass, header once (saver.py:203-213)
+    v = sysm.validation_step(batch, 0)
+    p1 = sv.on_validation_batch_end(v, batch, global_step=999, val_SQids2Tid={k: "val_003" for k in sq})
+    sv.on_validation_batch_end(v, batch, global_step=1999, val_SQids2Tid={k: "val_003" for k in sq})
+    ref2 = tmp_path / "ref2.csv"
+    for step in (1000, 2000):
+        pd.DataFrame(loss2dict(v["losses"]), columns=CSV_COLUMNS, index=[step]).to_csv(ref2, mode="a", header=not os.path.exists(ref2), index=True, index_label="Step")
+    assert open(p1, "rb").read() == ref2.read_bytes() and p1.endswith(os.path.join("log", "csv", "Validation", "val_003.csv"))
+    # 1-shot mode: several outputs per task -> task ids suffixed _<i> (saver.py:143-147)
+    alg["adapt"]["test"]["1-shot"] = True
+    one = sysm.test_step(batch, 0)
+    assert len(one) == 3
+    paths = sv.on_test_batch_end(one, batch, sq, 100000, sysm.adaptation_steps, sysm.test_adaptation_steps, None)
+    assert [os.path.basename(p) for p in paths] == ["test_007_0.csv", "test_007_1.csv", "test_007_2.csv"]
