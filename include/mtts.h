@@ -133,6 +133,19 @@ int mtts_meta_grad(mtts_handle* h, int steps, float inner_lr, float grad_scale, 
  * in the per-task gradient buffer (e.g. after mtts_backward): the building block of the second-order sweep,
  * exposed for parity tests against torch.autograd (export with which = 6). */
 int mtts_hvp_support(mtts_handle* h);
+/* ---- iMAML (lightning/systems/imaml.py:22-150, lightning/systems/utils.py:120-189; `hypergrad` is an empty submodule of the
+ * reference: its conjugate gradient is restated, parity unpinned there).  mtts_set_inner_prox(reg) adds the proximal term
+ * 0.5 * reg * |theta_a - w|^2 (imaml.py:41-46,69) to the inner loss of every subsequent mtts_adapt / mtts_meta_grad step (0 = off).
+ * Hypergradient of the query loss after mtts_adapt:  begin (query pass at the adapted weights; b = dL_q/dw, v = 0) ->
+ * K x cg_step (one conjugate-gradient iteration on a * (H_support + reg * I), a = inner_lr; the Hessian-vector product runs on the
+ * batch currently in slot 0, so a fresh support mini-batch may be set before each call: `imaml.stochastic`, imaml.py:88-91) ->
+ * finish: outer gradient buffer := sum over local tasks of grad_scale * clip_t(a * reg * v_t) on the adapted parameters, 0 elsewhere
+ * (imaml.py:125-131 clips every task's hypergradient to max_norm BEFORE the mean over ranks; max_norm <= 0: no clipping);
+ * task_norms_host [n_tasks] (optional) receives the unclipped norms. */
+int mtts_set_inner_prox(mtts_handle* h, float reg_param);
+int mtts_imaml_begin(mtts_handle* h, float* qry_losses_host /* [n_tasks][6] */);
+int mtts_imaml_cg_step(mtts_handle* h, float inner_lr, float reg_param, float tol);
+int mtts_imaml_finish(mtts_handle* h, float inner_lr, float reg_param, float grad_scale, float max_norm, float* task_norms_host);
 /* BaseAdaptorSystem.adapt alone (few-shot test loop, base_adaptor.py:155-189): `steps` first-order inner steps
  * on slot 0; reset != 0 starts from a fresh clone of theta, else continues on the current fast weights. */
 int mtts_adapt(mtts_handle* h, int steps, float inner_lr, int reset, float* sup_losses_host /* [steps][n_tasks][6] */);

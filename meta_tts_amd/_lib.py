@@ -61,6 +61,10 @@ EXPORTS = {
     "mtts_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]),
     "mtts_meta_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "mtts_hvp_support": (C.c_int, [C.c_void_p]),
+    "mtts_set_inner_prox": (C.c_int, [C.c_void_p, C.c_float]),
+    "mtts_imaml_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mtts_imaml_cg_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float]),
+    "mtts_imaml_finish": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mtts_plain_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "mtts_outer_grad_ptr": (C.c_void_p, [C.c_void_p]),
     "mtts_outer_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,

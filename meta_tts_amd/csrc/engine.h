@@ -505,6 +505,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (float* p : bn_rm) hipFree(p);
         for (float* p : bn_rv) hipFree(p);
         gx.release();
+        destroy_imaml();
         if (arena) hipFree(arena);
         if (arena_so) hipFree(arena_so);
         if (hv) hipFree(hv);
@@ -1350,6 +1351,16 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // =================================================================================
     // MAML (base_adaptor.py:98-124) and the outer update
     // =================================================================================
+    // inner SGD step on the per-task fast weights; with inner_prox > 0 the proximal term of iMAML joins the gradient
+    void inner_update(int nt, float inner_lr) {
+        if (n_adapt <= 0) return;
+        if (inner_prox > 0.f)
+            MTTS_LAUNCH(sgd_prox_kernel, dim3(blocks_for(n_adapt / 4), 1, nt), dim3(256), stream, fast, (const float*)(grad + adapt_start),
+                        (const float*)(theta + adapt_start), n_adapt / 4, inner_lr, inner_prox, n_adapt, n_total);
+        else
+            MTTS_LAUNCH(sgd_update_kernel, dim3(blocks_for(n_adapt / 4), 1, nt), dim3(256), stream, fast, (const float*)(grad + adapt_start),
+                        n_adapt / 4, inner_lr, n_adapt, n_total);
+    }
     // the inner-loop backward must reach the encoder when adapt.modules lists it (config/algorithm/dev.yaml does)
     bool encoder_adapted() const { return (cfg.adapt_mask >> MOD_ENCODER) & 1; }
     static unsigned blocks_for(long long n4) { return (unsigned)std::min<long long>(std::max<long long>((n4 + 255) / 256, 1), 4096); }
@@ -1372,9 +1383,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             if (forward(ps)) return -1;
             if (sup_losses_out && loss(ps, sup_losses_out + (long long)s * nt * 6)) return -1;
             if (backward(ps, 1.f, encoder_adapted())) return -1;
-            if (n_adapt > 0)
-                MTTS_LAUNCH(sgd_update_kernel, dim3(blocks_for(n_adapt / 4), 1, nt), dim3(256), stream, fast,
-                            (const float*)(grad + adapt_start), n_adapt / 4, inner_lr, n_adapt, n_total);
+            inner_update(nt, inner_lr);
         }
         Pass pq{&qp, true, true};
         if (forward(pq)) return -1;
@@ -1399,9 +1408,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             if (forward(ps)) return -1;
             if (sup_losses_out && loss(ps, sup_losses_out + (long long)s2 * nt * 6)) return -1;
             if (backward(ps, 1.f, encoder_adapted())) return -1;
-            if (n_adapt > 0)
-                MTTS_LAUNCH(sgd_update_kernel, dim3(blocks_for(n_adapt / 4), 1, nt), dim3(256), stream, fast,
-                            (const float*)(grad + adapt_start), n_adapt / 4, inner_lr, n_adapt, n_total);
+            inner_update(nt, inner_lr);
         }
         return 0;
     }
@@ -1438,6 +1445,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     }
 
 #include "engine_so.inc"
+#include "engine_imaml.inc"
 };
 
 }  // namespace mtts

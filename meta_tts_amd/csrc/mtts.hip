@@ -260,6 +260,26 @@ int mtts_meta_grad(mtts_handle* h, int steps, float inner_lr, float grad_scale, 
 
 int mtts_hvp_support(mtts_handle* h) { return launched(h->eng, h->eng.hvp_support()); }
 
+int mtts_set_inner_prox(mtts_handle* h, float reg_param) {
+    if (!(reg_param >= 0.f)) { h->eng.set_error("reg_param must be >= 0"); return -1; }
+    h->eng.inner_prox = reg_param;
+    return 0;
+}
+int mtts_imaml_begin(mtts_handle* h, float* qry_losses_host) {
+    Engine& e = h->eng;
+    for (int sl = 0; sl < 2; ++sl) if (e.plans[sl].tasks > 0 && e.retarget(sl, true)) return -1;
+    if (launched(e, e.imaml_begin(e.losses))) return -1;
+    return copy_losses(e, e.losses, qry_losses_host, e.plans[1].tasks * 6);
+}
+int mtts_imaml_cg_step(mtts_handle* h, float inner_lr, float reg_param, float tol) {
+    Engine& e = h->eng;
+    if (e.plans[0].tasks > 0 && e.retarget(0, true)) return -1;
+    return launched(e, e.imaml_cg_step(inner_lr, reg_param, tol));
+}
+int mtts_imaml_finish(mtts_handle* h, float inner_lr, float reg_param, float grad_scale, float max_norm, float* task_norms_host) {
+    return launched(h->eng, h->eng.imaml_finish(inner_lr, reg_param, grad_scale, max_norm, task_norms_host));
+}
+
 int mtts_plain_grad(mtts_handle* h, int slot, float grad_scale, float* losses_host) {
     Engine& e = h->eng;
     if (slot < 0 || slot > 1) { e.set_error("bad slot"); return -1; }

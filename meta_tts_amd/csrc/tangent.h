@@ -374,4 +374,116 @@ __global__ void copy_rows_kernel(const int* meta, int mfield, const float* in, l
     for (int c = lane * 4; c < C; c += 256) st4(po + c, ld4(pi + c));
 }
 
+
+// ---- iMAML (engine_imaml.inc): proximal SGD step and the conjugate-gradient vector updates; per-task scalars live in
+// scal[task * stride + {rs, pAp, alpha, beta, rs_new, active, norm, coef}] --------------------------------------------------
+// w <- w - lr * (g + reg * (w - theta))      (imaml.py:69: loss = L + 0.5 * reg * sum (theta - w)^2, one SGD step)
+__global__ void sgd_prox_kernel(float* w, const float* g, const float* theta, long long n4, float lr, float reg, long long w_ts, long long g_ts) {
+    float* pw = w + (long long)blockIdx.z * w_ts;
+    const float* pg = g + (long long)blockIdx.z * g_ts;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 x = ld4(pw + i * 4);
+        const float4 d = ld4(pg + i * 4), t = ld4(theta + i * 4);
+        x.x -= lr * (d.x + reg * (x.x - t.x)); x.y -= lr * (d.y + reg * (x.y - t.y));
+        x.z -= lr * (d.z + reg * (x.z - t.z)); x.w -= lr * (d.w + reg * (x.w - t.w));
+        st4(pw + i * 4, x);
+    }
+}
+__global__ void copy_tasks_kernel(const float* src, long long src_ts, float* dst, long long dst_ts, long long n4) {
+    const float* s = src + (long long)blockIdx.z * src_ts;
+    float* d = dst + (long long)blockIdx.z * dst_ts;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) st4(d + i * 4, ld4(s + i * 4));
+}
+// partial[task][block] = sum over this block's elements of a * (ca * b + cb * a)
+__global__ void dot_partial_kernel(const float* a, long long a_ts, const float* b, long long b_ts, float ca, float cb, long long n4, float* partial,
+                                   int nblocks) {
+    __shared__ float red[4];
+    const float* pa = a + (long long)blockIdx.z * a_ts;
+    const float* pb = b + (long long)blockIdx.z * b_ts;
+    float s = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 x = ld4(pa + i * 4), y = ld4(pb + i * 4);
+        s += (x.x * (ca * y.x + cb * x.x) + x.y * (ca * y.y + cb * x.y)) + (x.z * (ca * y.z + cb * x.z) + x.w * (ca * y.w + cb * x.w));
+    }
+    s = wave_sum(s);
+    if (((int)threadIdx.x & 63) == 0) red[(int)threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(long long)blockIdx.z * nblocks + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void dot_final_kernel(const float* partial, int nblocks, float* scal, int stride, int slot) {
+    if (threadIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < nblocks; ++i) s += (double)partial[(long long)blockIdx.x * nblocks + i];
+    scal[blockIdx.x * stride + slot] = (float)s;
+}
+// mode 0: start (active = 1); 1: alpha = rs / pAp; 2: after the residual update — a task whose residual norm fell below tol
+// stops WITHOUT adopting this iteration's x (hypergrad's cg breaks before `x_last = x`), else beta = rs_new / rs, rs <- rs_new
+__global__ void cg_scalar_kernel(float* scal, int tasks, int mode, float tol) {
+    const int t = (int)threadIdx.x;
+    if (t >= tasks) return;
+    float* s = scal + t * 8;
+    if (mode == 0) { s[5] = 1.f; s[2] = 0.f; s[3] = 0.f; return; }
+    if (mode == 1) { s[2] = (s[5] != 0.f && s[1] != 0.f) ? s[0] / s[1] : 0.f; return; }
+    if (s[5] == 0.f) { s[3] = 0.f; return; }
+    if (sqrtf(s[4]) < tol) { s[5] = 0.f; s[3] = 0.f; return; }
+    s[3] = s[4] / s[0];
+    s[0] = s[4];
+}
+// r -= alpha * (ca * Hp + cb * p)
+__global__ void cg_update_r_kernel(float* r, long long r_ts, const float* p, const float* Hp, long long p_ts, float ca, float cb,
+                                   const float* scal, int stride, long long n4) {
+    const int z = blockIdx.z;
+    const float alpha = scal[z * stride + 2];
+    if (alpha == 0.f) return;
+    float* pr = r + (long long)z * r_ts;
+    const float* pp = p + (long long)z * p_ts;
+    const float* ph = Hp + (long long)z * p_ts;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 R = ld4(pr + i * 4);
+        const float4 P = ld4(pp + i * 4), H = ld4(ph + i * 4);
+        R.x -= alpha * (ca * H.x + cb * P.x); R.y -= alpha * (ca * H.y + cb * P.y);
+        R.z -= alpha * (ca * H.z + cb * P.z); R.w -= alpha * (ca * H.w + cb * P.w);
+        st4(pr + i * 4, R);
+    }
+}
+// still-active tasks: x += alpha p ; p = r + beta p
+__global__ void cg_update_xp_kernel(float* x, long long x_ts, float* p, long long p_ts, const float* r, const float* scal, int stride, long long n4) {
+    const int z = blockIdx.z;
+    if (scal[z * stride + 5] == 0.f) return;
+    const float alpha = scal[z * stride + 2], beta = scal[z * stride + 3];
+    float* px = x + (long long)z * x_ts;
+    float* pp = p + (long long)z * p_ts;
+    const float* pr = r + (long long)z * x_ts;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 X = ld4(px + i * 4), P = ld4(pp + i * 4);
+        const float4 R = ld4(pr + i * 4);
+        X.x += alpha * P.x; X.y += alpha * P.y; X.z += alpha * P.z; X.w += alpha * P.w;
+        P.x = R.x + beta * P.x; P.y = R.y + beta * P.y; P.z = R.z + beta * P.z; P.w = R.w + beta * P.w;
+        st4(px + i * 4, X); st4(pp + i * 4, P);
+    }
+}
+// scal[norm] holds |x|^2 on entry: norm = scale_g * |x|, coef = grad_scale * scale_g * min(1, max_norm / (norm + 1e-6))
+__global__ void cg_clip_kernel(float* scal, int tasks, float scale_g, float max_norm, float grad_scale) {
+    const int t = (int)threadIdx.x;
+    if (t >= tasks) return;
+    float* s = scal + t * 8;
+    const float norm = fabsf(scale_g) * sqrtf(s[6]);
+    float c = 1.f;
+    if (max_norm > 0.f) { c = max_norm / (norm + 1e-6f); c = c > 1.f ? 1.f : c; }
+    s[6] = norm;
+    s[7] = grad_scale * scale_g * c;
+}
+// out[i] = sum_t scal[t][slot] * g[t][i]   (fixed task order)
+__global__ void sum_tasks_coef_kernel(const float* g, long long g_ts, int tasks, const float* scal, int stride, int slot, float* out, long long n4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 s = zero4();
+        for (int t = 0; t < tasks; ++t) {
+            const float c = scal[t * stride + slot];
+            const float4 x = ld4(g + (long long)t * g_ts + i * 4);
+            s.x += c * x.x; s.y += c * x.y; s.z += c * x.z; s.w += c * x.w;
+        }
+        st4(out + i * 4, s);
+    }
+}
+
 }  // namespace mtts

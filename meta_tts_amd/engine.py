@@ -272,6 +272,25 @@ class Engine:
         """H v of the support loss at the current fast weights, v = per-task gradient buffer (export with which=6)."""
         self._ck(self.lib.mtts_hvp_support(self.h))
 
+    # ---- iMAML (include/mtts.h) ---------------------------------------------------
+    def set_inner_prox(self, reg_param: float):
+        self._ck(self.lib.mtts_set_inner_prox(self.h, float(reg_param)))
+
+    def imaml_begin(self) -> np.ndarray:
+        self.epoch += 1
+        q = np.empty((self.n_tasks[1], 6), np.float32)
+        self._ck(self.lib.mtts_imaml_begin(self.h, q.ctypes.data_as(C.c_void_p)))
+        return q
+
+    def imaml_cg_step(self, inner_lr: float, reg_param: float, tol: float = 1e-10):
+        self.epoch += 1
+        self._ck(self.lib.mtts_imaml_cg_step(self.h, inner_lr, reg_param, tol))
+
+    def imaml_finish(self, inner_lr: float, reg_param: float, grad_scale: float, max_norm: float = 0.0) -> np.ndarray:
+        norms = np.empty((self.n_tasks[0],), np.float32)
+        self._ck(self.lib.mtts_imaml_finish(self.h, inner_lr, reg_param, grad_scale, max_norm, norms.ctypes.data_as(C.c_void_p)))
+        return norms
+
     def plain_grad(self, slot: int = 0, grad_scale: float = 1.0, fetch_losses: bool = True):
         self.epoch += 1
         if fetch_losses:

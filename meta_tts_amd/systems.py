@@ -200,11 +200,100 @@ class BaselineSystem(BaseAdaptorSystem):
         return MetaSystem.validation_step(self, batch, batch_idx)
 
 
-SYSTEM = {"meta": MetaSystem, "baseline": BaselineSystem}
+class IMAMLSystem(BaseAdaptorSystem):
+    """lightning/systems/imaml.py:22 — implicit MAML: a proximal first-order inner loop over support mini-batches
+    (`adapt.imaml.batch_size`, imaml.py:50-73) and a conjugate-gradient hypergradient (`adapt.imaml.K` iterations, a fresh
+    mini-batch per Hessian-vector product when `adapt.imaml.stochastic`, imaml.py:76-139; utils.py:120-189), clipped per task
+    before the mean over ranks.  Not restated: the codebook phoneme-table regeneration of `on_after_batch_transfer`
+    (imaml.py:27-39, `adapt.type: lang` — the front-end is outside the hot path; FastSpeech2 refuses that config)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        im = self.algorithm_config["adapt"]["imaml"]
+        self.cg_steps, self.reg_param = int(im["K"]), float(im["reg_param"])
+        self.im_batch_size, self.stochastic = int(im["batch_size"]), bool(im["stochastic"])
+        self.task_seed = 0
+
+    def _task(self, sup_batch, qry_batch):
+        from .data import Task
+        self.task_seed += 1
+        return Task(sup_data=sup_batch, qry_data=qry_batch, batch_size=self.im_batch_size, seed=self.task_seed)
+
+    def adapt_task(self, sup_batch, qry_batch, steps: int, task=None, reset: bool = True):
+        """imaml.py:50-73: `steps` regularised first-order inner steps, each on the task's next support mini-batch."""
+        task = task or self._task(sup_batch, qry_batch)
+        self.engine.set_inner_prox(self.reg_param)
+        try:
+            for k in range(steps):
+                self.engine.set_batches(0, [task.next_batch()])
+                self.engine.adapt(1, self.adaptation_lr, reset=(reset and k == 0), fetch_losses=False)
+        finally:
+            self.engine.set_inner_prox(0.0)
+        return task
+
+    def meta_learn(self, batch, batch_idx, train: bool = True, total_tasks: Optional[int] = None):
+        """imaml.py:76-139.  Leaves the (per-task clipped) hypergradient / total_tasks in the outer-gradient buffer when training;
+        returns the query 6-tuple."""
+        sup_batch, qry_batch = batch[0][0][0], batch[0][1][0]
+        task = self.adapt_task(sup_batch, qry_batch, self.adaptation_steps)
+        self.engine.set_batches(0, [sup_batch])
+        self.engine.set_batches(1, [qry_batch], spk_from=[sup_batch], average_spk=True)
+        if not train:
+            self.engine.forward(1, use_fast=True, train=True)
+            return self.engine.loss(1)[0]
+        q = self.engine.imaml_begin()
+        task.reset_iterator()
+        for _ in range(self.cg_steps):
+            if self.stochastic:
+                self.engine.set_batches(0, [task.next_batch()])
+            self.engine.imaml_cg_step(self.adaptation_lr, self.reg_param, 1e-10)
+        scale = 1.0 / (total_tasks or self.world_size)
+        self.engine.imaml_finish(self.adaptation_lr, self.reg_param, scale, self.train_config["optimizer"]["grad_clip_thresh"])
+        return q[0]
+
+    def optimizer_step(self, grad_ptr: Optional[int] = None):
+        """Manual optimisation (imaml.py:25,133-139): the clip already happened per task, Adam sees the reduced gradient as is."""
+        o = self.train_config["optimizer"]
+        lr = noam_lr(self.global_step, self.model.dims.d_model, self.train_config)
+        self.engine.outer_update(lr=lr, betas=tuple(o["betas"]), eps=o["eps"], weight_decay=o["weight_decay"], max_norm=0.0, grad_ptr=grad_ptr)
+        self.global_step += 1
+        self.adam_steps += 1
+        return lr
+
+    def training_step(self, batch, batch_idx):
+        self._on_meta_batch_start(batch)
+        q = self.meta_learn(batch, batch_idx, train=True)
+        return {"loss": float(q[0]), "losses": q, "log": {f"Train/{k}": float(v) for k, v in zip(LOSS_NAMES, q)}, "_batch": batch[0][1][0]}
+
+    def validation_step(self, batch, batch_idx):
+        self._on_meta_batch_start(batch)
+        q = self.meta_learn(batch, batch_idx, train=False)
+        return {"losses": q, "log": {f"Val/{k}": float(v) for k, v in zip(LOSS_NAMES, q)}}
+
+    def _test_step(self, batch, batch_idx):
+        """imaml.py:163-195: as BaseAdaptorSystem._test_step but every step-0 pass runs the learner in its current (train) mode
+        and the adaptation is the regularised mini-batch loop continued on one Task."""
+        outputs = {}
+        sup_batch, qry_batch = batch[0][0][0], batch[0][1][0]
+        outputs["_batch"] = qry_batch
+        preds = self._forward_learner(sup_batch, qry_batch, use_fast=False, train=True, teacher_forced=True)
+        outputs["step_0"] = {"recon": {"losses": self.loss_func(qry_batch, preds), "output": preds}}
+        outputs["step_0"]["synth"] = {"output": self._forward_learner(sup_batch, qry_batch, False, True, teacher_forced=False)}
+        task = None
+        for ft_step in range(self.adaptation_steps, self.test_adaptation_steps + 1, self.adaptation_steps):
+            task = self.adapt_task(sup_batch, qry_batch, self.adaptation_steps, task=task, reset=(task is None))
+            preds = self._forward_learner(sup_batch, qry_batch, use_fast=True, train=True, teacher_forced=True)
+            outputs[f"step_{ft_step}"] = {"recon": {"losses": self.loss_func(qry_batch, preds), "output": preds}}
+            if ft_step in [5, 10, 20, 50, 100]:
+                outputs[f"step_{ft_step}"]["synth"] = {"output": self._forward_learner(sup_batch, qry_batch, True, True, False)}
+        return outputs
+
+
+SYSTEM = {"meta": MetaSystem, "imaml": IMAMLSystem, "baseline": BaselineSystem}
 
 
 def get_system(algorithm: str):
-    """lightning/systems/__init__.py:13-14 ('imaml' is a later row of SURVEY.md section 8(f))."""
+    """lightning/systems/__init__.py:5-14."""
     if algorithm not in SYSTEM:
         raise KeyError(f"system type {algorithm!r} is not on the hot path (supported: {sorted(SYSTEM)})")
     return SYSTEM[algorithm]
@@ -243,6 +332,13 @@ class Trainer:
         self._allreduce()
         lr = self.system.optimizer_step()
         return q, s, lr
+
+    def imaml_step(self, batch, total_tasks: int):
+        """IMAMLSystem.meta_learn(train=True) on this rank's task, mean over ranks (imaml.py:132 `reduce`), manual optimizer step."""
+        q = self.system.meta_learn(batch, 0, train=True, total_tasks=total_tasks)
+        self._allreduce()
+        lr = self.system.optimizer_step()
+        return q, lr
 
     def plain_step(self, local_batches: Sequence[tuple], total_batches: int):
         losses = self.system.engine_plain_grad(local_batches, total_batches)

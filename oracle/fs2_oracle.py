@@ -330,6 +330,74 @@ def maml_task(p: Params, buffers, sup, qry, *, steps: int, lr: float, second_ord
 
 
 # --------------------------------------------------------------------------------------
+# iMAML (lightning/systems/imaml.py:41-139, lightning/systems/utils.py:120-189).  PARITY UNPINNED at two
+# un-vendored dependencies: learn2learn's `adapt` (plain SGD step, as above) and `hypergrad.CG_torch.cg` /
+# `hypergrad.CG` (the `hypertorch` submodule is empty in the reference tree): the conjugate-gradient
+# recurrence below restates that package's published implementation — x0 = 0, r0 = p0 = b, alpha = rTr / pAp,
+# the loop breaks BEFORE adopting an iterate whose residual norm is below tol — computed exactly as utils.py
+# drives it: A v = v - (dPhi/dw)^T v through autograd of the fixed-point map Phi.
+# --------------------------------------------------------------------------------------
+def imaml_task(p: Params, buffers, sup_batches: Sequence, cg_batches: Sequence, qry, sup_ids, *, lr: float,
+               reg_param: float, K: int, modules: Sequence[str], tol: float = 1e-10, n_head=(2, 2),
+               max_seq_len=1000, training=True):
+    """One iMAML task.  ``sup_batches``: the support mini-batch of every inner step (Task.next_batch,
+    imaml.py:64-70); ``cg_batches``: the mini-batch of every fixed-point-map evaluation inside CG
+    (`stochastic`, imaml.py:88-91; K of them are used); ``sup_ids``: the support speaker ids of the query pass.
+    Returns (query 6-tuple, fast weights after the inner loop, {name: hypergradient} for the adapted tensors,
+    CG solution v)."""
+    names = adapted_names(p, modules)
+    theta = {k: p[k].detach() for k in names}
+
+    def reg(fast):
+        return sum(((theta[k] - fast[k]) ** 2).sum() for k in names)   # bias_reg_f, imaml.py:41-46
+
+    def sup_loss(fast, batch):
+        cur = dict(p); cur.update(fast)
+        preds = fs2_forward(cur, buffers, *batch[2:], n_head=n_head, max_seq_len=max_seq_len, training=training)
+        return fs2_loss(batch, preds)[0] + 0.5 * reg_param * reg(fast)
+
+    fast = {k: p[k].detach().clone().requires_grad_(True) for k in names}
+    for batch in sup_batches:                                   # first-order regularised adapt, imaml.py:66-70
+        g = torch.autograd.grad(sup_loss(fast, batch), [fast[k] for k in names])
+        fast = {k: (fast[k] - lr * gi).detach().requires_grad_(True) for k, gi in zip(names, g)}
+    w = [fast[k] for k in names]
+    cur = dict(p); cur.update(fast)
+    preds = fs2_forward(cur, buffers, sup_ids, *qry[3:], n_head=n_head, max_seq_len=max_seq_len, training=training,
+                        average_spk_emb=True)
+    qloss = fs2_loss(qry, preds)
+    b = [x.detach() for x in torch.autograd.grad(qloss[0], w)]  # grad_outer_w, utils.py:155
+
+    def fp_map(batch):                                          # imaml.py:82-98: one differentiable SGD step on the regularised loss
+        g = torch.autograd.grad(sup_loss(fast, batch), w, create_graph=True)
+        return [wi - lr * gi for wi, gi in zip(w, g)]
+
+    it = iter(cg_batches)
+
+    def A(xs):                                                  # dfp_map_dw, utils.py:160-170
+        J = torch.autograd.grad(fp_map(next(it)), w, grad_outputs=xs)
+        return [v - j for v, j in zip(xs, J)]
+
+    dot = lambda u, v: sum((a * c).sum() for a, c in zip(u, v))
+    x_last = [torch.zeros_like(v) for v in b]
+    r_last = [v.clone() for v in b]
+    p_last = [v.clone() for v in b]
+    for _ in range(K):                                          # hypergrad.CG_torch.cg
+        Ap = A(p_last)
+        rTr = dot(r_last, r_last)
+        alpha = rTr / dot(p_last, Ap)
+        x = [xx + alpha * pp for xx, pp in zip(x_last, p_last)]
+        r = [rr - alpha * ap for rr, ap in zip(r_last, Ap)]
+        if float(torch.sqrt(dot(r, r))) < tol:
+            break
+        beta = dot(r, r) / rTr
+        p_last = [rr + beta * pp for rr, pp in zip(r, p_last)]
+        x_last, r_last = x, r
+    # grads = (dPhi/d theta)^T v + dL_q/d theta: the map sees theta only through the proximal term -> lr * reg * v
+    hyper = {k: lr * reg_param * v for k, v in zip(names, x_last)}
+    return qloss, fast, hyper, dict(zip(names, x_last))
+
+
+# --------------------------------------------------------------------------------------
 # outer update (lightning/optimizer.py:6-16, lightning/scheduler.py:6-29, main.py:61)
 # --------------------------------------------------------------------------------------
 def noam_lr(step: int, d_model: int = 256, warm_up_step: int = 4000,

@@ -428,3 +428,67 @@ def test_two_handles_on_two_host_threads_do_not_interfere(emu_lib):
     for i in range(len(jobs)):
         for a, b in zip(serial[i], threaded[i]):
             np.testing.assert_array_equal(a, b)
+
+
+def test_imaml_hypergradient_matches_oracle(emu_lib):
+    """iMAML (imaml.py:41-139, utils.py:120-189): proximal first-order inner loop on support mini-batches, then K conjugate-gradient
+    iterations on a (H + reg I) with a fresh mini-batch per Hessian-vector product (`stochastic: true`), per-task clip, and the
+    hypergradient a * reg * v on the adapted parameters only — two tasks in one grouped pass against the torch restatement."""
+    from meta_tts_amd import data as D
+    dims = tiny_dims()
+    eng = _engine(dims, emu_lib)
+    lr, reg, K = 0.02, 1.0, 3
+    tasks = [(synth.make_batch(50 + 2 * j, 3, speaker=2 + j, **_kw(dims)), synth.make_batch(51 + 2 * j, 2, speaker=2 + j, **_kw(dims)))
+             for j in range(2)]
+    sub = lambda b, idx: D.split_reprocess(b, idx)     # Task.next_batch (systems/utils.py:80-117): a re-cropped sub-batch
+    inner_idx = [[0, 1], [2, 0]]                       # 2 inner steps on 2-utterance mini-batches
+    cg_idx = [[1, 2], [0, 2], [0, 1]]                  # K mini-batches for the Hessian-vector products
+    eng.set_inner_prox(reg)
+    first = True
+    for idx in inner_idx:
+        eng.set_batches(0, [sub(t[0], idx) for t in tasks])
+        eng.adapt(1, lr, reset=first)
+        first = False
+    eng.set_batches(0, [t[0] for t in tasks])          # the speaker ids of the query pass come from the whole support set
+    eng.set_batches(1, [t[1] for t in tasks], spk_from=[t[0] for t in tasks], average_spk=True)
+    q = eng.imaml_begin()
+    for idx in cg_idx:
+        eng.set_batches(0, [sub(t[0], idx) for t in tasks])
+        eng.imaml_cg_step(lr, reg)
+    norms = eng.imaml_finish(lr, reg, grad_scale=0.5, max_norm=0.0)
+    tot, per_task = None, []
+    for j, (sup, qry) in enumerate(tasks):
+        p = torch_params(dims, requires_grad=True)
+        tsup = O.to_torch_batch(sup)
+        ql, fast, hyper, v = O.imaml_task(p, torch_buffers(dims), [O.to_torch_batch(sub(sup, i)) for i in inner_idx],
+                                          [O.to_torch_batch(sub(sup, i)) for i in cg_idx], O.to_torch_batch(qry), tsup[2], lr=lr, reg_param=reg,
+                                          K=K, modules=MODS, n_head=heads(dims), max_seq_len=dims.max_seq_len)
+        np.testing.assert_allclose(q[j], [float(x) for x in ql], rtol=1e-4)
+        for n in ("mel_linear.weight", "decoder.layer_stack.0.pos_ffn.w_1.weight"):
+            ref = fast[n].detach().numpy()
+            assert np.abs(eng.export(n, 3, j) - ref).max() <= 2e-5 * np.abs(ref).max(), n     # proximal inner loop
+        ref_norm = float(np.sqrt(sum(float((h.double() ** 2).sum()) for h in hyper.values())))
+        assert abs(norms[j] - ref_norm) <= 5e-3 * ref_norm
+        g = {n: 0.5 * h.numpy() for n, h in hyper.items()}
+        per_task.append({n: h.numpy() for n, h in hyper.items()})
+        tot = g if tot is None else {n: tot[n] + g[n] for n in g}
+    scale = max(np.abs(x).max() for x in tot.values())
+    for n in eng.params:
+        got = eng.export(n, 1)
+        if n in tot:
+            assert np.abs(got - tot[n]).max() <= 5e-3 * np.abs(tot[n]).max() + 1e-6 * scale, n
+        else:
+            assert not got.any(), n           # non-adapted parameters receive no hypergradient (utils.py:147-150)
+    # per-task clipping before the reduction (imaml.py:125-131)
+    clip = 0.5 * float(norms.min())
+    eng.imaml_finish(lr, reg, grad_scale=1.0, max_norm=clip)
+    n = "mel_linear.weight"
+    want = sum(min(1.0, clip / (float(norms[j]) + 1e-6)) * per_task[j][n] for j in range(2))
+    got = eng.export(n, 1)
+    assert np.abs(got - want).max() <= 5e-3 * np.abs(want).max()
+    assert min(1.0, clip / float(norms.max())) < 0.6   # both tasks really were clipped
+    # the proximal term must be switched off again for plain MAML, and second order refuses it
+    with pytest.raises(Exception):
+        eng.meta_grad(1, lr, 1.0, second_order=True)
+    eng.set_inner_prox(0.0)
+    eng.close()

@@ -41,8 +41,9 @@ def _system(cfgs, emu_lib, kind="meta", tasks=1):
 
 def test_registry_and_schedule():
     assert get_system("meta").__name__ == "MetaSystem" and get_system("baseline").__name__ == "BaselineSystem"
+    assert get_system("imaml").__name__ == "IMAMLSystem"      # lightning/systems/__init__.py:5-11 registers all three
     with pytest.raises(KeyError):
-        get_system("imaml")
+        get_system("anil")
     trn = default_train_config()
     for s in (0, 1, 3999, 4000, 300001):
         assert abs(noam_lr(s, 256, trn) - O.noam_lr(s)) < 1e-15
@@ -413,3 +414,42 @@ def test_test_stage_result_layout_matches_reference_saver(cfgs, emu_lib, tmp_pat
     assert len(one) == 3
     paths = sv.on_test_batch_end(one, batch, sq, 100000, sysm.adaptation_steps, sysm.test_adaptation_steps, None)
     assert [os.path.basename(p) for p in paths] == ["test_007_0.csv", "test_007_1.csv", "test_007_2.csv"]
+
+
+
+def test_imaml_system_training_step_and_test_loop(cfgs, emu_lib):
+    """IMAMLSystem (imaml.py:22-195) through the registry: the `adapt.imaml` block of config/algorithm/dev.yaml:22-26, one training
+    step (mini-batch proximal inner loop + CG hypergradient + manual optimiser step without a second clip), validation, test loop."""
+    pre, mod, trn, alg = cfgs
+    alg["type"] = "imaml"
+    alg["adapt"]["imaml"] = {"K": 2, "reg_param": 1.0, "batch_size": 2, "stochastic": True}
+    alg["adapt"]["train"]["steps"] = 2
+    alg["adapt"]["test"]["steps"] = 4
+    alg["adapt"]["task"]["lr"] = 0.02
+    sysm = _system((pre, mod, trn, alg), emu_lib, kind="imaml")
+    dims = sysm.model.dims
+    prm = synth.make_params(dims, 0)
+    prm["variance_adaptor.duration_predictor.linear_layer.bias"][:] = 1.2   # some predicted frames for the step-0 synthesis
+    sysm.model.load_state_dict(prm)
+    sup = synth.make_batch(5, 3, speaker=2, vocab=dims.vocab, **_kw(dims.n_mel))
+    qry = synth.make_batch(6, 2, speaker=2, vocab=dims.vocab, **_kw(dims.n_mel))
+    batch = [([sup], [qry])]
+    before = sysm.engine.export("mel_linear.weight")
+    enc_before = sysm.engine.export("encoder.layer_stack.0.slf_attn.fc.weight")
+    out = sysm.training_step(batch, 0)
+    assert np.isfinite(out["losses"]).all() and set(out["log"]) == {f"Train/{k}" for k in LOSS_KEYS}
+    g = sysm.engine.export("mel_linear.weight", 1)
+    assert np.abs(g).max() > 0 and not sysm.engine.export("encoder.layer_stack.0.slf_attn.fc.weight", 1).any()
+    assert float(np.sqrt(sum((sysm.engine.export(n, 1).astype(np.float64) ** 2).sum() for n in sysm.engine.params))) <= 1.0 + 1e-4  # per-task clip
+    sysm.optimizer_step()
+    assert np.abs(sysm.engine.export("mel_linear.weight") - before).max() > 0
+    np.testing.assert_array_equal(sysm.engine.export("encoder.layer_stack.0.slf_attn.fc.weight"), enc_before)  # zero hypergradient, Adam leaves it
+    v = sysm.validation_step(batch, 0)
+    assert np.isfinite(v["losses"]).all()
+    outs = sysm.test_step(batch, 0)
+    assert set(outs[0]) == {"_batch", "step_0", "step_2", "step_4"}
+    l0, l4 = float(outs[0]["step_0"]["recon"]["losses"][0]), float(outs[0]["step_4"]["recon"]["losses"][0])
+    assert np.isfinite([l0, l4]).all() and l4 != l0
+
+
+LOSS_KEYS = ("Total Loss", "Mel Loss", "Mel-Postnet Loss", "Pitch Loss", "Energy Loss", "Duration Loss")
