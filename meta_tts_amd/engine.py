@@ -32,7 +32,7 @@ class _DevView:
 
 class Engine:
     def __init__(self, dims: ModelDims, adapt_modules: Sequence[str] = (), max_tasks: int = 1, max_B: int = 16,
-                 max_S: int = 128, max_T: int = 1000, device: int = 0, lib_path: Optional[str] = None):
+                 max_S: int = 128, max_T: int = 1000, device: int = 0, lib_path: Optional[str] = None, shared_speaker: bool = False):
         self.lib = _lib.load(lib_path)
         self.dims = dims
         cfg = _lib.ModelCfg()
@@ -46,6 +46,10 @@ class Engine:
                 raise MttsError(f"adapt module {m!r} is not supported (supported: {sorted(MODULE_BITS)})")
             mask |= 1 << MODULE_BITS[m]
         cfg.adapt_mask = mask
+        # adapt.speaker_emb == "shared" (speaker_encoder.py:52-53,67-69): a one-row table looked up with zeros_like(speaker ids)
+        self.shared_speaker = bool(shared_speaker)
+        if self.shared_speaker and dims.n_speaker != 1:
+            raise MttsError("a shared speaker embedding is a table with exactly one row")
         self.adapt_modules = tuple(adapt_modules)
         self.max_tasks = max_tasks
         h = C.c_void_p()
@@ -177,6 +181,9 @@ class Engine:
             return a
         b = tuple(b) + (None,) * (12 - len(b))
         spk, texts, src_lens = np_(b[2], np.int64), np_(b[3], np.int64), np_(b[4], np.int64)
+        if self.shared_speaker:
+            spk = np.zeros_like(spk)
+            keep.append(spk)
         cb = _lib.Batch()
         cb.B, cb.S_max = int(texts.shape[0]), int(b[5])
         assert texts.shape == (cb.B, cb.S_max), texts.shape

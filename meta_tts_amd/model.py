@@ -49,16 +49,21 @@ class FastSpeech2:
 
     def __init__(self, preprocess_config, model_config, algorithm_config, *, max_tasks: int = 1, max_batch: int = 16,
                  max_src_len: int = 128, max_mel_len: Optional[int] = None, device: int = 0, lib_path: Optional[str] = None):
-        if algorithm_config["adapt"]["speaker_emb"] != "table":
-            raise MttsError("only adapt.speaker_emb == 'table' is on the hot path (SURVEY.md #3)")
+        spk_mode = algorithm_config["adapt"]["speaker_emb"]
+        if spk_mode not in ("table", "shared"):
+            raise MttsError("adapt.speaker_emb must be 'table' or 'shared' (the GE2E / d-vector encoders of speaker_encoder.py:54-60 "
+                            "are outside the hot path, SURVEY.md section 8(f) row 4)")
         if algorithm_config["adapt"]["type"] != "spk":
             raise MttsError("adapt.type == 'lang' (codebook phoneme embedding) is out of scope (SURVEY.md #8)")
         stats, n_spk = _read_preprocessed(preprocess_config)
+        if spk_mode == "shared":
+            n_spk = 1   # nn.Embedding(1, d): one vector for every speaker (speaker_encoder.py:52-53)
         self.dims = ModelDims(model_config, preprocess_config, n_speaker=n_spk, stats=stats)
         self.model_config, self.preprocess_config, self.algorithm_config = model_config, preprocess_config, algorithm_config
         self.adapt_modules = tuple(algorithm_config["adapt"].get("modules", ()))
         self.engine = Engine(self.dims, adapt_modules=self.adapt_modules, max_tasks=max_tasks, max_B=max_batch,
-                             max_S=max_src_len, max_T=max_mel_len or self.dims.max_seq_len, device=device, lib_path=lib_path)
+                             max_S=max_src_len, max_T=max_mel_len or self.dims.max_seq_len, device=device, lib_path=lib_path,
+                             shared_speaker=(spk_mode == "shared"))
         self.training = True
         self.load_state_dict(synth.make_params(self.dims, seed=0))
 

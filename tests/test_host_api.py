@@ -453,3 +453,31 @@ def test_imaml_system_training_step_and_test_loop(cfgs, emu_lib):
 
 
 LOSS_KEYS = ("Total Loss", "Mel Loss", "Mel-Postnet Loss", "Pitch Loss", "Energy Loss", "Duration Loss")
+
+
+def test_shared_speaker_embedding_mode(cfgs, emu_lib):
+    """adapt.speaker_emb: shared (config/algorithm/*share_emb*.yaml; speaker_encoder.py:52-53,67-69): nn.Embedding(1, d) indexed with
+    zeros_like(speaker ids) — every utterance of every speaker reads and trains the same row."""
+    pre, mod, trn, alg = cfgs
+    alg["adapt"]["speaker_emb"] = "shared"
+    sysm = _system((pre, mod, trn, alg), emu_lib)
+    dims = sysm.model.dims
+    assert dims.n_speaker == 1 and sysm.model.state_dict()["speaker_emb.model.weight"].shape == (1, dims.d_model)
+    sup = synth.make_batch(5, 3, speaker=7, vocab=dims.vocab, **_kw(dims.n_mel))     # ids 7 / 9 would be out of range for a 1-row table
+    qry = synth.make_batch(6, 2, speaker=9, vocab=dims.vocab, **_kw(dims.n_mel))
+    q, s = sysm.meta_learn_tasks([(sup, qry)], train=False)
+    prm = {k: torch.from_numpy(v.copy()) for k, v in synth.make_params(dims, 0).items()}
+    for k, v in prm.items():
+        if not k.endswith(("position_enc", "pitch_bins", "energy_bins")):
+            v.requires_grad_(True)
+    z = lambda b: tuple(b[:2]) + (np.zeros_like(b[2]),) + tuple(b[3:])
+    mods = alg["adapt"]["modules"]
+    ql, sl, fast, _ = O.maml_task(prm, torch_buffers(dims), O.to_torch_batch(z(sup)), O.to_torch_batch(z(qry)), steps=sysm.adaptation_steps,
+                                  lr=sysm.adaptation_lr, second_order=False, modules=mods, n_head=heads(dims), max_seq_len=dims.max_seq_len)
+    np.testing.assert_allclose(q[0], [float(x) for x in ql], rtol=1e-4)
+    g = torch.autograd.grad(ql[0], prm["speaker_emb.model.weight"])[0].numpy()
+    got = sysm.engine.export("speaker_emb.model.weight", 1)
+    assert got.shape == (1, dims.d_model) and np.abs(got - g).max() <= 2e-3 * np.abs(g).max()
+    alg["adapt"]["speaker_emb"] = "dvec"
+    with pytest.raises(Exception, match="speaker_emb"):
+        _system((pre, mod, trn, alg), emu_lib)
