@@ -30,6 +30,7 @@
 #include "gemm_bf16_launch.h"
 #include "gemm_glds.h"
 #include "rowops.h"
+#include "plan.h"
 #include "tangent.h"
 
 namespace mtts {
@@ -139,7 +140,17 @@ public:
         int* spk_ids;
         AttnSeq *enc_seqs, *dec_seqs;
         GemmGroupDesc *enc_tab[6], *dec_tab[6];
+        // compact batch image (plan.h): device copy + two pinned staging buffers (the host may prepare step k+1 while the copy of
+        // step k is still in flight)
+        char* img_dev = nullptr;
+        char* img_host[2] = {nullptr, nullptr};
+        hipEvent_t img_done[2] = {nullptr, nullptr};
+        bool img_pending[2] = {false, false};
+        int img_parity = 0;
+        float* dur_readback = nullptr;       // device [tasks][cap_B * cap_S]: predicted durations of a free-running pass
     };
+    // byte offsets inside a compact image (fixed by the capacities; computed in init)
+    struct ImgLayout { size_t meta, hdr, src_len, flen, foff, spk, texts, dur, pitch, energy, seq_e, seq_d, tab_e[6], tab_d[6], mels, total; } img;
     enum { TAB_QK = 0, TAB_PV, TAB_DP, TAB_DV, TAB_DQ, TAB_DK };
     Plan plans[2];
     long long row_ts_p, row_ts_f, row_ts_r;  // strides of per-row index arrays
@@ -394,7 +405,6 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         row_ts_p = capMp; row_ts_f = capMf; row_ts_r = capMr;
         for (int s = 0; s < 2; ++s) {
             Plan& p = plans[s];
-            p.meta = (int*)take((size_t)cap_tasks * META_STRIDE * sizeof(int));
             p.p_row_b = arr<int>(capMp); p.p_row_t = arr<int>(capMp); p.p_tok = arr<int>(capMp);
             p.p_first = arr<int>(capMp); p.p_count = arr<int>(capMp); p.p_dur = arr<int>(capMp);
             p.p_seg_start = arr<int>(cap_B); p.p_seg_len = arr<int>(cap_B);
@@ -406,12 +416,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             p.r2f = arr<int>(capMr); p.r_valid = arr<unsigned char>(capMr); p.r_inrect = arr<unsigned char>(capMr);
             p.mel_tgt = rows(capMr, cfg.n_mel).p;
             p.spk_ids = arr<int>(cap_B + 1);
-            p.enc_seqs = (AttnSeq*)take(sizeof(AttnSeq) * cap_tasks * cap_B * cfg.enc_heads);
-            p.dec_seqs = (AttnSeq*)take(sizeof(AttnSeq) * cap_tasks * cap_B * cfg.dec_heads);
-            for (int k = 0; k < 6; ++k) {
-                p.enc_tab[k] = (GemmGroupDesc*)take(sizeof(GemmGroupDesc) * cap_tasks * cap_B * cfg.enc_heads);
-                p.dec_tab[k] = (GemmGroupDesc*)take(sizeof(GemmGroupDesc) * cap_tasks * cap_B * cfg.dec_heads);
-            }
+            p.dur_readback = arr<float>((long long)cap_B * cap_S);
         }
     }
 
@@ -472,7 +477,58 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         HIP_CHECK(hipMemset(arena, 0, arena_bytes));
         arena_dry = false; arena_off = 0;
         layout();
+        return init_images();
+    }
+
+    // compact batch images: layout fixed by the capacities; one device copy + two pinned staging buffers per slot
+    int init_images() {
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t nt = cap_tasks, bs = (size_t)cap_B * cap_S, ne = nt * cap_B * cfg.enc_heads, nd = nt * cap_B * cfg.dec_heads;
+        size_t o = 0;
+        img.meta = o; o = al(o + nt * META_STRIDE * sizeof(int));
+        img.hdr = o; o = al(o + nt * sizeof(PlanTaskHdr));
+        img.src_len = o; o = al(o + nt * cap_B * sizeof(int));
+        img.flen = o; o = al(o + nt * cap_B * sizeof(int));
+        img.foff = o; o = al(o + nt * cap_B * sizeof(int));
+        img.spk = o; o = al(o + nt * (cap_B + 1) * sizeof(int));
+        img.texts = o; o = al(o + nt * bs * sizeof(int));
+        img.dur = o; o = al(o + nt * bs * sizeof(int));
+        img.pitch = o; o = al(o + nt * bs * sizeof(float));
+        img.energy = o; o = al(o + nt * bs * sizeof(float));
+        img.seq_e = o; o = al(o + ne * sizeof(AttnSeq));
+        img.seq_d = o; o = al(o + nd * sizeof(AttnSeq));
+        for (int k = 0; k < 6; ++k) { img.tab_e[k] = o; o = al(o + ne * sizeof(GemmGroupDesc)); }
+        for (int k = 0; k < 6; ++k) { img.tab_d[k] = o; o = al(o + nd * sizeof(GemmGroupDesc)); }
+        img.mels = o; o = al(o + nt * (size_t)cap_B * cap_T * cfg.n_mel * sizeof(float));
+        img.total = o;
+        for (int sl = 0; sl < 2; ++sl) {
+            Plan& p = plans[sl];
+            HIP_CHECK(hipMalloc((void**)&p.img_dev, img.total));
+            HIP_CHECK(hipMemset(p.img_dev, 0, img.mels));
+            for (int b = 0; b < 2; ++b) {
+                HIP_CHECK(hipHostMalloc((void**)&p.img_host[b], img.total));
+                memset(p.img_host[b], 0, img.mels);
+                HIP_CHECK(hipEventCreate(&p.img_done[b]));
+            }
+            p.meta = (int*)(p.img_dev + img.meta);
+            p.enc_seqs = (AttnSeq*)(p.img_dev + img.seq_e);
+            p.dec_seqs = (AttnSeq*)(p.img_dev + img.seq_d);
+            for (int k = 0; k < 6; ++k) {
+                p.enc_tab[k] = (GemmGroupDesc*)(p.img_dev + img.tab_e[k]);
+                p.dec_tab[k] = (GemmGroupDesc*)(p.img_dev + img.tab_d[k]);
+            }
+        }
         return 0;
+    }
+    void destroy_images() {
+        for (int sl = 0; sl < 2; ++sl) {
+            Plan& p = plans[sl];
+            if (p.img_dev) hipFree(p.img_dev);
+            for (int b = 0; b < 2; ++b) {
+                if (p.img_host[b]) hipHostFree(p.img_host[b]);
+                if (p.img_done[b]) hipEventDestroy(p.img_done[b]);
+            }
+        }
     }
 
     void set_bins(float pmin, float pmax, float emin, float emax) {
@@ -506,6 +562,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (float* p : bn_rv) hipFree(p);
         gx.release();
         destroy_imaml();
+        destroy_images();
         if (arena) hipFree(arena);
         if (arena_so) hipFree(arena_so);
         if (hv) hipFree(hv);
@@ -573,12 +630,6 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // =================================================================================
     // batch plans
     // =================================================================================
-    template <class T> int upload(T* dst, long long ts, int task, const std::vector<T>& v) {
-        if (v.empty()) return 0;
-        HIP_CHECK(hipMemcpyAsync(dst + ts * task, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream));
-        return 0;
-    }
-
     // Copy `tasks` host batches into plan slot `slot` and build its row spaces.  Teacher-forced batches
     // (durations given) get all three spaces now; free-running batches (no durations) get the phoneme
     // space only — forward() sizes the frame spaces once the predicted durations are known.
@@ -634,8 +685,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                 p.over_max = true;
                 in.mels_keep.assign(in.mels, in.mels + (size_t)in.B * in.T_max * cfg.n_mel);
             }
-        const int rc = build_plan(slot, any_tf, true);
-        for (auto& in : p.in) in.mels = in.mels_keep.empty() ? nullptr : in.mels_keep.data();  // caller memory is only borrowed
+        const int rc = build_plan(slot, any_tf, true);  // copies the caller's mels into the pinned image: nothing borrowed afterwards
+        for (auto& in : p.in) in.mels = in.mels_keep.empty() ? nullptr : in.mels_keep.data();
         return rc;
     }
 
@@ -648,8 +699,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         return build_plan(slot, true, train);
     }
 
-    // (Re)build the row spaces of plan `slot` from p.in.  with_frames: durations / mel_lens are known.
-    // truncate: frames beyond max_seq_len are dropped (Decoder in training mode, Models.py:154-162).
+    // (Re)build plan `slot` from p.in.  with_frames: durations / mel_lens are known.  truncate: frames beyond max_seq_len are
+    // dropped (Decoder in training mode, Models.py:154-162).  The host computes O(B) scalars per task and the attention
+    // descriptor tables, packs the batch into the pinned compact image and enqueues ONE copy + the four plan kernels (plan.h):
+    // nothing here waits for the device (the staging buffer is double-buffered behind an event).
     int build_plan(int slot, bool with_frames, bool truncate) {
         Plan& p = plans[slot];
         const int tasks = p.tasks;
@@ -660,92 +713,87 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         p.truncated = truncate;
         p.sum_nP = p.sum_nF = p.sum_attn_p = p.sum_attn_f = 0;
         p.sumMp = p.sumMf = p.sumMr = p.sumLp = p.sumLf = 0;
-        std::vector<int> meta((size_t)tasks * META_STRIDE, 0);
-        std::vector<AttnSeq> eseq, dseq;
-        std::vector<GemmGroupDesc> etab[6], dtab[6];
+        const int par = p.img_parity;
+        p.img_parity ^= 1;
+        if (p.img_pending[par]) { HIP_CHECK(hipEventSynchronize(p.img_done[par])); p.img_pending[par] = false; }
+        char* H = p.img_host[par];
+        int* meta = (int*)(H + img.meta);
+        PlanTaskHdr* hdr = (PlanTaskHdr*)(H + img.hdr);
+        int* h_src = (int*)(H + img.src_len); int* h_flen = (int*)(H + img.flen); int* h_foff = (int*)(H + img.foff);
+        int* h_spk = (int*)(H + img.spk); int* h_txt = (int*)(H + img.texts); int* h_dur = (int*)(H + img.dur);
+        float* h_pit = (float*)(H + img.pitch); float* h_ene = (float*)(H + img.energy);
+        float* h_mel = (float*)(H + img.mels);
+        AttnSeq* seqs[2] = {(AttnSeq*)(H + img.seq_e), (AttnSeq*)(H + img.seq_d)};
+        GemmGroupDesc* tabs[2][6];
+        for (int k = 0; k < 6; ++k) { tabs[0][k] = (GemmGroupDesc*)(H + img.tab_e[k]); tabs[1][k] = (GemmGroupDesc*)(H + img.tab_d[k]); }
+        int nseq[2] = {0, 0};
+        long long mel_used = 0;
         const int d = cfg.d_model;
+        const size_t bs = (size_t)cap_B * cap_S;
+        bool any_mels = false;
         for (int t = 0; t < tasks; ++t) {
             const TaskIn& b = p.in[t];
             const int B = b.B, S = b.S;
             const int Tcap = with_frames ? (truncate ? std::min(b.T_max, cfg.max_seq_len) : b.T_max) : 0;
             if (with_frames && (Tcap < 1 || Tcap > cap_T)) { set_error("mel length exceeds engine capacity (T_max)"); return -1; }
             const int Mp = G + B * (S + G);
-            std::vector<int> row_b(Mp, 0), row_t(Mp, -1), tok(Mp, 0), first(Mp, 0), count(Mp, 0), dur(Mp, 0);
-            std::vector<unsigned char> valid(Mp, 0), inrect(Mp, 0);
-            std::vector<float> pt(Mp, 0.f), et(Mp, 0.f);
-            std::vector<int> pseg_s(B), pseg_l(B), fseg_s(B, 0), fseg_l(B, 0), flen(B, 0);
-            // frame space: packed valid frames
             int foff = G, nP = 0, nF = 0;
-            std::vector<int> foffs(B, 0);
-            if (with_frames)
-                for (int i = 0; i < B; ++i) {
-                    const int ml = (int)std::max<long long>(0, std::min<long long>(b.mel_lens[i], Tcap));
-                    flen[i] = ml; foffs[i] = foff; fseg_s[i] = foff; fseg_l[i] = ml;
-                    foff += ml + G;
-                    nF += ml;
-                }
-            const int Mf = with_frames ? foff : 0, Mr = with_frames ? G + B * (Tcap + G) : 0;
-            if (Mf > capMf || Mr > capMr || Mp > capMp) { set_error("row space exceeds capacity"); return -1; }
-            std::vector<int> f_row_b(Mf, 0), f_row_t(Mf, -1), f_src(Mf, -1), f2r(Mf, -1), r2f(Mr, -1);
-            std::vector<unsigned char> f_valid(Mf, 0), r_valid(Mr, 0), r_inrect(Mr, 0);
-            std::vector<float> mel_t(b.mels ? (size_t)Mr * cfg.n_mel : 0, 0.f);
-            long long soff[2] = {0, 0};  // running offsets inside this task's score buffers (enc, dec)
             for (int i = 0; i < B; ++i) {
                 const int sl = (int)b.src_lens[i];
-                pseg_s[i] = G + i * (S + G); pseg_l[i] = S;
-                int cum = 0;
-                for (int s = 0; s < S; ++s) {
-                    const int r = G + i * (S + G) + s;
-                    row_b[r] = i; row_t[r] = s; inrect[r] = 1;
-                    const bool v = s < sl;
-                    valid[r] = v;
-                    tok[r] = v ? (int)b.texts[(size_t)i * S + s] : 0;
-                    if (!b.pitches.empty()) { pt[r] = b.pitches[(size_t)i * S + s]; et[r] = b.energies[(size_t)i * S + s]; }
-                    if (!with_frames) { if (v) ++nP; continue; }
-                    long long dd = b.durations[(size_t)i * S + s];
-                    if (dd < 0) dd = 0;
-                    dur[r] = (int)dd;
-                    // frames of this phoneme inside the (possibly truncated) frame window
-                    const int lo = std::min(cum, flen[i]), hi = (int)std::min<long long>(cum + dd, flen[i]);
-                    first[r] = foffs[i] + lo; count[r] = hi - lo;
-                    for (int f = lo; f < hi; ++f) f_src[foffs[i] + f] = r;
-                    cum = (int)std::min<long long>(cum + dd, 1 << 28);
-                    if (v) ++nP;
+                const int ml = with_frames ? (int)std::max<long long>(0, std::min<long long>(b.mel_lens[i], Tcap)) : 0;
+                h_src[(size_t)t * cap_B + i] = sl;
+                h_flen[(size_t)t * cap_B + i] = ml;
+                h_foff[(size_t)t * cap_B + i] = foff;
+                if (with_frames) { foff += ml + G; nF += ml; }
+                nP += sl;
+                for (int s2 = 0; s2 < S; ++s2) {
+                    const size_t e = (size_t)t * bs + (size_t)i * S + s2;
+                    h_txt[e] = (int)b.texts[(size_t)i * S + s2];
+                    if (with_frames) h_dur[e] = (int)std::max<long long>(std::min<long long>(b.durations[(size_t)i * S + s2], 1 << 28), -1);
+                    if (!b.pitches.empty()) { h_pit[e] = b.pitches[(size_t)i * S + s2]; h_ene[e] = b.energies[(size_t)i * S + s2]; }
                 }
-                for (int f = 0; f < flen[i]; ++f) {
-                    const int fr = foffs[i] + f, rr = G + i * (Tcap + G) + f;
-                    f_row_b[fr] = i; f_row_t[fr] = f; f_valid[fr] = 1; f2r[fr] = rr; r2f[rr] = fr; r_valid[rr] = 1;
-                    if (b.mels) memcpy(&mel_t[(size_t)rr * cfg.n_mel], &b.mels[((size_t)i * b.T_max + f) * cfg.n_mel], cfg.n_mel * sizeof(float));
-                }
-                for (int f = 0; f < Tcap; ++f) r_inrect[G + i * (Tcap + G) + f] = 1;
-                // attention groups (valid rows only)
+            }
+            const int Mf = with_frames ? foff : 0, Mr = with_frames ? G + B * (Tcap + G) : 0;
+            if (Mf > capMf || Mr > capMr || Mp > capMp) { set_error("row space exceeds capacity"); return -1; }
+            for (int i = 0; i <= cap_B; ++i) h_spk[(size_t)t * (cap_B + 1) + i] = b.spk_ids[i];
+            PlanTaskHdr& h = hdr[t];
+            h.B = B; h.S = S; h.Tmax_in = b.T_max; h.Tcap = Tcap; h.Mp = Mp; h.Mf = Mf; h.Mr = Mr; h.with_frames = with_frames;
+            h.has_targets = !b.pitches.empty(); h.has_mels = b.mels != nullptr; h.pad0 = h.pad1 = 0; h.mel_off = mel_used;
+            if (b.mels) {
+                const size_t n = (size_t)B * b.T_max * cfg.n_mel;
+                memcpy(h_mel + mel_used, b.mels, n * sizeof(float));
+                mel_used += (long long)n;
+                any_mels = true;
+            }
+            // attention groups (valid rows only)
+            long long soff[2] = {0, 0};
+            for (int i = 0; i < B; ++i)
                 for (int which = 0; which < (with_frames ? 2 : 1); ++which) {
-                    const int H = which ? cfg.dec_heads : cfg.enc_heads, dk = d / H;
-                    const int L = which ? flen[i] : sl, ro = which ? foffs[i] : G + i * (S + G);
-                    std::vector<AttnSeq>& sq = which ? dseq : eseq;
-                    std::vector<GemmGroupDesc>* tb = which ? dtab : etab;
+                    const int Hh = which ? cfg.dec_heads : cfg.enc_heads, dk = d / Hh;
+                    const int L = which ? h_flen[(size_t)t * cap_B + i] : h_src[(size_t)t * cap_B + i];
+                    const int ro = which ? h_foff[(size_t)t * cap_B + i] : G + i * (S + G);
                     const long long task_s = which ? S_ts_f : S_ts_p;
                     int& maxL = which ? p.dec_maxL : p.enc_maxL;
                     maxL = std::max(maxL, L);
-                    (which ? p.sum_attn_f : p.sum_attn_p) += (double)H * L * L;
-                    (which ? p.sumLf : p.sumLp) += (long long)H * L;
+                    (which ? p.sum_attn_f : p.sum_attn_p) += (double)Hh * L * L;
+                    (which ? p.sumLf : p.sumLp) += (long long)Hh * L;
                     const int ldS = (L + 3) & ~3;
                     const int capM = which ? capMf : capMp;
-                    for (int h = 0; h < H; ++h) {
+                    for (int hh = 0; hh < Hh; ++hh) {
                         const long long so = (long long)t * task_s + soff[which];
                         soff[which] += (long long)L * ldS;
-                        sq.push_back(AttnSeq{so, L, ldS});
-                        const long long qo = (long long)t * ((long long)(capM + 2 * G) * 3 * d) + (long long)ro * 3 * d + h * dk;
-                        const long long oo = (long long)t * ((long long)(capM + 2 * G) * d) + (long long)ro * d + h * dk;
-                        tb[TAB_QK].push_back(GemmGroupDesc{qo, qo + d, so, L, L, dk, 0, 0, ldS});          // S  = Q K^T
-                        tb[TAB_PV].push_back(GemmGroupDesc{so, qo + 2 * d, oo, L, dk, L, ldS, 0, 0});     // O  = P V
-                        tb[TAB_DP].push_back(GemmGroupDesc{oo, qo + 2 * d, so, L, L, dk, 0, 0, ldS});     // dP = dO V^T
-                        tb[TAB_DV].push_back(GemmGroupDesc{so, oo, qo + 2 * d, L, dk, L, ldS, 0, 0});     // dV = P^T dO
-                        tb[TAB_DQ].push_back(GemmGroupDesc{so, qo + d, qo, L, dk, L, ldS, 0, 0});         // dQ = dS K
-                        tb[TAB_DK].push_back(GemmGroupDesc{so, qo, qo + d, L, dk, L, ldS, 0, 0});         // dK = dS^T Q
+                        const int n = nseq[which]++;
+                        seqs[which][n] = AttnSeq{so, L, ldS};
+                        const long long qo = (long long)t * ((long long)(capM + 2 * G) * 3 * d) + (long long)ro * 3 * d + hh * dk;
+                        const long long oo = (long long)t * ((long long)(capM + 2 * G) * d) + (long long)ro * d + hh * dk;
+                        tabs[which][TAB_QK][n] = GemmGroupDesc{qo, qo + d, so, L, L, dk, 0, 0, ldS};          // S  = Q K^T
+                        tabs[which][TAB_PV][n] = GemmGroupDesc{so, qo + 2 * d, oo, L, dk, L, ldS, 0, 0};     // O  = P V
+                        tabs[which][TAB_DP][n] = GemmGroupDesc{oo, qo + 2 * d, so, L, L, dk, 0, 0, ldS};     // dP = dO V^T
+                        tabs[which][TAB_DV][n] = GemmGroupDesc{so, oo, qo + 2 * d, L, dk, L, ldS, 0, 0};     // dV = P^T dO
+                        tabs[which][TAB_DQ][n] = GemmGroupDesc{so, qo + d, qo, L, dk, L, ldS, 0, 0};         // dQ = dS K
+                        tabs[which][TAB_DK][n] = GemmGroupDesc{so, qo, qo + d, L, dk, L, ldS, 0, 0};         // dK = dS^T Q
                     }
                 }
-            }
             p.hB[t] = B; p.hSmax[t] = S; p.hTcap[t] = Tcap; p.hMp[t] = Mp; p.hMf[t] = Mf; p.hMr[t] = Mr;
             p.maxMp = std::max(p.maxMp, Mp); p.maxMf = std::max(p.maxMf, Mf); p.maxMr = std::max(p.maxMr, Mr);
             p.maxB = std::max(p.maxB, B);
@@ -754,31 +802,35 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             m[META_NP] = nP; m[META_NF] = nF;
             p.sum_nP += nP; p.sum_nF += nF;
             p.sumMp += Mp; p.sumMf += Mf; p.sumMr += Mr;
-            if (upload(p.p_row_b, row_ts_p, t, row_b) || upload(p.p_row_t, row_ts_p, t, row_t) || upload(p.p_tok, row_ts_p, t, tok) ||
-                upload(p.p_first, row_ts_p, t, first) || upload(p.p_count, row_ts_p, t, count) || upload(p.p_dur, row_ts_p, t, dur) ||
-                upload(p.p_valid, row_ts_p, t, valid) || upload(p.p_inrect, row_ts_p, t, inrect) ||
-                upload(p.p_pitch_t, row_ts_p, t, pt) || upload(p.p_energy_t, row_ts_p, t, et) ||
-                upload(p.p_seg_start, (long long)cap_B, t, pseg_s) || upload(p.p_seg_len, (long long)cap_B, t, pseg_l) ||
-                upload(p.f_seg_start, (long long)cap_B, t, fseg_s) || upload(p.f_seg_len, (long long)cap_B, t, fseg_l) ||
-                upload(p.f_row_b, row_ts_f, t, f_row_b) || upload(p.f_row_t, row_ts_f, t, f_row_t) || upload(p.f_src, row_ts_f, t, f_src) ||
-                upload(p.f2r, row_ts_f, t, f2r) || upload(p.f_valid, row_ts_f, t, f_valid) || upload(p.r2f, row_ts_r, t, r2f) ||
-                upload(p.r_valid, row_ts_r, t, r_valid) || upload(p.r_inrect, row_ts_r, t, r_inrect) ||
-                upload(p.spk_ids, (long long)cap_B + 1, t, b.spk_ids))
-                return -1;
-            if (!mel_t.empty())
-                HIP_CHECK(hipMemcpyAsync(p.mel_tgt + (long long)t * ((long long)(capMr + 2 * G) * cfg.n_mel), mel_t.data(),
-                                         mel_t.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));  // host vectors go out of scope
         }
-        HIP_CHECK(hipMemcpyAsync(p.meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-        p.n_enc_groups = (int)eseq.size(); p.n_dec_groups = (int)dseq.size();
-        HIP_CHECK(hipMemcpyAsync(p.enc_seqs, eseq.data(), eseq.size() * sizeof(AttnSeq), hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipMemcpyAsync(p.dec_seqs, dseq.data(), dseq.size() * sizeof(AttnSeq), hipMemcpyHostToDevice, stream));
-        for (int k = 0; k < 6; ++k) {
-            HIP_CHECK(hipMemcpyAsync(p.enc_tab[k], etab[k].data(), etab[k].size() * sizeof(GemmGroupDesc), hipMemcpyHostToDevice, stream));
-            HIP_CHECK(hipMemcpyAsync(p.dec_tab[k], dtab[k].data(), dtab[k].size() * sizeof(GemmGroupDesc), hipMemcpyHostToDevice, stream));
+        p.n_enc_groups = nseq[0]; p.n_dec_groups = nseq[1];
+        // ONE transfer: everything up to the mel area, plus the used part of the mel area
+        const size_t bytes = any_mels ? img.mels + (size_t)mel_used * sizeof(float) : img.mels;
+        HIP_CHECK(hipMemcpyAsync(p.img_dev, H, bytes, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipEventRecord(p.img_done[par], stream));
+        p.img_pending[par] = true;
+        PlanImage im;
+        im.hdr = (const PlanTaskHdr*)(p.img_dev + img.hdr);
+        im.src_len = (const int*)(p.img_dev + img.src_len); im.flen = (const int*)(p.img_dev + img.flen);
+        im.foff = (const int*)(p.img_dev + img.foff); im.spk = (const int*)(p.img_dev + img.spk);
+        im.texts = (const int*)(p.img_dev + img.texts); im.dur = (const int*)(p.img_dev + img.dur);
+        im.pitch = (const float*)(p.img_dev + img.pitch); im.energy = (const float*)(p.img_dev + img.energy);
+        im.mels = (const float*)(p.img_dev + img.mels);
+        im.cap_B = cap_B; im.cap_S = cap_S;
+        PlanOut o;
+        o.p_row_b = p.p_row_b; o.p_row_t = p.p_row_t; o.p_tok = p.p_tok; o.p_first = p.p_first; o.p_count = p.p_count; o.p_dur = p.p_dur;
+        o.p_seg_start = p.p_seg_start; o.p_seg_len = p.p_seg_len; o.p_valid = p.p_valid; o.p_inrect = p.p_inrect;
+        o.p_pitch_t = p.p_pitch_t; o.p_energy_t = p.p_energy_t;
+        o.f_row_b = p.f_row_b; o.f_row_t = p.f_row_t; o.f_src = p.f_src; o.f_seg_start = p.f_seg_start; o.f_seg_len = p.f_seg_len;
+        o.f2r = p.f2r; o.f_valid = p.f_valid; o.r2f = p.r2f; o.r_valid = p.r_valid; o.r_inrect = p.r_inrect; o.mel_tgt = p.mel_tgt;
+        o.spk_ids = p.spk_ids;
+        o.ts_p = row_ts_p; o.ts_f = row_ts_f; o.ts_r = row_ts_r; o.ts_mel = (long long)(capMr + 2 * G) * cfg.n_mel; o.ts_seg = cap_B; o.ts_spk = cap_B + 1;
+        MTTS_LAUNCH(plan_rows_p_kernel, dim3((unsigned)((p.maxMp + 255) / 256), 1, (unsigned)tasks), dim3(256), stream, im, o);
+        if (with_frames) {
+            MTTS_LAUNCH(plan_rows_f_kernel, dim3((unsigned)((p.maxMf + 255) / 256), 1, (unsigned)tasks), dim3(256), stream, im, o);
+            MTTS_LAUNCH(plan_prefix_kernel, dim3(1, 1, (unsigned)tasks), dim3(64), stream, im, o);
+            MTTS_LAUNCH(plan_rows_r_kernel, row_grid(p.maxMr, tasks), dim3(256), stream, im, o, cfg.n_mel);
         }
-        HIP_CHECK(hipStreamSynchronize(stream));
         return 0;
     }
 
@@ -1190,17 +1242,24 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         return 0;
     }
 
+    // free-running (modules.py:132-137,167-190): durations = clamp(round(exp(logd) - 1) * d_control, 0) on the device, ONE
+    // device -> host copy of the compact [task][B * S] image for ALL tasks (the reference reads every duration with .item()),
+    // then the frame spaces are sized on the host (O(B) per task) and built on the device like any other plan
     int frames_from_predictions_impl(const Pass& ps) {
         Plan& p = *ps.pl;
         const int nt = p.tasks;
         MTTS_LAUNCH(duration_round_kernel, dim3(4, 1, nt), dim3(256), stream, (const int*)p.meta, (const float*)durB.out.p, durB.out.ts,
                     ps.d_control, (const unsigned char*)p.p_valid, row_ts_p, d_rounded.p);
+        const long long bs = (long long)cap_B * cap_S;
+        MTTS_LAUNCH(plan_gather_durations_kernel, dim3(2, 1, nt), dim3(256), stream, (const int*)p.meta, (const float*)d_rounded.p, d_rounded.ts,
+                    p.dur_readback, cap_B, cap_S);
+        fr_host.resize((size_t)nt * bs);
+        HIP_CHECK(hipMemcpyAsync(fr_host.data(), p.dur_readback, (size_t)nt * bs * sizeof(float), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         const int slot = (int)(&p - &plans[0]);
         for (int t = 0; t < nt; ++t) {
             TaskIn& in = p.in[t];
-            std::vector<float> dr(p.hMp[t]);
-            HIP_CHECK(hipMemcpy(dr.data(), d_rounded.p + (long long)t * d_rounded.ts, dr.size() * sizeof(float), hipMemcpyDeviceToHost));
+            const float* dr = fr_host.data() + (size_t)t * bs;
             in.durations.assign((size_t)in.B * in.S, 0);
             in.d_rounded.assign((size_t)in.B * in.S, 0.f);
             in.mel_lens.assign(in.B, 0);
@@ -1208,9 +1267,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             for (int i = 0; i < in.B; ++i) {
                 long long tot = 0;
                 for (int s2 = 0; s2 < in.S; ++s2) {
-                    const long long dd = std::max<long long>((long long)dr[G + i * (in.S + G) + s2], 0);  // max(int(expand_size), 0)
+                    const float v = dr[(size_t)i * in.S + s2];
+                    const long long dd = std::max<long long>((long long)v, 0);  // max(int(expand_size), 0)
                     in.durations[(size_t)i * in.S + s2] = dd;
-                    in.d_rounded[(size_t)i * in.S + s2] = dr[G + i * (in.S + G) + s2];
+                    in.d_rounded[(size_t)i * in.S + s2] = v;
                     tot += dd;
                 }
                 in.mel_lens[i] = tot;
@@ -1222,6 +1282,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         return build_plan(slot, true, ps.train);
     }
+    std::vector<float> fr_host;
 
     LossArgs loss_args(const Plan& p) const {
         LossArgs a;

@@ -52,6 +52,8 @@ enum { hipSuccess = 0 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);
+static inline hipError_t hipHostMalloc(void** p, size_t n) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void* p) { return hipFree(p); }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
