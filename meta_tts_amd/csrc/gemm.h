@@ -515,12 +515,12 @@ inline int& gemm_xcd_swizzle() {
     static int v = [] { const char* e = getenv("MTTS_XCD_GROUP"); return e ? (atoi(e) != 0) : 1; }();
     return v;
 }
-inline int gemm_numerics_default() {  // 0: exact fp32 MFMA (default), 1: split-bf16 "bf16x3", 2: plain bf16 operands (gemm_bf16.h); MTTS_NUMERICS sets the initial mode of every context
-    static const int v = [] { const char* e = getenv("MTTS_NUMERICS"); return (e && atoi(e) >= 1 && atoi(e) <= 2) ? atoi(e) : 0; }();
+inline int gemm_numerics_default() {  // 0: exact fp32 MFMA (default), 1: split-bf16 "bf16x3" (gemm_bf16.h); MTTS_NUMERICS sets the initial mode of every context
+    static const int v = [] { const char* e = getenv("MTTS_NUMERICS"); return (e && atoi(e) == 1) ? 1 : 0; }();
     return v;
 }
 inline bool gemm_launch_bf16x3(int form, const GemmArgs& g, int max_M, int max_N, int groups, hipStream_t stream, int tile,
-                               double rows, int terms);  // gemm_bf16_launch.h
+                               double rows);  // gemm_bf16_launch.h
 inline int& gemm_default_bk() {  // MTTS_GEMM_BK=16/32
     static int v = [] { const char* e = getenv("MTTS_GEMM_BK"); return (e && atoi(e) == 32) ? 32 : 16; }();
     return v;
@@ -624,7 +624,7 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
         hipEvent_t b0 = nullptr, b1 = nullptr;
         if (prof0.enabled) { b0 = prof0.get(); b1 = prof0.get(); hipEventRecord(b0, stream); }
         const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
-        const bool big = gemm_launch_bf16x3(form, g, max_M, max_N, groups, stream, user_tile, rows, cx.numerics == 1 ? 3 : 1);
+        const bool big = gemm_launch_bf16x3(form, g, max_M, max_N, groups, stream, user_tile, rows);
         if (prof0.enabled) { hipEventRecord(b1, stream); GemmProfiler::Rec rec{form * 2 + (big ? 1 : 0), alg_flops, b0, b1}; rec.bytes = alg_bytes; prof0.recs.push_back(rec); }
         return;
     }

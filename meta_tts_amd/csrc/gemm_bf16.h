@@ -100,8 +100,9 @@ __device__ __forceinline__ void mma16_emu(const unsigned short* Ah, const unsign
             }
 }
 #else
-// TERMS = 3: hi*hi + hi*mid + mid*hi ("bf16x3", ~fp32 accuracy); TERMS = 1: hi*hi only = plain bf16 operands with fp32
-// accumulation (BASELINE config C2's numerics; misses the 1e-4 mel gate by an order of magnitude)
+// TERMS = 3: hi*hi + hi*mid + mid*hi ("bf16x3", ~fp32 accuracy).  (A plain-bf16 single-term variant existed in round 1 as a
+// numerics experiment; it was not faster than the fp32 MFMA path — operands are still fp32 in HBM and converted in the K-loop —
+// and misses the 1e-4 mel gate by an order of magnitude, so it was removed rather than advertised.)
 template <int TM, int TN, int TERMS>
 __device__ __forceinline__ void mma16(const Frags16<TM, TN>& f, f32x16 (&acc)[TM][TN]) {
 #pragma unroll

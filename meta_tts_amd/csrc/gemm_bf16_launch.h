@@ -5,7 +5,7 @@
 namespace mtts {
 
 inline bool gemm_launch_bf16x3(int form, const GemmArgs& g, int max_M, int max_N, int groups, hipStream_t stream, int tile,
-                               double rows, int terms) {
+                               double rows) {
     auto ntiles = [&](int t) { return (long)((max_M + t - 1) / t) * ((max_N + t - 1) / t); };
     if (tile != 64 && tile != 128) {
         // same wave-quantisation model as the fp32 launcher; the 64x64 tile does 6 MFMAs per barrier here, so its
@@ -18,10 +18,7 @@ inline bool gemm_launch_bf16x3(int form, const GemmArgs& g, int max_M, int max_N
     }
     dim3 block(256), grid((unsigned)ntiles(tile), 1, (unsigned)groups);
 #define MTTS_GEMM16_CASE(F, T) \
-    if (form == F && tile == T) {                                                                     \
-        if (terms == 3) { MTTS_LAUNCH((gemm_bf16x3_kernel<F, T, T, 3>), grid, block, stream, g); }     \
-        else { MTTS_LAUNCH((gemm_bf16x3_kernel<F, T, T, 1>), grid, block, stream, g); }                \
-    }
+    if (form == F && tile == T) { MTTS_LAUNCH((gemm_bf16x3_kernel<F, T, T, 3>), grid, block, stream, g); }
     MTTS_GEMM16_CASE(GEMM_NT, 128) MTTS_GEMM16_CASE(GEMM_NT, 64)
     MTTS_GEMM16_CASE(GEMM_NN, 128) MTTS_GEMM16_CASE(GEMM_NN, 64)
     MTTS_GEMM16_CASE(GEMM_TN, 128) MTTS_GEMM16_CASE(GEMM_TN, 64)

@@ -305,7 +305,7 @@ int mtts_reset_optimizer(mtts_handle* h) {
 
 int mtts_set_numerics(mtts_handle* h, int mode) {
     if (!h) return -1;
-    if (mode < 0 || mode > 2) { h->eng.set_error("numerics mode must be 0, 1 or 2"); return -1; }
+    if (mode < 0 || mode > 1) { h->eng.set_error("numerics mode must be 0 (exact fp32 MFMA) or 1 (bf16x3)"); return -1; }
     h->eng.gx.numerics = mode;
     return 0;
 }
@@ -338,7 +338,7 @@ int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const 
     g.bias = bias; g.alpha = alpha; g.flags = flags & 0xff;
     GemmCtx& cx = kernel_ctx();
     cx.numerics = (flags >> 8) & 3;
-    if (cx.numerics > 2) return -1;
+    if (cx.numerics > 1) return -1;
     gemm_launch(cx, form, g, M, N, 1, (hipStream_t)stream, tile);
     cx.numerics = gemm_numerics_default();
     return hipGetLastError() == hipSuccess ? 0 : -1;

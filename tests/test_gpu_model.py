@@ -221,8 +221,7 @@ def test_full_size_properties_meta_step():
 
 def test_c2_baseline_batch16_vs_oracle():
     """BASELINE config 2 (algorithm=baseline, one batch of 16 LibriTTS-shaped utterances, full-size model): the 6 losses
-    and sampled parameter gradients of one plain step against the oracle; then the same step in the config's bf16-operand
-    numerics (mode 2): finite, and within bf16 distance of the fp32 result."""
+    and sampled parameter gradients of one plain step against the oracle."""
     batch = synth.make_batch(0, 16)
     eng = _engine(1, 16, 80, int(batch[8]))
     eng.set_batches(0, [batch])
@@ -240,16 +239,8 @@ def test_c2_baseline_batch16_vs_oracle():
         got = eng.export(n, 1)
         fp32[n] = got
         assert np.abs(got - x.numpy()).max() <= 3e-3 * np.abs(x.numpy()).max() + 1e-7, n
-    try:
-        eng.set_numerics(2)
-        q2 = eng.plain_grad(0, 1.0)
-        assert np.all(np.isfinite(q2))
-        np.testing.assert_allclose(q2[0], q[0], rtol=3e-2)
-        for n in check:
-            got = eng.export(n, 1)
-            assert np.isfinite(got).all() and np.abs(got - fp32[n]).max() <= 0.25 * np.abs(fp32[n]).max(), n
-    finally:
-        eng.set_numerics(0)
+    with pytest.raises(Exception):
+        eng.set_numerics(2)   # the round-1 plain-bf16 mode is gone (slower than fp32 and outside the gate): only 0 / 1 exist
     eng.close()
 
 
