@@ -375,7 +375,19 @@ def main():
         eng.set_batches(1, qry_b, spk_from=sup_b, average_spk=True)
 
     ingest()
-    outer = torch.as_tensor(eng.outer_grad_view(), device=f"cuda:{local_rank}") if n > 1 else None
+    # the exchange step: RCCL all-reduce of the flat outer gradient, issued by the library on its own stream (mtts_allreduce_outer);
+    # torch.distributed only carries the 128-byte unique id.  If the in-library communicator cannot be set up, fall back to
+    # torch.distributed's all_reduce on a zero-copy view of the same buffer and say so in the line.
+    outer, ar_impl = None, None
+    if n > 1:
+        try:
+            ids = [eng.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            eng.comm_init(ids[0], rank, n)
+            ar_impl = "libmtts: ncclAllReduce via dlopen(librccl.so) on the engine stream"
+        except Exception as ex:  # noqa: BLE001
+            outer = torch.as_tensor(eng.outer_grad_view(), device=f"cuda:{local_rank}")
+            ar_impl = f"torch.distributed all_reduce (library communicator failed: {ex})"
 
     step_no = [0]
     eng.set_numerics(1 if args.numerics == "bf16x3" else 0)
@@ -389,7 +401,10 @@ def main():
             if timed_ar:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            dist.all_reduce(outer, op=dist.ReduceOp.SUM)
+            if outer is None:
+                eng.allreduce_outer()
+            else:
+                dist.all_reduce(outer, op=dist.ReduceOp.SUM)
             if timed_ar:
                 e1.record()
                 ar_events.append((e0, e1))
@@ -502,7 +517,7 @@ def main():
                            "batch_ingestion": "resident (uploaded once before the timed region)" if args.resident_batches else "inside every timed step (host 12-tuples -> HBM + plans)"},
                 **({"emulated_world": part, "note": "diagnostic: rank-0 share of an emulated multi-rank run, no collective"} if part != n else {}),
                 "batch_ingest_ms_per_step": round(ingest_ms, 3),
-                "rccl_ranks": n if n > 1 else None, "allreduce_ms_per_step": round(ar_ms, 3) if ar_ms is not None else None,
+                "rccl_ranks": n if n > 1 else None, "allreduce_impl": ar_impl, "allreduce_ms_per_step": round(ar_ms, 3) if ar_ms is not None else None,
                 "allreduce_payload_mbytes": round(4e-6 * eng.n_total, 1) if n > 1 else None,
                 "query_total_loss_mean": round(float(q_losses[:, 0].mean()), 5) if q_losses is not None else None}
         if so is not None:

@@ -154,6 +154,15 @@ int mtts_plain_grad(mtts_handle* h, int slot, float grad_scale, float* losses_ho
 /* device pointer of the outer gradient (mtts_param_total floats) — the buffer the host all-reduces
  * over RCCL between ranks (PL strategy="ddp", main.py:32) */
 float* mtts_outer_grad_ptr(mtts_handle* h);
+/* The exchange step over RCCL / xGMI without leaving the library (PL strategy="ddp", main.py:30-38: DDP's gradient all-reduce): one
+ * communicator per handle = per rank.  Rank 0 calls mtts_comm_unique_id (128 bytes = NCCL_UNIQUE_ID_BYTES) and hands the id to the
+ * other ranks over any out-of-band channel; every rank then calls mtts_comm_init (collective).  mtts_allreduce_outer enqueues
+ * ncclAllReduce(SUM, fp32, in place) of the whole outer-gradient buffer on the handle's stream: ordered after the meta-gradient
+ * kernels and before the following mtts_outer_update, no host synchronisation.  Each rank scales its contribution by
+ * 1 / total_tasks through grad_scale, so the sum is the mean the reference takes.  librccl.so is resolved with dlopen on first use. */
+int mtts_comm_unique_id(mtts_handle* h, void* id128);
+int mtts_comm_init(mtts_handle* h, const void* id128, int rank, int world_size);
+int mtts_allreduce_outer(mtts_handle* h);
 /* clip_grad_norm_(max_norm) (main.py:61) + Adam (lightning/optimizer.py:9-15) with the learning rate of
  * lightning/scheduler.py:11-23 supplied by the caller.  grad_dev NULL = the internal outer gradient. */
 int mtts_outer_update(mtts_handle* h, const float* grad_dev, float lr, float beta1, float beta2, float eps,

@@ -67,6 +67,9 @@ EXPORTS = {
     "mtts_imaml_finish": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mtts_plain_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "mtts_outer_grad_ptr": (C.c_void_p, [C.c_void_p]),
+    "mtts_comm_unique_id": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mtts_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "mtts_allreduce_outer": (C.c_int, [C.c_void_p]),
     "mtts_outer_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_void_p]),
     "mtts_reset_optimizer": (C.c_int, [C.c_void_p]),

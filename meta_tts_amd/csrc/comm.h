@@ -1,0 +1,81 @@
+// RCCL binding of the one exchange step of the hot path: the all-reduce of the flat outer-gradient buffer between the ranks of a
+// node (one process per GPU; the reference gets it from PL's strategy="ddp", main.py:30-38: DDP's gradient all-reduce over NCCL).
+// librccl is resolved with dlopen at first use — libmtts has no link-time dependency on it, and inside a torch process the soname
+// resolves to the RCCL instance torch already loaded, so both share one library.  The unique id travels through the caller
+// (any out-of-band channel: torch.distributed's store, MPI, a file); nothing here talks to the network itself.
+#pragma once
+#include <string>
+
+#include "compat.h"
+
+#if !defined(MTTS_EMU)
+#include <dlfcn.h>
+#endif
+
+namespace mtts {
+
+constexpr int kNcclUniqueIdBytes = 128;       // NCCL_UNIQUE_ID_BYTES (rccl.h)
+struct NcclUniqueId { char internal[kNcclUniqueIdBytes]; };
+
+struct Comm {
+    void* lib = nullptr;
+    void* comm = nullptr;
+    int rank = 0, world = 1;
+    std::string err;
+    // rccl.h prototypes (ncclResult_t = int, ncclDataType_t ncclFloat32 = 7, ncclRedOp_t ncclSum = 0)
+    int (*get_id)(NcclUniqueId*) = nullptr;
+    int (*init_rank)(void**, int, NcclUniqueId, int) = nullptr;
+    int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*destroy)(void*) = nullptr;
+    const char* (*err_str)(int) = nullptr;
+
+    int load() {
+#if defined(MTTS_EMU)
+        err = "RCCL is not available in the emulator build";
+        return -1;
+#else
+        if (lib) return 0;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("dlopen(librccl.so) failed: ") + dlerror(); return -1; }
+        get_id = (int (*)(NcclUniqueId*))dlsym(lib, "ncclGetUniqueId");
+        init_rank = (int (*)(void**, int, NcclUniqueId, int))dlsym(lib, "ncclCommInitRank");
+        all_reduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
+        destroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+        err_str = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+        if (!get_id || !init_rank || !all_reduce || !destroy) { err = "librccl.so lacks an expected symbol"; return -1; }
+        return 0;
+#endif
+    }
+    int fail(const char* what, int rc) {
+        err = std::string(what) + ": " + (err_str ? err_str(rc) : "RCCL error") + " (" + std::to_string(rc) + ")";
+        return -1;
+    }
+    int unique_id(NcclUniqueId* id) {
+        if (load()) return -1;
+        const int rc = get_id(id);
+        return rc ? fail("ncclGetUniqueId", rc) : 0;
+    }
+    int init(const NcclUniqueId& id, int rank_, int world_) {
+        if (load()) return -1;
+        if (comm) { err = "communicator already initialised"; return -1; }
+        if (world_ < 1 || rank_ < 0 || rank_ >= world_) { err = "bad rank / world size"; return -1; }
+        const int rc = init_rank(&comm, world_, id, rank_);
+        if (rc) { comm = nullptr; return fail("ncclCommInitRank", rc); }
+        rank = rank_; world = world_;
+        return 0;
+    }
+    int sum(float* buf, size_t n, hipStream_t stream) {
+        if (!comm) { err = "communicator not initialised (mtts_comm_init)"; return -1; }
+        const int rc = all_reduce(buf, buf, n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, comm, stream);
+        return rc ? fail("ncclAllReduce", rc) : 0;
+    }
+    void release() {
+        if (comm && destroy) destroy(comm);
+        comm = nullptr;
+    }
+};
+
+}  // namespace mtts

@@ -3,6 +3,7 @@
 // (tests/emu builds the same file for the host with -DMTTS_EMU; see compat.h).
 #include "../../include/mtts.h"
 
+#include "comm.h"
 #include "engine.h"
 #include "vocoder.h"
 
@@ -13,6 +14,7 @@ static int copy_losses(Engine& e, const float* dev, float* host, int n) { return
 
 struct mtts_handle {
     Engine eng;
+    Comm comm;
     float* sup_losses_dev = nullptr;
     int sup_losses_cap = 0;
 };
@@ -64,6 +66,7 @@ int mtts_create(const mtts_model_cfg* c, int device, int max_tasks, int max_B, i
 void mtts_destroy(mtts_handle* h) {
     if (!h) return;
     hipDeviceSynchronize();
+    h->comm.release();
     h->eng.destroy();
     if (h->sup_losses_dev) hipFree(h->sup_losses_dev);
     delete h;
@@ -289,6 +292,24 @@ int mtts_plain_grad(mtts_handle* h, int slot, float grad_scale, float* losses_ho
 }
 
 float* mtts_outer_grad_ptr(mtts_handle* h) { return h->eng.outer; }
+
+int mtts_comm_unique_id(mtts_handle* h, void* id128) {
+    if (!id128) { h->eng.set_error("null id buffer"); return -1; }
+    if (h->comm.unique_id((NcclUniqueId*)id128)) { h->eng.set_error(h->comm.err); return -1; }
+    return 0;
+}
+int mtts_comm_init(mtts_handle* h, const void* id128, int rank, int world_size) {
+    if (!id128) { h->eng.set_error("null id buffer"); return -1; }
+    NcclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    if (h->comm.init(id, rank, world_size)) { h->eng.set_error(h->comm.err); return -1; }
+    return 0;
+}
+int mtts_allreduce_outer(mtts_handle* h) {
+    Engine& e = h->eng;
+    if (h->comm.sum(e.outer, (size_t)e.n_total, e.stream)) { e.set_error(h->comm.err); return -1; }
+    return 0;
+}
 
 int mtts_outer_update(mtts_handle* h, const float* grad_dev, float lr, float b1, float b2, float eps, float wd, float max_norm,
                       float* norm_host) {

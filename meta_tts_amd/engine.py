@@ -314,6 +314,20 @@ class Engine:
         """Device buffer of the outer gradient as an object torch.as_tensor(..., device='cuda') can alias."""
         return _DevView(self.outer_grad_ptr(), self.n_total)
 
+    # ---- RCCL inside the library (include/mtts.h: mtts_comm_*) -------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._ck(self.lib.mtts_comm_unique_id(self.h, buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world_size: int):
+        assert len(unique_id) == 128
+        self._ck(self.lib.mtts_comm_init(self.h, C.create_string_buffer(unique_id, 128), rank, world_size))
+
+    def allreduce_outer(self):
+        """ncclAllReduce(SUM) of the outer-gradient buffer on the engine's stream (asynchronous)."""
+        self._ck(self.lib.mtts_allreduce_outer(self.h))
+
     def outer_update(self, lr: float, betas=(0.9, 0.98), eps: float = 1e-9, weight_decay: float = 0.0,
                      max_norm: float = 1.0, grad_ptr: Optional[int] = None, fetch_norm: bool = False):
         norm = C.c_float()

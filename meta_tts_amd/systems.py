@@ -312,15 +312,26 @@ class Trainer:
         self.group = process_group
         self.system.world_size = self.dist.get_world_size(self.group) if self.dist else 1
         self.outer = outer_grad_tensor  # torch view of engine.outer_grad_ptr() (zero copy on GPU)
+        self.library_comm = False
         if self.dist is not None and self.dist.get_backend(self.group) == "nccl":
             # RCCL orders its collective after torch's CURRENT stream of the engine's device: put the engine's launches on that
             # stream so the all-reduce sees the finished outer gradient and the clip + Adam after it sees the reduced one
             import torch
             dev = self.system.engine.device
             self.system.engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            if outer_grad_tensor is None and self.system.world_size > 1:
+                # the all-reduce itself runs inside the library (mtts_allreduce_outer); torch only carries the unique id
+                eng = self.system.engine
+                ids = [eng.comm_unique_id() if self.dist.get_rank(self.group) == 0 else None]
+                self.dist.broadcast_object_list(ids, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                eng.comm_init(ids[0], self.dist.get_rank(self.group), self.system.world_size)
+                self.library_comm = True
 
     def _allreduce(self):
         if self.dist is None or self.system.world_size == 1:
+            return
+        if self.library_comm:
+            self.system.engine.allreduce_outer()
             return
         if self.outer is None:
             import torch

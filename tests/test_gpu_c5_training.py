@@ -363,3 +363,29 @@ def test_feature_tree_episodes_through_the_engine_vs_oracle(tmp_path):
     for n in check:
         assert np.abs(eng.export(n, 1) - tot[n]).max() <= 3e-3 * np.abs(tot[n]).max() + 1e-7, n
     eng.close()
+
+
+def test_in_library_rccl_allreduce_world_size_one():
+    """mtts_comm_unique_id / mtts_comm_init / mtts_allreduce_outer (include/mtts.h): librccl resolved with dlopen, one rank here
+    (the 8-GPU launch belongs to the driver): the collective runs on the engine's stream, leaves a 1-rank sum unchanged, and the
+    fused clip + Adam after it sees the buffer."""
+    sup = synth.make_batch(21, 3, speaker=9, **SMALL)
+    qry = synth.make_batch(22, 3, speaker=9, **SMALL)
+    eng = _engine(1, 3, 16, 96)
+    eng.set_batches(0, [sup])
+    eng.set_batches(1, [qry], spk_from=[sup], average_spk=True)
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    with pytest.raises(Exception):
+        eng.allreduce_outer()            # no communicator yet
+    eng.comm_init(uid, 0, 1)
+    with pytest.raises(Exception):
+        eng.comm_init(uid, 0, 1)         # already initialised
+    eng.meta_grad(1, 1e-4, 1.0, fetch_losses=False)
+    before = eng.export("mel_linear.weight", 1)
+    eng.allreduce_outer()
+    eng.synchronize()
+    np.testing.assert_array_equal(eng.export("mel_linear.weight", 1), before)
+    norm = eng.outer_update(lr=1e-3, fetch_norm=True)
+    assert np.isfinite(norm) and norm > 0
+    eng.close()
