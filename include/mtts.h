@@ -40,6 +40,10 @@ typedef struct mtts_model_cfg {
     /* transformer.{encoder,decoder}_dropout, variance_predictor.dropout (config/model/base.yaml:10-11,16); the PostNet's
      * 0.5 is hard-coded in the reference (transformer/Layers.py:133-134).  Only used after mtts_set_dropout(h, 1, seed). */
     float enc_dropout, dec_dropout, vp_dropout;
+    /* preprocess_config["preprocessing"]["pitch" | "energy"]["feature"] == "frame_level" (lightning/model/modules.py:28-33,139-148,
+     * loss.py:54-63): that feature's targets are [B][T_max] (one value per mel frame) and its predictor / embedding / loss run on
+     * the frame rectangle after the length regulator.  0 = phoneme_level (config/preprocess/LibriTTS.yaml).  First-order only. */
+    int pitch_frame_level, energy_frame_level;
 } mtts_model_cfg;
 
 /* One padded batch: elements [2:] of the reference 12-tuple (lightning/collate.py:47-60), host memory,
@@ -51,8 +55,8 @@ typedef struct mtts_batch {
     const int64_t* src_lens;  /* [B]                 batch[4]  */
     const float* mels;        /* [B][T_max][n_mel]   batch[6]  */
     const int64_t* mel_lens;  /* [B]                 batch[7]  */
-    const float* pitches;     /* [B][S_max]          batch[9]  */
-    const float* energies;    /* [B][S_max]          batch[10] */
+    const float* pitches;     /* [B][S_max]          batch[9]   ([B][T_max] when pitch is frame-level)  */
+    const float* energies;    /* [B][S_max]          batch[10]  ([B][T_max] when energy is frame-level) */
     const int64_t* durations; /* [B][S_max]          batch[11] */
 } mtts_batch;
 
@@ -112,7 +116,7 @@ int mtts_synthesize(mtts_handle* h, int slot, int use_fast_weights, int train_mo
 /* d_rounded [B][S_max] (duration_rounded of the 10-tuple), mel_lens [B], T_cap = width of mel / mel_post rows */
 int mtts_get_durations(mtts_handle* h, int slot, int task, float* d_rounded, int64_t* mel_lens, int* t_cap);
 /* copy the outputs of task `task` to host: mel, mel_post [B][T_cap][n_mel] (T_cap = min(T_max, max_seq_len));
- * p, e, logd [B][S_max].  Any pointer may be NULL. */
+ * p, e, logd [B][S_max] (p / e are [B][T_cap] for a frame-level feature).  Any pointer may be NULL. */
 /* device view of the last forward's mel (postnet = 0) or mel_post (1) of one task: utterance b, frame t, channel c at
  * mel_dev[b * utt_stride + t * n_mel + c], t < t_cap.  Valid until the next set_batches / forward on that slot. */
 int mtts_get_mel_device(mtts_handle* h, int slot, int task, int postnet, const float** mel_dev, int* t_cap, int64_t* utt_stride);

@@ -20,7 +20,8 @@ class ModelCfg(C.Structure):
         "vp_filter", "vp_kernel", "n_bins", "max_seq_len", "n_mel", "vocab", "n_speaker",
         "postnet_dim", "postnet_kernel", "postnet_layers")] + [
         ("pitch_min", C.c_float), ("pitch_max", C.c_float), ("energy_min", C.c_float), ("energy_max", C.c_float),
-        ("adapt_mask", C.c_int), ("enc_dropout", C.c_float), ("dec_dropout", C.c_float), ("vp_dropout", C.c_float)]
+        ("adapt_mask", C.c_int), ("enc_dropout", C.c_float), ("dec_dropout", C.c_float), ("vp_dropout", C.c_float),
+        ("pitch_frame_level", C.c_int), ("energy_frame_level", C.c_int)]
 
 
 class Batch(C.Structure):

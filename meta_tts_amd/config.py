@@ -138,8 +138,10 @@ class ModelDims:
         st = stats or SYNTH_STATS
         t = mc["transformer"]
         assert t["encoder_hidden"] == t["decoder_hidden"], "encoder/decoder hidden must match (speaker add)"
-        assert pc["preprocessing"]["pitch"]["feature"] == "phoneme_level"
-        assert pc["preprocessing"]["energy"]["feature"] == "phoneme_level"
+        levels = ("phoneme_level", "frame_level")
+        assert pc["preprocessing"]["pitch"]["feature"] in levels and pc["preprocessing"]["energy"]["feature"] in levels
+        self.pitch_frame_level = pc["preprocessing"]["pitch"]["feature"] == "frame_level"
+        self.energy_frame_level = pc["preprocessing"]["energy"]["feature"] == "frame_level"
         assert mc["variance_embedding"]["pitch_quantization"] == "linear"
         assert mc["variance_embedding"]["energy_quantization"] == "linear"
         self.d_model = int(t["encoder_hidden"])

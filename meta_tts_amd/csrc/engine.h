@@ -43,6 +43,9 @@ struct ModelCfg {
     int postnet_dim, postnet_kernel, postnet_layers;
     float pitch_min, pitch_max, energy_min, energy_max;
     float enc_dropout = 0.f, dec_dropout = 0.f, vp_dropout = 0.f, postnet_dropout = 0.5f;
+    // preprocess_config["preprocessing"]["pitch" | "energy"]["feature"] == "frame_level" (modules.py:28-33,139-148): the predictor,
+    // the bucketised embedding and the loss of that feature live on the mel-frame rectangle instead of the phoneme rectangle
+    int pitch_frame = 0, energy_frame = 0;
     // which top-level modules are adapted in the inner loop (bit i of: encoder,
     // variance_adaptor, decoder, mel_linear, postnet, speaker_emb)
     int adapt_mask;
@@ -136,6 +139,7 @@ public:
         // R space
         int* r2f;
         unsigned char *r_valid, *r_inrect;
+        float *r_pitch_t = nullptr, *r_energy_t = nullptr;  // frame-level targets on the R rows
         float* mel_tgt;
         int* spk_ids;
         AttnSeq *enc_seqs, *dec_seqs;
@@ -150,6 +154,7 @@ public:
         float* dur_readback = nullptr;       // device [tasks][cap_B * cap_S]: predicted durations of a free-running pass
     };
     // byte offsets inside a compact image (fixed by the capacities; computed in init)
+    size_t pe_cap_p = 0, pe_cap_e = 0;  // per-task floats of the pitch / energy areas of an image
     struct ImgLayout { size_t meta, hdr, src_len, flen, foff, spk, texts, dur, pitch, energy, seq_e, seq_d, tab_e[6], tab_d[6], mels, total; } img;
     enum { TAB_QK = 0, TAB_PV, TAB_DP, TAB_DV, TAB_DQ, TAB_DK };
     Plan plans[2];
@@ -164,6 +169,12 @@ public:
     std::vector<PostBuf> postB;
     TS emb_out, spk, x0, x1, x2, dec_in, mel, mel_post;
     int *pidx = nullptr, *eidx = nullptr;
+    // frame-level features: activations of the variance adaptor's second half on the frame rectangle (row space R, d channels)
+    bool any_frame_level() const { return cfg.pitch_frame || cfg.energy_frame; }
+    TS xr0, xr1, xr2, gRx, gRf1, gRf2, gFx, dpred_r[2];
+    TS va_out{nullptr, 0};
+    PredBuf pitR, eneR;
+    int *pidx_r = nullptr, *eidx_r = nullptr;
     TS d_rounded;
     // backward scratch
     TS gPm, gFm;  // dropout-masked copies of a LayerNorm input gradient
@@ -377,6 +388,17 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         pidx = arr<int>(capMp); eidx = arr<int>(capMp);
         d_rounded = rows(capMp, 1);
         dec_in = rows(capMf, d);
+        if (any_frame_level()) {
+            xr0 = rows(capMr, d); xr1 = rows(capMr, d); xr2 = rows(capMr, d);
+            for (PredBuf* pb : {&pitR, &eneR}) {
+                pb->r1 = rows(capMr, f); pb->st1 = rows(capMr, 2); pb->n1 = rows(capMr, f);
+                pb->r2 = rows(capMr, f); pb->st2 = rows(capMr, 2); pb->n2 = rows(capMr, f);
+                pb->out = rows(capMr, 1);
+            }
+            pidx_r = arr<int>(capMr); eidx_r = arr<int>(capMr);
+            gRx = rows(capMr, d); gRf1 = rows(capMr, f); gRf2 = rows(capMr, f); gFx = rows(capMf, d);
+            dpred_r[0] = rows(capMr, 1); dpred_r[1] = rows(capMr, 1);
+        }
         layer(capMf, S_ts_f, decB, cfg.dec_layers);
         mel = rows(capMr, cfg.n_mel); mel_post = rows(capMr, cfg.n_mel);
         postB.resize(cfg.postnet_layers);
@@ -396,7 +418,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         gMelF = rows(capMf, cfg.n_mel);
         dspk = flat((long long)cap_B * d);
         for (int i = 0; i < 3; ++i) dpred[i] = rows(capMp, 1);
-        col_max_chunks = (std::max(capMp, capMf) + kRC - 1) / kRC;
+        col_max_chunks = (std::max(std::max(capMp, capMf), capMr) + kRC - 1) / kRC;
         col_partial = (float*)take((size_t)cap_tasks * col_max_chunks * 3 * 1024 * sizeof(float));
         col_ctr = (int*)take((size_t)cap_tasks * kColCtrPerTask * sizeof(int));
         loss_partial = (float*)take((size_t)cap_tasks * kLossBlocks * 5 * sizeof(float));
@@ -415,6 +437,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             p.f_valid = arr<unsigned char>(capMf);
             p.r2f = arr<int>(capMr); p.r_valid = arr<unsigned char>(capMr); p.r_inrect = arr<unsigned char>(capMr);
             p.mel_tgt = rows(capMr, cfg.n_mel).p;
+            if (any_frame_level()) { p.r_pitch_t = arr<float>(capMr); p.r_energy_t = arr<float>(capMr); }
             p.spk_ids = arr<int>(cap_B + 1);
             p.dur_readback = arr<float>((long long)cap_B * cap_S);
         }
@@ -493,8 +516,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         img.spk = o; o = al(o + nt * (cap_B + 1) * sizeof(int));
         img.texts = o; o = al(o + nt * bs * sizeof(int));
         img.dur = o; o = al(o + nt * bs * sizeof(int));
-        img.pitch = o; o = al(o + nt * bs * sizeof(float));
-        img.energy = o; o = al(o + nt * bs * sizeof(float));
+        pe_cap_p = cfg.pitch_frame ? (size_t)cap_B * cap_T : bs;
+        pe_cap_e = cfg.energy_frame ? (size_t)cap_B * cap_T : bs;
+        img.pitch = o; o = al(o + nt * pe_cap_p * sizeof(float));
+        img.energy = o; o = al(o + nt * pe_cap_e * sizeof(float));
         img.seq_e = o; o = al(o + ne * sizeof(AttnSeq));
         img.seq_d = o; o = al(o + nd * sizeof(AttnSeq));
         for (int k = 0; k < 6; ++k) { img.tab_e[k] = o; o = al(o + ne * sizeof(GemmGroupDesc)); }
@@ -661,8 +686,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                 }
             if (in.has_targets) {
                 if (b.T_max < 1 || b.T_max > cap_T) { set_error("batch exceeds engine capacity (T_max)"); return -1; }
-                in.pitches.assign(b.pitches, b.pitches + BS);
-                in.energies.assign(b.energies, b.energies + BS);
+                const size_t BT = (size_t)b.B * b.T_max;
+                in.pitches.assign(b.pitches, b.pitches + (cfg.pitch_frame ? BT : BS));     // [B][T_max] when the feature is frame-level
+                in.energies.assign(b.energies, b.energies + (cfg.energy_frame ? BT : BS));
+                if (any_frame_level() && b.T_max > cfg.max_seq_len) { set_error("frame-level pitch / energy with T_max > max_seq_len is not supported"); return -1; }
                 in.durations.assign(b.durations, b.durations + BS);
                 in.mel_lens.assign(b.mel_lens, b.mel_lens + b.B);
                 in.mels = b.mels;
@@ -750,9 +777,12 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                     const size_t e = (size_t)t * bs + (size_t)i * S + s2;
                     h_txt[e] = (int)b.texts[(size_t)i * S + s2];
                     if (with_frames) h_dur[e] = (int)std::max<long long>(std::min<long long>(b.durations[(size_t)i * S + s2], 1 << 28), -1);
-                    if (!b.pitches.empty()) { h_pit[e] = b.pitches[(size_t)i * S + s2]; h_ene[e] = b.energies[(size_t)i * S + s2]; }
+                    if (!b.pitches.empty() && !cfg.pitch_frame) h_pit[(size_t)t * pe_cap_p + (size_t)i * S + s2] = b.pitches[(size_t)i * S + s2];
+                    if (!b.energies.empty() && !cfg.energy_frame) h_ene[(size_t)t * pe_cap_e + (size_t)i * S + s2] = b.energies[(size_t)i * S + s2];
                 }
             }
+            if (!b.pitches.empty() && cfg.pitch_frame) memcpy(h_pit + (size_t)t * pe_cap_p, b.pitches.data(), b.pitches.size() * sizeof(float));
+            if (!b.energies.empty() && cfg.energy_frame) memcpy(h_ene + (size_t)t * pe_cap_e, b.energies.data(), b.energies.size() * sizeof(float));
             const int Mf = with_frames ? foff : 0, Mr = with_frames ? G + B * (Tcap + G) : 0;
             if (Mf > capMf || Mr > capMr || Mp > capMp) { set_error("row space exceeds capacity"); return -1; }
             for (int i = 0; i <= cap_B; ++i) h_spk[(size_t)t * (cap_B + 1) + i] = b.spk_ids[i];
@@ -817,7 +847,9 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         im.pitch = (const float*)(p.img_dev + img.pitch); im.energy = (const float*)(p.img_dev + img.energy);
         im.mels = (const float*)(p.img_dev + img.mels);
         im.cap_B = cap_B; im.cap_S = cap_S;
+        im.pe_cap_p = (long long)pe_cap_p; im.pe_cap_e = (long long)pe_cap_e; im.pitch_frame = cfg.pitch_frame; im.energy_frame = cfg.energy_frame;
         PlanOut o;
+        o.r_pitch_t = p.r_pitch_t; o.r_energy_t = p.r_energy_t;
         o.p_row_b = p.p_row_b; o.p_row_t = p.p_row_t; o.p_tok = p.p_tok; o.p_first = p.p_first; o.p_count = p.p_count; o.p_dur = p.p_dur;
         o.p_seg_start = p.p_seg_start; o.p_seg_len = p.p_seg_len; o.p_valid = p.p_valid; o.p_inrect = p.p_inrect;
         o.p_pitch_t = p.p_pitch_t; o.p_energy_t = p.p_energy_t;
@@ -1095,44 +1127,45 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // =================================================================================
     // variance predictor (lightning/model/modules.py:242-250)
     // =================================================================================
-    void pred_fwd(const Pass& ps, const PredP& P, PredBuf& b, TS xin) {
+    void pred_fwd(const Pass& ps, const PredP& P, PredBuf& b, TS xin, Space s = SP_P) {
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, f = cfg.vp_filter, k = cfg.vp_kernel;
-        const unsigned char* im = p.p_inrect;
+        const unsigned char* im = inrect_mask(p, s);   // conv outputs / LayerNorm live on every position of the rectangle
         TS none{nullptr, 0};
-        conv_fwd(ps, SP_P, xin, d, k, W(ps, P.c1w), W(ps, P.c1b), f, b.r1, GEMM_RELU, im);
-        ln_fwd(ps, SP_P, b.r1, none, P.l1g, P.l1b, im, none, b.n1, b.st1, f, DropSpec(), drop_spec(ps, cfg.vp_dropout, site_base));
-        conv_fwd(ps, SP_P, b.n1, f, k, W(ps, P.c2w), W(ps, P.c2b), f, b.r2, GEMM_RELU, im);
-        ln_fwd(ps, SP_P, b.r2, none, P.l2g, P.l2b, im, none, b.n2, b.st2, f, DropSpec(), drop_spec(ps, cfg.vp_dropout, site_base + 1));
+        conv_fwd(ps, s, xin, d, k, W(ps, P.c1w), W(ps, P.c1b), f, b.r1, GEMM_RELU, im);
+        ln_fwd(ps, s, b.r1, none, P.l1g, P.l1b, im, none, b.n1, b.st1, f, DropSpec(), drop_spec(ps, cfg.vp_dropout, site_base));
+        conv_fwd(ps, s, b.n1, f, k, W(ps, P.c2w), W(ps, P.c2b), f, b.r2, GEMM_RELU, im);
+        ln_fwd(ps, s, b.r2, none, P.l2g, P.l2b, im, none, b.n2, b.st2, f, DropSpec(), drop_spec(ps, cfg.vp_dropout, site_base + 1));
         TS w = W(ps, P.lw), bb = W(ps, P.lb);
-        MTTS_LAUNCH(rowdot_kernel, row_grid(p.maxMp, p.tasks), dim3(256), stream, (const int*)p.meta, (int)META_MP,
-                    (const float*)b.n2.p, b.n2.ts, (const float*)w.p, (const float*)bb.p, w.ts, (const unsigned char*)p.p_valid,
-                    row_ts_p, b.out.p, b.out.ts, f);
+        MTTS_LAUNCH(rowdot_kernel, row_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
+                    (const float*)b.n2.p, b.n2.ts, (const float*)w.p, (const float*)bb.p, w.ts, valid_mask(p, s),
+                    row_ts(s), b.out.p, b.out.ts, f);
     }
     // dout: [Mp] gradient of the prediction (0 on masked rows); dx accumulates the input gradient
-    void pred_bwd(const Pass& ps, const PredP& P, PredBuf& b, TS xin, TS dout, TS dx) {
+    void pred_bwd(const Pass& ps, const PredP& P, PredBuf& b, TS xin, TS dout, TS dx, Space s = SP_P) {
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, f = cfg.vp_filter, k = cfg.vp_kernel;
-        const unsigned char* im = p.p_inrect;
+        const unsigned char* im = inrect_mask(p, s);
+        TS g1 = (s == SP_P) ? gPf1 : gRf1, g2 = (s == SP_P) ? gPf2 : gRf2;
         TS none{nullptr, 0};
-        colsum(ps, SP_P, dout, 1, nullptr, none, Gd(P.lb));
-        colsum(ps, SP_P, b.n2, f, nullptr, dout, Gd(P.lw));
+        colsum(ps, s, dout, 1, nullptr, none, Gd(P.lb));
+        colsum(ps, s, b.n2, f, nullptr, dout, Gd(P.lw));
         TS w = W(ps, P.lw);
-        MTTS_LAUNCH(rowdot_bwd_kernel, row_grid(p.maxMp, p.tasks), dim3(256), stream, (const int*)p.meta, (int)META_MP,
-                    (const float*)dout.p, dout.ts, (const float*)w.p, w.ts, gPf1.p, gPf1.ts, f);
-        drop(ps, SP_P, gPf1, gPf1, f, cfg.vp_dropout, site_base + 1);
-        ln_bwd(ps, SP_P, gPf1, b.r2, b.st2, P.l2g, P.l2b, im, gPf2, f, 1);       // gPf2 = d conv2 out
+        MTTS_LAUNCH(rowdot_bwd_kernel, row_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
+                    (const float*)dout.p, dout.ts, (const float*)w.p, w.ts, g1.p, g1.ts, f);
+        drop(ps, s, g1, g1, f, cfg.vp_dropout, site_base + 1);
+        ln_bwd(ps, s, g1, b.r2, b.st2, P.l2g, P.l2b, im, g2, f, 1);       // g2 = d conv2 out
         {
             GemmBatchScope pair(gx, stream);
-            conv_wgrad(ps, SP_P, gPf2, f, k, b.n1, f, P.c2w, P.c2b, im);
-            conv_dgrad(ps, SP_P, gPf2, f, k, W(ps, P.c2w), f, gPf1, 0, im);     // gPf1 = d n1
+            conv_wgrad(ps, s, g2, f, k, b.n1, f, P.c2w, P.c2b, im);
+            conv_dgrad(ps, s, g2, f, k, W(ps, P.c2w), f, g1, 0, im);     // g1 = d n1
         }
-        drop(ps, SP_P, gPf1, gPf1, f, cfg.vp_dropout, site_base);
-        ln_bwd(ps, SP_P, gPf1, b.r1, b.st1, P.l1g, P.l1b, im, gPf2, f, 1);       // gPf2 = d conv1 out
+        drop(ps, s, g1, g1, f, cfg.vp_dropout, site_base);
+        ln_bwd(ps, s, g1, b.r1, b.st1, P.l1g, P.l1b, im, g2, f, 1);       // g2 = d conv1 out
         {
             GemmBatchScope pair(gx, stream);
-            conv_wgrad(ps, SP_P, gPf2, f, k, xin, d, P.c1w, P.c1b, im);
-            conv_dgrad(ps, SP_P, gPf2, f, k, W(ps, P.c1w), d, dx, GEMM_ACCUM, im);
+            conv_wgrad(ps, s, g2, f, k, xin, d, P.c1w, P.c1b, im);
+            conv_dgrad(ps, s, g2, f, k, W(ps, P.c1w), d, dx, GEMM_ACCUM, im);
         }
     }
 
@@ -1166,25 +1199,61 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         MTTS_LAUNCH(add_rowvec_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
                     (const float*)x.p, x.ts, (const float*)spk.p, spk.ts, (const int*)p.p_row_b, (const unsigned char*)p.p_inrect,
                     row_ts_p, x0.p, x0.ts, d);
-        // variance adaptor: targets select the embeddings when given, else the (controlled) predictions
+        // variance adaptor: targets select the embeddings when given, else the (controlled) predictions.  A phoneme-level feature
+        // (modules.py:118-127) is handled on the phoneme rectangle before the length regulator, a frame-level one (:139-148) on the
+        // frame rectangle after it.
         site_base = 128; pred_fwd(ps, durP, durB, x0);
-        site_base = 132; pred_fwd(ps, pitP, pitB, x0);
         TS pe = W(ps, pitch_emb), ee = W(ps, energy_emb);
         const bool tf = p.has_targets;
-        MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
-                    (const float*)x0.p, x0.ts, tf ? (const float*)p.p_pitch_t : (const float*)pitB.out.p, tf ? row_ts_p : pitB.out.ts,
-                    tf ? 1.f : ps.p_control, (const float*)pitch_bins, cfg.n_bins - 1, (const float*)pe.p, pe.ts,
-                    (const unsigned char*)p.p_inrect, row_ts_p, pidx, x1.p, x1.ts, d);
-        site_base = 136; pred_fwd(ps, eneP, eneB, x1);
-        MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
-                    (const float*)x1.p, x1.ts, tf ? (const float*)p.p_energy_t : (const float*)eneB.out.p, tf ? row_ts_p : eneB.out.ts,
-                    tf ? 1.f : ps.e_control, (const float*)energy_bins, cfg.n_bins - 1, (const float*)ee.p, ee.ts,
-                    (const unsigned char*)p.p_inrect, row_ts_p, eidx, x2.p, x2.ts, d);
+        TS xp = x0;
+        if (!cfg.pitch_frame) {
+            site_base = 132; pred_fwd(ps, pitP, pitB, xp);
+            MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
+                        (const float*)xp.p, xp.ts, tf ? (const float*)p.p_pitch_t : (const float*)pitB.out.p, tf ? row_ts_p : pitB.out.ts,
+                        tf ? 1.f : ps.p_control, (const float*)pitch_bins, cfg.n_bins - 1, (const float*)pe.p, pe.ts,
+                        (const unsigned char*)p.p_inrect, row_ts_p, pidx, x1.p, x1.ts, d);
+            xp = x1;
+        }
+        if (!cfg.energy_frame) {
+            site_base = 136; pred_fwd(ps, eneP, eneB, xp);
+            MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
+                        (const float*)xp.p, xp.ts, tf ? (const float*)p.p_energy_t : (const float*)eneB.out.p, tf ? row_ts_p : eneB.out.ts,
+                        tf ? 1.f : ps.e_control, (const float*)energy_bins, cfg.n_bins - 1, (const float*)ee.p, ee.ts,
+                        (const unsigned char*)p.p_inrect, row_ts_p, eidx, x2.p, x2.ts, d);
+            xp = x2;
+        }
+        va_out = xp;  // what the length regulator expands (backward needs to know which buffer it was)
         if (!tf && frames_from_predictions_impl(ps)) return -1;
-        // length regulator + speaker + decoder positions
-        MTTS_LAUNCH(length_regulate_fwd_kernel, row_grid(p.maxMf, nt), dim3(256), stream, (const int*)p.meta, (const float*)x2.p,
-                    x2.ts, (const int*)p.f_src, (const int*)p.f_row_b, (const int*)p.f_row_t, row_ts_f, (const float*)spk.p, spk.ts,
-                    (const float*)pos_table, dec_in.p, dec_in.ts, d);
+        if (!any_frame_level()) {
+            // length regulator + speaker + decoder positions
+            MTTS_LAUNCH(length_regulate_fwd_kernel, row_grid(p.maxMf, nt), dim3(256), stream, (const int*)p.meta, (const float*)xp.p,
+                        xp.ts, (const int*)p.f_src, (const int*)p.f_row_b, (const int*)p.f_row_t, row_ts_f, (const float*)spk.p, spk.ts,
+                        (const float*)pos_table, dec_in.p, dec_in.ts, d);
+        } else {
+            MTTS_LAUNCH(length_regulate_rect_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (const float*)xp.p, xp.ts,
+                        (const int*)p.f_src, row_ts_f, (const int*)p.r2f, row_ts_r, xr0.p, xr0.ts, d);
+            TS xr = xr0;
+            if (cfg.pitch_frame) {
+                site_base = 132; pred_fwd(ps, pitP, pitR, xr, SP_R);
+                MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (int)META_MR,
+                            (const float*)xr.p, xr.ts, tf ? (const float*)p.r_pitch_t : (const float*)pitR.out.p, tf ? row_ts_r : pitR.out.ts,
+                            tf ? 1.f : ps.p_control, (const float*)pitch_bins, cfg.n_bins - 1, (const float*)pe.p, pe.ts,
+                            (const unsigned char*)p.r_inrect, row_ts_r, pidx_r, xr1.p, xr1.ts, d);
+                xr = xr1;
+            }
+            if (cfg.energy_frame) {
+                site_base = 136; pred_fwd(ps, eneP, eneR, xr, SP_R);
+                MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (int)META_MR,
+                            (const float*)xr.p, xr.ts, tf ? (const float*)p.r_energy_t : (const float*)eneR.out.p, tf ? row_ts_r : eneR.out.ts,
+                            tf ? 1.f : ps.e_control, (const float*)energy_bins, cfg.n_bins - 1, (const float*)ee.p, ee.ts,
+                            (const unsigned char*)p.r_inrect, row_ts_r, eidx_r, xr2.p, xr2.ts, d);
+                xr = xr2;
+            }
+            // packed decoder input = rectangle rows of the valid frames + speaker + positions
+            MTTS_LAUNCH(length_regulate_fwd_kernel, row_grid(p.maxMf, nt), dim3(256), stream, (const int*)p.meta, (const float*)xr.p,
+                        xr.ts, (const int*)p.f2r, (const int*)p.f_row_b, (const int*)p.f_row_t, row_ts_f, (const float*)spk.p, spk.ts,
+                        (const float*)pos_table, dec_in.p, dec_in.ts, d);
+        }
         x = dec_in;
         for (int l = 0; l < cfg.dec_layers; ++l) { site_base = 64 + 2 * l; fft_fwd(ps, SP_F, cfg.dec_heads, decP[l], decB[l], x, none); x = decB[l].y2; }
         // mel_linear: packed frames -> mel rectangle; padded frames carry the bias
@@ -1292,6 +1361,11 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         a.p_tgt = p.p_pitch_t; a.e_tgt = p.p_energy_t; a.dur = p.p_dur; a.pvalid = p.p_valid;
         a.mel_ts = mel.ts; a.rrow_ts = row_ts_r; a.prow_ts = row_ts_p; a.pred_ts = pitB.out.ts;
         a.n_mel = cfg.n_mel;
+        a.pitch_frame = cfg.pitch_frame; a.energy_frame = cfg.energy_frame;
+        if (any_frame_level()) {
+            a.pp_r = pitR.out.p; a.ep_r = eneR.out.p; a.pred_r_ts = pitR.out.ts;
+            a.p_tgt_r = p.r_pitch_t; a.e_tgt_r = p.r_energy_t;
+        }
         return a;
     }
 
@@ -1303,7 +1377,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         LossArgs a = loss_args(p);
         MTTS_LAUNCH(loss_partial_kernel, dim3(kLossBlocks, 1, p.tasks), dim3(256), stream, (const int*)p.meta, a, loss_partial);
         MTTS_LAUNCH(loss_final_kernel, dim3(p.tasks), dim3(64), stream, (const int*)p.meta, (const float*)loss_partial,
-                    (int)kLossBlocks, cfg.n_mel, losses_out);
+                    (int)kLossBlocks, cfg.n_mel, losses_out, cfg.pitch_frame, cfg.energy_frame);
         return 0;
     }
 
@@ -1319,7 +1393,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         LossArgs a = loss_args(p);
         // prediction strides in the phoneme space: the [Mp] vectors were allocated as rows(capMp, 1)
         MTTS_LAUNCH(loss_grad_kernel, dim3(kLossBlocks, 1, nt), dim3(256), stream, (const int*)p.meta, a, scale, gRm.p, gRp.p,
-                    dpred[1].p, dpred[2].p, dpred[0].p);
+                    dpred[1].p, dpred[2].p, dpred[0].p, dpred_r[0].p, dpred_r[1].p);
         // ---- PostNet: cur = dL/d(a_i), starts as dL/d(mel_post); dc -> gR0, layer-input grad -> gR1
         TS cur = gRp;
         for (int i = cfg.postnet_layers - 1; i >= 0; --i) {
@@ -1373,21 +1447,41 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             site_base = 64 + 2 * l;
             fft_bwd(ps, SP_F, cfg.dec_heads, decP[l], decB[l], xin, gF0, gF1, gFqkv, gFh, dSf);
         }
-        // ---- length regulator -> gP0 = dL/d(x2) -------------------------------------------
-        MTTS_LAUNCH(length_regulate_bwd_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (const float*)gF0.p,
-                    gF0.ts, (const int*)p.p_first, (const int*)p.p_count, row_ts_p, gP0.p, gP0.ts, d, 0);
         // speaker vector gradient, part 1: every valid frame
         MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(256), stream, (const int*)p.meta, (const float*)gF0.p,
                     gF0.ts, (const int*)p.f_seg_start, (const int*)p.f_seg_len, (long long)cap_B, dspk.p, dspk.ts, d, 0);
-        // ---- variance adaptor ---------------------------------------------------------------
-        const bool va_needed = true;
-        (void)va_needed;
-        MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MP,
-                    (const float*)gP0.p, gP0.ts, (const int*)eidx, row_ts_p, -1, Gd(energy_emb).p, n_total, d);
-        site_base = 136; pred_bwd(ps, eneP, eneB, x1, dpred[2], gP0);
-        MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MP,
-                    (const float*)gP0.p, gP0.ts, (const int*)pidx, row_ts_p, -1, Gd(pitch_emb).p, n_total, d);
-        site_base = 132; pred_bwd(ps, pitP, pitB, x0, dpred[1], gP0);
+        // ---- frame-level half of the variance adaptor (frame rectangle), then the length regulator -> gP0 = dL/d(va_out) --------
+        TS gLR = gF0;
+        if (any_frame_level()) {
+            MTTS_LAUNCH(gather_rows_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (int)META_MR, (const float*)gF0.p,
+                        gF0.ts, (const int*)p.r2f, row_ts_r, gRx.p, gRx.ts, d);          // dL/d(xr_last): 0 on padded frames
+            if (cfg.energy_frame) {
+                MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MR,
+                            (const float*)gRx.p, gRx.ts, (const int*)eidx_r, row_ts_r, -1, Gd(energy_emb).p, n_total, d);
+                site_base = 136; pred_bwd(ps, eneP, eneR, cfg.pitch_frame ? xr1 : xr0, dpred_r[1], gRx, SP_R);
+            }
+            if (cfg.pitch_frame) {
+                MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MR,
+                            (const float*)gRx.p, gRx.ts, (const int*)pidx_r, row_ts_r, -1, Gd(pitch_emb).p, n_total, d);
+                site_base = 132; pred_bwd(ps, pitP, pitR, xr0, dpred_r[0], gRx, SP_R);
+            }
+            MTTS_LAUNCH(gather_rows_kernel, row_grid(p.maxMf, nt), dim3(256), stream, (const int*)p.meta, (int)META_MF, (const float*)gRx.p,
+                        gRx.ts, (const int*)p.f2r, row_ts_f, gFx.p, gFx.ts, d);
+            gLR = gFx;
+        }
+        MTTS_LAUNCH(length_regulate_bwd_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (const float*)gLR.p,
+                    gLR.ts, (const int*)p.p_first, (const int*)p.p_count, row_ts_p, gP0.p, gP0.ts, d, 0);
+        // ---- phoneme-level half of the variance adaptor ---------------------------------------------------------------------
+        if (!cfg.energy_frame) {
+            MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MP,
+                        (const float*)gP0.p, gP0.ts, (const int*)eidx, row_ts_p, -1, Gd(energy_emb).p, n_total, d);
+            site_base = 136; pred_bwd(ps, eneP, eneB, cfg.pitch_frame ? x0 : x1, dpred[2], gP0);
+        }
+        if (!cfg.pitch_frame) {
+            MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MP,
+                        (const float*)gP0.p, gP0.ts, (const int*)pidx, row_ts_p, -1, Gd(pitch_emb).p, n_total, d);
+            site_base = 132; pred_bwd(ps, pitP, pitB, x0, dpred[1], gP0);
+        }
         site_base = 128; pred_bwd(ps, durP, durB, x0, dpred[0], gP0);
         // speaker vector gradient, part 2: every position of the phoneme rectangle
         MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(256), stream, (const int*)p.meta, (const float*)gP0.p,

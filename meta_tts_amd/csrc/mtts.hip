@@ -48,6 +48,7 @@ int mtts_create(const mtts_model_cfg* c, int device, int max_tasks, int max_B, i
     m.postnet_layers = c->postnet_layers; m.pitch_min = c->pitch_min; m.pitch_max = c->pitch_max;
     m.energy_min = c->energy_min; m.energy_max = c->energy_max; m.adapt_mask = c->adapt_mask;
     m.enc_dropout = c->enc_dropout; m.dec_dropout = c->dec_dropout; m.vp_dropout = c->vp_dropout;
+    m.pitch_frame = c->pitch_frame_level != 0; m.energy_frame = c->energy_frame_level != 0;
     if (h->eng.init(m, max_tasks, max_B, max_S, max_T) != 0) {
         g_create_error = h->eng.last_error;
         delete h;
@@ -209,8 +210,11 @@ int mtts_get_outputs(mtts_handle* h, int slot, int task, float* mel, float* mel_
         if (mel && hipMemcpy(mel + (size_t)b * T * nm, e.mel.p + task * e.mel.ts + r0 * nm, (size_t)T * nm * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (mel_post && hipMemcpy(mel_post + (size_t)b * T * nm, e.mel_post.p + task * e.mel_post.ts + r0 * nm, (size_t)T * nm * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
         const long long p0 = G + (long long)b * (S + G);
-        if (p && hipMemcpy(p + (size_t)b * S, e.pitB.out.p + task * e.pitB.out.ts + p0, S * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        if (en && hipMemcpy(en + (size_t)b * S, e.eneB.out.p + task * e.eneB.out.ts + p0, S * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        // a frame-level feature's prediction lives on the mel rows: [B][T_cap]
+        if (p && !e.cfg.pitch_frame && hipMemcpy(p + (size_t)b * S, e.pitB.out.p + task * e.pitB.out.ts + p0, S * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (p && e.cfg.pitch_frame && hipMemcpy(p + (size_t)b * T, e.pitR.out.p + task * e.pitR.out.ts + r0, T * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (en && !e.cfg.energy_frame && hipMemcpy(en + (size_t)b * S, e.eneB.out.p + task * e.eneB.out.ts + p0, S * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (en && e.cfg.energy_frame && hipMemcpy(en + (size_t)b * T, e.eneR.out.p + task * e.eneR.out.ts + r0, T * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (logd && hipMemcpy(logd + (size_t)b * S, e.durB.out.p + task * e.durB.out.ts + p0, S * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     }
     return 0;

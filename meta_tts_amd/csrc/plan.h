@@ -24,10 +24,12 @@ struct PlanImage {  // device view of one slot's compact image (fixed capacity s
     const int* spk;       // [task][cap_B + 1]
     const int* texts;     // [task][cap_B * cap_S]   (row-major [B][S] of THIS task, S = hdr.S)
     const int* dur;       // [task][cap_B * cap_S]
-    const float* pitch;   // [task][cap_B * cap_S]
-    const float* energy;  // [task][cap_B * cap_S]
+    const float* pitch;   // [task][pe_cap_p]: [B][S] phoneme-level or [B][Tmax_in] frame-level targets
+    const float* energy;  // [task][pe_cap_e]
     const float* mels;    // mel area
     int cap_B, cap_S;
+    long long pe_cap_p, pe_cap_e;      // per-task capacity of the pitch / energy areas (floats)
+    int pitch_frame, energy_frame;     // feature levels (preprocess config)
 };
 
 struct PlanOut {  // the plan arrays the kernels of rowops.h / gemm.h consume (per-task strides in elements)
@@ -38,6 +40,7 @@ struct PlanOut {  // the plan arrays the kernels of rowops.h / gemm.h consume (p
     unsigned char* f_valid;
     int* r2f;
     unsigned char *r_valid, *r_inrect;
+    float *r_pitch_t, *r_energy_t;   // frame-level targets on the mel rows (null when the feature is phoneme-level)
     float* mel_tgt;
     int* spk_ids;
     long long ts_p, ts_f, ts_r, ts_mel, ts_seg, ts_spk;
@@ -71,7 +74,9 @@ __global__ void plan_rows_p_kernel(PlanImage im, PlanOut o) {
                 valid = s < im.src_len[(long long)z * im.cap_B + i];
                 const long long e = (long long)z * bs + (long long)i * h.S + s;
                 tok = valid ? im.texts[e] : 0;
-                if (h.has_targets) { pt = im.pitch[e]; et = im.energy[e]; }
+                const long long ei = (long long)i * h.S + s;
+                if (h.has_targets && !im.pitch_frame) pt = im.pitch[(long long)z * im.pe_cap_p + ei];
+                if (h.has_targets && !im.energy_frame) et = im.energy[(long long)z * im.pe_cap_e + ei];
             }
         }
         o.p_row_b[q] = rb; o.p_row_t[q] = rt; o.p_tok[q] = tok; o.p_valid[q] = valid; o.p_inrect[q] = inrect;
@@ -135,6 +140,10 @@ __global__ void plan_rows_r_kernel(PlanImage im, PlanOut o, int n_mel) {
     if (lane == 0) {
         o.r_inrect[q] = inrect; o.r_valid[q] = valid;
         o.r2f[q] = valid ? im.foff[(long long)z * im.cap_B + i] + t : -1;
+        // frame-level targets: the padded part of the caller's [B][T_max] array is kept as it is (the reference bucketises it too)
+        const bool intgt = inrect && h.has_targets && t < h.Tmax_in;
+        if (im.pitch_frame) o.r_pitch_t[q] = intgt ? im.pitch[(long long)z * im.pe_cap_p + (long long)i * h.Tmax_in + t] : 0.f;
+        if (im.energy_frame) o.r_energy_t[q] = intgt ? im.energy[(long long)z * im.pe_cap_e + (long long)i * h.Tmax_in + t] : 0.f;
     }
     if (!h.has_mels) return;
     float* dst = o.mel_tgt + (long long)z * o.ts_mel + (long long)row * n_mel;

@@ -622,6 +622,18 @@ __global__ void length_regulate_fwd_kernel(const int* meta, const float* x, long
     }
 }
 
+// frame-level features: the length regulator's output on the zero-padded frame RECTANGLE (modules.py:128-137 + pad), before the
+// frame-level pitch / energy predictors: out[rr] = x[f_src[r2f[rr]]] on valid frames, 0 elsewhere
+__global__ void length_regulate_rect_kernel(const int* meta, const float* x, long long x_ts, const int* f_src, long long f_ts, const int* r2f,
+                                            long long r_ts, float* out, long long out_ts, int C) {
+    ROW_PROLOGUE(META_MR)
+    const int fr = r2f[(long long)z * r_ts + row];
+    const int s = fr >= 0 ? f_src[(long long)z * f_ts + fr] : -1;
+    float* po = out + (long long)z * out_ts + (long long)row * C;
+    const float* px = s >= 0 ? x + (long long)z * x_ts + (long long)s * C : nullptr;
+    for (int c = lane * 4; c < C; c += 256) st4(po + c, px ? ld4(px + c) : zero4());
+}
+
 // dx[p] (+)= sum_{r in [first[p], first[p]+count[p])} dout[r]   (rows of the phoneme space)
 __global__ void length_regulate_bwd_kernel(const int* meta, const float* dout, long long dout_ts, const int* first,
                                            const int* count, long long row_ts, float* dx, long long dx_ts, int C,
@@ -983,6 +995,11 @@ struct LossArgs {
     const unsigned char* pvalid;                 // phoneme rows
     long long mel_ts, rrow_ts, prow_ts, pred_ts; // strides
     int n_mel;
+    // frame-level pitch / energy (preprocess `feature: frame_level`; loss.py:54-63): predictions and targets live on the mel rows
+    int pitch_frame = 0, energy_frame = 0;
+    const float *pp_r = nullptr, *ep_r = nullptr;      // [Mr], stride pred_r_ts
+    const float *p_tgt_r = nullptr, *e_tgt_r = nullptr; // [Mr], stride rrow_ts
+    long long pred_r_ts = 0;
 };
 
 constexpr int kLossBlocks = 64;
@@ -1010,10 +1027,17 @@ __global__ void loss_partial_kernel(const int* meta, LossArgs a, float* partial)
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < Mp; r += gridDim.x * blockDim.x) {
         if (!pv[r]) continue;
         const long long q = (long long)z * a.pred_ts + r, qt = (long long)z * a.prow_ts + r;
-        const float dp = a.pp[q] - a.p_tgt[qt], de = a.ep[q] - a.e_tgt[qt];
+        const float dp = a.pitch_frame ? 0.f : a.pp[q] - a.p_tgt[qt], de = a.energy_frame ? 0.f : a.ep[q] - a.e_tgt[qt];
         const float dd = a.logd[q] - logf((float)a.dur[qt] + 1.f);
         s[2] += dp * dp; s[3] += de * de; s[4] += dd * dd;
     }
+    if (a.pitch_frame || a.energy_frame)
+        for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < Mr; r += gridDim.x * blockDim.x) {
+            if (!rv[r]) continue;
+            const long long q = (long long)z * a.pred_r_ts + r, qt = (long long)z * a.rrow_ts + r;
+            if (a.pitch_frame) { const float dp = a.pp_r[q] - a.p_tgt_r[qt]; s[2] += dp * dp; }
+            if (a.energy_frame) { const float de = a.ep_r[q] - a.e_tgt_r[qt]; s[3] += de * de; }
+        }
     for (int k = 0; k < 5; ++k) s[k] = wave_sum(s[k]);
     if (((int)threadIdx.x & 63) == 0) for (int k = 0; k < 5; ++k) red[(int)threadIdx.x >> 6][k] = s[k];
     __syncthreads();
@@ -1024,13 +1048,16 @@ __global__ void loss_partial_kernel(const int* meta, LossArgs a, float* partial)
 }
 
 // losses[task][6] = (total, mel, postnet mel, pitch, energy, duration)
-__global__ void loss_final_kernel(const int* meta, const float* partial, int nblocks, int n_mel, float* losses) {
+__global__ void loss_final_kernel(const int* meta, const float* partial, int nblocks, int n_mel, float* losses, int pitch_frame = 0,
+                                  int energy_frame = 0) {
     const int z = blockIdx.x;
     if (threadIdx.x != 0) return;
     double s[5] = {0, 0, 0, 0, 0};
     for (int b = 0; b < nblocks; ++b) for (int k = 0; k < 5; ++k) s[k] += (double)partial[((long long)z * nblocks + b) * 5 + k];
     const double nF = (double)meta[z * META_STRIDE + META_NF] * n_mel, nP = (double)meta[z * META_STRIDE + META_NP];
-    const float mel = (float)(s[0] / nF), post = (float)(s[1] / nF), p = (float)(s[2] / nP), e = (float)(s[3] / nP), d = (float)(s[4] / nP);
+    const double nFr = (double)meta[z * META_STRIDE + META_NF];   // valid frames: the element count of a frame-level MSE
+    const float mel = (float)(s[0] / nF), post = (float)(s[1] / nF), p = (float)(s[2] / (pitch_frame ? nFr : nP)),
+                e = (float)(s[3] / (energy_frame ? nFr : nP)), d = (float)(s[4] / nP);
     float* o = losses + (long long)z * 6;
     o[0] = mel + post + d + p + e; o[1] = mel; o[2] = post; o[3] = p; o[4] = e; o[5] = d;
 }
@@ -1040,7 +1067,7 @@ __device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : ((x < 
 // d(total)/d(predictions) * scale.  dmel, dpost: [Mr][n_mel] (0 on padded / guard rows);
 // dpp, dep, dlogd: [Mp]
 __global__ void loss_grad_kernel(const int* meta, LossArgs a, float scale, float* dmel, float* dpost, float* dpp,
-                                 float* dep, float* dlogd) {
+                                 float* dep, float* dlogd, float* dpp_r = nullptr, float* dep_r = nullptr) {
     const int z = blockIdx.z;
     const int Mr = meta[z * META_STRIDE + META_MR], Mp = meta[z * META_STRIDE + META_MP];
     const float wF = scale / ((float)meta[z * META_STRIDE + META_NF] * (float)a.n_mel);
@@ -1069,11 +1096,19 @@ __global__ void loss_grad_kernel(const int* meta, LossArgs a, float scale, float
         const long long q = (long long)z * a.pred_ts + r, qt = (long long)z * a.prow_ts + r;
         float gp = 0.f, ge = 0.f, gd = 0.f;
         if (pv[r]) {
-            gp = wP * (a.pp[q] - a.p_tgt[qt]);
-            ge = wP * (a.ep[q] - a.e_tgt[qt]);
+            if (!a.pitch_frame) gp = wP * (a.pp[q] - a.p_tgt[qt]);
+            if (!a.energy_frame) ge = wP * (a.ep[q] - a.e_tgt[qt]);
             gd = wP * (a.logd[q] - logf((float)a.dur[qt] + 1.f));
         }
         dpp[q] = gp; dep[q] = ge; dlogd[q] = gd;
+    }
+    if (a.pitch_frame || a.energy_frame) {
+        const float wR = 2.f * scale / (float)meta[z * META_STRIDE + META_NF];
+        for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < Mr; r += gridDim.x * blockDim.x) {
+            const long long q = (long long)z * a.pred_r_ts + r, qt = (long long)z * a.rrow_ts + r;
+            if (a.pitch_frame) dpp_r[q] = rv[r] ? wR * (a.pp_r[q] - a.p_tgt_r[qt]) : 0.f;
+            if (a.energy_frame) dep_r[q] = rv[r] ? wR * (a.ep_r[q] - a.e_tgt_r[qt]) : 0.f;
+        }
     }
 }
 

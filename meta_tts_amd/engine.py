@@ -40,6 +40,7 @@ class Engine:
                   "vp_kernel", "n_bins", "max_seq_len", "n_mel", "vocab", "n_speaker", "postnet_dim", "postnet_kernel",
                   "postnet_layers", "pitch_min", "pitch_max", "energy_min", "energy_max", "enc_dropout", "dec_dropout", "vp_dropout"):
             setattr(cfg, f, getattr(dims, f))
+        cfg.pitch_frame_level, cfg.energy_frame_level = int(dims.pitch_frame_level), int(dims.energy_frame_level)
         mask = 0
         for m in adapt_modules:
             if m not in MODULE_BITS:
@@ -193,6 +194,8 @@ class Engine:
             p, e, d = np_(b[9], np.float32), np_(b[10], np.float32), np_(b[11], np.int64)
             cb.T_max = int(b[8])
             assert mels.shape == (cb.B, cb.T_max, self.dims.n_mel), mels.shape
+            assert p.shape == (cb.B, cb.T_max if self.dims.pitch_frame_level else cb.S_max), ("pitch targets", p.shape)
+            assert e.shape == (cb.B, cb.T_max if self.dims.energy_frame_level else cb.S_max), ("energy targets", e.shape)
             fields += [("mels", mels), ("mel_lens", mel_lens), ("pitches", p), ("energies", e), ("durations", d)]
         for f, a in fields:
             setattr(cb, f, a.ctypes.data_as(C.c_void_p))
@@ -234,7 +237,8 @@ class Engine:
         d_rounded, mel_lens, T = self.durations(slot, task)
         nm = self.dims.n_mel
         o = {"mel": np.empty((B, T, nm), np.float32), "mel_post": np.empty((B, T, nm), np.float32),
-             "p": np.empty((B, S), np.float32), "e": np.empty((B, S), np.float32), "logd": np.empty((B, S), np.float32)}
+             "p": np.empty((B, T if self.dims.pitch_frame_level else S), np.float32),
+             "e": np.empty((B, T if self.dims.energy_frame_level else S), np.float32), "logd": np.empty((B, S), np.float32)}
         self._ck(self.lib.mtts_get_outputs(self.h, slot, task, *[o[k].ctypes.data_as(C.c_void_p) for k in ("mel", "mel_post", "p", "e", "logd")]))
         o["d_rounded"], o["mel_lens"] = d_rounded, mel_lens
         return o

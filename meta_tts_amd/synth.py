@@ -158,7 +158,7 @@ def make_buffers(dims: ModelDims) -> "OrderedDict[str, np.ndarray]":
 
 def make_batch(seed: int, B: int, speaker: int = 7, n_mel: int = 80, vocab: int = 361,
                s_range: Tuple[int, int] = (40, 81), d_range: Tuple[int, int] = (2, 13),
-               first_len: int | None = 80):
+               first_len: int | None = 80, pitch_level: str = "phoneme_level", energy_level: str = "phoneme_level"):
     """One padded batch in the reference 12-tuple layout (lightning/collate.py:47-60) as numpy arrays.
 
     Draw order is fixed by SURVEY.md section 8(d): src_lens, then per utterance dur, then per
@@ -182,6 +182,15 @@ def make_batch(seed: int, B: int, speaker: int = 7, n_mel: int = 80, vocab: int 
         energies[i, :s] = g.standard_normal(s).astype(np.float32)
         mels[i, :t] = g.standard_normal((t, n_mel)).astype(np.float32)
         durations[i, :s] = durs[i]
+    # frame-level features (preprocess config `pitch.feature: frame_level`): one value per mel frame, drawn after everything else
+    if pitch_level == "frame_level":
+        pitches = np.zeros((B, T), np.float32)
+        for i in range(B):
+            pitches[i, :int(mel_lens[i])] = g.standard_normal(int(mel_lens[i])).astype(np.float32)
+    if energy_level == "frame_level":
+        energies = np.zeros((B, T), np.float32)
+        for i in range(B):
+            energies[i, :int(mel_lens[i])] = g.standard_normal(int(mel_lens[i])).astype(np.float32)
     ids = [f"synth-{seed}-{i}" for i in range(B)]
     raw_texts = ["" for _ in range(B)]
     speakers = np.full((B,), speaker, np.int64)

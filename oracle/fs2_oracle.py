@@ -173,27 +173,30 @@ def length_regulate(x, durations, max_len: Optional[int]):
 
 
 def variance_adaptor(x, src_mask, mel_mask, max_len, p_t, e_t, d_t, p: Params,
-                     p_control=1.0, e_control=1.0, d_control=1.0):
-    """lightning/model/modules.py:102-158, phoneme-level features: duration predictor on x;
-    pitch predictor on x, x += pitch_emb[bucketize(target or pred*ctl)]; energy predictor on the
-    updated x, x += energy_emb[...]; length regulation with the targets or
-    clamp(round(exp(logd) - 1) * ctl, 0)."""
+                     p_control=1.0, e_control=1.0, d_control=1.0, pitch_level="phoneme_level", energy_level="phoneme_level"):
+    """lightning/model/modules.py:102-158: duration predictor on x; phoneme-level features (:118-127): pitch predictor on x,
+    x += pitch_emb[bucketize(target or pred*ctl, bins)]; energy predictor on the updated x, x += energy_emb[...]; length
+    regulation with the targets or clamp(round(exp(logd) - 1) * ctl, 0); frame-level features (:139-148): the same two steps
+    AFTER the length regulator, on the zero-padded frame rectangle with the mel mask."""
     va = "variance_adaptor"
+
+    def embed(x, target, mask, control, name):               # get_pitch_embedding / get_energy_embedding, modules.py:80-100
+        pred = variance_predictor(x, mask, p, f"{va}.{name}_predictor")
+        if target is not None:
+            idx = torch.bucketize(target, p[f"{va}.{name}_bins"])
+        else:
+            pred = pred * control
+            idx = torch.bucketize(pred, p[f"{va}.{name}_bins"])
+        return pred, F.embedding(idx, p[f"{va}.{name}_embedding.weight"])
+
     logd = variance_predictor(x, src_mask, p, f"{va}.duration_predictor")
-    pp = variance_predictor(x, src_mask, p, f"{va}.pitch_predictor")
-    if p_t is not None:
-        idx = torch.bucketize(p_t, p[f"{va}.pitch_bins"])
-    else:
-        pp = pp * p_control
-        idx = torch.bucketize(pp, p[f"{va}.pitch_bins"])
-    x = x + F.embedding(idx, p[f"{va}.pitch_embedding.weight"])
-    ep = variance_predictor(x, src_mask, p, f"{va}.energy_predictor")
-    if e_t is not None:
-        idx = torch.bucketize(e_t, p[f"{va}.energy_bins"])
-    else:
-        ep = ep * e_control
-        idx = torch.bucketize(ep, p[f"{va}.energy_bins"])
-    x = x + F.embedding(idx, p[f"{va}.energy_embedding.weight"])
+    pp = ep = None
+    if pitch_level == "phoneme_level":
+        pp, emb = embed(x, p_t, src_mask, p_control, "pitch")
+        x = x + emb
+    if energy_level == "phoneme_level":
+        ep, emb = embed(x, e_t, src_mask, e_control, "energy")
+        x = x + emb
     if d_t is not None:
         x, mel_len = length_regulate(x, d_t, max_len)
         d_rounded = d_t
@@ -201,6 +204,12 @@ def variance_adaptor(x, src_mask, mel_mask, max_len, p_t, e_t, d_t, p: Params,
         d_rounded = torch.clamp(torch.round(torch.exp(logd) - 1) * d_control, min=0)
         x, mel_len = length_regulate(x, d_rounded, max_len)
         mel_mask = mask_from_lengths(mel_len)
+    if pitch_level == "frame_level":
+        pp, emb = embed(x, p_t, mel_mask, p_control, "pitch")
+        x = x + emb
+    if energy_level == "frame_level":
+        ep, emb = embed(x, e_t, mel_mask, e_control, "energy")
+        x = x + emb
     return x, pp, ep, logd, d_rounded, mel_len, mel_mask
 
 
@@ -239,7 +248,7 @@ def postnet(x, p: Params, buffers: Optional[Dict[str, torch.Tensor]], training: 
 def fs2_forward(p: Params, buffers, speakers, texts, src_lens, max_src_len, mels=None, mel_lens=None,
                 max_mel_len=None, p_targets=None, e_targets=None, d_targets=None,
                 p_control=1.0, e_control=1.0, d_control=1.0, *, n_head=(2, 2), max_seq_len=1000,
-                training=False, average_spk_emb=False):
+                training=False, average_spk_emb=False, pitch_level="phoneme_level", energy_level="phoneme_level"):
     """lightning/model/fastspeech2.py:40-112 and, with ``average_spk_emb``, the learner variant
     lightning/systems/base_adaptor.py:41-95 (mean of the support speakers' rows, expanded)."""
     src_masks = mask_from_lengths(src_lens, max_src_len)
@@ -251,7 +260,7 @@ def fs2_forward(p: Params, buffers, speakers, texts, src_lens, max_src_len, mels
     out = out + spk.unsqueeze(1).expand(-1, max_src_len, -1)
     out, pp, ep, logd, d_rounded, mel_lens, mel_masks = variance_adaptor(
         out, src_masks, mel_masks, max_mel_len, p_targets, e_targets, d_targets, p,
-        p_control, e_control, d_control)
+        p_control, e_control, d_control, pitch_level, energy_level)
     out = out + spk.unsqueeze(1).expand(-1, out.shape[1], -1)
     out, mel_masks = decoder(out, mel_masks, p, n_head[1], training, max_seq_len)
     mel = F.linear(out, p["mel_linear.weight"], p["mel_linear.bias"])
@@ -259,9 +268,10 @@ def fs2_forward(p: Params, buffers, speakers, texts, src_lens, max_src_len, mels
     return (mel, mel_post, pp, ep, logd, d_rounded, src_masks, mel_masks, src_lens, mel_lens)
 
 
-def fs2_loss(batch, preds):
+def fs2_loss(batch, preds, pitch_level="phoneme_level", energy_level="phoneme_level"):
     """lightning/model/loss.py:19-92 — L1 over valid frames x n_mel for mel / postnet mel, MSE over
-    valid phonemes for pitch, energy, log-duration (target log(d + 1)); total = plain sum."""
+    valid phonemes (or valid frames for a frame-level feature, :54-63) for pitch and energy, over valid
+    phonemes for log-duration (target log(d + 1)); total = plain sum."""
     mel_t, _, _, p_t, e_t, d_t = batch[6:]
     mel, mel_post, pp, ep, logd, _, src_masks, mel_masks, _, _ = preds
     sm, mm = ~src_masks, ~mel_masks
@@ -269,8 +279,10 @@ def fs2_loss(batch, preds):
     mel_t = mel_t[:, : mm.shape[1], :]
     mel_l = F.l1_loss(mel.masked_select(mm.unsqueeze(-1)), mel_t.masked_select(mm.unsqueeze(-1)))
     post_l = F.l1_loss(mel_post.masked_select(mm.unsqueeze(-1)), mel_t.masked_select(mm.unsqueeze(-1)))
-    p_l = F.mse_loss(pp.masked_select(sm), p_t.masked_select(sm))
-    e_l = F.mse_loss(ep.masked_select(sm), e_t.masked_select(sm))
+    pm = sm if pitch_level == "phoneme_level" else mm
+    em = sm if energy_level == "phoneme_level" else mm
+    p_l = F.mse_loss(pp.masked_select(pm), p_t.masked_select(pm))
+    e_l = F.mse_loss(ep.masked_select(em), e_t.masked_select(em))
     d_l = F.mse_loss(logd.masked_select(sm), logd_t.masked_select(sm))
     total = mel_l + post_l + d_l + p_l + e_l
     return (total, mel_l, post_l, p_l, e_l, d_l)

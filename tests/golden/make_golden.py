@@ -55,10 +55,13 @@ def install_shims():
     sys.modules["resemblyzer"] = m
 
 
-def build_reference_model():
+def build_reference_model(pitch_level="phoneme_level", energy_level="phoneme_level"):
     install_shims()
-    sys.path.insert(0, REF)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
     pre = load_yaml(os.path.join(REF, "config/preprocess/LibriTTS.yaml"))
+    pre["preprocessing"]["pitch"]["feature"] = pitch_level
+    pre["preprocessing"]["energy"]["feature"] = energy_level
     mod = load_yaml(os.path.join(REF, "config/model/base.yaml"))
     alg = load_yaml(os.path.join(REF, "config/algorithm/meta_emb_vad.yaml"))
     trn = load_yaml(os.path.join(REF, "config/train/base.yaml"))
@@ -72,7 +75,8 @@ def build_reference_model():
     from lightning.model.loss import FastSpeech2Loss
     model = FastSpeech2(pre, mod, alg)
     loss_fn = FastSpeech2Loss(pre, mod)
-    dims = ModelDims(mod, pre)
+    pre_ph = load_yaml(os.path.join(REF, "config/preprocess/LibriTTS.yaml"))   # ModelDims only reads sizes from it
+    dims = ModelDims(mod, pre_ph)
     params = synth.make_params(dims, seed=0)
     sd = model.state_dict()
     # how far numpy linspace (our bins) is from torch.linspace (reference bins)
@@ -191,6 +195,38 @@ def maml_fixture(model, loss_fn, modules, lr):
     return res
 
 
+def frame_level_fixture():
+    """Frame-level pitch / energy (preprocess `feature: frame_level`; modules.py:139-148, loss.py:54-63): the reference model built
+    with that preprocess config on the padded SMALL batch with one value per mel frame — losses, predictions, every gradient
+    norm (train mode), and the loss 6-tuple of the two mixed configurations."""
+    out = {}
+    for tag, pl, el in (("ff", "frame_level", "frame_level"), ("pf", "phoneme_level", "frame_level"), ("fp", "frame_level", "phoneme_level")):
+        model, loss_fn, dims, cfgs, _ = build_reference_model(pl, el)
+        patch_dropout_identity(model)
+        batch = synth.make_batch(11, 3, speaker=5, pitch_level=pl, energy_level=el, **SMALL)
+        b = tb(batch)
+        model.train(); reset_bn(model)
+        o = model(*b[2:])
+        lo = loss_fn(b, o)
+        out[f"{tag}_losses"] = np.array([float(x) for x in lo], np.float64)
+        out[f"{tag}_mel_post"] = o[1].detach().numpy()
+        out[f"{tag}_p"] = o[2].detach().numpy(); out[f"{tag}_e"] = o[3].detach().numpy()
+        if tag == "ff":
+            g = grads_of(model, lo[0])
+            out["ff_grad_names"] = np.array(list(g.keys()))
+            out["ff_grad_norms"] = np.array([float(v.double().norm()) for v in g.values()], np.float64)
+            for n in FULL_GRADS:
+                out["ff_grad::" + n] = head(g[n])
+            model.eval()
+            with torch.no_grad():
+                oe = model(*b[2:])
+                fr = model(*b[2:6], p_control=1.1, e_control=0.9)
+            out["ff_eval_mel_post"] = oe[1].numpy()
+            out["ff_fr_mel_post"] = fr[1].numpy(); out["ff_fr_d_rounded"] = fr[5].numpy(); out["ff_fr_mel_len"] = fr[9].numpy()
+            out["ff_fr_p"] = fr[2].numpy(); out["ff_fr_e"] = fr[3].numpy()
+    return out
+
+
 def c5_edit(params):
     """The random-init duration predictor emits ~0 frames; bias ln(8) and a damped weight give LibriTTS-like durations
     (about 7 frames per phoneme) — the same edit bench.py's inference leg applies."""
@@ -281,6 +317,11 @@ def main():
     small["eval_mel_post"] = oe[1].numpy()
     if not (os.environ.get("MTTS_GOLDEN_ONLY_MAML") or os.environ.get("MTTS_GOLDEN_ONLY_C5")):
         np.savez_compressed(os.path.join(out_dir, "small_grad.npz"), **small)
+
+    # ---------------- frame-level pitch / energy ------------------------------------------------------
+    if os.environ.get("MTTS_GOLDEN_ONLY_FRAME"):
+        np.savez_compressed(os.path.join(out_dir, "frame_level.npz"), **frame_level_fixture())
+        return
 
     # ---------------- C5: free-running synthesis with realistic predicted durations --------------
     if os.environ.get("MTTS_GOLDEN_ONLY_C5") or not os.environ.get("MTTS_GOLDEN_ONLY_MAML"):

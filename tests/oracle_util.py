@@ -56,5 +56,7 @@ def tiny_dims(**over):
     mc["_postnet_dim"] = 48
     pc = default_preprocess_config()
     pc["preprocessing"]["mel"]["n_mel_channels"] = 32
+    pc["preprocessing"]["pitch"]["feature"] = over.pop("pitch_level", "phoneme_level")
+    pc["preprocessing"]["energy"]["feature"] = over.pop("energy_level", "phoneme_level")
     mc.update(over.pop("model", {}))
     return ModelDims(mc, pc, n_speaker=over.pop("n_speaker", 12), vocab=over.pop("vocab", 40))

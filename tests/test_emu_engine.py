@@ -492,3 +492,82 @@ def test_imaml_hypergradient_matches_oracle(emu_lib):
         eng.meta_grad(1, lr, 1.0, second_order=True)
     eng.set_inner_prox(0.0)
     eng.close()
+
+
+@pytest.mark.parametrize("pl,el", [("frame_level", "frame_level"), ("phoneme_level", "frame_level"), ("frame_level", "phoneme_level")])
+def test_frame_level_pitch_energy_matches_oracle(emu_lib, pl, el):
+    """preprocess `pitch.feature / energy.feature: frame_level` (modules.py:139-148, loss.py:54-63): predictor, bucketised embedding
+    and loss of that feature on the frame rectangle after the length regulator — forward, 6 losses, every parameter gradient,
+    first-order MAML and free-running synthesis with controls, two ragged tasks, all three level combinations."""
+    dims = tiny_dims(pitch_level=pl, energy_level=el)
+    eng = _engine(dims, emu_lib)
+    kw = dict(pitch_level=pl, energy_level=el, **_kw(dims))
+    b0 = synth.make_batch(3, 3, speaker=2, **kw)
+    b1 = synth.make_batch(4, 2, speaker=5, **kw)
+    assert b0[9].shape == (3, b0[8] if pl == "frame_level" else b0[5])
+    eng.set_batches(0, [b0, b1])
+    eng.forward(0, use_fast=False, train=True)
+    dev_loss = eng.loss(0)
+    eng.backward(0, use_fast=False, scale=1.0, need_encoder=True)
+    okw = dict(n_head=heads(dims), max_seq_len=dims.max_seq_len, pitch_level=pl, energy_level=el)
+    for ti, b in enumerate([b0, b1]):
+        p = torch_params(dims, requires_grad=True)
+        tb = O.to_torch_batch(b)
+        o = O.fs2_forward(p, torch_buffers(dims), *tb[2:], training=True, **okw)
+        lo = O.fs2_loss(tb, o, pl, el)
+        out = eng.outputs(0, ti)
+        for k, ref in (("mel", o[0]), ("mel_post", o[1]), ("p", o[2]), ("e", o[3]), ("logd", o[4])):
+            assert out[k].shape == tuple(ref.shape), (k, out[k].shape, ref.shape)
+            assert np.abs(out[k] - ref.detach().numpy()).max() < 5e-5, (ti, k)
+        np.testing.assert_allclose(dev_loss[ti], [float(x) for x in lo], rtol=2e-5)
+        names = list(eng.params)
+        gs = torch.autograd.grad(lo[0], [p[n] for n in names], allow_unused=True)
+        for n, g in zip(names, gs):
+            ref = g.numpy() if g is not None else np.zeros(eng.params[n][0], np.float32)
+            assert np.abs(eng.export(n, 2, ti) - ref).max() <= 1e-3 * np.abs(ref).max() + 2e-7, (ti, n)
+    # first-order MAML on top of it
+    q0 = synth.make_batch(13, 2, speaker=2, **kw); q1 = synth.make_batch(14, 2, speaker=5, **kw)
+    eng.set_batches(1, [q0, q1], spk_from=[b0, b1], average_spk=True)
+    q, s_ = eng.meta_grad(2, 0.01, 0.5)
+    tot = {}
+    check = ["variance_adaptor.pitch_predictor.conv_layer.conv1d_1.conv.weight", "variance_adaptor.energy_embedding.weight", "mel_linear.weight",
+             "encoder.layer_stack.0.pos_ffn.w_1.weight"]
+    for j, (sup, qry) in enumerate([(b0, q0), (b1, q1)]):
+        p = torch_params(dims, requires_grad=True)
+        names = O.adapted_names(p, MODS)
+        fast = {k: p[k] for k in names}
+        ts, tq = O.to_torch_batch(sup), O.to_torch_batch(qry)
+        for _ in range(2):
+            cur = dict(p); cur.update(fast)
+            l = O.fs2_loss(ts, O.fs2_forward(cur, torch_buffers(dims), *ts[2:], training=True, **okw), pl, el)
+            g = torch.autograd.grad(l[0], [fast[k] for k in names])
+            fast = {k: fast[k] - 0.01 * gi for k, gi in zip(names, g)}
+        cur = dict(p); cur.update(fast)
+        ql = O.fs2_loss(tq, O.fs2_forward(cur, torch_buffers(dims), ts[2], *tq[3:], training=True, average_spk_emb=True, **okw), pl, el)
+        np.testing.assert_allclose(q[j], [float(x) for x in ql], rtol=1e-4)
+        for n, x in zip(check, torch.autograd.grad(ql[0], [p[n] for n in check])):
+            tot[n] = tot.get(n, 0) + 0.5 * x.numpy()
+    for n in check:
+        assert np.abs(eng.export(n, 1) - tot[n]).max() <= 2e-3 * np.abs(tot[n]).max() + 2e-7, n
+    with pytest.raises(Exception, match="frame-level"):
+        eng.meta_grad(1, 0.01, 1.0, second_order=True)
+    # free-running with controls
+    params = synth.make_params(dims, 0)
+    params["variance_adaptor.duration_predictor.linear_layer.bias"][:] = 1.2
+    eng.close()
+    eng = _engine(dims, emu_lib)       # fresh BatchNorm running statistics for the eval-mode pass
+    eng.load_params(params)
+    pt = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
+    for train in (False, True):
+        eng.set_batches(0, [b0[:6], b1[:6]])
+        eng.synthesize(0, train=train, p_control=1.1, e_control=0.9)
+        for ti, b in enumerate([b0, b1]):
+            tb = O.to_torch_batch(b)
+            with torch.no_grad():
+                o = O.fs2_forward(pt, torch_buffers(dims), *tb[2:6], p_control=1.1, e_control=0.9, training=train, **okw)
+            out = eng.outputs(0, ti)
+            np.testing.assert_array_equal(out["d_rounded"], o[5].numpy())
+            assert out["mel_post"].shape == tuple(o[1].shape) and np.abs(out["mel_post"] - o[1].numpy()).max() < 5e-5
+            np.testing.assert_allclose(out["p"] * 1.1, o[2].numpy(), atol=5e-5)
+            np.testing.assert_allclose(out["e"] * 0.9, o[3].numpy(), atol=5e-5)
+    eng.close()

@@ -389,3 +389,50 @@ def test_in_library_rccl_allreduce_world_size_one():
     norm = eng.outer_update(lr=1e-3, fetch_norm=True)
     assert np.isfinite(norm) and norm > 0
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f4: frame-level pitch / energy (preprocess `feature: frame_level`) and the shared speaker embedding on hardware
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pl,el", [("frame_level", "frame_level"), ("phoneme_level", "frame_level"), ("frame_level", "phoneme_level")])
+def test_frame_level_tiny_on_device(pl, el):
+    import test_emu_engine as E
+    E.test_frame_level_pitch_energy_matches_oracle(None, pl, el)
+
+
+def test_frame_level_full_size_matches_reference_fixture(golden_dir):
+    """tests/golden/frame_level.npz: the reference FastSpeech2 / FastSpeech2Loss built with `pitch.feature = energy.feature =
+    frame_level` on the padded SMALL batch (one value per mel frame): 6 losses, mel, the per-frame predictions and every
+    gradient norm."""
+    from meta_tts_amd.config import default_model_config, default_preprocess_config
+    g = _load(golden_dir, "frame_level.npz")
+    pc = default_preprocess_config()
+    pc["preprocessing"]["pitch"]["feature"] = pc["preprocessing"]["energy"]["feature"] = "frame_level"
+    dims = ModelDims(default_model_config(), pc)
+    eng = Engine(dims, adapt_modules=MODS, max_tasks=1, max_B=3, max_S=16, max_T=96)
+    eng.load_params(synth.make_params(dims, 0))
+    batch = synth.make_batch(11, 3, speaker=5, pitch_level="frame_level", energy_level="frame_level", **SMALL)
+    eng.set_batches(0, [batch])
+    eng.forward(0, train=True)
+    np.testing.assert_allclose(eng.loss(0)[0], g["ff_losses"], rtol=2e-5)
+    out = eng.outputs(0, 0)
+    assert out["p"].shape == g["ff_p"].shape
+    assert np.abs(out["mel_post"] - g["ff_mel_post"]).max() < 3e-4 and np.abs(out["mel_post"] - g["ff_mel_post"]).mean() < 5e-5
+    assert np.abs(out["p"] - g["ff_p"]).max() < 5e-5 and np.abs(out["e"] - g["ff_e"]).max() < 5e-5
+    eng.backward(0, scale=1.0, need_encoder=True)
+    names = [str(n) for n in g["ff_grad_names"]]
+    norms = np.array([float(np.linalg.norm(eng.export(n, 2, 0).astype(np.float64))) for n in names])
+    np.testing.assert_allclose(norms, g["ff_grad_norms"], rtol=5e-3, atol=2e-6)
+    for key in g.files:
+        if key.startswith("ff_grad::"):
+            got = eng.export(key[len("ff_grad::"):], 2, 0)
+            got = got[:4] if got.ndim >= 2 else got
+            assert np.abs(got - g[key]).max() <= 1e-3 * max(1e-3, np.abs(g[key]).max()), key
+    eng.forward(0, train=False)
+    assert np.abs(eng.outputs(0, 0)["mel_post"] - g["ff_eval_mel_post"]).max() < 3e-4
+    eng.set_batches(0, [batch[:6]])
+    eng.synthesize(0, train=False, p_control=1.1, e_control=0.9)
+    out = eng.outputs(0, 0)
+    np.testing.assert_array_equal(out["d_rounded"], g["ff_fr_d_rounded"])
+    np.testing.assert_array_equal(out["mel_lens"], g["ff_fr_mel_len"])
+    eng.close()

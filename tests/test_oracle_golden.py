@@ -158,3 +158,33 @@ def test_noam_schedule_clip_and_adam(golden_dir):
         np.testing.assert_allclose(norm, g["traj"][it][-2], rtol=1e-6)
         np.testing.assert_allclose(O.noam_lr(it + 1), g["traj"][it][-1], rtol=1e-9)
         np.testing.assert_allclose(x.numpy(), g["traj"][it][:-2], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag,pl,el", [("ff", "frame_level", "frame_level"), ("pf", "phoneme_level", "frame_level"), ("fp", "frame_level", "phoneme_level")])
+def test_frame_level_features(golden_dir, tag, pl, el):
+    """Frame-level pitch / energy (modules.py:139-148, loss.py:54-63) against the reference model built with that preprocess config."""
+    g = _load(golden_dir, "frame_level.npz")
+    p = torch_params(DIMS, requires_grad=True)
+    batch = synth.make_batch(11, 3, speaker=5, pitch_level=pl, energy_level=el, **SMALL)
+    b = O.to_torch_batch(batch)
+    kw = dict(n_head=heads(DIMS), pitch_level=pl, energy_level=el)
+    o = O.fs2_forward(p, torch_buffers(DIMS), *b[2:], training=True, **kw)
+    lo = O.fs2_loss(b, o, pl, el)
+    np.testing.assert_allclose([float(x) for x in lo], g[f"{tag}_losses"], rtol=1e-5)
+    assert np.abs(o[1].detach().numpy() - g[f"{tag}_mel_post"]).max() < TOL
+    assert np.abs(o[2].detach().numpy() - g[f"{tag}_p"]).max() < TOL and np.abs(o[3].detach().numpy() - g[f"{tag}_e"]).max() < TOL
+    if tag != "ff":
+        return
+    names = [str(n) for n in g["ff_grad_names"]]
+    grads = torch.autograd.grad(lo[0], [p[n] for n in names], allow_unused=True)
+    norms = np.array([float(x.double().norm()) if x is not None else 0.0 for x in grads])
+    np.testing.assert_allclose(norms, g["ff_grad_norms"], rtol=2e-4, atol=1e-7)
+    buf = torch_buffers(DIMS)
+    with torch.no_grad():
+        O.fs2_forward(p, buf, *b[2:], training=True, **kw)          # the reference's eval pass follows one train pass (BN buffers)
+        oe = O.fs2_forward(p, buf, *b[2:], training=False, **kw)
+        fr = O.fs2_forward(p, buf, *b[2:6], p_control=1.1, e_control=0.9, training=False, **kw)
+    assert np.abs(oe[1].numpy() - g["ff_eval_mel_post"]).max() < TOL
+    np.testing.assert_array_equal(fr[5].numpy(), g["ff_fr_d_rounded"])
+    np.testing.assert_array_equal(fr[9].numpy(), g["ff_fr_mel_len"])
+    assert np.abs(fr[1].numpy() - g["ff_fr_mel_post"]).max() < TOL and np.abs(fr[2].numpy() - g["ff_fr_p"]).max() < TOL
