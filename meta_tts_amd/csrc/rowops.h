@@ -233,15 +233,22 @@ struct ColArgs {
     int C = 0, mode = 0, do_tanh = 0, mfield = 0, accumulate = 0;
 };
 
-__device__ __forceinline__ void colpart_body(const int* meta, const ColArgs& a, float* partial, int max_chunks) {
-    __shared__ __attribute__((aligned(16))) float red[3][8][132];
+// CG column groups of 4 floats x RL row lanes per 256-thread workgroup.  STRIPE = false: rows [chunk * kRC, +kRC) of a 128-column
+// group -> partial sums (stage 1 of the two-stage reduction).  STRIPE = true: ALL rows of a 32-column stripe in one workgroup,
+// final values written directly (one launch instead of two, no cross-workgroup hand-off): the per-task row counts of this workload
+// (<= ~5 k) keep a stripe at a few hundred KB, and a task's column count / 32 x tasks workgroups still spread over the chip.
+template <int CG, int RL, bool STRIPE>
+__device__ __forceinline__ void col_body(const int* meta, const ColArgs& a, float* partial, int max_chunks, float* out0, float* out1,
+                                         long long out_ts, float eps) {
+    static_assert(CG * RL == 256, "256 threads");
+    __shared__ __attribute__((aligned(16))) float red[3][RL][CG * 4 + 4];
     const int z = blockIdx.z, chunk = blockIdx.y;
     const int M_ = meta[z * META_STRIDE + a.mfield];
-    const int r0 = chunk * kRC;
+    const int r0 = STRIPE ? 0 : chunk * kRC;
     if (r0 >= M_) return;
-    const int r1 = (r0 + kRC < M_) ? r0 + kRC : M_;
-    const int cg = (int)threadIdx.x & 31, ry = (int)threadIdx.x >> 5;
-    const int c = blockIdx.x * 128 + cg * 4;
+    const int r1 = STRIPE ? M_ : ((r0 + kRC < M_) ? r0 + kRC : M_);
+    const int cg = (int)threadIdx.x % CG, ry = (int)threadIdx.x / CG;
+    const int c = blockIdx.x * (CG * 4) + cg * 4;
     const bool cin = c < a.C;
     const int C = a.C;
     const float* px = a.X + (long long)z * a.x_ts;
@@ -261,7 +268,7 @@ __device__ __forceinline__ void colpart_body(const int* meta, const ColArgs& a, 
     if (cin) {
         if (a.mode == 2) {
             float mean[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int m = r0 + ry; m < r1; m += 8) if (!pm || pm[m]) { float v[4]; ldv(px, m, v); for (int k = 0; k < 4; ++k) acc0[k] += v[k]; cnt += 1.f; }
+            for (int m = r0 + ry; m < r1; m += RL) if (!pm || pm[m]) { float v[4]; ldv(px, m, v); for (int k = 0; k < 4; ++k) acc0[k] += v[k]; cnt += 1.f; }
             (void)mean;
         } else {
             float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f}, q1[4] = {0.f, 0.f, 0.f, 0.f}, q0[4] = {0.f, 0.f, 0.f, 0.f};
@@ -272,7 +279,7 @@ __device__ __forceinline__ void colpart_body(const int* meta, const ColArgs& a, 
             const float* ps2 = a.stats2 ? a.stats2 + (long long)z * a.st2_ts : nullptr;
             if (a.mode == 6) { ldv(ps2, 0, q1); const float* p3 = ps2 + C; ldv(p3, 0, q0); }
             const float inv_n6 = 1.f / (float)(meta[z * META_STRIDE + META_B] * meta[z * META_STRIDE + META_TCAP]);
-            for (int m = r0 + ry; m < r1; m += 8) {
+            for (int m = r0 + ry; m < r1; m += RL) {
                 if (pm && !pm[m]) continue;
                 float x[4]; ldv(px, m, x);
                 if (a.mode == 0) {
@@ -315,26 +322,30 @@ __device__ __forceinline__ void colpart_body(const int* meta, const ColArgs& a, 
     for (int k = 0; k < 4; ++k) { red[0][ry][cg * 4 + k] = acc0[k]; red[1][ry][cg * 4 + k] = acc1[k]; }
     if (cg == 0) red[2][ry][0] = cnt;
     __syncthreads();
-    float* out = partial + ((long long)z * max_chunks + chunk) * 3 * C;
+    float* out = STRIPE ? nullptr : partial + ((long long)z * max_chunks + chunk) * 3 * C;
     if (a.mode != 2) {
-        if (ry < 2) {  // row lane 0 folds acc0, row lane 1 folds acc1
+        if (ry < 2) {  // row lane 0 folds acc0, row lane 1 folds acc1 (row-lane order: fixed, run-to-run identical)
             for (int k = 0; k < 4; ++k) {
                 if (c + k >= C) break;
                 float s0 = 0.f;
-                for (int i = 0; i < 8; ++i) s0 += red[ry][i][cg * 4 + k];
-                out[(long long)ry * C + c + k] = s0;
+                for (int i = 0; i < RL; ++i) s0 += red[ry][i][cg * 4 + k];
+                if (!STRIPE) { out[(long long)ry * C + c + k] = s0; continue; }
+                float* o = ry == 0 ? out0 : out1;
+                if (!o) continue;
+                if (a.accumulate) s0 += o[(long long)z * out_ts + c + k];
+                o[(long long)z * out_ts + c + k] = s0;
             }
         }
         return;
     }
     // mode 2: chunk mean, then chunk M2 (second pass over the same rows)
     float n = 0.f;
-    for (int i = 0; i < 8; ++i) n += red[2][i][0];
+    for (int i = 0; i < RL; ++i) n += red[2][i][0];
     float mean[4];
-    for (int k = 0; k < 4; ++k) { float s0 = 0.f; for (int i = 0; i < 8; ++i) s0 += red[0][i][cg * 4 + k]; mean[k] = n > 0.f ? s0 / n : 0.f; }
+    for (int k = 0; k < 4; ++k) { float s0 = 0.f; for (int i = 0; i < RL; ++i) s0 += red[0][i][cg * 4 + k]; mean[k] = n > 0.f ? s0 / n : 0.f; }
     float m2[4] = {0.f, 0.f, 0.f, 0.f};
     if (cin)
-        for (int m = r0 + ry; m < r1; m += 8) if (!pm || pm[m]) { float v[4]; ldv(px, m, v); for (int k = 0; k < 4; ++k) { const float d = v[k] - mean[k]; m2[k] += d * d; } }
+        for (int m = r0 + ry; m < r1; m += RL) if (!pm || pm[m]) { float v[4]; ldv(px, m, v); for (int k = 0; k < 4; ++k) { const float d = v[k] - mean[k]; m2[k] += d * d; } }
     __syncthreads();
     for (int k = 0; k < 4; ++k) red[1][ry][cg * 4 + k] = m2[k];
     __syncthreads();
@@ -342,10 +353,22 @@ __device__ __forceinline__ void colpart_body(const int* meta, const ColArgs& a, 
         for (int k = 0; k < 4; ++k) {
             if (c + k >= C) break;
             float s = 0.f;
-            for (int i = 0; i < 8; ++i) s += red[1][i][cg * 4 + k];
-            out[c + k] = n; out[(long long)C + c + k] = mean[k]; out[2LL * C + c + k] = s;
+            for (int i = 0; i < RL; ++i) s += red[1][i][cg * 4 + k];
+            if (!STRIPE) { out[c + k] = n; out[(long long)C + c + k] = mean[k]; out[2LL * C + c + k] = s; continue; }
+            float* so = out0 + (long long)z * out_ts;   // BatchNorm statistics: [mean | rstd | unbiased var]
+            so[c + k] = mean[k];
+            so[C + c + k] = rsqrtf(s / n + eps);
+            so[2 * C + c + k] = s / fmaxf(n - 1.f, 1.f);
         }
 }
+__device__ __forceinline__ void colpart_body(const int* meta, const ColArgs& a, float* partial, int max_chunks) {
+    col_body<32, 8, false>(meta, a, partial, max_chunks, nullptr, nullptr, 0, 0.f);
+}
+// single-launch column reduction over a 32-column stripe of ALL rows of a task (see col_body)
+__global__ void colstripe_kernel(const int* meta, ColArgs a, float* out0, float* out1, long long out_ts, float eps) {
+    col_body<8, 32, true>(meta, a, nullptr, 0, out0, out1, out_ts, eps);
+}
+
 
 // 64 columns x 4 chunk lanes per workgroup: lane q folds chunks q, q+4, ... of its column, the four lane results are
 // merged in lane order through LDS (fixed order => run-to-run identical).
