@@ -979,15 +979,16 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     }
     // two-stage deterministic column reduction (rowops.h colpart/colfinal)
     void colreduce(const Plan& p, ColArgs a, float* out0, float* out1, long long out_ts, int maxM) {
-        // one launch per reduction: a workgroup per (32-column stripe, task) walks all rows (rowops.h: colstripe_kernel) — the per-task
-        // row counts here are a few thousand at most, so a stripe is a few hundred KB; MTTS_COL_STRIPE=0 restores the two-stage pair
-        static const int stripe_max_rows = [] { const char* e = getenv("MTTS_COL_STRIPE"); return e ? atoi(e) : 8192; }();
+        // single-launch variant A: a workgroup per (32-column stripe, task) walks all rows (rowops.h: colstripe_kernel).  Measured
+        // SLOWER (8-task step 189.5 -> 208 ms, single-task rank 44 -> 59 ms): 8-256 workgroups streaming ~70 dependent row
+        // iterations each are latency-bound, the two-stage pair keeps ~1000 workgroups in flight.  Opt-in: MTTS_COL_STRIPE=<max rows>
+        static const int stripe_max_rows = [] { const char* e = getenv("MTTS_COL_STRIPE"); return e ? atoi(e) : 0; }();
         if (maxM <= stripe_max_rows && (a.C & 3) == 0) {
             MTTS_LAUNCH(colstripe_kernel, dim3((a.C + 31) / 32, 1, p.tasks), dim3(256), stream, (const int*)p.meta, a, out0, out1, out_ts, 1e-5f);
             return;
         }
         const int chunks = (maxM + kRC - 1) / kRC;
-        // single-launch variant (last-arriving workgroup folds): measured SLOWER (+10 % on the whole meta-step) — its agent-scope
+        // single-launch variant B (last-arriving workgroup folds): measured SLOWER (+10 % on the whole meta-step) — its agent-scope
         // release / acquire writes back and invalidates an L2 that the neighbouring GEMMs keep full of dirty lines; opt-in only
         static const bool fused = [] { const char* e = getenv("MTTS_COL_FUSED"); return e ? atoi(e) != 0 : false; }();
         if (fused && col_ctr && (a.C + 127) / 128 <= kColCtrPerTask) {
