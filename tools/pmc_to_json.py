@@ -2,7 +2,8 @@
 """Fold rocprofv3 --pmc rocpd databases (one pass per counter group, as the MI355X guide prescribes) into the per-kernel
 JSON that bench.py's roofline leg reads (profiles/rNN_pmc_hbm.json).
 
-usage: pmc_to_json.py OUT.json DB [DB ...]
+usage: pmc_to_json.py OUT.json[:KEY] DB [DB ...]      (KEY = top-level key of the per-kernel table, default "kernels"; an existing
+OUT.json is updated, so the first- and second-order passes can share one file)
 Counters used when present: FETCH_SIZE, WRITE_SIZE (KB; gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B/lane
 loads -> doubled), SQ_BUSY_CYCLES, SQ_VALU_MFMA_BUSY_CYCLES (MFMA-pipe busy fraction = MFMA_BUSY / (BUSY * 32 SIMDs per SE),
 both summed over the shader engines)."""
@@ -41,7 +42,7 @@ for path in sys.argv[2:]:
         a = acc[cat][ctr]
         a[0] += val
         a[1] += 1
-out = {"source": "rocprofv3 --pmc passes (one counter group per pass) over `bench.py --steps 1 --warmup 0` (fp32, dropout on), 1x MI355X",
+out = {"source": "rocprofv3 --pmc passes (one counter group per pass: FETCH_SIZE | WRITE_SIZE | SQ_BUSY_CYCLES + SQ_VALU_MFMA_BUSY_CYCLES) over `bench.py --steps 1 --warmup 0` (fp32, dropout on; `--order 2` for kernels_second_order), 1x MI355X",
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B/lane loads -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported; both KB",
        "kernels": {}}
 for cat, d in sorted(acc.items()):
@@ -56,5 +57,14 @@ for cat, d in sorted(acc.items()):
     if "SQ_BUSY_CYCLES" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["SQ_BUSY_CYCLES"][0] > 0:
         k["mfma_busy_frac"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (32.0 * d["SQ_BUSY_CYCLES"][0]), 4)
     out["kernels"][cat] = k
-json.dump(out, open(sys.argv[1], "w"), indent=1)
-print(json.dumps(out["kernels"], indent=1))
+import os
+target, _, key = sys.argv[1].partition(":")
+key = key or "kernels"
+if key != "kernels":
+    out[key] = out.pop("kernels")
+if os.path.exists(target):
+    old = json.load(open(target))
+    old.update({k: v for k, v in out.items() if k not in ("source", "correction") or k not in old})
+    out = old
+json.dump(out, open(target, "w"), indent=1)
+print(json.dumps(out[key], indent=1))
