@@ -329,14 +329,21 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
 
     float4 areg[A_LD4], breg[B_LD4];
 
+    // tap of the K-slice starting at k0 WITHOUT a runtime integer division per slice (k0 only ever grows inside a workgroup, so
+    // a running (tap, tap * tap_k) pair is advanced instead; the division cost ~25 scalar/vector instructions per operand per slice)
+    int a_tap_i = 0, a_tap_base = 0, b_tap_i = 0, b_tap_base = 0;
+    auto a_tap_of = [&](int k0) { while (k0 - a_tap_base >= g.a_tap_k) { a_tap_base += g.a_tap_k; ++a_tap_i; } return a_tap_i; };
+    auto b_tap_of = [&](int k0) { while (k0 - b_tap_base >= g.tap_k) { b_tap_base += g.tap_k; ++b_tap_i; } return b_tap_i; };
+
     auto load_a = [&](int k0) {
+        const int atap = A_KC ? a_tap_of(k0) : 0;   // 0 unless the operand has dilated taps
+        const int atap_k0 = a_tap_base;
 #pragma unroll
         for (int i = 0; i < A_LD4; ++i) {
             if (A_KC) {
                 const int row = tid / KQ + RPP * i, gk = k0 + (tid % KQ) * 4;
                 const int gm = m0 + row;
-                const int atap = k0 / g.a_tap_k;   // 0 unless the operand has dilated taps
-                areg[i] = (gm < M && gk < K4) ? ld4(A + ((long long)gm + (long long)atap * g.a_tap_rows) * lda + (gk - atap * g.a_tap_k)) : zero4();
+                areg[i] = (gm < M && gk < K4) ? ld4(A + ((long long)gm + (long long)atap * g.a_tap_rows) * lda + (gk - atap_k0)) : zero4();
             } else {
                 const int idx = tid + NTH * i, kk = idx / (BM / 4), c4 = idx % (BM / 4);
                 const int gk = k0 + kk, gc = m0 + c4 * 4;
@@ -345,7 +352,7 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
         }
     };
     auto load_b = [&](int k0) {
-        const int tap = k0 / g.tap_k, kin = k0 - tap * g.tap_k;
+        const int tap = B_KC ? 0 : b_tap_of(k0), kin = k0 - (B_KC ? 0 : b_tap_base);
         const float* Bc = B + (long long)(g.taps - 1 - tap) * g.tap_bstride;
 #pragma unroll
         for (int i = 0; i < B_LD4; ++i) {

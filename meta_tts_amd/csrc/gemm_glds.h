@@ -107,6 +107,10 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
     const int kb0 = c_lo * BK;
 
     auto is_full = [&](int c) { return kb0 + (c + 1) * BK <= K; };
+    // running tap state instead of a runtime integer division per slice (gemm.h: a_tap_of / b_tap_of)
+    int a_tap_i = 0, a_tap_base = 0, b_tap_i = 0, b_tap_base = 0;
+    auto a_tap_of = [&](int k0) { while (k0 - a_tap_base >= g.a_tap_k) { a_tap_base += g.a_tap_k; ++a_tap_i; } return a_tap_i; };
+    auto b_tap_of = [&](int k0) { while (k0 - b_tap_base >= g.tap_k) { b_tap_base += g.tap_k; ++b_tap_i; } return b_tap_i; };
     // stage slice c into ring slot st: 4 DMA instructions per wave, or (partial last slice) zero-filled register staging
     auto stage = [&](int c, int st) {
         const int k0 = kb0 + c * BK;
@@ -114,12 +118,12 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
         float* Bs = As + kGldsTile;
         if (is_full(c)) {
             const unsigned sa = lds_base + (unsigned)(st * kGldsStage) * 4u, sb = sa + (unsigned)kGldsTile * 4u;
-            const int atap = A_KC ? k0 / g.a_tap_k : 0;   // dilated taps of a K-contiguous A operand (gemm.h)
-            const float* Ab = A_KC ? A + (long long)atap * g.a_tap_rows * lda + (k0 - atap * g.a_tap_k) : A + (long long)k0 * lda;
+            const int atap = A_KC ? a_tap_of(k0) : 0;   // dilated taps of a K-contiguous A operand (gemm.h)
+            const float* Ab = A_KC ? A + (long long)atap * g.a_tap_rows * lda + (k0 - a_tap_base) : A + (long long)k0 * lda;
             const float* Bb;
             if (B_KC) Bb = B + k0;
             else {
-                const int tap = k0 / g.tap_k, kin = k0 - tap * g.tap_k;
+                const int tap = b_tap_of(k0), kin = k0 - b_tap_base;
                 Bb = B + (long long)(g.taps - 1 - tap) * g.tap_bstride + (long long)kin * ldb;
             }
 #pragma unroll
@@ -137,8 +141,8 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
                     if (A_KC) {
                         const int r = idx >> 3, pos = idx & 7, kq = pos ^ ((r >> 1) & 7), gk = k0 + 4 * kq;
                         if (m0 + r < M) {
-                            const int atap = k0 / g.a_tap_k;
-                            const float* p = A + ((long long)(m0 + r) + (long long)atap * g.a_tap_rows) * lda + (gk - atap * g.a_tap_k);
+                            const int atap = a_tap_of(k0);
+                            const float* p = A + ((long long)(m0 + r) + (long long)atap * g.a_tap_rows) * lda + (gk - a_tap_base);
                             if (gk + 3 < K) v = ld4(p);
                             else { if (gk < K) v.x = p[0]; if (gk + 1 < K) v.y = p[1]; if (gk + 2 < K) v.z = p[2]; }
                         }
@@ -161,7 +165,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
                         st4(Bs + r * 32 + pos * 4, v);
                     } else {
                         const int kk = idx >> 4, c4 = (idx & 15) * 4;
-                        const int tap = k0 / g.tap_k, kin = k0 - tap * g.tap_k;
+                        const int tap = b_tap_of(k0), kin = k0 - b_tap_base;
                         const float* Bc = B + (long long)(g.taps - 1 - tap) * g.tap_bstride;
                         if (k0 + kk < K && n0 + c4 < N4) v = ld4(Bc + (long long)(kin + kk) * ldb + n0 + c4);
                         st4(Bs + kk * 64 + c4, v);

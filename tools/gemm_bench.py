@@ -34,7 +34,9 @@ NUM = int(os.environ.get('BENCH_NUMERICS', '0'))  # passed per call in flags bit
 TILES = (64, 128) if NUM else tuple(int(t) for t in os.environ.get('BENCH_TILES', '1064,1128').split(','))
 shapes = [("square4096", 4096, 4096, 4096), ("conv1_fwd 8 tasks", 17047, 1024, 2304), ("conv1_dgrad", 17047, 256, 9216), ("conv2_fwd", 17047, 256, 1024),
           ("qkv", 17047, 768, 256), ("out_proj", 17047, 256, 256), ("postnet_mid", 22132, 512, 2560), ("dec 1 task", 2100, 256, 1024)]
-if os.environ.get("BENCH_SHAPES"):
+if os.environ.get("BENCH_CUSTOM"):   # "name,M,N,K;name,M,N,K": extra shapes (e.g. tile-quantisation experiments)
+    shapes = [(a.split(",")[0], int(a.split(",")[1]), int(a.split(",")[2]), int(a.split(",")[3])) for a in os.environ["BENCH_CUSTOM"].split(";")]
+elif os.environ.get("BENCH_SHAPES"):
     shapes = [s for s in shapes if any(k in s[0] for k in os.environ["BENCH_SHAPES"].split(","))]
 for name, M, N, K in shapes:
     for form in (0, 1, 2):
