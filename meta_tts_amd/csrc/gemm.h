@@ -335,35 +335,76 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
     auto a_tap_of = [&](int k0) { while (k0 - a_tap_base >= g.a_tap_k) { a_tap_base += g.a_tap_k; ++a_tap_i; } return a_tap_i; };
     auto b_tap_of = [&](int k0) { while (k0 - b_tap_base >= g.tap_k) { b_tap_base += g.tap_k; ++b_tap_i; } return b_tap_i; };
 
+    // Per-thread operand offsets are hoisted out of the K-loop; a slice then costs one uniform 64-bit base per operand
+    // (the per-slice 64-bit row * lda multiplies and the exec-mask branches of predicated loads cost ~60 instructions
+    // per slice before).  Rows / columns beyond the operand are CLAMPED to the last valid one instead of predicated: their products
+    // only reach accumulator entries the epilogue never stores (m >= M or n >= N).  Only a partial LAST K-slice is predicated
+    // (zero fill: there both operands would otherwise contribute garbage to valid outputs).
+    // Loop-carried per-thread pointers, advanced in place by the uniform distance between consecutive slices (one 64-bit add per
+    // pointer per slice, no temporaries: an address temporary that aliases a load destination made hipcc drain vmcnt between the A
+    // and the B loads of a slice).
+    const float* a_ptr[A_LD4];
+    const float* b_ptr[B_LD4];
+#pragma unroll
+    for (int i = 0; i < A_LD4; ++i) {
+        if (A_KC) {
+            int gm = m0 + tid / KQ + RPP * i;
+            gm = gm < M ? gm : M - 1;
+            a_ptr[i] = A + (long long)gm * lda + (tid % KQ) * 4;
+        } else {
+            const int idx = tid + NTH * i, kk = idx / (BM / 4), c4 = idx % (BM / 4);
+            int gc = m0 + c4 * 4;
+            gc = gc < M4 ? gc : M4 - 4;
+            a_ptr[i] = A + (long long)kk * lda + gc;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD4; ++i) {
+        if (B_KC) {
+            int gn = n0 + tid / KQ + RPP * i;
+            gn = gn < N ? gn : N - 1;
+            b_ptr[i] = B + (long long)gn * ldb + (tid % KQ) * 4;
+        } else {
+            const int idx = tid + NTH * i, kk = idx / (BN / 4), c4 = idx % (BN / 4);
+            int gc = n0 + c4 * 4;
+            gc = gc < N4 ? gc : N4 - 4;
+            b_ptr[i] = B + (long long)kk * ldb + gc;
+        }
+    }
+    long long a_koff = 0, b_koff = 0;   // uniform element offset of the slice the pointers currently address
     auto load_a = [&](int k0) {
         const int atap = A_KC ? a_tap_of(k0) : 0;   // 0 unless the operand has dilated taps
-        const int atap_k0 = a_tap_base;
+        const long long koff = A_KC ? (long long)atap * g.a_tap_rows * lda + (k0 - a_tap_base) : (long long)k0 * lda;
+        const long long delta = koff - a_koff;
+        a_koff = koff;
 #pragma unroll
-        for (int i = 0; i < A_LD4; ++i) {
-            if (A_KC) {
-                const int row = tid / KQ + RPP * i, gk = k0 + (tid % KQ) * 4;
-                const int gm = m0 + row;
-                areg[i] = (gm < M && gk < K4) ? ld4(A + ((long long)gm + (long long)atap * g.a_tap_rows) * lda + (gk - atap_k0)) : zero4();
-            } else {
-                const int idx = tid + NTH * i, kk = idx / (BM / 4), c4 = idx % (BM / 4);
-                const int gk = k0 + kk, gc = m0 + c4 * 4;
-                areg[i] = (gk < K && gc < M4) ? ld4(A + (long long)gk * lda + gc) : zero4();
+        for (int i = 0; i < A_LD4; ++i) a_ptr[i] += delta;
+        if (k0 + BK <= K) {
+#pragma unroll
+            for (int i = 0; i < A_LD4; ++i) areg[i] = ld4(a_ptr[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_LD4; ++i) {
+                const bool ok = A_KC ? (k0 + (tid % KQ) * 4 < K4) : (k0 + (tid + NTH * i) / (BM / 4) < K);
+                areg[i] = ok ? ld4(a_ptr[i]) : zero4();
             }
         }
     };
     auto load_b = [&](int k0) {
-        const int tap = B_KC ? 0 : b_tap_of(k0), kin = k0 - (B_KC ? 0 : b_tap_base);
-        const float* Bc = B + (long long)(g.taps - 1 - tap) * g.tap_bstride;
+        const int tap = B_KC ? 0 : b_tap_of(k0);
+        const long long koff = B_KC ? (long long)k0 : (long long)(g.taps - 1 - tap) * g.tap_bstride + (long long)(k0 - b_tap_base) * ldb;
+        const long long delta = koff - b_koff;
+        b_koff = koff;
 #pragma unroll
-        for (int i = 0; i < B_LD4; ++i) {
-            if (B_KC) {
-                const int row = tid / KQ + RPP * i, gk = k0 + (tid % KQ) * 4;
-                const int gn = n0 + row;
-                breg[i] = (gn < N && gk < K4) ? ld4(B + (long long)gn * ldb + gk) : zero4();
-            } else {
-                const int idx = tid + NTH * i, kk = idx / (BN / 4), c4 = idx % (BN / 4);
-                const int gc = n0 + c4 * 4;
-                breg[i] = (k0 + kk < K && gc < N4) ? ld4(Bc + (long long)(kin + kk) * ldb + gc) : zero4();
+        for (int i = 0; i < B_LD4; ++i) b_ptr[i] += delta;
+        if (k0 + BK <= K) {
+#pragma unroll
+            for (int i = 0; i < B_LD4; ++i) breg[i] = ld4(b_ptr[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_LD4; ++i) {
+                const bool ok = B_KC ? (k0 + (tid % KQ) * 4 < K4) : (k0 + (tid + NTH * i) / (BN / 4) < K);
+                breg[i] = ok ? ld4(b_ptr[i]) : zero4();
             }
         }
     };
