@@ -132,6 +132,7 @@ public:
         // P space
         int *p_row_b, *p_row_t, *p_tok, *p_first, *p_count, *p_dur, *p_seg_start, *p_seg_len;
         unsigned char *p_valid, *p_inrect;
+        float *p_valid_w, *p_inrect_w, *f_valid_w, *r_valid_w, *r_inrect_w;   // [row][4] float images of the masks (plan.h)
         float *p_pitch_t, *p_energy_t;
         // F space
         int *f_row_b, *f_row_t, *f_src, *f_seg_start, *f_seg_len, *f2r;
@@ -431,6 +432,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             p.p_first = arr<int>(capMp); p.p_count = arr<int>(capMp); p.p_dur = arr<int>(capMp);
             p.p_seg_start = arr<int>(cap_B); p.p_seg_len = arr<int>(cap_B);
             p.p_valid = arr<unsigned char>(capMp); p.p_inrect = arr<unsigned char>(capMp);
+            p.p_valid_w = arr<float>(4LL * capMp); p.p_inrect_w = arr<float>(4LL * capMp); p.f_valid_w = arr<float>(4LL * capMf);
+            p.r_valid_w = arr<float>(4LL * capMr); p.r_inrect_w = arr<float>(4LL * capMr);
             p.p_pitch_t = arr<float>(capMp); p.p_energy_t = arr<float>(capMp);
             p.f_row_b = arr<int>(capMf); p.f_row_t = arr<int>(capMf); p.f_src = arr<int>(capMf);
             p.f_seg_start = arr<int>(cap_B); p.f_seg_len = arr<int>(cap_B); p.f2r = arr<int>(capMf);
@@ -856,6 +859,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         o.f_row_b = p.f_row_b; o.f_row_t = p.f_row_t; o.f_src = p.f_src; o.f_seg_start = p.f_seg_start; o.f_seg_len = p.f_seg_len;
         o.f2r = p.f2r; o.f_valid = p.f_valid; o.r2f = p.r2f; o.r_valid = p.r_valid; o.r_inrect = p.r_inrect; o.mel_tgt = p.mel_tgt;
         o.spk_ids = p.spk_ids;
+        o.p_valid_w = p.p_valid_w; o.p_inrect_w = p.p_inrect_w; o.f_valid_w = p.f_valid_w; o.r_valid_w = p.r_valid_w; o.r_inrect_w = p.r_inrect_w;
         o.ts_p = row_ts_p; o.ts_f = row_ts_f; o.ts_r = row_ts_r; o.ts_mel = (long long)(capMr + 2 * G) * cfg.n_mel; o.ts_seg = cap_B; o.ts_spk = cap_B + 1;
         MTTS_LAUNCH(plan_rows_p_kernel, dim3((unsigned)((p.maxMp + 255) / 256), 1, (unsigned)tasks), dim3(256), stream, im, o);
         if (with_frames) {
@@ -889,6 +893,15 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     TS Gd(long long off) const { return TS{grad_dst + off, n_total}; }
     int mfield(Space s) const { return s == SP_P ? META_MP : (s == SP_F ? META_MF : META_MR); }
     int maxM(const Plan& p, Space s) const { return s == SP_P ? p.maxMp : (s == SP_F ? p.maxMf : p.maxMr); }
+    // [row][4] float image of one of the plan's byte masks
+    const float* mask_w(const Plan& p, const unsigned char* m) const {
+        if (m == p.p_valid) return p.p_valid_w;
+        if (m == p.p_inrect) return p.p_inrect_w;
+        if (m == p.f_valid) return p.f_valid_w;
+        if (m == p.r_valid) return p.r_valid_w;
+        if (m == p.r_inrect) return p.r_inrect_w;
+        return nullptr;
+    }
     const unsigned char* valid_mask(const Plan& p, Space s) const { return s == SP_P ? p.p_valid : (s == SP_F ? p.f_valid : p.r_valid); }
     const unsigned char* inrect_mask(const Plan& p, Space s) const { return s == SP_P ? p.p_inrect : (s == SP_F ? p.f_valid : p.r_inrect); }
     long long sumM(const Plan& p, Space s) const { return s == SP_P ? p.sumMp : (s == SP_F ? p.sumMf : p.sumMr); }
@@ -973,9 +986,19 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         g.M = cout; g.N = k * cin;
         g.K = maxM(p, s);  // upper bound of the per-task reduction length (the kernel reads the exact one through dimptr)
         g.flags = flags;
+        // the bias gradient rides on the weight-gradient GEMM (GemmArgs::colsum: one extra n-tile against the mask's float image)
+        // instead of two reduction launches per layer; the split-bf16 kernels have no such arm.  MTTS_FUSE_COLSUM=0 restores the
+        // separate reduction.
+        static const bool fuse_cs = [] { const char* e = getenv("MTTS_FUSE_COLSUM"); return e ? atoi(e) != 0 : true; }();
+        const float* mw = mask_w(p, bias_mask);
+        const bool fused = b_off >= 0 && fuse_cs && gx.numerics == 0 && mw != nullptr;
+        if (fused) {
+            TS gb = Gd(b_off);
+            g.colsum = gb.p; g.colsum_gs = gb.ts; g.colsum_w = mw; g.colsum_w_gs = 4 * row_ts(s);
+        }
         gemm_launch(gx, GEMM_TN, g, cout, k * cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, (long long)cout * p.tasks,
                     4.0 * (alg_rows(p, s) * (cin + cout) + (double)p.tasks * cout * k * cin));
-        if (b_off >= 0) colsum(ps, s, dy, cout, bias_mask, TS{nullptr, 0}, Gd(b_off));
+        if (b_off >= 0 && !fused) colsum(ps, s, dy, cout, bias_mask, TS{nullptr, 0}, Gd(b_off));
     }
     // two-stage deterministic column reduction (rowops.h colpart/colfinal)
     void colreduce(const Plan& p, ColArgs a, float* out0, float* out1, long long out_ts, int maxM) {

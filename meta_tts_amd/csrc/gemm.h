@@ -82,6 +82,15 @@ struct GemmArgs {
     int tiles_pg = 0;  // output tiles per group (workspace slot = group * tiles_pg + tile)
     float* ws = nullptr;
     int* tile_ctr = nullptr;
+    // TN form only: column sums of the A operand over the reduction rows (the bias gradient db = sum_rows dY beside the weight
+    // gradient dW = dY^T X) as ONE EXTRA n-tile per m-tile whose B operand is `colsum_w`: [rows][4] floats, 1.0 on the rows
+    // that count and 0.0 on masked ones, read with ldb = 4 — column 0 of that tile is the masked column sum, produced by the same
+    // K-loop (k-ordered fp32 MFMA chain, so the order of summation is fixed), no extra registers or instructions in the loop and
+    // no separate reduction launches.  Launchers add the n-tile to the grid (gemm_tiles_n) and keep splitk == 1.
+    float* colsum = nullptr;
+    long long colsum_gs = 0;
+    const float* colsum_w = nullptr;
+    long long colsum_w_gs = 0;
 };
 
 
@@ -317,18 +326,21 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
             if (g.dim_sel == 0) M = v; else K = v;
         }
     }
-    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const bool has_cs = (FORM == GEMM_TN) && g.colsum != nullptr && !g.table;   // one extra n-tile: GemmArgs::colsum
+    const int tiles_nc = (N + BN - 1) / BN, tiles_n = tiles_nc + (has_cs ? 1 : 0), tiles_m = (M + BM - 1) / BM;
     const int S = g.splitk > 1 ? g.splitk : 1;
     const int tile_lin = bxs / S, split = bxs - tile_lin * S;
     if (tile_lin >= tiles_m * tiles_n || K <= 0) return;
     const int m0 = (tile_lin / tiles_n) * BM, n0 = (tile_lin % tiles_n) * BN;
+    const bool cs_tile = has_cs && n0 == tiles_nc * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
     const int M4 = (M + 3) & ~3, N4 = (N + 3) & ~3, K4 = (K + 3) & ~3;
+    int n0b = n0, N4b = N4;   // column window of the B operand
+    if (cs_tile) { B = g.colsum_w + (long long)z * g.colsum_w_gs; ldb = 4; n0b = 0; N4b = 4; }
 
     float4 areg[A_LD4], breg[B_LD4];
-
     // tap of the K-slice starting at k0 WITHOUT a runtime integer division per slice (k0 only ever grows inside a workgroup, so
     // a running (tap, tap * tap_k) pair is advanced instead; the division cost ~25 scalar/vector instructions per operand per slice)
     int a_tap_i = 0, a_tap_base = 0, b_tap_i = 0, b_tap_base = 0;
@@ -366,15 +378,16 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
             b_ptr[i] = B + (long long)gn * ldb + (tid % KQ) * 4;
         } else {
             const int idx = tid + NTH * i, kk = idx / (BN / 4), c4 = idx % (BN / 4);
-            int gc = n0 + c4 * 4;
-            gc = gc < N4 ? gc : N4 - 4;
+            int gc = n0b + c4 * 4;
+            gc = gc < N4b ? gc : N4b - 4;
             b_ptr[i] = B + (long long)kk * ldb + gc;
         }
     }
     long long a_koff = 0, b_koff = 0;   // uniform element offset of the slice the pointers currently address
+    const long long a_tap_stride = (long long)g.a_tap_rows * lda;
     auto load_a = [&](int k0) {
         const int atap = A_KC ? a_tap_of(k0) : 0;   // 0 unless the operand has dilated taps
-        const long long koff = A_KC ? (long long)atap * g.a_tap_rows * lda + (k0 - a_tap_base) : (long long)k0 * lda;
+        const long long koff = A_KC ? (long long)atap * a_tap_stride + (k0 - a_tap_base) : (long long)k0 * lda;
         const long long delta = koff - a_koff;
         a_koff = koff;
 #pragma unroll
@@ -477,6 +490,18 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
         }
     }
 
+    if (cs_tile) {  // column 0 of the extra n-tile = masked column sums of A
+        if (wn0 == 0 && (lane & 31) == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < M) g.colsum[(long long)z * g.colsum_gs + row] = acc[i][0][r];
+                }
+        }
+        return;
+    }
     if (S > 1 && !splitk_combine<TM, TN, NTH>(g, z, tile_lin, split, S, acc)) return;
     gemm_epilogue<TM, TN>(g, z, acc, C, ldc, M, N, m0 + wm0, n0 + wn0, lane);
 }
@@ -633,6 +658,8 @@ inline bool& gemm_use_glds() {
     return v;
 }
 inline bool gemm_glds_ok(const GemmArgs& g) { return !(g.taps > 1 && g.tap_k % 32 != 0); }
+// n-tiles of a problem's grid: the tiles of C plus the column-sum tile (GemmArgs::colsum)
+inline int gemm_tiles_n(const GemmArgs& g, int max_N, int t) { return (max_N + t - 1) / t + (g.colsum ? 1 : 0); }
 // Launches up to this many workgroups take the LDS-DMA kernels (latency regime: few workgroups per CU, where the DMA
 // ring's two slices in flight replace the occupancy the register-staged kernel needs; measured +8 % / +14 % on the
 // single-task first- / second-order step), larger ones the register-staged kernels (5 vs 3 workgroups per CU resident:
@@ -657,11 +684,11 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     GemmArgs g = g_in;
     g.swizzle = gemm_xcd_swizzle();
     const int user_tile = tile;
-    auto ntiles = [&](int t) { return (long)((max_M + t - 1) / t) * ((max_N + t - 1) / t); };
+    auto ntiles = [&](int t) { return (long)((max_M + t - 1) / t) * gemm_tiles_n(g, max_N, t); };
     if (tile == 0) {
         const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
         auto eff = [&](int t, double base) {
-            const double b = std::ceil(rows / t) * ((max_N + t - 1) / t) / 256.0;
+            const double b = std::ceil(rows / t) * gemm_tiles_n(g, max_N, t) / 256.0;
             return base * b / std::ceil(b);
         };
         static const double eff128 = [] { const char* e = getenv("MTTS_TILE128_EFF"); return e ? atof(e) : 0.85; }();
@@ -689,7 +716,7 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     if (tile == 4064) { glds = gemm_glds_ok(g); tile = 64; }            // explicit request (kernel tests, microbenchmarks)
     else if (user_tile == 0 && tile == 64) {
         const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
-        const long wgs = (long)std::ceil(rows / 64.0) * ((max_N + 63) / 64);
+        const long wgs = (long)std::ceil(rows / 64.0) * gemm_tiles_n(g, max_N, 64);
         glds = gemm_use_glds() && gemm_glds_ok(g) && wgs <= gemm_glds_max_wgs();
     }
 #else
@@ -703,9 +730,9 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     // split-K for under-filled grids (single-task ranks, the phoneme-side GEMMs, small wgrads): enough workgroups for
     // ~4 per CU, each still reducing >= 4 K-chunks
     int S = 1;
-    if (!g.table && gemm_splitk_target() > 0) {  // stand-alone launches: opt-in (measured neutral on the model's forward shapes)
+    if (!g.table && gemm_splitk_target() > 0 && !g.colsum) {  // stand-alone launches: opt-in (measured neutral on the model's forward shapes)
         const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
-        const long wgs = (long)std::ceil(rows / tile) * ((max_N + tile - 1) / tile);
+        const long wgs = (long)std::ceil(rows / tile) * gemm_tiles_n(g, max_N, tile);
         const int nch = (g.K + bk - 1) / bk;
         S = (int)std::min<long>(std::min<long>(gemm_splitk_target() / std::max<long>(wgs, 1), nch / gemm_splitk_minchunks()), 8);
         const long long slots = (long long)ntiles(tile) * groups;
@@ -763,7 +790,7 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
 
 inline bool batch_full_regime(const std::vector<GemmPending>& q) {  // more workgroups than the latency regime's limit
     double wgs = 0.0;
-    for (const GemmPending& p : q) wgs += std::ceil(p.rows / 64.0) * ((p.max_N + 63) / 64);
+    for (const GemmPending& p : q) wgs += std::ceil(p.rows / 64.0) * gemm_tiles_n(p.g, p.max_N, 64);
     return wgs > (double)gemm_glds_max_wgs();
 }
 inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
@@ -790,10 +817,10 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     // swept: 1.25-1.5 best) of the whole batch's per-CU work would finish last on its own (single-task ranks: the k=9 dgrad tile, 576 slices, beside a
     // batch that is worth ~590 slices per CU), so it is cut into S workgroups (rendezvous in splitk_combine)
     double work = 0.0;
-    for (const GemmPending& p : b.q) work += std::ceil(p.rows / 64.0) * ((p.max_N + 63) / 64) * std::max(1, (p.g.K + 15) / 16);
+    for (const GemmPending& p : b.q) work += std::ceil(p.rows / 64.0) * gemm_tiles_n(p.g, p.max_N, 64) * std::max(1, (p.g.K + 15) / 16);
     const double per_cu = work / 256.0;
     double batch_wgs = 0.0;
-    for (const GemmPending& p : b.q) batch_wgs += std::ceil(p.rows / 64.0) * ((p.max_N + 63) / 64);
+    for (const GemmPending& p : b.q) batch_wgs += std::ceil(p.rows / 64.0) * gemm_tiles_n(p.g, p.max_N, 64);
     const bool small_batch = batch_wgs <= (double)gemm_glds_max_wgs();  // latency regime: split-K and the LDS-DMA kernels apply
     GemmWorkspace* wsp = nullptr;
     long long ws_off = 0, ctr_off = 0;
@@ -801,11 +828,11 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
         const GemmPending& p = b.q[i];
         mp.form[i] = p.form; mp.groups[i] = p.groups; mp.g[i] = p.g;
         mp.g[i].swizzle = 0; mp.g[i].splitk = 1;
-        const int tiles = ((p.max_M + 63) / 64) * ((p.max_N + 63) / 64);
+        const int tiles = ((p.max_M + 63) / 64) * gemm_tiles_n(p.g, p.max_N, 64);
         int S = 1;
         const int nch = (p.g.K + 15) / 16;
         static const double ratio = [] { const char* e = getenv("MTTS_SPLIT_RATIO"); return e ? atof(e) : 1.5; }();
-        if (small_batch && !p.g.table && gemm_splitk_target() != 0 && nch > per_cu / ratio) {
+        if (small_batch && !p.g.table && !p.g.colsum && gemm_splitk_target() != 0 && nch > per_cu / ratio) {
             S = (int)std::min<double>(std::min<double>(std::ceil(nch / std::max(per_cu / ratio, 1.0)), nch / 16), 8);
             const long long slots = (long long)tiles * p.groups;
             if (S >= 2 && ((ws_off + slots * S * 4096) > kSplitWsFloats || ctr_off + slots > kSplitCtrs)) S = 1;
@@ -817,7 +844,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
                 } else S = 1;
             } else S = 1;
         }
-        mp.xcd_group[i] = gemm_xcd_swizzle() ? std::min(((p.max_N + 63) / 64) * S, 64) : 0;
+        mp.xcd_group[i] = gemm_xcd_swizzle() ? std::min(gemm_tiles_n(p.g, p.max_N, 64) * S, 64) : 0;
         mp.start[i + 1] = mp.start[i] + tiles * S * p.groups;
         max_groups = std::max(max_groups, p.groups);
         flops += p.flops; rows += p.rows; bytes += p.bytes;

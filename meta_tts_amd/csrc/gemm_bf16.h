@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
             }
         }
     };
+    int b_tap_i = 0, b_tap_base = 0;   // running tap state (k0 only grows): no integer division per slice
     auto load_b = [&](int k0) {
         if (B_KC) {
 #pragma unroll
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
                 breg[4 * i] = v.x; breg[4 * i + 1] = v.y; breg[4 * i + 2] = v.z; breg[4 * i + 3] = v.w;
             }
         } else {
-            const int tap = k0 / g.tap_k, kin = k0 - tap * g.tap_k;
+            while (k0 - b_tap_base >= g.tap_k) { b_tap_base += g.tap_k; ++b_tap_i; }
+            const int tap = b_tap_i, kin = k0 - b_tap_base;
             const float* Bc = B + (long long)(g.taps - 1 - tap) * g.tap_bstride;
             const int col = tid % BN, kg = tid / BN, gc = n0 + col;
 #pragma unroll

@@ -61,17 +61,21 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
             if (g.dim_sel == 0) M = v; else K = v;
         }
     }
-    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const bool has_cs = (FORM == GEMM_TN) && g.colsum != nullptr && !g.table;   // one extra n-tile: GemmArgs::colsum
+    const int tiles_nc = (N + BN - 1) / BN, tiles_n = tiles_nc + (has_cs ? 1 : 0), tiles_m = (M + BM - 1) / BM;
     const int S = g.splitk > 1 ? g.splitk : 1;
     const int tile_lin = bxs / S, split = bxs - tile_lin * S;
     if (tile_lin >= tiles_m * tiles_n || K <= 0) return;
     const int m0 = (tile_lin / tiles_n) * BM, n0 = (tile_lin % tiles_n) * BN;
+    const bool cs_tile = has_cs && n0 == tiles_nc * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
     const int l31 = lane & 31, h = lane >> 5;
     const int M4 = (M + 3) & ~3, N4 = (N + 3) & ~3;
+    int n0b = n0, N4b = N4;   // column window of the B operand
+    if (cs_tile) { B = g.colsum_w + (long long)z * g.colsum_w_gs; ldb = 4; n0b = 0; N4b = 4; }
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
 
     // ---- per-lane source offsets of this wave's two DMA pieces per operand (k0 term added per slice) ----
@@ -95,8 +99,8 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
             b_off[q] = (long long)gn * ldb + 4 * kq;
         } else {
             const int krow = 4 * i + (lane >> 4);
-            int col = n0 + (lane & 15) * 4;
-            if (col > N4 - 4) col = N4 - 4 > 0 ? N4 - 4 : 0;
+            int col = n0b + (lane & 15) * 4;
+            if (col > N4b - 4) col = N4b - 4 > 0 ? N4b - 4 : 0;
             b_off[q] = (long long)krow * ldb + col;
         }
     }
@@ -167,7 +171,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
                         const int kk = idx >> 4, c4 = (idx & 15) * 4;
                         const int tap = b_tap_of(k0), kin = k0 - b_tap_base;
                         const float* Bc = B + (long long)(g.taps - 1 - tap) * g.tap_bstride;
-                        if (k0 + kk < K && n0 + c4 < N4) v = ld4(Bc + (long long)(kin + kk) * ldb + n0 + c4);
+                        if (k0 + kk < K && n0b + c4 < N4b) v = ld4(Bc + (long long)(kin + kk) * ldb + n0b + c4);
                         st4(Bs + kk * 64 + c4, v);
                     }
                 }
@@ -225,6 +229,16 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = acc0[r] + acc1[r];
+    if (cs_tile) {  // column 0 of the extra n-tile = masked column sums of A
+        if (wn0 == 0 && l31 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) g.colsum[(long long)z * g.colsum_gs + row] = acc[0][0][r];
+            }
+        }
+        return;
+    }
     if (S > 1 && !splitk_combine<1, 1, 256>(g, z, tile_lin, split, S, acc)) return;
     gemm_epilogue<1, 1>(g, z, acc, C, ldc, M, N, m0 + wm0, n0 + wn0, lane);
 }

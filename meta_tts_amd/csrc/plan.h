@@ -40,6 +40,8 @@ struct PlanOut {  // the plan arrays the kernels of rowops.h / gemm.h consume (p
     unsigned char* f_valid;
     int* r2f;
     unsigned char *r_valid, *r_inrect;
+    // the same masks as [row][4] floats (1.0 / 0.0): the B operand of the column-sum tile of a weight-gradient GEMM (gemm.h: GemmArgs::colsum_w)
+    float *p_valid_w, *p_inrect_w, *f_valid_w, *r_valid_w, *r_inrect_w;
     float *r_pitch_t, *r_energy_t;   // frame-level targets on the mel rows (null when the feature is phoneme-level)
     float* mel_tgt;
     int* spk_ids;
@@ -80,6 +82,7 @@ __global__ void plan_rows_p_kernel(PlanImage im, PlanOut o) {
             }
         }
         o.p_row_b[q] = rb; o.p_row_t[q] = rt; o.p_tok[q] = tok; o.p_valid[q] = valid; o.p_inrect[q] = inrect;
+        { const float v = valid ? 1.f : 0.f, w = inrect ? 1.f : 0.f; st4(o.p_valid_w + 4 * q, make_float4(v, v, v, v)); st4(o.p_inrect_w + 4 * q, make_float4(w, w, w, w)); }
         o.p_pitch_t[q] = pt; o.p_energy_t[q] = et;
         if (!inrect || !h.with_frames) { o.p_first[q] = 0; o.p_count[q] = 0; o.p_dur[q] = 0; }
     }
@@ -99,6 +102,7 @@ __global__ void plan_rows_f_kernel(PlanImage im, PlanOut o) {
             if (r >= f0 && r < f0 + n) { rb = i; rt = r - f0; valid = 1; f2r = kPlanG + i * (h.Tcap + kPlanG) + rt; break; }
         }
         o.f_row_b[q] = rb; o.f_row_t[q] = rt; o.f_valid[q] = valid; o.f2r[q] = f2r; o.f_src[q] = -1;
+        { const float v = valid ? 1.f : 0.f; st4(o.f_valid_w + 4 * q, make_float4(v, v, v, v)); }
     }
 }
 
@@ -139,6 +143,7 @@ __global__ void plan_rows_r_kernel(PlanImage im, PlanOut o, int n_mel) {
     const bool valid = inrect && t < im.flen[(long long)z * im.cap_B + i];
     if (lane == 0) {
         o.r_inrect[q] = inrect; o.r_valid[q] = valid;
+        { const float v = valid ? 1.f : 0.f, w = inrect ? 1.f : 0.f; st4(o.r_valid_w + 4 * q, make_float4(v, v, v, v)); st4(o.r_inrect_w + 4 * q, make_float4(w, w, w, w)); }
         o.r2f[q] = valid ? im.foff[(long long)z * im.cap_B + i] + t : -1;
         // frame-level targets: the padded part of the caller's [B][T_max] array is kept as it is (the reference bucketises it too)
         const bool intgt = inrect && h.has_targets && t < h.Tmax_in;
