@@ -222,6 +222,18 @@ int mtts_batchnorm_fwd(int rows, int C, const float* x, const unsigned char* inr
 int mtts_batchnorm_bwd(int rows, int n_in, int C, const float* dy, const float* y, const float* x, const float* stats, const unsigned char* inrect,
                        const float* gamma, int do_tanh, float* dx, float* dgamma, float* dbeta, void* ws, void* hip_stream);
 int mtts_table_grad(int rows, int C, int V, const float* dx, const int* idx, int skip_row, float* dtable, void* ws, void* hip_stream);
+/* length_regulate (replaces LengthRegulator.LR / expand, lightning/model/modules.py:167-190, and its autograd transpose):
+ *   fwd: out[r][:] = x[src[r]][:] (+ spk[:]) (+ pos[row_t[r]][:]) for r < n_frames, zeros where src[r] < 0; spk [C], pos [*][C] and row_t
+ *   may be NULL (plain gather; pos needs row_t).  bwd: dx[p][:] (+)= sum of dout over frame rows [first[p], first[p] + count[p]).
+ * layernorm_jvp / softmax_jvp: the forward-mode (tangent) twins the second-order path is built from (csrc/tangent.h), on the z / stats
+ *   written by mtts_layernorm_fwd resp. the probabilities written by mtts_softmax_fwd; tgamma / tbeta / tres / mask may be NULL. */
+int mtts_length_regulate_fwd(int n_frames, int C, const float* x, const int* src, const float* spk, const float* pos, const int* row_t, float* out,
+                             void* ws, void* hip_stream);
+int mtts_length_regulate_bwd(int n_phonemes, int C, const float* dout, const int* first, const int* count, float* dx, int accumulate, void* ws,
+                             void* hip_stream);
+int mtts_layernorm_jvp(int rows, int C, const float* ta, const float* tres, const float* z, const float* stats, const float* gamma, const float* tgamma,
+                       const float* tbeta, const unsigned char* mask, float* ty, void* ws, void* hip_stream);
+int mtts_softmax_jvp(int n_mat, int L, const float* P, float* tS, void* ws, void* hip_stream);
 
 /* ---- MelGAN generator: mel -> waveform --------------------------------------------
  * Replaces `LightningMelGAN.inverse / infer`, lightning/utils.py:8-30 (vocoder.mel2wav of torch.hub

@@ -92,6 +92,10 @@ EXPORTS = {
     "mtts_batchnorm_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_table_grad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtts_length_regulate_fwd": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 8),
+    "mtts_length_regulate_bwd": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mtts_layernorm_jvp": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 11),
+    "mtts_softmax_jvp": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_vocoder_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]),
     "mtts_vocoder_destroy": (None, [C.c_void_p]),

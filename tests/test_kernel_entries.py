@@ -180,3 +180,74 @@ def test_bad_arguments_are_rejected(dev):
     assert dev.lib.mtts_layernorm_fwd(8, 30, None, None, None, None, None, None, None, None, dev.ptr(ws), None) != 0  # C % 4, null pointers
     assert dev.lib.mtts_softmax_fwd(0, 4, None, dev.ptr(ws), None) != 0
     assert dev.lib.mtts_kernel_ws_bytes(100, 4) > dev.lib.mtts_kernel_ws_bytes(10, 0) > 0
+
+
+@pytest.mark.parametrize("S,Cc,with_extras", [(13, 256, True), (40, 32, False)])
+def test_length_regulate_fwd_bwd(dev, S, Cc, with_extras):
+    """modules.py:167-190: expand every phoneme row by its duration (zero durations drop the phoneme), and the transpose."""
+    g = np.random.RandomState(S + Cc)
+    dur = g.randint(0, 6, size=S)
+    dur[1] = 0
+    x = g.standard_normal((S, Cc)).astype(np.float32)
+    src = np.repeat(np.arange(S), dur).astype(np.int32)
+    T = len(src)
+    src = np.concatenate([src, -np.ones(3, np.int32)])          # three padded frame rows
+    nf = len(src)
+    row_t = np.concatenate([np.arange(T), np.zeros(3)]).astype(np.int32)
+    spk = g.standard_normal(Cc).astype(np.float32)
+    pos = g.standard_normal((nf + 1, Cc)).astype(np.float32)
+    out = dev.empty((nf, Cc), fill=7)
+    d = {k: dev.put(v) for k, v in dict(x=x, src=src, row_t=row_t, spk=spk, pos=pos).items()}
+    ws = dev.ws(max(nf, S))
+    P = dev.ptr
+    assert dev.lib.mtts_length_regulate_fwd(nf, Cc, P(d["x"]), P(d["src"]), P(d["spk"]) if with_extras else None, P(d["pos"]) if with_extras else None,
+                                            P(d["row_t"]) if with_extras else None, P(out), P(ws), None) == 0
+    ref = np.zeros((nf, Cc), np.float32)
+    ref[:T] = x[src[:T]] + ((spk[None] + pos[row_t[:T]]) if with_extras else 0)
+    np.testing.assert_allclose(dev.get(out), ref, rtol=1e-6, atol=1e-6)
+    # transpose: dx[p] = sum of dout over the phoneme's frames (torch: index_add of the gather)
+    dout = g.standard_normal((nf, Cc)).astype(np.float32)
+    first = np.concatenate([[0], np.cumsum(dur)[:-1]]).astype(np.int32)
+    dx = dev.empty((S, Cc), fill=3)
+    dd = dev.put(dout)
+    assert dev.lib.mtts_length_regulate_bwd(S, Cc, P(dd), P(dev.put(first)), P(dev.put(dur.astype(np.int32))), P(dx), 0, P(ws), None) == 0
+    tx = torch.from_numpy(x).requires_grad_(True)
+    tx[torch.from_numpy(src[:T].astype(np.int64))].backward(torch.from_numpy(dout[:T]))
+    np.testing.assert_allclose(dev.get(dx), tx.grad.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,Cc,full", [(19, 256, True), (6, 64, False)])
+def test_layernorm_and_softmax_jvp(dev, rows, Cc, full):
+    """Tangent twins (csrc/tangent.h) against torch.func.jvp of layer_norm / softmax."""
+    g = np.random.RandomState(rows * 3 + Cc)
+    a, ta = (g.standard_normal((rows, Cc)).astype(np.float32) for _ in range(2))
+    tres = g.standard_normal((rows, Cc)).astype(np.float32)
+    gamma, beta = (1 + 0.1 * g.standard_normal(Cc)).astype(np.float32), (0.1 * g.standard_normal(Cc)).astype(np.float32)
+    tgamma, tbeta = (g.standard_normal(Cc).astype(np.float32) for _ in range(2))
+    mask = (g.rand(rows) > 0.3).astype(np.uint8)
+    d = {k: dev.put(v) for k, v in dict(a=a, ta=ta, tres=tres, gamma=gamma, beta=beta, tgamma=tgamma, tbeta=tbeta, mask=mask).items()}
+    z, y, st, ty = dev.empty((rows, Cc)), dev.empty((rows, Cc)), dev.empty((rows, 2)), dev.empty((rows, Cc), fill=5)
+    ws = dev.ws(rows)
+    P = dev.ptr
+    assert dev.lib.mtts_layernorm_fwd(rows, Cc, P(d["a"]), None, P(d["gamma"]), P(d["beta"]), P(d["mask"]) if full else None, P(z), P(y), P(st), P(ws), None) == 0
+    assert dev.lib.mtts_layernorm_jvp(rows, Cc, P(d["ta"]), P(d["tres"]) if full else None, P(z), P(st), P(d["gamma"]), P(d["tgamma"]) if full else None,
+                                      P(d["tbeta"]) if full else None, P(d["mask"]) if full else None, P(ty), P(ws), None) == 0
+    m = torch.from_numpy(mask.astype(np.float32))[:, None] if full else torch.ones(rows, 1)
+    f = lambda x, gm, bt: torch.nn.functional.layer_norm(x, (Cc,), gm, bt, 1e-5) * m
+    tin = torch.from_numpy(ta + (tres if full else 0))
+    tg = torch.from_numpy(tgamma) if full else torch.zeros(Cc)
+    tb = torch.from_numpy(tbeta) if full else torch.zeros(Cc)
+    _, ref = torch.func.jvp(f, (torch.from_numpy(a), torch.from_numpy(gamma), torch.from_numpy(beta)), (tin, tg, tb))
+    np.testing.assert_allclose(dev.get(ty), ref.numpy(), rtol=2e-4, atol=2e-5)
+    # softmax
+    n_mat, L = 3, rows
+    ldS = (L + 3) & ~3
+    S0, tS0 = (g.standard_normal((n_mat, L, L)).astype(np.float32) for _ in range(2))
+    Sp, tSp = np.zeros((n_mat, L, ldS), np.float32), np.zeros((n_mat, L, ldS), np.float32)
+    Sp[:, :, :L], tSp[:, :, :L] = S0, tS0
+    dS, dtS = dev.put(Sp), dev.put(tSp)
+    ws2 = dev.ws(1, n_mat)
+    assert dev.lib.mtts_softmax_fwd(n_mat, L, P(dS), P(ws2), None) == 0
+    assert dev.lib.mtts_softmax_jvp(n_mat, L, P(dS), P(dtS), P(ws2), None) == 0
+    _, ref = torch.func.jvp(lambda s: torch.softmax(s, -1), (torch.from_numpy(S0),), (torch.from_numpy(tS0),))
+    np.testing.assert_allclose(dev.get(dtS)[:, :, :L], ref.numpy(), rtol=2e-4, atol=2e-6)
