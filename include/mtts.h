@@ -58,6 +58,10 @@ typedef struct mtts_batch {
     const float* pitches;     /* [B][S_max]          batch[9]   ([B][T_max] when pitch is frame-level)  */
     const float* energies;    /* [B][S_max]          batch[10]  ([B][T_max] when energy is frame-level) */
     const int64_t* durations; /* [B][S_max]          batch[11] */
+    /* NULL, or [B][d_model] speaker embeddings used INSTEAD of the table lookup — `speaker_emb: dvec`, where batch[2] is
+     * (ref_mels, ref_slices) and the embedding is the d-vector encoder's output (speaker_encoder.py:71-76; mtts_dvector_embed).
+     * `speakers` is ignored then; no speaker-table gradient; first-order / baseline passes only. */
+    const float* spk_emb;
 } mtts_batch;
 
 /* ---- lifecycle (System.__init__, lightning/systems/system.py:30-48) ---------------------------- */
@@ -260,6 +264,25 @@ int mtts_vocoder_load(mtts_vocoder* h, const char* name, const float* data, int6
 int mtts_vocoder_infer(mtts_vocoder* h, const float* mel, int B, int T_max, const int* mel_lens, float mel_scale, float* wav);
 int mtts_vocoder_infer_device(mtts_vocoder* h, const float* mel_dev, int64_t mel_utt_stride, int B, int T_max, const int* mel_lens,
                               float mel_scale, float* wav_dev);
+
+/* ---- d-vector speaker encoder, forward only (`speaker_emb: dvec`) -------------------------
+ * Replaces `SpeakerEncoder.forward` for emb_type "dvec" (lightning/model/speaker_encoder.py:54-60,71-76): the frozen
+ * resemblyzer `VoiceEncoder` (un-vendored; architecture restated by the reference's own GE2E class, :11-31: LSTM(n_mels -> hidden,
+ * `layers` layers, batch_first) + Linear(hidden -> emb) + ReLU), applied to the partial utterances of the batch
+ * (`spk_ref_mel_slices`, lightning/collate.py:29-43): partial embedding = L2-normalised ReLU(Linear(final hidden state of the last
+ * layer)); utterance embedding = F.normalize(mean of its partials).  The trained variants ("encoder", "scratch_encoder") need the
+ * LSTM backward and are not built.
+ * Tensors (torch names and layouts): lstm.weight_ih_l{k} [4*hidden][in], lstm.weight_hh_l{k} [4*hidden][hidden],
+ * lstm.bias_ih_l{k}, lstm.bias_hh_l{k} [4*hidden] (gate order i, f, g, o), linear.weight [emb][hidden], linear.bias [emb].
+ * embed: mels [n_partials][frames][n_mels] (host), utt_offsets [n_utts + 1] (partials of utterance b = [off[b], off[b+1]),
+ * off[0] = 0, off[n_utts] = n_partials) -> out [n_utts][emb] (host; feed it to mtts_batch.spk_emb); partial_out
+ * [n_partials][emb] or NULL.  Synchronous. */
+typedef struct mtts_dvector mtts_dvector;
+int mtts_dvector_create(int n_mels, int hidden, int layers, int emb, int max_partials, int frames, int max_utts, int device, mtts_dvector** out);
+void mtts_dvector_destroy(mtts_dvector* h);
+const char* mtts_dvector_last_error(mtts_dvector* h);
+int mtts_dvector_load(mtts_dvector* h, const char* name, const float* data, int64_t numel);
+int mtts_dvector_embed(mtts_dvector* h, const float* mels, int n_partials, const int* utt_offsets, int n_utts, float* out, float* partial_out);
 
 #ifdef __cplusplus
 }

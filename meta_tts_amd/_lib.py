@@ -28,7 +28,7 @@ class Batch(C.Structure):
     _fields_ = [("B", C.c_int), ("S_max", C.c_int), ("T_max", C.c_int),
                 ("speakers", C.c_void_p), ("texts", C.c_void_p), ("src_lens", C.c_void_p),
                 ("mels", C.c_void_p), ("mel_lens", C.c_void_p), ("pitches", C.c_void_p),
-                ("energies", C.c_void_p), ("durations", C.c_void_p)]
+                ("energies", C.c_void_p), ("durations", C.c_void_p), ("spk_emb", C.c_void_p)]
 
 
 EXPORTS = {
@@ -96,6 +96,11 @@ EXPORTS = {
     "mtts_length_regulate_bwd": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mtts_layernorm_jvp": (C.c_int, [C.c_int, C.c_int] + [C.c_void_p] * 11),
     "mtts_softmax_jvp": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtts_dvector_create": (C.c_int, [C.c_int] * 8 + [C.POINTER(C.c_void_p)]),
+    "mtts_dvector_destroy": (None, [C.c_void_p]),
+    "mtts_dvector_last_error": (C.c_char_p, [C.c_void_p]),
+    "mtts_dvector_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "mtts_dvector_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mtts_vocoder_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]),
     "mtts_vocoder_destroy": (None, [C.c_void_p]),

@@ -63,6 +63,7 @@ struct HostBatch {  // one padded batch in the reference 12-tuple layout (collat
     const float* pitches;        // [B][S_max] or null
     const float* energies;       // [B][S_max] or null
     const long long* durations;  // [B][S_max] or null
+    const float* spk_emb = nullptr;  // [B][d_model] or null: external speaker embeddings instead of the table lookup (speaker_emb: dvec)
 };
 
 struct ParamEntry {
@@ -116,12 +117,14 @@ public:
         const float* mels = nullptr;
         std::vector<float> mels_keep;  // own copy, only when T_max > max_seq_len (the plan may be rebuilt untruncated, see retarget)
         std::vector<int> spk_ids;
+        std::vector<float> spk_emb;    // [B][d_model] external speaker embeddings (empty: table lookup)
     };
     struct Plan {
         int tasks = 0;
         std::vector<int> hB, hSmax, hTcap, hMp, hMf, hMr;
         int maxMp = 0, maxMf = 0, maxMr = 0, maxB = 0, enc_maxL = 0, dec_maxL = 0, n_enc_groups = 0, n_dec_groups = 0;
         int average_spk = 0;
+        bool ext_spk = false;   // speaker vectors come with the batch (speaker_emb: dvec), no table lookup and no table gradient
         bool has_targets = false, frames_ready = false;
         bool over_max = false, truncated = true;  // some T_max > max_seq_len / frames beyond it dropped in the current row spaces
         unsigned drop_seed = 0;  // seed of the last train-mode forward on this plan (backward replays it)
@@ -156,7 +159,7 @@ public:
     };
     // byte offsets inside a compact image (fixed by the capacities; computed in init)
     size_t pe_cap_p = 0, pe_cap_e = 0;  // per-task floats of the pitch / energy areas of an image
-    struct ImgLayout { size_t meta, hdr, src_len, flen, foff, spk, texts, dur, pitch, energy, seq_e, seq_d, tab_e[6], tab_d[6], mels, total; } img;
+    struct ImgLayout { size_t meta, hdr, src_len, flen, foff, spk, spk_emb, texts, dur, pitch, energy, seq_e, seq_d, tab_e[6], tab_d[6], mels, total; } img;
     enum { TAB_QK = 0, TAB_PV, TAB_DP, TAB_DV, TAB_DQ, TAB_DK };
     Plan plans[2];
     long long row_ts_p, row_ts_f, row_ts_r;  // strides of per-row index arrays
@@ -517,6 +520,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         img.flen = o; o = al(o + nt * cap_B * sizeof(int));
         img.foff = o; o = al(o + nt * cap_B * sizeof(int));
         img.spk = o; o = al(o + nt * (cap_B + 1) * sizeof(int));
+        img.spk_emb = o; o = al(o + nt * (size_t)cap_B * cfg.d_model * sizeof(float));
         img.texts = o; o = al(o + nt * bs * sizeof(int));
         img.dur = o; o = al(o + nt * bs * sizeof(int));
         pe_cap_p = cfg.pitch_frame ? (size_t)cap_B * cap_T : bs;
@@ -706,7 +710,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             }
             in.spk_ids[cap_B] = sb.B;
             if (!average_spk && sb.B != b.B) { set_error("speaker id count != batch size"); return -1; }
+            in.spk_emb.clear();
+            if (b.spk_emb) {
+                if (average_spk || spk_from) { set_error("external speaker embeddings cannot be combined with spk_from / average_spk"); return -1; }
+                in.spk_emb.assign(b.spk_emb, b.spk_emb + (size_t)b.B * cfg.d_model);
+            }
+            if (t > 0 && (in.spk_emb.empty() != p.in[0].spk_emb.empty())) { set_error("either every task or none carries speaker embeddings"); return -1; }
         }
+        p.ext_spk = !p.in[0].spk_emb.empty();
         if (any_tf && any_fr) { set_error("cannot mix teacher-forced and free-running batches in one slot"); return -1; }
         p.has_targets = any_tf;
         p.over_max = false;
@@ -789,6 +800,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             const int Mf = with_frames ? foff : 0, Mr = with_frames ? G + B * (Tcap + G) : 0;
             if (Mf > capMf || Mr > capMr || Mp > capMp) { set_error("row space exceeds capacity"); return -1; }
             for (int i = 0; i <= cap_B; ++i) h_spk[(size_t)t * (cap_B + 1) + i] = b.spk_ids[i];
+            if (!b.spk_emb.empty()) memcpy((float*)(H + img.spk_emb) + (size_t)t * cap_B * d, b.spk_emb.data(), b.spk_emb.size() * sizeof(float));
             PlanTaskHdr& h = hdr[t];
             h.B = B; h.S = S; h.Tmax_in = b.T_max; h.Tcap = Tcap; h.Mp = Mp; h.Mf = Mf; h.Mr = Mr; h.with_frames = with_frames;
             h.has_targets = !b.pitches.empty(); h.has_mels = b.mels != nullptr; h.pad0 = h.pad1 = 0; h.mel_off = mel_used;
@@ -1225,6 +1237,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (int l = 0; l < cfg.enc_layers; ++l) { site_base = 2 * l; fft_fwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], x, none); x = encB[l].y2; }
         // speaker vector, added on every position of the phoneme rectangle
         TS tb = W(ps, spk_table);
+        if (p.ext_spk)   // the batch's own embeddings (speaker_encoder.py:71-76 computed by the d-vector encoder): rows of the image
+            MTTS_LAUNCH(copy_tasks_kernel, dim3((unsigned)(((long long)p.maxB * d / 4 + 255) / 256), 1, nt), dim3(256), stream,
+                        (const float*)(p.img_dev + img.spk_emb), (long long)cap_B * d, spk.p, spk.ts, (long long)p.maxB * d / 4);
+        else
         MTTS_LAUNCH(speaker_vec_kernel, dim3(p.maxB, 1, nt), dim3(64), stream, (const int*)p.meta, (const float*)tb.p, tb.ts,
                     (const int*)p.spk_ids, (long long)cap_B + 1, cap_B, p.average_spk, spk.p, spk.ts, d);
         MTTS_LAUNCH(add_rowvec_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
@@ -1517,6 +1533,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         // speaker vector gradient, part 2: every position of the phoneme rectangle
         MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(256), stream, (const int*)p.meta, (const float*)gP0.p,
                     gP0.ts, (const int*)p.p_seg_start, (const int*)p.p_seg_len, (long long)cap_B, dspk.p, dspk.ts, d, 1);
+        if (!p.ext_spk)
         MTTS_LAUNCH(speaker_table_grad_kernel, dim3(cfg.n_speaker, 1, nt), dim3(64), stream, (const int*)p.meta,
                     (const float*)dspk.p, dspk.ts, (const int*)p.spk_ids, (long long)cap_B + 1, cap_B, p.average_spk,
                     Gd(spk_table).p, n_total, d);

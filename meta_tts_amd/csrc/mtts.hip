@@ -6,6 +6,7 @@
 #include "comm.h"
 #include "engine.h"
 #include "vocoder.h"
+#include "dvector.h"
 
 using namespace mtts;
 
@@ -32,6 +33,9 @@ static int launched(Engine& e, int rc) {
 
 struct mtts_vocoder {
     Vocoder v;
+};
+struct mtts_dvector {
+    DVector d;
 };
 
 extern "C" {
@@ -154,6 +158,7 @@ static HostBatch to_host_batch(const mtts_batch& b) {
     o.speakers = (const long long*)b.speakers; o.texts = (const long long*)b.texts; o.src_lens = (const long long*)b.src_lens;
     o.mels = b.mels; o.mel_lens = (const long long*)b.mel_lens; o.pitches = b.pitches; o.energies = b.energies;
     o.durations = (const long long*)b.durations;
+    o.spk_emb = b.spk_emb;
     return o;
 }
 
@@ -428,6 +433,27 @@ int mtts_vocoder_infer(mtts_vocoder* h, const float* mel, int B, int T_max, cons
 int mtts_vocoder_infer_device(mtts_vocoder* h, const float* mel_dev, int64_t mel_utt_stride, int B, int T_max, const int* mel_lens,
                               float mel_scale, float* wav_dev) {
     return h->v.run(mel_dev, B, T_max, mel_lens, mel_scale, wav_dev, (long long)T_max * h->v.hop, (long long)mel_utt_stride);
+}
+
+// ---- d-vector speaker encoder (dvector.h; reference lightning/model/speaker_encoder.py:11-31,54-60,71-76) ----------------
+int mtts_dvector_create(int n_mels, int hidden, int layers, int emb, int max_partials, int frames, int max_utts, int device, mtts_dvector** out) {
+    if (!out) { g_create_error = "bad arguments"; return -1; }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed (no MI355X visible?)"; return -1; }
+    mtts_dvector* h = new mtts_dvector();
+    if (h->d.init(n_mels, hidden, layers, emb, max_partials, frames, max_utts) != 0) { g_create_error = h->d.last_error; h->d.destroy(); delete h; return -1; }
+    *out = h;
+    return 0;
+}
+void mtts_dvector_destroy(mtts_dvector* h) {
+    if (!h) return;
+    hipDeviceSynchronize();
+    h->d.destroy();
+    delete h;
+}
+const char* mtts_dvector_last_error(mtts_dvector* h) { return h ? h->d.last_error.c_str() : g_create_error.c_str(); }
+int mtts_dvector_load(mtts_dvector* h, const char* name, const float* data, int64_t numel) { return h->d.load(name, data, numel); }
+int mtts_dvector_embed(mtts_dvector* h, const float* mels, int n_partials, const int* utt_offsets, int n_utts, float* out, float* partial_out) {
+    return h->d.embed(mels, n_partials, utt_offsets, n_utts, out, partial_out);
 }
 
 }  // extern "C"

@@ -38,15 +38,29 @@ def pad_2D(xs: Sequence[np.ndarray]) -> np.ndarray:                          # u
     return np.stack([np.pad(x, ((0, n - x.shape[0]), (0, 0)), mode="constant") for x in xs])
 
 
+def _ref_mel_args(ref_mels):
+    """collate.py:29-43: concatenate the utterances' partial-utterance stacks, one consecutive slice per utterance."""
+    slices, start = [], 0
+    for m in ref_mels:
+        slices.append(slice(start, start + m.shape[0]))
+        start += m.shape[0]
+    return np.concatenate(ref_mels, axis=0).astype(np.float32), slices
+
+
 def reprocess(data: Sequence[dict], idxs: Sequence[int]):
-    """lightning/collate.py:9-60 (table-speaker path: `speaker_args` = int64 ids)."""
+    """lightning/collate.py:9-60.  `speaker_args` = int64 speaker ids, or — when the samples carry `spk_ref_mel_slices` (the dvec /
+    encoder speaker modes, dataset.py:83-91) — the pair (ref_mels (n_partials, 160, 40), [slice per utterance])."""
     pick = [data[i] for i in idxs]
     texts = [np.asarray(d["text"]) for d in pick]
     mels = [np.asarray(d["mel"], np.float32) for d in pick]
     text_lens = np.array([t.shape[0] for t in texts])
     mel_lens = np.array([m.shape[0] for m in mels])
+    if "spk_ref_mel_slices" in data[0]:
+        speaker_args = _ref_mel_args([np.asarray(d["spk_ref_mel_slices"]) for d in pick])
+    else:
+        speaker_args = np.array([d["speaker"] for d in pick], np.int64)
     return ([d["id"] for d in pick], [d["raw_text"] for d in pick],
-            np.array([d["speaker"] for d in pick], np.int64),
+            speaker_args,
             pad_1D(texts).astype(np.int64), text_lens, int(text_lens.max()),
             pad_2D(mels).astype(np.float32), mel_lens, int(mel_lens.max()),
             pad_1D([np.asarray(d["pitch"]) for d in pick]).astype(np.float32),
@@ -63,7 +77,11 @@ def split_reprocess(batch, idxs):
     tl, ml = A(tlens)[idxs], A(mlens)[idxs]
     st, sm = int(tl.max()), int(ml.max())
     crop = lambda x: A(x)[idxs][:, :st] if A(x).shape[1] == int(tmax) else A(x)[idxs][:, :sm]
-    return ([ids[i] for i in idxs], [raw[i] for i in idxs], A(spk)[idxs], A(texts)[idxs][:, :st], tl, st,
+    if isinstance(spk, tuple):   # (ref_mels, ref_slices): collate.py:84-94
+        sub_spk = _ref_mel_args([A(spk[0])[spk[1][i]] for i in idxs])
+    else:
+        sub_spk = A(spk)[idxs]
+    return ([ids[i] for i in idxs], [raw[i] for i in idxs], sub_spk, A(texts)[idxs][:, :st], tl, st,
             A(mels)[idxs][:, :sm], ml, sm, crop(pit), crop(ene), A(dur)[idxs][:, :st])
 
 
@@ -131,9 +149,10 @@ class SpeakerTaskCollate:
 class FeatureDataset:
     """dataset.py:12-109 reader of the preprocessed feature tree (see module docstring)."""
 
-    def __init__(self, preprocessed_path: str, filename: str, text_to_sequence: Callable[[str], Sequence[int]]):
+    def __init__(self, preprocessed_path: str, filename: str, text_to_sequence: Callable[[str], Sequence[int]], spk_refer_wav: bool = False):
         self.root = preprocessed_path
         self.text_to_sequence = text_to_sequence
+        self.spk_refer_wav = spk_refer_wav   # dataset.py:16,83-91: also read spk_ref_mel_slices/{spk}-mel-{basename}.npy
         self.basename, self.speaker, self.text, self.raw_text = [], [], [], []
         with open(os.path.join(preprocessed_path, filename), encoding="utf-8") as f:
             for line in f:
@@ -149,10 +168,13 @@ class FeatureDataset:
         return np.load(os.path.join(self.root, kind, f"{self.speaker[idx]}-{kind}-{self.basename[idx]}.npy"))
 
     def __getitem__(self, idx):
-        return {"id": self.basename[idx], "speaker": self.speaker_map[self.speaker[idx]],
-                "text": np.array(self.text_to_sequence(self.text[idx])), "raw_text": self.raw_text[idx],
-                "mel": self._load("mel", idx), "pitch": self._load("pitch", idx), "energy": self._load("energy", idx),
-                "duration": self._load("duration", idx)}
+        sample = {"id": self.basename[idx], "speaker": self.speaker_map[self.speaker[idx]],
+                  "text": np.array(self.text_to_sequence(self.text[idx])), "raw_text": self.raw_text[idx],
+                  "mel": self._load("mel", idx), "pitch": self._load("pitch", idx), "energy": self._load("energy", idx),
+                  "duration": self._load("duration", idx)}
+        if self.spk_refer_wav:
+            sample["spk_ref_mel_slices"] = np.load(os.path.join(self.root, "spk_ref_mel_slices", f"{self.speaker[idx]}-mel-{self.basename[idx]}.npy"))
+        return sample
 
 
 class ConcatDataset:

@@ -49,6 +49,7 @@ class Engine:
         cfg.adapt_mask = mask
         # adapt.speaker_emb == "shared" (speaker_encoder.py:52-53,67-69): a one-row table looked up with zeros_like(speaker ids)
         self.shared_speaker = bool(shared_speaker)
+        self.speaker_encoder = None   # speaker_emb: dvec — callable (ref_mels, ref_slices) -> (B, d_model), e.g. speaker_encoder.DVectorEncoder
         if self.shared_speaker and dims.n_speaker != 1:
             raise MttsError("a shared speaker embedding is a table with exactly one row")
         self.adapt_modules = tuple(adapt_modules)
@@ -181,7 +182,23 @@ class Engine:
             keep.append(a)
             return a
         b = tuple(b) + (None,) * (12 - len(b))
-        spk, texts, src_lens = np_(b[2], np.int64), np_(b[3], np.int64), np_(b[4], np.int64)
+        texts, src_lens = np_(b[3], np.int64), np_(b[4], np.int64)
+        spk_emb = None
+        sa = b[2]
+        if isinstance(sa, (tuple, list)) and len(sa) == 2 and isinstance(sa[1], (tuple, list)):
+            # speaker_emb: dvec — batch[2] is (ref_mels, ref_slices) (collate.py:29-43); the d-vector encoder turns it into (B, d_model)
+            if self.speaker_encoder is None:
+                raise MttsError("batch carries (ref_mels, ref_slices) speaker args but no speaker encoder is attached (Engine.speaker_encoder)")
+            sa = self.speaker_encoder(sa)
+        if hasattr(sa, "detach"):
+            sa = sa.detach().cpu().numpy()
+        if np.ndim(sa) == 2 and np.asarray(sa).dtype.kind == "f":   # already embedded: (B, d_model) floats
+            spk_emb = np_(sa, np.float32)
+            assert spk_emb.shape == (texts.shape[0], self.dims.d_model), ("speaker embeddings", spk_emb.shape)
+            spk = np.zeros(texts.shape[0], np.int64)
+            keep.append(spk)
+        else:
+            spk = np_(sa, np.int64)
         if self.shared_speaker:
             spk = np.zeros_like(spk)
             keep.append(spk)
@@ -197,6 +214,8 @@ class Engine:
             assert p.shape == (cb.B, cb.T_max if self.dims.pitch_frame_level else cb.S_max), ("pitch targets", p.shape)
             assert e.shape == (cb.B, cb.T_max if self.dims.energy_frame_level else cb.S_max), ("energy targets", e.shape)
             fields += [("mels", mels), ("mel_lens", mel_lens), ("pitches", p), ("energies", e), ("durations", d)]
+        if spk_emb is not None:
+            fields.append(("spk_emb", spk_emb))
         for f, a in fields:
             setattr(cb, f, a.ctypes.data_as(C.c_void_p))
         return cb

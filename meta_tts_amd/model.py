@@ -50,22 +50,33 @@ class FastSpeech2:
     def __init__(self, preprocess_config, model_config, algorithm_config, *, max_tasks: int = 1, max_batch: int = 16,
                  max_src_len: int = 128, max_mel_len: Optional[int] = None, device: int = 0, lib_path: Optional[str] = None):
         spk_mode = algorithm_config["adapt"]["speaker_emb"]
-        if spk_mode not in ("table", "shared"):
-            raise MttsError("adapt.speaker_emb must be 'table' or 'shared' (the GE2E / d-vector encoders of speaker_encoder.py:54-60 "
-                            "are outside the hot path, SURVEY.md section 8(f) row 4)")
+        if spk_mode not in ("table", "shared", "dvec"):
+            raise MttsError("adapt.speaker_emb must be 'table', 'shared' or 'dvec' (the trained speaker encoders 'encoder' / 'scratch_encoder' "
+                            "of speaker_encoder.py:54-60 need the LSTM backward, which is not built; SURVEY.md section 8(f) row 4)")
         if algorithm_config["adapt"]["type"] != "spk":
             raise MttsError("adapt.type == 'lang' (codebook phoneme embedding) is out of scope (SURVEY.md #8)")
         stats, n_spk = _read_preprocessed(preprocess_config)
-        if spk_mode == "shared":
-            n_spk = 1   # nn.Embedding(1, d): one vector for every speaker (speaker_encoder.py:52-53)
+        if spk_mode in ("shared", "dvec"):
+            n_spk = 1   # shared: nn.Embedding(1, d), one vector for every speaker (speaker_encoder.py:52-53); dvec: no table at all (the
+                        # engine's one-row table is an unused placeholder, the embeddings come with the batch)
+        self.spk_mode = spk_mode
         self.dims = ModelDims(model_config, preprocess_config, n_speaker=n_spk, stats=stats)
         self.model_config, self.preprocess_config, self.algorithm_config = model_config, preprocess_config, algorithm_config
         self.adapt_modules = tuple(algorithm_config["adapt"].get("modules", ()))
         self.engine = Engine(self.dims, adapt_modules=self.adapt_modules, max_tasks=max_tasks, max_B=max_batch,
                              max_S=max_src_len, max_T=max_mel_len or self.dims.max_seq_len, device=device, lib_path=lib_path,
                              shared_speaker=(spk_mode == "shared"))
+        self.speaker_encoder = None
+        if spk_mode == "dvec":   # frozen d-vector encoder in front of the acoustic model (speaker_encoder.py:56-58,71-76)
+            from .speaker_encoder import DVectorEncoder
+            # the reference's encoder is fixed at 40 mels / 3 x 256 / 160-frame partials and emits encoder_hidden = 256 values; the optional
+            # `adapt.dvector` block (not a reference key) only exists so that tests can run a small one
+            kw = dict(algorithm_config["adapt"].get("dvector", {}))
+            self.speaker_encoder = DVectorEncoder(max_partials=max(256, 16 * max_batch), max_utts=max_batch, emb=self.dims.d_model, device=device,
+                                                  lib_path=lib_path, **kw)
+            self.engine.speaker_encoder = self.speaker_encoder
         self.training = True
-        self.load_state_dict(synth.make_params(self.dims, seed=0))
+        self.load_state_dict(synth.make_params(self.dims, seed=0), strict=spk_mode != "dvec")
 
     # -- nn.Module-like surface ---------------------------------------------------------
     def train(self, mode: bool = True):
@@ -85,10 +96,20 @@ class FastSpeech2:
             sd[f"postnet.convolutions.{i}.1.running_mean"] = m
             sd[f"postnet.convolutions.{i}.1.running_var"] = v
             sd[f"postnet.convolutions.{i}.1.num_batches_tracked"] = np.array(t, np.int64)
+        if self.speaker_encoder is not None:   # the reference's keys: speaker_emb.model.{lstm,linear}.* instead of an embedding table
+            sd.pop("speaker_emb.model.weight", None)
+            sd.update({"speaker_emb.model." + k: v for k, v in self.speaker_encoder.state_dict().items()})
         return sd
 
     def load_state_dict(self, sd: Dict[str, np.ndarray], strict: bool = True):
         sd = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()}
+        if self.speaker_encoder is not None:
+            sd = dict(sd)
+            sd["speaker_emb.model.weight"] = np.zeros((1, self.dims.d_model), np.float32)   # the engine's unused placeholder row
+            if any(k.startswith("speaker_emb.model.lstm.") for k in sd):
+                self.speaker_encoder.load_state_dict(sd, prefix="speaker_emb.model.")
+            elif strict:
+                raise KeyError("speaker_emb.model.lstm.* missing from the state dict (speaker_emb: dvec)")
         self.engine.load_params(sd, strict=strict)
         # frozen nn.Parameters that torch restores from the checkpoint (modules.py:57-71): a checkpoint trained on another
         # corpus carries that corpus' pitch / energy quantisation (system.py corpus-mismatch branch)

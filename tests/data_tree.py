@@ -27,6 +27,13 @@ def write_tree(root, n_mel=32, seed=0):
             np.save(os.path.join(root, "duration", f"{spk}-duration-{base}.npy"), dur)
             phones = " ".join(PHONES[int(x)] for x in g.randint(0, len(PHONES), size=S))
             lines.append(f"{base}|{spk}|{{{phones}}}|raw text of {base}")
+    # partial-utterance reference mels of the dvec / encoder speaker modes (dataset.py:83-91): (n_partials, frames, 40); written
+    # from their own generator so that the files above stay byte-identical to the ones the older fixtures were made from
+    os.makedirs(os.path.join(root, "spk_ref_mel_slices"), exist_ok=True)
+    g2 = np.random.RandomState(seed + 1)
+    for ln in lines:
+        base, spk = ln.split("|")[:2]
+        np.save(os.path.join(root, "spk_ref_mel_slices", f"{spk}-mel-{base}.npy"), g2.standard_normal((int(g2.randint(1, 4)), 6, 40)).astype(np.float32))
     with open(os.path.join(root, "train.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     with open(os.path.join(root, "speakers.json"), "w") as f:

@@ -67,6 +67,18 @@ def main():
     whole = SpeakerTaskCollate().meta_collate_fn(task, shots=3, queries=3, sort=False, split=False)
     tup("nosplit_", whole[0], out)
     tup("sub_", split_reprocess(whole[0], [4, 1]), out)                       # 1-shot test mode re-crop (systems/utils.py:80-117)
+    # dvec / encoder speaker modes: samples carry spk_ref_mel_slices and speaker_args becomes (ref_mels, ref_slices) (collate.py:29-43,84-94)
+    ds_ref = TTSDataset("train.txt", pre, trn, spk_refer_wav=True)
+    ref_samples = [ds_ref[i] for i in range(len(ds_ref))]
+
+    def tup_ref(prefix, b):
+        mels_, slices_ = b[2]
+        out[prefix + "refmels"] = mels_.numpy()
+        out[prefix + "refbounds"] = np.array([[s.start, s.stop] for s in slices_], np.int64)
+        tup(prefix, b[:2] + (np.zeros(0),) + b[3:], out)
+    rb = reprocess(ref_samples, [2, 0, 13, 22])
+    tup_ref("ref_", rb)
+    tup_ref("refsub_", split_reprocess(rb, [3, 1]))
     np.savez_compressed(os.path.join(HERE, "collate.npz"), **out)
     print("collate golden written:", len(out), "entries")
 

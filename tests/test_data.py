@@ -127,3 +127,21 @@ def test_collate_matches_reference_golden_exactly(tmp_path):
     whole = D.SpeakerTaskCollate().meta_collate_fn(task, shots=3, queries=3, sort=False, split=False)
     _check("nosplit_", whole[0], g)
     _check("sub_", D.split_reprocess(whole[0], [4, 1]), g)
+
+
+def test_ref_mel_speaker_args_match_reference_golden(tmp_path):
+    """dvec / encoder speaker modes: `speaker_args` = (ref_mels, ref_slices) from the samples' spk_ref_mel_slices
+    (dataset.py:83-91, collate.py:29-43) and its re-slicing for a sub-batch (collate.py:84-94)."""
+    g = np.load(GOLDEN, allow_pickle=False)
+    lines = _write_tree(str(tmp_path))
+    ids_of = {ln.split("|")[2]: g[f"text_{i}"].tolist() for i, ln in enumerate(lines)}
+    ds = D.FeatureDataset(str(tmp_path), "train.txt", lambda t: ids_of[t], spk_refer_wav=True)
+    samples = [ds[i] for i in range(len(ds))]
+    rb = D.reprocess(samples, [2, 0, 13, 22])
+    for prefix, b in (("ref_", rb), ("refsub_", D.split_reprocess(rb, [3, 1]))):
+        mels, slices = b[2]
+        assert mels.dtype == np.float32
+        np.testing.assert_array_equal(mels, g[prefix + "refmels"])
+        assert [[s.start, s.stop] for s in slices] == g[prefix + "refbounds"].tolist()
+        _check(prefix, b[:2] + (np.zeros(0),) + b[3:], g)
+

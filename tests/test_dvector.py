@@ -1,0 +1,62 @@
+"""d-vector speaker encoder (csrc/dvector.h through include/mtts.h: mtts_dvector_*) against oracle/dvector_oracle.py — torch's own
+nn.LSTM / nn.Linear (the operators the reference's GE2E class is made of, speaker_encoder.py:11-31) and the utterance reduction of
+speaker_encoder.py:71-76.  Small shapes through the SIMT emulator on CPU, the reference's shapes (40 mels, 160 frames, 3 x 256)
+on the MI355X."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from meta_tts_amd import speaker_encoder as se
+from oracle import dvector_oracle as orc
+
+
+def _case(seed, n_utts, frames, cfg):
+    g = np.random.RandomState(seed)
+    counts = g.randint(1, 4, size=n_utts)
+    n = int(counts.sum())
+    mels = g.standard_normal((n, frames, cfg["n_mels"])).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(counts)])
+    slices = [slice(int(off[i]), int(off[i + 1])) for i in range(n_utts)]
+    return mels, slices
+
+
+def _run(lib_path, cfg, frames, seed, n_utts):
+    sd = se.synthetic_state_dict(seed, **cfg)
+    enc = se.DVectorEncoder(sd, max_partials=64, max_utts=16, frames=frames, lib_path=lib_path, **cfg)
+    mels, slices = _case(seed + 1, n_utts, frames, cfg)
+    out, part = enc.embed(mels, slices, return_partials=True)
+    ref_p = orc.partial_embeds(sd, mels, **cfg).numpy()
+    ref = orc.speaker_embeds(sd, mels, slices, **cfg).numpy()
+    np.testing.assert_allclose(part, ref_p, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(out, ref, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, rtol=1e-5)
+    # __call__ keeps the reference's (ref_mels, ref_slices) signature
+    np.testing.assert_array_equal(enc((mels, slices)), out)
+    with pytest.raises(ValueError):
+        enc.embed(mels, slices[:-1])
+    enc.close()
+
+
+def test_dvector_emulator_small():
+    _run(ge.build_emulator(), dict(n_mels=8, hidden=64, emb=64, layers=2), frames=7, seed=3, n_utts=3)
+
+
+def test_state_dict_names_and_errors():
+    cfg = dict(n_mels=8, hidden=64, emb=64, layers=1)
+    sd = se.synthetic_state_dict(0, **cfg)
+    ck = {"model.speaker_emb.model." + k: v for k, v in sd.items()}          # the reference checkpoint's prefix
+    enc = se.DVectorEncoder(ck, max_partials=4, max_utts=2, frames=5, lib_path=ge.build_emulator(), **cfg)
+    assert set(enc.state_dict()) == set(sd)
+    bad = dict(sd)
+    bad["linear.weight"] = np.zeros((3, 3), np.float32)
+    with pytest.raises(ValueError):
+        enc.load_state_dict(bad)
+    with pytest.raises(ValueError):
+        enc.embed(np.zeros((1, 6, 8), np.float32), [slice(0, 1)])            # wrong frame count
+    enc.close()
+
+
+@pytest.mark.gpu
+def test_dvector_gpu_reference_shapes():
+    ge.build_device()
+    _run(None, dict(n_mels=40, hidden=256, emb=256, layers=3), frames=160, seed=11, n_utts=5)

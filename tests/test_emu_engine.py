@@ -571,3 +571,40 @@ def test_frame_level_pitch_energy_matches_oracle(emu_lib, pl, el):
             np.testing.assert_allclose(out["p"] * 1.1, o[2].numpy(), atol=5e-5)
             np.testing.assert_allclose(out["e"] * 0.9, o[3].numpy(), atol=5e-5)
     eng.close()
+
+
+def test_external_speaker_embeddings_match_a_table_of_the_same_rows(emu_lib):
+    """`speaker_emb: dvec` (speaker_encoder.py:71-76 -> fastspeech2.py:65-68,91-94): the batch carries one (d_model) embedding per
+    utterance instead of a speaker id.  Against the oracle with those embeddings as the rows of the table and ids 0..B-1 (the same
+    arithmetic): outputs, losses and every non-speaker gradient agree; the (placeholder) table receives no gradient."""
+    dims = tiny_dims()
+    eng = _engine(dims, emu_lib, tasks=2)
+    g = np.random.RandomState(5)
+    bs = [synth.make_batch(3, 3, speaker=0, **_kw(dims)), synth.make_batch(4, 2, speaker=0, **_kw(dims))]
+    embs = [g.standard_normal((len(b[4]), dims.d_model)).astype(np.float32) for b in bs]
+    ext = [tuple(b[:2]) + (e,) + tuple(b[3:]) for b, e in zip(bs, embs)]
+    eng.set_batches(0, ext)
+    eng.forward(0, use_fast=False, train=True)
+    dev_loss = eng.loss(0)
+    eng.backward(0, use_fast=False, scale=1.0, need_encoder=True)
+    for ti, (b, e) in enumerate(zip(bs, embs)):
+        p = torch_params(dims, requires_grad=True)
+        p["speaker_emb.model.weight"] = torch.from_numpy(e.copy()).requires_grad_(True)
+        tb = list(O.to_torch_batch(b))
+        tb[2] = torch.arange(e.shape[0])
+        o = O.fs2_forward(p, torch_buffers(dims), *tb[2:], n_head=heads(dims), max_seq_len=dims.max_seq_len, training=True)
+        lo = O.fs2_loss(tuple(tb), o)
+        out = eng.outputs(0, ti)
+        for k, ref in (("mel", o[0]), ("mel_post", o[1]), ("p", o[2]), ("e", o[3]), ("logd", o[4])):
+            assert np.abs(out[k] - ref.detach().numpy()).max() < 5e-5, (ti, k)
+        np.testing.assert_allclose(dev_loss[ti], [float(x) for x in lo], rtol=2e-5)
+        names = [n for n in eng.params if n != "speaker_emb.model.weight"]
+        gs = torch.autograd.grad(lo[0], [p[n] for n in names], allow_unused=True)
+        for n, gr in zip(names, gs):
+            ref = gr.numpy() if gr is not None else np.zeros(eng.params[n][0], np.float32)
+            assert np.abs(eng.export(n, 2, ti) - ref).max() <= 1e-3 * np.abs(ref).max() + 2e-7, (ti, n)
+        assert not eng.export("speaker_emb.model.weight", 2, ti).any()
+    # mixing embedded and id batches in one call, or asking for Hessian-vector products, is rejected loudly
+    with pytest.raises(Exception, match="every task or none"):
+        eng.set_batches(0, [ext[0], bs[1]])
+    eng.close()

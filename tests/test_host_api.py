@@ -478,6 +478,49 @@ def test_shared_speaker_embedding_mode(cfgs, emu_lib):
     g = torch.autograd.grad(ql[0], prm["speaker_emb.model.weight"])[0].numpy()
     got = sysm.engine.export("speaker_emb.model.weight", 1)
     assert got.shape == (1, dims.d_model) and np.abs(got - g).max() <= 2e-3 * np.abs(g).max()
-    alg["adapt"]["speaker_emb"] = "dvec"
+    alg["adapt"]["speaker_emb"] = "encoder"     # the trained speaker encoders need the LSTM backward: rejected
     with pytest.raises(Exception, match="speaker_emb"):
         _system((pre, mod, trn, alg), emu_lib)
+
+
+def test_dvec_speaker_mode_baseline_system(cfgs, emu_lib):
+    """config/algorithm/dvec.yaml: `type: baseline`, `speaker_emb: dvec`, `modules: []` — batch[2] is (ref_mels, ref_slices)
+    (collate.py:29-43) and the frozen d-vector encoder (speaker_encoder.py:56-58,71-76) supplies the speaker embedding.  The training
+    step equals the oracle's forward/backward with the oracle encoder's embeddings in place of the table rows."""
+    from oracle import dvector_oracle as dvo
+    pre, mod, trn, alg = cfgs
+    alg["type"] = "baseline"
+    alg["adapt"]["speaker_emb"] = "dvec"
+    alg["adapt"]["modules"] = []
+    dv = dict(n_mels=8, hidden=64, layers=2, frames=6)
+    alg["adapt"]["dvector"] = dv
+    sysm = _system((pre, mod, trn, alg), emu_lib, kind="baseline")
+    dims = sysm.model.dims
+    sd = sysm.model.state_dict()
+    assert "speaker_emb.model.weight" not in sd and sd["speaker_emb.model.lstm.weight_hh_l1"].shape == (256, 64)
+    assert sd["speaker_emb.model.linear.weight"].shape == (dims.d_model, 64)
+    b = list(synth.make_batch(8, 3, speaker=1, vocab=dims.vocab, **_kw(dims.n_mel)))
+    g = np.random.RandomState(2)
+    counts = [2, 1, 3]
+    ref_mels = g.standard_normal((sum(counts), dv["frames"], dv["n_mels"])).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(counts)])
+    slices = [slice(int(off[i]), int(off[i + 1])) for i in range(3)]
+    b[2] = (ref_mels, slices)
+    out = sysm.training_step(tuple(b), 0)
+    enc_sd = {k[len("speaker_emb.model."):]: v for k, v in sd.items() if k.startswith("speaker_emb.model.")}
+    emb = dvo.speaker_embeds(enc_sd, ref_mels, slices, n_mels=8, hidden=64, emb=dims.d_model, layers=2)
+    prm = {k: torch.from_numpy(v.copy()) for k, v in synth.make_params(dims, 0).items()}
+    prm["speaker_emb.model.weight"] = emb
+    prm["mel_linear.weight"].requires_grad_(True)
+    tb = list(O.to_torch_batch(tuple(b[:2]) + (np.arange(3),) + tuple(b[3:])))
+    lo = O.fs2_loss(tuple(tb), O.fs2_forward(prm, torch_buffers(dims), *tb[2:], n_head=heads(dims), max_seq_len=dims.max_seq_len, training=True))
+    gr = torch.autograd.grad(lo[0], prm["mel_linear.weight"])[0].numpy()
+    assert abs(out["loss"] - float(lo[0])) < 1e-4
+    assert np.abs(sysm.engine.export("mel_linear.weight", 1) - gr).max() < 1e-3 * np.abs(gr).max()
+    # a checkpoint round trip keeps the encoder's tensors under the reference's names
+    sysm.model.load_state_dict(sd)
+    np.testing.assert_array_equal(sysm.model.state_dict()["speaker_emb.model.linear.bias"], sd["speaker_emb.model.linear.bias"])
+    # the trained encoders are not built
+    alg["adapt"]["speaker_emb"] = "scratch_encoder"
+    with pytest.raises(Exception, match="speaker_emb"):
+        _system((pre, mod, trn, alg), emu_lib, kind="baseline")
