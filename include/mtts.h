@@ -284,6 +284,22 @@ const char* mtts_dvector_last_error(mtts_dvector* h);
 int mtts_dvector_load(mtts_dvector* h, const char* name, const float* data, int64_t numel);
 int mtts_dvector_embed(mtts_dvector* h, const float* mels, int n_partials, const int* utt_offsets, int n_utts, float* out, float* partial_out);
 
+/* ---- waveform -> log-mel spectrogram + frame energy (front-end STFT / mel extraction) ------
+ * Replaces `TacotronSTFT.mel_spectrogram` behind `Audio.tools.get_mel_from_wav` (audio/stft.py:128-178, audio/tools.py:8-15):
+ * clip to [-1, 1], reflect-pad filter_length / 2, windowed DFT of every hop-spaced frame (STFT.transform, stft.py:52-77), magnitude,
+ * mel = log(max(mel_basis @ magnitude, 1e-5)), energy = ||magnitude||_2 per frame.
+ * load: forward_basis [2 * (filter_length / 2 + 1)][filter_length] = the reference's `STFT.forward_basis` buffer (real rows then
+ * imaginary rows, window folded in, stft.py:27-46); mel_basis [n_mel][filter_length / 2 + 1] = `TacotronSTFT.mel_basis`
+ * (librosa.filters.mel, stft.py:143-147).  Either may be NULL to keep what was loaded before.
+ * mel_spectrogram: wav [n_samples] (host) -> mel [T][n_mel] (host; the reference returns the transpose, (n_mel, T)), energy [T],
+ * T = n_samples / hop_length + 1; returns T, or < 0 on error.  Synchronous. */
+typedef struct mtts_stft mtts_stft;
+int mtts_stft_create(int filter_length, int hop_length, int n_mel, int max_samples, int device, mtts_stft** out);
+void mtts_stft_destroy(mtts_stft* h);
+const char* mtts_stft_last_error(mtts_stft* h);
+int mtts_stft_load(mtts_stft* h, const float* forward_basis, const float* mel_basis);
+int mtts_stft_mel_spectrogram(mtts_stft* h, const float* wav, int n_samples, float* mel, float* energy);
+
 #ifdef __cplusplus
 }
 #endif

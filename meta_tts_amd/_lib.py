@@ -101,6 +101,11 @@ EXPORTS = {
     "mtts_dvector_last_error": (C.c_char_p, [C.c_void_p]),
     "mtts_dvector_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     "mtts_dvector_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mtts_stft_create": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_void_p)]),
+    "mtts_stft_destroy": (None, [C.c_void_p]),
+    "mtts_stft_last_error": (C.c_char_p, [C.c_void_p]),
+    "mtts_stft_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mtts_stft_mel_spectrogram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mtts_vocoder_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]),
     "mtts_vocoder_destroy": (None, [C.c_void_p]),

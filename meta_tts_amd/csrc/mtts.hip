@@ -7,6 +7,7 @@
 #include "engine.h"
 #include "vocoder.h"
 #include "dvector.h"
+#include "melfront.h"
 
 using namespace mtts;
 
@@ -36,6 +37,9 @@ struct mtts_vocoder {
 };
 struct mtts_dvector {
     DVector d;
+};
+struct mtts_stft {
+    MelFront m;
 };
 
 extern "C" {
@@ -454,6 +458,27 @@ const char* mtts_dvector_last_error(mtts_dvector* h) { return h ? h->d.last_erro
 int mtts_dvector_load(mtts_dvector* h, const char* name, const float* data, int64_t numel) { return h->d.load(name, data, numel); }
 int mtts_dvector_embed(mtts_dvector* h, const float* mels, int n_partials, const int* utt_offsets, int n_utts, float* out, float* partial_out) {
     return h->d.embed(mels, n_partials, utt_offsets, n_utts, out, partial_out);
+}
+
+// ---- waveform -> log-mel + energy (melfront.h; reference audio/stft.py:128-178, audio/tools.py:8-15) ----------------------
+int mtts_stft_create(int filter_length, int hop_length, int n_mel, int max_samples, int device, mtts_stft** out) {
+    if (!out) { g_create_error = "bad arguments"; return -1; }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed (no MI355X visible?)"; return -1; }
+    mtts_stft* h = new mtts_stft();
+    if (h->m.init(filter_length, hop_length, n_mel, max_samples) != 0) { g_create_error = h->m.last_error; h->m.destroy(); delete h; return -1; }
+    *out = h;
+    return 0;
+}
+void mtts_stft_destroy(mtts_stft* h) {
+    if (!h) return;
+    hipDeviceSynchronize();
+    h->m.destroy();
+    delete h;
+}
+const char* mtts_stft_last_error(mtts_stft* h) { return h ? h->m.last_error.c_str() : g_create_error.c_str(); }
+int mtts_stft_load(mtts_stft* h, const float* forward_basis, const float* mel_basis) { return h->m.load(forward_basis, mel_basis); }
+int mtts_stft_mel_spectrogram(mtts_stft* h, const float* wav, int n_samples, float* mel, float* energy) {
+    return h->m.mel_spectrogram(wav, n_samples, mel, energy);
 }
 
 }  // extern "C"

@@ -145,7 +145,8 @@ def _emu_tests():
             E.test_hessian_vector_product_matches_double_backward, E.test_second_order_maml_matches_oracle,
             E.test_free_running_synthesis_matches_oracle, E.test_adapted_encoder_moves_in_the_inner_loop,
             E.test_forward_loss_backward_two_ragged_tasks, E.test_first_order_maml_and_outer_update,
-            E.test_imaml_hypergradient_matches_oracle, E.test_two_handles_on_two_host_threads_do_not_interfere]
+            E.test_imaml_hypergradient_matches_oracle, E.test_two_handles_on_two_host_threads_do_not_interfere,
+            E.test_external_speaker_embeddings_match_a_table_of_the_same_rows]
 
 
 @pytest.mark.parametrize("fn", _emu_tests(), ids=lambda f: f.__name__)

@@ -1,0 +1,57 @@
+"""Waveform -> log-mel + energy (csrc/melfront.h through include/mtts.h: mtts_stft_*) against oracle/stft_oracle.py (torch
+restatement of audio/stft.py:15-77,128-178 and audio/tools.py:8-15).  Small transform through the SIMT emulator, the reference's
+LibriTTS configuration (1024 / 256 / 1024, 80 mels, 22050 Hz) on the MI355X."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from meta_tts_amd.audio import stft as S
+from meta_tts_amd.audio import tools
+from oracle import stft_oracle as orc
+
+
+def _wave(n, sr, seed):
+    g = np.random.RandomState(seed)
+    t = np.arange(n) / sr
+    w = 0.4 * np.sin(2 * np.pi * 220 * t) + 0.3 * np.sin(2 * np.pi * 1870 * t + 1.0) + 0.05 * g.standard_normal(n)
+    w[n // 3] = 1.7   # one sample outside [-1, 1]: get_mel_from_wav clips
+    return w.astype(np.float32)
+
+
+def _run(lib_path, n_fft, hop, win, n_mel, sr, n, max_samples):
+    st = S.TacotronSTFT(n_fft, hop, win, n_mel, sr, 0, None, max_samples=max_samples, lib_path=lib_path)
+    wav = _wave(n, sr, n_fft + n)
+    mel, energy = tools.get_mel_from_wav(wav, st)
+    rmel, renergy = orc.mel_spectrogram(wav, n_fft, hop, win, st.mel_basis)
+    assert mel.shape == rmel.shape == (n_mel, n // hop + 1) and mel.dtype == np.float32
+    np.testing.assert_allclose(energy, renergy, rtol=2e-5, atol=2e-5)
+    # log of a clamped value: compare where the mel energy is above the clamp, and exactly at the clamp elsewhere
+    live = rmel > np.log(2e-5)
+    np.testing.assert_allclose(mel[live], rmel[live], rtol=0, atol=2e-4)
+    assert np.all(mel[~live] <= np.log(3e-5))
+    with pytest.raises(Exception):
+        tools.get_mel_from_wav(wav[: n_fft // 2], st)      # too short for the reflection padding
+    st.close()
+
+
+def test_bases_follow_the_reference_construction():
+    b = S.forward_basis(64, 64)
+    assert b.shape == (66, 64) and b.dtype == np.float32
+    np.testing.assert_allclose(b, orc.forward_basis(64, 64)[:, 0, :].numpy(), rtol=0, atol=0)
+    m = S.mel_filterbank(22050, 1024, 80, 0, None)
+    assert m.shape == (80, 513) and (m >= 0).all() and (m.sum(axis=1) > 0).all()
+    # slaney normalisation: every triangle has (approximately) unit area in Hz
+    hz_per_bin = 22050 / 1024
+    np.testing.assert_allclose(m.sum(axis=1) * hz_per_bin, 1.0, rtol=0.12)
+    peak = m.argmax(axis=1)
+    assert np.all(np.diff(peak) > 0)                       # centre frequencies increase
+
+
+def test_stft_emulator_small():
+    _run(ge.build_emulator(), 64, 16, 64, 12, 8000, 500, 1024)
+
+
+@pytest.mark.gpu
+def test_stft_gpu_libritts_configuration():
+    ge.build_device()
+    _run(None, 1024, 256, 1024, 80, 22050, 22050 * 3 + 77, 22050 * 4)
