@@ -176,6 +176,12 @@ int mtts_allreduce_outer(mtts_handle* h);
 int mtts_outer_update(mtts_handle* h, const float* grad_dev, float lr, float beta1, float beta2, float eps,
                       float weight_decay, float max_norm, float* grad_norm_host);
 int mtts_reset_optimizer(mtts_handle* h);
+/* Hooks for a module trained in front of the engine (the speaker encoder): the gradient of the last backward pass w.r.t. the
+ * per-utterance speaker vectors of `task` (out [B][d_model], host); a device scalar added to the squared gradient norm inside
+ * mtts_outer_update (NULL: none); the device address of the norm mtts_outer_update computes. */
+int mtts_get_speaker_grad(mtts_handle* h, int task, int B, float* out);
+int mtts_set_extra_grad_sumsq(mtts_handle* h, const float* sumsq_dev);
+const float* mtts_grad_norm_dev(mtts_handle* h);
 
 /* ---- numerics of the contraction kernels of this handle.  0 (default): exact fp32 MFMA, the parity reference.
  * 1: "bf16x3" — fp32 operands split into two bf16 (16 mantissa bits) at LDS-staging time, three bf16 MFMAs per
@@ -283,6 +289,22 @@ void mtts_dvector_destroy(mtts_dvector* h);
 const char* mtts_dvector_last_error(mtts_dvector* h);
 int mtts_dvector_load(mtts_dvector* h, const char* name, const float* data, int64_t numel);
 int mtts_dvector_embed(mtts_dvector* h, const float* mels, int n_partials, const int* utt_offsets, int n_utts, float* out, float* partial_out);
+/* Trained speaker encoders (`speaker_emb: encoder` / `scratch_encoder`, config/algorithm/{encoder,scratch_encoder}.yaml: baseline
+ * systems whose optimizer also owns the LSTM; speaker_encoder.py:54-55,59-60).  enable_training allocates the saved-state, gradient
+ * and Adam buffers.  embed_train = embed that keeps the gate activations / cell states for the backward sweep; backward takes
+ * dout [n_utts][emb] (host) = dLoss/d(embedding) — mtts_get_speaker_grad of the engine — and fills the parameter gradients by
+ * back-propagation through time (hand-derived; autograd of nn.LSTM in the reference).  grad_sumsq returns a DEVICE scalar, the sum
+ * of squares of those gradients, to be handed to mtts_set_extra_grad_sumsq so that mtts_outer_update clips by the joint norm of all
+ * parameters (main.py:61); adam_step then applies the same clip coefficient (norm_dev = mtts_grad_norm_dev(engine), NULL: no clip)
+ * and the Adam rule of optimizer.py:9-15.  export / import: which = 0 parameter, 1 gradient, 2 Adam m, 3 Adam v. */
+int mtts_dvector_enable_training(mtts_dvector* h);
+int mtts_dvector_embed_train(mtts_dvector* h, const float* mels, int n_partials, const int* utt_offsets, int n_utts, float* out);
+int mtts_dvector_backward(mtts_dvector* h, const float* dout);
+const float* mtts_dvector_grad_sumsq(mtts_dvector* h);
+int mtts_dvector_adam_step(mtts_dvector* h, const float* norm_dev, float max_norm, float lr, float b1, float b2, float eps, float weight_decay);
+int mtts_dvector_set_optimizer_step(mtts_dvector* h, int step);
+int mtts_dvector_export(mtts_dvector* h, const char* name, int which, float* out, int64_t numel);
+int mtts_dvector_import(mtts_dvector* h, const char* name, int which, const float* data, int64_t numel);
 
 /* ---- waveform -> log-mel spectrogram + frame energy (front-end STFT / mel extraction) ------
  * Replaces `TacotronSTFT.mel_spectrogram` behind `Audio.tools.get_mel_from_wav` (audio/stft.py:128-178, audio/tools.py:8-15):

@@ -101,6 +101,17 @@ EXPORTS = {
     "mtts_dvector_last_error": (C.c_char_p, [C.c_void_p]),
     "mtts_dvector_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     "mtts_dvector_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mtts_dvector_enable_training": (C.c_int, [C.c_void_p]),
+    "mtts_dvector_embed_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "mtts_dvector_backward": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mtts_dvector_grad_sumsq": (C.c_void_p, [C.c_void_p]),
+    "mtts_dvector_adam_step": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_float] * 6),
+    "mtts_dvector_set_optimizer_step": (C.c_int, [C.c_void_p, C.c_int]),
+    "mtts_dvector_export": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64]),
+    "mtts_dvector_import": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int64]),
+    "mtts_get_speaker_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "mtts_set_extra_grad_sumsq": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mtts_grad_norm_dev": (C.c_void_p, [C.c_void_p]),
     "mtts_stft_create": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_void_p)]),
     "mtts_stft_destroy": (None, [C.c_void_p]),
     "mtts_stft_last_error": (C.c_char_p, [C.c_void_p]),

@@ -18,7 +18,22 @@ def _param_order(system):
     ``model.parameters()``); the four frozen tables (position_enc x2, pitch_bins, energy_bins) sit in the param group but never
     receive a gradient, so they have no state entry."""
     from . import synth
-    return [(n, trainable) for n, (_, trainable) in synth.param_spec(system.model.dims).items()]
+    order = [(n, trainable) for n, (_, trainable) in synth.param_spec(system.model.dims).items()]
+    enc = getattr(system.model, "speaker_encoder", None)
+    if enc is not None:   # speaker_emb is an LSTM encoder, not a table: its nn.LSTM / nn.Linear parameters take the table's place
+        from .speaker_encoder import tensor_shapes
+        trained = getattr(system.model, "spk_mode", "dvec") != "dvec"   # dvec: frozen (speaker_encoder.py:58), listed but stateless
+        order = [(n, t) for n, t in order if n != "speaker_emb.model.weight"]
+        order += [("speaker_emb.model." + n, trained) for n in tensor_shapes(**enc.cfg)]
+    return order
+
+
+def _enc_name(system, n):
+    """The speaker encoder's own tensor name when parameter `n` belongs to it (speaker_emb.model.{lstm,linear}.*), else None."""
+    pre = "speaker_emb.model."
+    if getattr(system.model, "speaker_encoder", None) is not None and n.startswith(pre) and n != pre + "weight":
+        return n[len(pre):]
+    return None
 
 
 def optimizer_state_dict(system) -> Dict:
@@ -32,7 +47,11 @@ def optimizer_state_dict(system) -> Dict:
     order = _param_order(system)
     if steps > 0:
         for i, (n, trainable) in enumerate(order):
-            if trainable:
+            if trainable and _enc_name(system, n):
+                enc = system.model.speaker_encoder
+                state[i] = {"step": torch.tensor(float(steps)), "exp_avg": torch.from_numpy(enc.export(_enc_name(system, n), 2)),
+                            "exp_avg_sq": torch.from_numpy(enc.export(_enc_name(system, n), 3))}
+            elif trainable:
                 state[i] = {"step": torch.tensor(float(steps)), "exp_avg": torch.from_numpy(eng.export(n, 4)),
                             "exp_avg_sq": torch.from_numpy(eng.export(n, 5))}
     group = {"lr": noam_lr(system.global_step, system.model.dims.d_model, system.train_config), "betas": tuple(o["betas"]), "eps": o["eps"],
@@ -129,10 +148,16 @@ def load_checkpoint(system, path: str, strict: bool = False):
                     continue
                 if not trainable:
                     raise ValueError(f"optimizer state for the frozen parameter {n}")
-                system.engine.import_state(n, 4, np.asarray(st["exp_avg"]))
-                system.engine.import_state(n, 5, np.asarray(st["exp_avg_sq"]))
+                if _enc_name(system, n):
+                    system.model.speaker_encoder.import_state(_enc_name(system, n), 2, np.asarray(st["exp_avg"]))
+                    system.model.speaker_encoder.import_state(_enc_name(system, n), 3, np.asarray(st["exp_avg_sq"]))
+                else:
+                    system.engine.import_state(n, 4, np.asarray(st["exp_avg"]))
+                    system.engine.import_state(n, 5, np.asarray(st["exp_avg_sq"]))
                 step = max(step, int(float(st["step"])))
             system.engine.set_optimizer_step(step)
+            if getattr(system.model, "speaker_encoder", None) is not None and getattr(system.model, "spk_mode", "dvec") != "dvec":
+                system.model.speaker_encoder.set_optimizer_step(step)
             system.adam_steps = step
         else:
             import warnings

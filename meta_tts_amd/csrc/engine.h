@@ -1630,11 +1630,20 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     }
 
     // clip_grad_norm_(max_norm) + Adam on theta from `g` (device, n_total floats; usually outer[])
+    const float* extra_sumsq = nullptr;   // device scalar added to the squared gradient norm before the clip (see sumsq_final_kernel)
+    // gradient of the last backward's loss w.r.t. the per-utterance speaker vectors of `task` ([B][d_model]): what a speaker
+    // encoder in front of the model back-propagates (speaker_emb: encoder / scratch_encoder)
+    int get_speaker_grad(int task, int B, float* out_host) {
+        if (task < 0 || task >= cap_tasks || B < 1 || B > cap_B || !out_host) { set_error("bad arguments"); return -1; }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipMemcpy(out_host, dspk.p + (long long)task * dspk.ts, (size_t)B * cfg.d_model * sizeof(float), hipMemcpyDeviceToHost));
+        return 0;
+    }
     int outer_update(const float* g, float lr, float b1, float b2, float eps, float weight_decay, float max_norm,
                      float* norm_out_host) {
         const int nb = 512;
         MTTS_LAUNCH(sumsq_partial_kernel, dim3(nb), dim3(256), stream, g, n_total / 4, norm_partial);
-        MTTS_LAUNCH(sumsq_final_kernel, dim3(1), dim3(64), stream, (const float*)norm_partial, nb, norm_out);
+        MTTS_LAUNCH(sumsq_final_kernel, dim3(1), dim3(64), stream, (const float*)norm_partial, nb, norm_out, extra_sumsq);
         ++adam_step_count;
         const float bc1 = 1.f - (float)std::pow((double)b1, (double)adam_step_count);
         const float bc2 = 1.f - (float)std::pow((double)b2, (double)adam_step_count);

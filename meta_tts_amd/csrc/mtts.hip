@@ -329,6 +329,10 @@ int mtts_outer_update(mtts_handle* h, const float* grad_dev, float lr, float b1,
     return launched(h->eng, h->eng.outer_update(grad_dev ? grad_dev : h->eng.outer, lr, b1, b2, eps, wd, max_norm, norm_host));
 }
 
+int mtts_get_speaker_grad(mtts_handle* h, int task, int B, float* out) { return h->eng.get_speaker_grad(task, B, out); }
+int mtts_set_extra_grad_sumsq(mtts_handle* h, const float* sumsq_dev) { h->eng.extra_sumsq = sumsq_dev; return 0; }
+const float* mtts_grad_norm_dev(mtts_handle* h) { return h->eng.norm_out; }
+
 int mtts_reset_optimizer(mtts_handle* h) {
     Engine& e = h->eng;
     e.adam_step_count = 0;
@@ -459,6 +463,18 @@ int mtts_dvector_load(mtts_dvector* h, const char* name, const float* data, int6
 int mtts_dvector_embed(mtts_dvector* h, const float* mels, int n_partials, const int* utt_offsets, int n_utts, float* out, float* partial_out) {
     return h->d.embed(mels, n_partials, utt_offsets, n_utts, out, partial_out);
 }
+int mtts_dvector_enable_training(mtts_dvector* h) { return h->d.enable_training(); }
+int mtts_dvector_embed_train(mtts_dvector* h, const float* mels, int n_partials, const int* utt_offsets, int n_utts, float* out) {
+    return h->d.embed(mels, n_partials, utt_offsets, n_utts, out, nullptr, true);
+}
+int mtts_dvector_backward(mtts_dvector* h, const float* dout) { return h->d.backward(dout); }
+const float* mtts_dvector_grad_sumsq(mtts_dvector* h) { return h->d.train_ready ? h->d.grad_sumsq() : nullptr; }
+int mtts_dvector_adam_step(mtts_dvector* h, const float* norm_dev, float max_norm, float lr, float b1, float b2, float eps, float wd) {
+    return h->d.adam_step(norm_dev, max_norm, lr, b1, b2, eps, wd);
+}
+int mtts_dvector_set_optimizer_step(mtts_dvector* h, int step) { h->d.adam_steps = step; return 0; }
+int mtts_dvector_export(mtts_dvector* h, const char* name, int which, float* out, int64_t numel) { return h->d.export_state(name, which, out, numel); }
+int mtts_dvector_import(mtts_dvector* h, const char* name, int which, const float* data, int64_t numel) { return h->d.import_state(name, which, data, numel); }
 
 // ---- waveform -> log-mel + energy (melfront.h; reference audio/stft.py:128-178, audio/tools.py:8-15) ----------------------
 int mtts_stft_create(int filter_length, int hop_length, int n_mel, int max_samples, int device, mtts_stft** out) {

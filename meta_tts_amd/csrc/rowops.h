@@ -975,9 +975,11 @@ __global__ void sumsq_partial_kernel(const float* g, long long n4, float* partia
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void sumsq_final_kernel(const float* partial, int n, float* out_norm) {
+// extra (optional): a device scalar holding the squared gradient norm of parameters that live outside this buffer (a co-trained
+// speaker encoder) — clip_grad_norm_ takes the norm over ALL parameters of the model (main.py:61)
+__global__ void sumsq_final_kernel(const float* partial, int n, float* out_norm, const float* extra) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
+        double s = extra ? (double)extra[0] : 0.0;
         for (int i = 0; i < n; ++i) s += (double)partial[i];
         out_norm[0] = (float)sqrt(s);
     }

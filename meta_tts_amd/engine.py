@@ -172,6 +172,27 @@ class Engine:
         return pb, eb
 
     # ---- batches -----------------------------------------------------------------
+    @staticmethod
+    def _is_ref_mel_args(sa):
+        return isinstance(sa, (tuple, list)) and len(sa) == 2 and isinstance(sa[1], (tuple, list))
+
+    def _has_speaker_embeddings(self, b):
+        sa = b[2]
+        if self._is_ref_mel_args(sa):
+            return True
+        if hasattr(sa, "detach"):
+            sa = sa.detach().cpu().numpy()
+        return np.ndim(sa) == 2 and np.asarray(sa).dtype.kind == "f"
+
+    def _embed_speaker_args(self, sa):
+        if self._is_ref_mel_args(sa):
+            if self.speaker_encoder is None:
+                raise MttsError("batch carries (ref_mels, ref_slices) speaker args but no speaker encoder is attached (Engine.speaker_encoder)")
+            return np.asarray(self.speaker_encoder(sa), np.float32)
+        if hasattr(sa, "detach"):
+            sa = sa.detach().cpu().numpy()
+        return np.asarray(sa, np.float32)
+
     def _cbatch(self, b, keep):
         """12-tuple (collate.py:47-60) of numpy arrays / torch CPU tensors -> mtts_batch.  A tuple whose
         mels / durations are None (or that stops after max_src_len, i.e. ``batch[:6]``) is a free-running batch."""
@@ -224,6 +245,20 @@ class Engine:
                     average_spk: bool = False):
         keep: List = []
         n = len(batches)
+        if self._has_speaker_embeddings(batches[0]) or (spk_from is not None and self._has_speaker_embeddings(spk_from[0])):
+            # embedded speaker args (speaker_emb: dvec / encoder): `spk_from` + `average_spk` (forward_learner's average_spk_emb,
+            # base_adaptor.py:64-67) are resolved here — embed the source batch, average, expand to this batch's size
+            new = []
+            for i, b in enumerate(batches):
+                src = spk_from[i] if spk_from is not None else b
+                emb = self._embed_speaker_args(src[2])
+                B = int(np.shape(b[3])[0])
+                if average_spk:
+                    emb = np.repeat(emb.mean(axis=0, keepdims=True), B, axis=0)
+                if emb.shape[0] != B:
+                    raise MttsError("speaker embedding count != batch size")
+                new.append(tuple(b[:2]) + (np.ascontiguousarray(emb, np.float32),) + tuple(b[3:]))
+            batches, spk_from, average_spk = new, None, False
         arr = (_lib.Batch * n)(*[self._cbatch(b, keep) for b in batches])
         sarr = None
         if spk_from is not None:
@@ -357,6 +392,18 @@ class Engine:
         self._ck(self.lib.mtts_outer_update(self.h, C.c_void_p(grad_ptr) if grad_ptr else None, lr, betas[0], betas[1], eps,
                                             weight_decay, max_norm, C.byref(norm) if fetch_norm else None))
         return float(norm.value) if fetch_norm else None
+
+    # hooks for a module trained in front of the engine (the LSTM speaker encoder)
+    def speaker_grad(self, task: int, B: int) -> np.ndarray:
+        out = np.empty((B, self.dims.d_model), np.float32)
+        self._ck(self.lib.mtts_get_speaker_grad(self.h, task, B, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_extra_grad_sumsq(self, dev_ptr):
+        self._ck(self.lib.mtts_set_extra_grad_sumsq(self.h, C.c_void_p(dev_ptr) if dev_ptr else None))
+
+    def grad_norm_ptr(self):
+        return C.c_void_p(self.lib.mtts_grad_norm_dev(self.h))
 
     def reset_optimizer(self):
         self._ck(self.lib.mtts_reset_optimizer(self.h))

@@ -50,13 +50,15 @@ class FastSpeech2:
     def __init__(self, preprocess_config, model_config, algorithm_config, *, max_tasks: int = 1, max_batch: int = 16,
                  max_src_len: int = 128, max_mel_len: Optional[int] = None, device: int = 0, lib_path: Optional[str] = None):
         spk_mode = algorithm_config["adapt"]["speaker_emb"]
-        if spk_mode not in ("table", "shared", "dvec"):
-            raise MttsError("adapt.speaker_emb must be 'table', 'shared' or 'dvec' (the trained speaker encoders 'encoder' / 'scratch_encoder' "
-                            "of speaker_encoder.py:54-60 need the LSTM backward, which is not built; SURVEY.md section 8(f) row 4)")
+        if spk_mode not in ("table", "shared", "dvec", "encoder", "scratch_encoder"):
+            raise MttsError("adapt.speaker_emb must be one of table / shared / dvec / encoder / scratch_encoder (speaker_encoder.py:45-60)")
+        if spk_mode in ("encoder", "scratch_encoder") and algorithm_config.get("type", "baseline") != "baseline":
+            raise MttsError("a trained speaker encoder (speaker_emb: encoder / scratch_encoder) is only supported by the baseline system, as in "
+                            "config/algorithm/{encoder,scratch_encoder}.yaml: the MAML passes have no tangent / inner-loop path through the LSTM")
         if algorithm_config["adapt"]["type"] != "spk":
             raise MttsError("adapt.type == 'lang' (codebook phoneme embedding) is out of scope (SURVEY.md #8)")
         stats, n_spk = _read_preprocessed(preprocess_config)
-        if spk_mode in ("shared", "dvec"):
+        if spk_mode in ("shared", "dvec", "encoder", "scratch_encoder"):
             n_spk = 1   # shared: nn.Embedding(1, d), one vector for every speaker (speaker_encoder.py:52-53); dvec: no table at all (the
                         # engine's one-row table is an unused placeholder, the embeddings come with the batch)
         self.spk_mode = spk_mode
@@ -67,7 +69,8 @@ class FastSpeech2:
                              max_S=max_src_len, max_T=max_mel_len or self.dims.max_seq_len, device=device, lib_path=lib_path,
                              shared_speaker=(spk_mode == "shared"))
         self.speaker_encoder = None
-        if spk_mode == "dvec":   # frozen d-vector encoder in front of the acoustic model (speaker_encoder.py:56-58,71-76)
+        if spk_mode in ("dvec", "encoder", "scratch_encoder"):   # LSTM speaker encoder in front of the acoustic model (speaker_encoder.py:54-60,
+            # 71-76): frozen for dvec (`self.freeze()`), trained with the model for encoder (pretrained init) / scratch_encoder
             from .speaker_encoder import DVectorEncoder
             # the reference's encoder is fixed at 40 mels / 3 x 256 / 160-frame partials and emits encoder_hidden = 256 values; the optional
             # `adapt.dvector` block (not a reference key) only exists so that tests can run a small one
@@ -75,12 +78,16 @@ class FastSpeech2:
             self.speaker_encoder = DVectorEncoder(max_partials=max(256, 16 * max_batch), max_utts=max_batch, emb=self.dims.d_model, device=device,
                                                   lib_path=lib_path, **kw)
             self.engine.speaker_encoder = self.speaker_encoder
+            if spk_mode != "dvec":
+                self.speaker_encoder.enable_training()
         self.training = True
-        self.load_state_dict(synth.make_params(self.dims, seed=0), strict=spk_mode != "dvec")
+        self.load_state_dict(synth.make_params(self.dims, seed=0), strict=self.speaker_encoder is None)
 
     # -- nn.Module-like surface ---------------------------------------------------------
     def train(self, mode: bool = True):
         self.training = mode
+        if self.speaker_encoder is not None and self.spk_mode != "dvec":
+            self.speaker_encoder.training = bool(mode)   # keep the BPTT state only for training forwards
         return self
 
     def eval(self):

@@ -108,4 +108,52 @@ class DVectorEncoder:
 
     def __call__(self, args):
         ref_mels, ref_slices = args
-        return self.embed(ref_mels, ref_slices)
+        return self.embed_train(ref_mels, ref_slices) if self.training else self.embed(ref_mels, ref_slices)
+
+    # ---- trained variants: speaker_emb: encoder / scratch_encoder (speaker_encoder.py:54-55,59-60) -------------------------------
+    training = False   # True: __call__ keeps the state the backward sweep needs
+
+    def enable_training(self):
+        self._check(self.lib.mtts_dvector_enable_training(self.h))
+        self.training = True
+
+    def _offsets(self, ref_mels, ref_slices):
+        ref_mels = np.ascontiguousarray(np.asarray(ref_mels.detach().cpu().numpy() if hasattr(ref_mels, "detach") else ref_mels, np.float32))
+        off = np.asarray([0] + [sl.stop for sl in ref_slices], np.int32)
+        assert all((sl.start or 0) == off[i] for i, sl in enumerate(ref_slices)) and off[-1] == ref_mels.shape[0]
+        return ref_mels, off
+
+    def embed_train(self, ref_mels, ref_slices):
+        ref_mels, off = self._offsets(ref_mels, ref_slices)
+        out = np.empty((len(ref_slices), self.cfg["emb"]), np.float32)
+        self._check(self.lib.mtts_dvector_embed_train(self.h, ref_mels.ctypes.data_as(C.c_void_p), ref_mels.shape[0], off.ctypes.data_as(C.c_void_p),
+                                                      len(ref_slices), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def backward(self, dout):
+        """dout (B, emb): dLoss/d(embeddings of the last embed_train) -> parameter gradients (`export(name, 1)`)."""
+        d = np.ascontiguousarray(np.asarray(dout, np.float32))
+        self._check(self.lib.mtts_dvector_backward(self.h, d.ctypes.data_as(C.c_void_p)))
+
+    def export(self, name, which=0):
+        out = np.empty(tensor_shapes(**self.cfg)[name], np.float32)
+        self._check(self.lib.mtts_dvector_export(self.h, name.encode(), which, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def import_state(self, name, which, value):
+        a = np.ascontiguousarray(np.asarray(value, np.float32))
+        self._check(self.lib.mtts_dvector_import(self.h, name.encode(), which, a.ctypes.data_as(C.c_void_p), a.size))
+        if which == 0:
+            self.state[name] = a.reshape(tensor_shapes(**self.cfg)[name]).copy()
+
+    def grad_sumsq_ptr(self):
+        """Device address of sum(grad^2) — the encoder's term of the joint clip_grad_norm_ (main.py:61)."""
+        return self.lib.mtts_dvector_grad_sumsq(self.h)
+
+    def adam_step(self, norm_dev, max_norm, lr, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.0):
+        self._check(self.lib.mtts_dvector_adam_step(self.h, norm_dev, float(max_norm), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                                    float(weight_decay)))
+        self.state = {n: self.export(n, 0) for n in tensor_shapes(**self.cfg)}
+
+    def set_optimizer_step(self, step):
+        self._check(self.lib.mtts_dvector_set_optimizer_step(self.h, int(step)))

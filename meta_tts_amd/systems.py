@@ -57,8 +57,18 @@ class System:
 
     def training_step(self, batch, batch_idx):
         """system.py:58-64 / baseline.py:25-36 — plain multi-task gradient of one batch."""
+        enc = self._trained_speaker_encoder()
+        if enc is not None:
+            self.model.train(True)
         losses = self.engine_plain_grad([batch])
+        if enc is not None:   # back-propagate dLoss/d(speaker embedding) through the LSTM encoder (autograd does this in the reference)
+            assert self.world_size == 1, "a trained speaker encoder is single-rank here (its gradients are not all-reduced)"
+            enc.backward(self.engine.speaker_grad(0, int(np.shape(batch[3])[0])))
         return {"loss": losses[0][0], "losses": losses[0], "_batch": batch}
+
+    def _trained_speaker_encoder(self):
+        enc = getattr(self.model, "speaker_encoder", None)
+        return enc if enc is not None and getattr(self.model, "spk_mode", "") in ("encoder", "scratch_encoder") else None
 
     def engine_plain_grad(self, batches: Sequence[tuple], total_batches: Optional[int] = None):
         self.engine.set_batches(0, list(batches))
@@ -68,8 +78,14 @@ class System:
     def optimizer_step(self, grad_ptr: Optional[int] = None):
         o = self.train_config["optimizer"]
         lr = noam_lr(self.global_step, self.model.dims.d_model, self.train_config)
+        enc = self._trained_speaker_encoder()
+        if enc is not None:   # clip_grad_norm_ over ALL parameters (main.py:61): the encoder's sum of squares joins the engine's norm
+            self.engine.set_extra_grad_sumsq(enc.grad_sumsq_ptr())
         self.engine.outer_update(lr=lr, betas=tuple(o["betas"]), eps=o["eps"], weight_decay=o["weight_decay"],
                                  max_norm=o["grad_clip_thresh"], grad_ptr=grad_ptr)
+        if enc is not None:
+            enc.adam_step(self.engine.grad_norm_ptr(), o["grad_clip_thresh"], lr, betas=tuple(o["betas"]), eps=o["eps"], weight_decay=o["weight_decay"])
+            self.engine.set_extra_grad_sumsq(None)
         self.global_step += 1
         self.adam_steps += 1
         return lr

@@ -60,3 +60,63 @@ def test_state_dict_names_and_errors():
 def test_dvector_gpu_reference_shapes():
     ge.build_device()
     _run(None, dict(n_mels=40, hidden=256, emb=256, layers=3), frames=160, seed=11, n_utts=5)
+
+
+def _train_case(lib_path, cfg, frames, seed, n_utts, tol):
+    """Back-propagation through time of the trained variants (speaker_emb: encoder / scratch_encoder) against torch autograd of the
+    oracle (nn.LSTM + nn.Linear), then one joint-norm-clipped Adam step against torch.optim.Adam."""
+    import ctypes as C
+    import torch
+    sd = se.synthetic_state_dict(seed, **cfg)
+    enc = se.DVectorEncoder(sd, max_partials=64, max_utts=16, frames=frames, lib_path=lib_path, **cfg)
+    enc.enable_training()
+    mels, slices = _case(seed + 1, n_utts, frames, cfg)
+    g = np.random.RandomState(seed + 2)
+    dout = g.standard_normal((n_utts, cfg["emb"])).astype(np.float32)
+    out = enc((mels, slices))                                   # training forward
+    enc.backward(dout)
+    lstm, linear = orc.build(sd, **cfg)
+    _, (hidden, _) = lstm(torch.from_numpy(mels))
+    raw = torch.relu(linear(hidden[-1]))
+    pe = raw / torch.norm(raw, dim=1, keepdim=True)
+    emb = torch.stack([torch.nn.functional.normalize(pe[sl].mean(dim=0), dim=0) for sl in slices])
+    np.testing.assert_allclose(out, emb.detach().numpy(), rtol=2e-4, atol=2e-5)
+    (emb * torch.from_numpy(dout)).sum().backward()
+    ref = {f"lstm.{n}": p.grad.numpy() for n, p in lstm.named_parameters()}
+    ref.update({f"linear.{n}": p.grad.numpy() for n, p in linear.named_parameters()})
+    for name, r in ref.items():
+        got = enc.export(name, 1)
+        assert np.abs(got - r).max() <= tol * np.abs(r).max() + 1e-7, (name, np.abs(got - r).max(), np.abs(r).max())
+    # Adam with the clip coefficient of a joint norm (here: the encoder alone, handed over as a device scalar)
+    total = float(np.sqrt(sum((r.astype(np.float64) ** 2).sum() for r in ref.values())))
+    max_norm = 0.5 * total
+    lib = enc.lib
+    norm = np.array([total], np.float32)
+    if lib_path is None:
+        tn = torch.from_numpy(norm).cuda()
+        ptr = C.c_void_p(tn.data_ptr())
+    else:
+        ptr = norm.ctypes.data_as(C.c_void_p)
+    enc.adam_step(ptr, max_norm, 1e-2)
+    params = list(lstm.parameters()) + list(linear.parameters())
+    torch.nn.utils.clip_grad_norm_(params, max_norm)
+    opt = torch.optim.Adam(params, lr=1e-2, betas=(0.9, 0.98), eps=1e-9)
+    opt.step()
+    for (n, p) in list(lstm.named_parameters()):
+        np.testing.assert_allclose(enc.export(f"lstm.{n}"), p.detach().numpy(), rtol=1e-4, atol=5e-5, err_msg=n)   # step size 1e-2; entries whose gradient is of the order of eps = 1e-9 move by a gradient-noise-dependent fraction of it
+    np.testing.assert_allclose(enc.export("linear.weight"), linear.weight.detach().numpy(), rtol=1e-4, atol=5e-5)
+    # the updated weights are the ones the next forward uses
+    out2 = enc.embed(mels, slices)
+    ref2 = orc.speaker_embeds({k: enc.export(k) for k in sd}, mels, slices, **cfg).numpy()
+    np.testing.assert_allclose(out2, ref2, rtol=2e-4, atol=2e-5)
+    enc.close()
+
+
+def test_dvector_training_emulator_small():
+    _train_case(ge.build_emulator(), dict(n_mels=8, hidden=64, emb=64, layers=2), frames=7, seed=4, n_utts=3, tol=2e-4)
+
+
+@pytest.mark.gpu
+def test_dvector_training_gpu_reference_shapes():
+    ge.build_device()
+    _train_case(None, dict(n_mels=40, hidden=256, emb=256, layers=3), frames=160, seed=12, n_utts=4, tol=2e-3)

@@ -478,7 +478,7 @@ def test_shared_speaker_embedding_mode(cfgs, emu_lib):
     g = torch.autograd.grad(ql[0], prm["speaker_emb.model.weight"])[0].numpy()
     got = sysm.engine.export("speaker_emb.model.weight", 1)
     assert got.shape == (1, dims.d_model) and np.abs(got - g).max() <= 2e-3 * np.abs(g).max()
-    alg["adapt"]["speaker_emb"] = "encoder"     # the trained speaker encoders need the LSTM backward: rejected
+    alg["adapt"]["speaker_emb"] = "ge2e"     # not one of the reference's modes
     with pytest.raises(Exception, match="speaker_emb"):
         _system((pre, mod, trn, alg), emu_lib)
 
@@ -520,7 +520,121 @@ def test_dvec_speaker_mode_baseline_system(cfgs, emu_lib):
     # a checkpoint round trip keeps the encoder's tensors under the reference's names
     sysm.model.load_state_dict(sd)
     np.testing.assert_array_equal(sysm.model.state_dict()["speaker_emb.model.linear.bias"], sd["speaker_emb.model.linear.bias"])
-    # the trained encoders are not built
+
+
+def test_trained_speaker_encoder_baseline_step_and_checkpoint(cfgs, emu_lib, tmp_path):
+    """config/algorithm/scratch_encoder.yaml (`type: baseline`, `speaker_emb: scratch_encoder`): the LSTM speaker encoder is trained
+    with the acoustic model — one training step + optimizer step against torch (oracle forward, autograd through nn.LSTM, joint
+    clip_grad_norm_, Adam), then the checkpoint keeps the encoder's Adam moments at torch's parameter positions."""
+    from oracle import dvector_oracle as dvo
+    from meta_tts_amd.checkpoint import load_checkpoint, save_checkpoint
+    pre, mod, trn, alg = cfgs
+    alg["type"] = "baseline"
     alg["adapt"]["speaker_emb"] = "scratch_encoder"
-    with pytest.raises(Exception, match="speaker_emb"):
-        _system((pre, mod, trn, alg), emu_lib, kind="baseline")
+    alg["adapt"]["modules"] = []
+    dv = dict(n_mels=8, hidden=64, layers=2, frames=6)
+    alg["adapt"]["dvector"] = dv
+    sysm = _system((pre, mod, trn, alg), emu_lib, kind="baseline")
+    dims = sysm.model.dims
+    kw = dict(n_mels=8, hidden=64, emb=dims.d_model, layers=2)
+    sd0 = sysm.model.state_dict()
+    enc_sd = {k[len("speaker_emb.model."):]: v.copy() for k, v in sd0.items() if k.startswith("speaker_emb.model.")}
+    b = list(synth.make_batch(8, 3, speaker=1, vocab=dims.vocab, **_kw(dims.n_mel)))
+    g = np.random.RandomState(3)
+    counts = [1, 3, 2]
+    ref_mels = g.standard_normal((sum(counts), dv["frames"], dv["n_mels"])).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(counts)])
+    slices = [slice(int(off[i]), int(off[i + 1])) for i in range(3)]
+    b[2] = (ref_mels, slices)
+    out = sysm.training_step(tuple(b), 0)
+    # torch side: encoder (autograd) -> embeddings as the "table" rows of the oracle model -> loss
+    lstm, linear = dvo.build(enc_sd, **kw)
+    _, (hidden, _) = lstm(torch.from_numpy(ref_mels))
+    raw = torch.relu(linear(hidden[-1]))
+    pe = raw / torch.norm(raw, dim=1, keepdim=True)
+    emb = torch.stack([torch.nn.functional.normalize(pe[sl].mean(dim=0), dim=0) for sl in slices])
+    prm = {k: torch.from_numpy(v.copy()) for k, v in synth.make_params(dims, 0).items()}
+    names = [k for k in prm if not k.endswith(("position_enc", "pitch_bins", "energy_bins")) and k != "speaker_emb.model.weight"]
+    for k in names:
+        prm[k].requires_grad_(True)
+    prm["speaker_emb.model.weight"] = emb
+    tb = list(O.to_torch_batch(tuple(b[:2]) + (np.arange(3),) + tuple(b[3:])))
+    lo = O.fs2_loss(tuple(tb), O.fs2_forward(prm, torch_buffers(dims), *tb[2:], n_head=heads(dims), max_seq_len=dims.max_seq_len, training=True))
+    assert abs(out["loss"] - float(lo[0])) < 1e-4
+    enc_params = list(lstm.parameters()) + list(linear.parameters())
+    lo[0].backward()
+    enc = sysm.model.speaker_encoder
+    for (n, p) in [(f"lstm.{n}", p) for n, p in lstm.named_parameters()] + [(f"linear.{n}", p) for n, p in linear.named_parameters()]:
+        r = p.grad.numpy()
+        assert np.abs(enc.export(n, 1) - r).max() <= 2e-3 * np.abs(r).max() + 1e-8, n
+    # joint clip + Adam
+    allp = [prm[k] for k in names] + enc_params
+    total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in allp if p.grad is not None)))
+    o = trn["optimizer"]
+    lr = sysm.optimizer_step()
+    torch.nn.utils.clip_grad_norm_([p for p in allp if p.grad is not None], o["grad_clip_thresh"])
+    opt = torch.optim.Adam([p for p in allp if p.grad is not None], lr=lr, betas=tuple(o["betas"]), eps=o["eps"], weight_decay=o["weight_decay"])
+    opt.step()
+    assert total > o["grad_clip_thresh"]          # the clip is active: the coefficient depends on BOTH parameter sets
+    # first Adam step = lr * sign(g) for |g| >> eps: compare where the clipped gradient is well above eps
+    w_new, w_ref, gr = enc.export("linear.weight"), linear.weight.detach().numpy(), linear.weight.grad.numpy()
+    big = np.abs(gr) > 1e-6
+    np.testing.assert_allclose(w_new[big], w_ref[big], rtol=0, atol=2e-3 * lr + 1e-7)
+    m_new, m_ref = sysm.engine.export("mel_linear.weight"), prm["mel_linear.weight"].detach().numpy()
+    bigm = np.abs(prm["mel_linear.weight"].grad.numpy()) > 1e-6
+    np.testing.assert_allclose(m_new[bigm], m_ref[bigm], rtol=0, atol=2e-3 * lr + 1e-7)
+    # the Adam moment of the encoder equals (1 - beta1) * clipped gradient
+    coef = min(1.0, o["grad_clip_thresh"] / (total + 1e-6))
+    np.testing.assert_allclose(enc.export("linear.weight", 2), (1 - o["betas"][0]) * coef * enc.export("linear.weight", 1), rtol=1e-4, atol=1e-9)
+    # checkpoint: the encoder's tensors replace the table in the parameter order, its moments sit at their torch positions
+    path = str(tmp_path / "enc.ckpt")
+    save_checkpoint(sysm, path)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    n_params = len(ck["optimizer_states"][0]["param_groups"][0]["params"])
+    st = ck["optimizer_states"][0]["state"]
+    assert "model.speaker_emb.model.lstm.weight_ih_l0" in ck["state_dict"] and "model.speaker_emb.model.weight" not in ck["state_dict"]
+    np.testing.assert_allclose(st[n_params - 1]["exp_avg"].numpy(), enc.export("linear.bias", 2))      # linear.bias is the last parameter
+    np.testing.assert_allclose(st[n_params - 2]["exp_avg_sq"].numpy(), enc.export("linear.weight", 3))
+    sys2 = _system((pre, mod, trn, alg), emu_lib, kind="baseline")
+    load_checkpoint(sys2, path)
+    np.testing.assert_array_equal(sys2.model.speaker_encoder.export("lstm.weight_hh_l1"), enc.export("lstm.weight_hh_l1"))
+    np.testing.assert_array_equal(sys2.model.speaker_encoder.export("lstm.weight_hh_l1", 3), enc.export("lstm.weight_hh_l1", 3))
+    assert sys2.adam_steps == 1
+    # a MAML system cannot train the encoder
+    alg["type"] = "meta"
+    with pytest.raises(Exception, match="baseline"):
+        _system((pre, mod, trn, alg), emu_lib, kind="meta")
+
+
+def test_dvec_few_shot_test_step_averages_support_embeddings(cfgs, emu_lib):
+    """base_adaptor.py:64-67 with an encoder speaker mode: the query pass of `_test_step` uses the MEAN of the support utterances'
+    d-vectors (speaker_args of the support batch, average_spk_emb=True), expanded to the query batch."""
+    from oracle import dvector_oracle as dvo
+    pre, mod, trn, alg = cfgs
+    alg["type"] = "baseline"
+    alg["adapt"]["speaker_emb"] = "dvec"
+    alg["adapt"]["modules"] = []
+    alg["adapt"]["test"]["steps"] = 0
+    dv = dict(n_mels=8, hidden=64, layers=2, frames=6)
+    alg["adapt"]["dvector"] = dv
+    sysm = _system((pre, mod, trn, alg), emu_lib, kind="baseline")
+    dims = sysm.model.dims
+    g = np.random.RandomState(9)
+
+    def with_refs(b, counts):
+        mels = g.standard_normal((sum(counts), dv["frames"], dv["n_mels"])).astype(np.float32)
+        off = np.concatenate([[0], np.cumsum(counts)])
+        return tuple(b[:2]) + ((mels, [slice(int(off[i]), int(off[i + 1])) for i in range(len(counts))]),) + tuple(b[3:])
+    sup = with_refs(synth.make_batch(5, 3, speaker=1, vocab=dims.vocab, **_kw(dims.n_mel)), [2, 1, 2])
+    qry = with_refs(synth.make_batch(6, 2, speaker=1, vocab=dims.vocab, **_kw(dims.n_mel)), [1, 1])
+    outs = sysm.test_step([((sup,), (qry,))], 0)
+    got = float(outs[0]["step_0"]["recon"]["losses"][0])
+    sd = sysm.model.state_dict()
+    enc_sd = {k[len("speaker_emb.model."):]: v for k, v in sd.items() if k.startswith("speaker_emb.model.")}
+    emb = dvo.speaker_embeds(enc_sd, sup[2][0], sup[2][1], n_mels=8, hidden=64, emb=dims.d_model, layers=2).mean(dim=0, keepdim=True).expand(2, -1)
+    prm = {k: torch.from_numpy(v.copy()) for k, v in synth.make_params(dims, 0).items()}
+    prm["speaker_emb.model.weight"] = emb
+    tb = list(O.to_torch_batch(tuple(qry[:2]) + (np.arange(2),) + tuple(qry[3:])))
+    with torch.no_grad():
+        lo = O.fs2_loss(tuple(tb), O.fs2_forward(prm, torch_buffers(dims), *tb[2:], n_head=heads(dims), max_seq_len=dims.max_seq_len, training=False))
+    assert abs(got - float(lo[0])) < 2e-4 * max(1.0, abs(float(lo[0])))
