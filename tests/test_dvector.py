@@ -102,9 +102,12 @@ def _train_case(lib_path, cfg, frames, seed, n_utts, tol):
     torch.nn.utils.clip_grad_norm_(params, max_norm)
     opt = torch.optim.Adam(params, lr=1e-2, betas=(0.9, 0.98), eps=1e-9)
     opt.step()
-    for (n, p) in list(lstm.named_parameters()):
-        np.testing.assert_allclose(enc.export(f"lstm.{n}"), p.detach().numpy(), rtol=1e-4, atol=5e-5, err_msg=n)   # step size 1e-2; entries whose gradient is of the order of eps = 1e-9 move by a gradient-noise-dependent fraction of it
-    np.testing.assert_allclose(enc.export("linear.weight"), linear.weight.detach().numpy(), rtol=1e-4, atol=5e-5)
+    # first Adam step: w -= lr * g / (|g| + eps) — entries whose (clipped) gradient is of the order of eps = 1e-9 move by a
+    # rounding-dependent fraction of the step, so compare where |g| >> eps
+    for n, p in [(f"lstm.{n}", p) for n, p in lstm.named_parameters()] + [("linear.weight", linear.weight)]:
+        live = np.abs(p.grad.numpy()) > 1e-6
+        assert live.mean() > 0.2      # rows of dead ReLU units have no gradient at all
+        np.testing.assert_allclose(enc.export(n)[live], p.detach().numpy()[live], rtol=1e-4, atol=5e-6, err_msg=n)
     # the updated weights are the ones the next forward uses
     out2 = enc.embed(mels, slices)
     ref2 = orc.speaker_embeds({k: enc.export(k) for k in sd}, mels, slices, **cfg).numpy()
