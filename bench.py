@@ -191,6 +191,48 @@ def inference_leg(dims, mods, device, iters=5):
     return res
 
 
+def frontend_leg(device, iters=10):
+    """The two components in front of the acoustic model: the d-vector speaker encoder (speaker_emb: dvec; the reference runs it on
+    the CPU before every forward) on 5 utterances x 6 partial utterances of 160 x 40 mels, and the waveform -> log-mel + energy
+    front-end on 10 s of 22.05 kHz audio (filter 1024 / hop 256 / 80 mels).  Host buffers in, host buffers out (PCIe inside)."""
+    import torch
+    from meta_tts_amd.audio import stft as S
+    from meta_tts_amd.speaker_encoder import DVectorEncoder
+    g = np.random.RandomState(0)
+    res = {}
+    enc = DVectorEncoder(max_partials=64, max_utts=8, device=device)
+    mels = g.standard_normal((30, 160, 40)).astype(np.float32)
+    slices = [slice(6 * i, 6 * i + 6) for i in range(5)]
+    enc.embed(mels, slices)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(iters):
+        enc.embed(mels, slices)
+    dt = (time.perf_counter() - t0) / iters
+    flop = 30 * 160 * 2.0 * (4 * 256 * (40 + 256) + 2 * 4 * 256 * (256 + 256))
+    res["dvector_5utt_30partials"] = {"ms_per_call": round(1e3 * dt, 3), "partials_per_sec": round(30 / dt, 1), "gflop": round(flop * 1e-9, 2)}
+    enc.enable_training()
+    dout = g.standard_normal((5, 256)).astype(np.float32)
+    enc.embed_train(mels, slices); enc.backward(dout)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(iters):
+        enc.embed_train(mels, slices); enc.backward(dout)
+    torch.cuda.synchronize()
+    res["dvector_train_fwd_bwd"] = {"ms_per_call": round(1e3 * (time.perf_counter() - t0) / iters, 3)}
+    enc.close()
+    st = S.TacotronSTFT(1024, 256, 1024, 80, 22050, 0, None, max_samples=22050 * 11, device=device)
+    wav = np.clip(0.3 * g.standard_normal((1, 22050 * 10)), -1, 1).astype(np.float32)
+    st.mel_spectrogram(wav)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        st.mel_spectrogram(wav)
+    dt = (time.perf_counter() - t0) / iters
+    T = wav.shape[1] // 256 + 1
+    res["mel_frontend_10s_audio"] = {"ms_per_call": round(1e3 * dt, 3), "audio_seconds_per_sec": round(10.0 / dt, 1), "frames": T,
+                                     "gflop": round(2.0 * T * (1026 * 1024 + 80 * 513) * 1e-9, 2)}
+    st.close()
+    return res
+
+
 def mel_l1_leg(dims, device):
     """The metric's third component: mel L1 of this path against the REFERENCE model's output on config C1 (one LibriTTS-shaped
     utterance, S = 80, T = 555), from the committed fixture tests/golden/c1_forward.npz (produced by importing the reference,
@@ -305,6 +347,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-inference", action="store_true")
+    ap.add_argument("--no-frontend", action="store_true", help="skip the d-vector encoder / mel front-end timing")
     ap.add_argument("--no-baseline-c2", action="store_true", help="skip the extra C2 (multi-task baseline, batch 16, fp32 + bf16x3) measurement")
     ap.add_argument("--order", type=int, default=1, choices=(1, 2),
                     help="MAML order of the timed meta-step: 1 = BASELINE config C3 (first-order), 2 = the reference's training mode / config C4")
@@ -502,6 +545,9 @@ def main():
     c2 = None
     if rank == 0 and n == 1 and not args.no_baseline_c2:
         c2 = baseline_c2_leg(dims, local_rank, noam_lr, trn)
+    front = None
+    if rank == 0 and n == 1 and not args.no_frontend and part == n:
+        front = frontend_leg(local_rank)
     if n > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -530,6 +576,8 @@ def main():
             line["inference_c5"] = infer
         if c2 is not None:
             line["baseline_c2"] = c2
+        if front is not None:
+            line["frontend"] = front
         if roof is not None:
             line["roofline"] = roof
         if hbm is not None:
