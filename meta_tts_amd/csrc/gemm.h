@@ -537,8 +537,16 @@ __device__ __forceinline__ void gemm_multi_locate(const GemmMulti& mp, int& p, i
     while (p + 1 < mp.n && lin >= mp.start[p + 1]) ++p;
     lin -= mp.start[p];
     const int total = mp.start[p + 1] - mp.start[p];
-    lin = xcd_group_remap(lin, total, mp.xcd_group[p]);
     const int tiles = total / mp.groups[p];
+    if (mp.xcd_group[p] < 0) {
+        // group-per-XCD order (8 | groups): workgroup slot lin belongs to group lin % groups, so the dispatcher's round-robin puts ALL
+        // tiles of a group (a task) on one XCD and the operand every tile of that task streams (the weight image of a dgrad) is fetched
+        // into one L2 instead of eight.  Unbalanced by the raggedness of the tasks.
+        z = lin % mp.groups[p];
+        bx = lin / mp.groups[p];
+        return;
+    }
+    lin = xcd_group_remap(lin, total, mp.xcd_group[p]);
     z = lin / tiles;
     bx = lin - z * tiles;
 }
@@ -845,6 +853,8 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
             } else S = 1;
         }
         mp.xcd_group[i] = gemm_xcd_swizzle() ? std::min(gemm_tiles_n(p.g, p.max_N, 64) * S, 64) : 0;
+        static const int task_xcd = [] { const char* e = getenv("MTTS_XCD_TASK"); return e ? atoi(e) : 0; }();   // experiment: 1 = NN problems, 2 = all
+        if (task_xcd && !p.g.table && p.groups % 8 == 0 && (mp.start[i] & 7) == 0 && (task_xcd >= 2 || p.form == GEMM_NN)) mp.xcd_group[i] = -1;
         mp.start[i + 1] = mp.start[i] + tiles * S * p.groups;
         max_groups = std::max(max_groups, p.groups);
         flops += p.flops; rows += p.rows; bytes += p.bytes;
