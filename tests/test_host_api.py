@@ -22,6 +22,10 @@ def emu_lib():
 
 @pytest.fixture()
 def cfgs(tmp_path):
+    return make_cfgs(tmp_path)
+
+
+def make_cfgs(tmp_path):
     dims = tiny_dims()
     pre = dims.preprocess_config
     pre["path"] = {"preprocessed_path": str(tmp_path)}
