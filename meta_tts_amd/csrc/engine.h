@@ -1184,6 +1184,32 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                     (const float*)b.n2.p, b.n2.ts, (const float*)w.p, (const float*)bb.p, w.ts, valid_mask(p, s),
                     row_ts(s), b.out.p, b.out.ts, f);
     }
+    // The three predictors of a teacher-forced pass are independent (their inputs come from the TARGET embeddings): run them stage by
+    // stage so that the three conv1 (then the three conv2) GEMMs — 28 workgroups each on a single-task rank — go out as ONE
+    // multi-problem launch each.  Same arithmetic and dropout sites as three pred_fwd calls.
+    void pred_fwd3(const Pass& ps, const PredP* const P[3], PredBuf* const b[3], const TS xin[3], const int sites[3]) {
+        const Plan& p = *ps.pl;
+        const int d = cfg.d_model, f = cfg.vp_filter, k = cfg.vp_kernel;
+        const unsigned char* im = inrect_mask(p, SP_P);
+        TS none{nullptr, 0};
+        {
+            GemmBatchScope batch(gx, stream);
+            for (int i = 0; i < 3; ++i) conv_fwd(ps, SP_P, xin[i], d, k, W(ps, P[i]->c1w), W(ps, P[i]->c1b), f, b[i]->r1, GEMM_RELU, im);
+        }
+        for (int i = 0; i < 3; ++i)
+            ln_fwd(ps, SP_P, b[i]->r1, none, P[i]->l1g, P[i]->l1b, im, none, b[i]->n1, b[i]->st1, f, DropSpec(), drop_spec(ps, cfg.vp_dropout, sites[i]));
+        {
+            GemmBatchScope batch(gx, stream);
+            for (int i = 0; i < 3; ++i) conv_fwd(ps, SP_P, b[i]->n1, f, k, W(ps, P[i]->c2w), W(ps, P[i]->c2b), f, b[i]->r2, GEMM_RELU, im);
+        }
+        for (int i = 0; i < 3; ++i)
+            ln_fwd(ps, SP_P, b[i]->r2, none, P[i]->l2g, P[i]->l2b, im, none, b[i]->n2, b[i]->st2, f, DropSpec(), drop_spec(ps, cfg.vp_dropout, sites[i] + 1));
+        for (int i = 0; i < 3; ++i) {
+            TS w = W(ps, P[i]->lw), bb = W(ps, P[i]->lb);
+            MTTS_LAUNCH(rowdot_kernel, row_grid(p.maxMp, p.tasks), dim3(256), stream, (const int*)p.meta, (int)META_MP, (const float*)b[i]->n2.p,
+                        b[i]->n2.ts, (const float*)w.p, (const float*)bb.p, w.ts, valid_mask(p, SP_P), row_ts_p, b[i]->out.p, b[i]->out.ts, f);
+        }
+    }
     // dout: [Mp] gradient of the prediction (0 on masked rows); dx accumulates the input gradient
     void pred_bwd(const Pass& ps, const PredP& P, PredBuf& b, TS xin, TS dout, TS dx, Space s = SP_P) {
         const Plan& p = *ps.pl;
@@ -1249,10 +1275,27 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         // variance adaptor: targets select the embeddings when given, else the (controlled) predictions.  A phoneme-level feature
         // (modules.py:118-127) is handled on the phoneme rectangle before the length regulator, a frame-level one (:139-148) on the
         // frame rectangle after it.
-        site_base = 128; pred_fwd(ps, durP, durB, x0);
         TS pe = W(ps, pitch_emb), ee = W(ps, energy_emb);
         const bool tf = p.has_targets;
         TS xp = x0;
+        static const bool pred_batch = [] { const char* e = getenv("MTTS_PRED_BATCH"); return e ? atoi(e) != 0 : true; }();
+        if (tf && pred_batch && !any_frame_level()) {
+            // teacher-forced: both embeddings come from the targets, so x1 / x2 do not wait for a predictor — embed first, then the three
+            // predictors side by side
+            MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP, (const float*)x0.p, x0.ts,
+                        (const float*)p.p_pitch_t, row_ts_p, 1.f, (const float*)pitch_bins, cfg.n_bins - 1, (const float*)pe.p, pe.ts,
+                        (const unsigned char*)p.p_inrect, row_ts_p, pidx, x1.p, x1.ts, d);
+            MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP, (const float*)x1.p, x1.ts,
+                        (const float*)p.p_energy_t, row_ts_p, 1.f, (const float*)energy_bins, cfg.n_bins - 1, (const float*)ee.p, ee.ts,
+                        (const unsigned char*)p.p_inrect, row_ts_p, eidx, x2.p, x2.ts, d);
+            const PredP* const PP[3] = {&durP, &pitP, &eneP};
+            PredBuf* const BB[3] = {&durB, &pitB, &eneB};
+            const TS XX[3] = {x0, x0, x1};
+            const int SS[3] = {128, 132, 136};
+            pred_fwd3(ps, PP, BB, XX, SS);
+            xp = x2;
+        } else {
+        site_base = 128; pred_fwd(ps, durP, durB, x0);
         if (!cfg.pitch_frame) {
             site_base = 132; pred_fwd(ps, pitP, pitB, xp);
             MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
@@ -1268,6 +1311,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                         tf ? 1.f : ps.e_control, (const float*)energy_bins, cfg.n_bins - 1, (const float*)ee.p, ee.ts,
                         (const unsigned char*)p.p_inrect, row_ts_p, eidx, x2.p, x2.ts, d);
             xp = x2;
+        }
         }
         va_out = xp;  // what the length regulator expands (backward needs to know which buffer it was)
         if (!tf && frames_from_predictions_impl(ps)) return -1;
