@@ -1547,12 +1547,12 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             MTTS_LAUNCH(gather_rows_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (int)META_MR, (const float*)gF0.p,
                         gF0.ts, (const int*)p.r2f, row_ts_r, gRx.p, gRx.ts, d);          // dL/d(xr_last): 0 on padded frames
             if (cfg.energy_frame) {
-                MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MR,
+                MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(256), stream, (const int*)p.meta, (int)META_MR,
                             (const float*)gRx.p, gRx.ts, (const int*)eidx_r, row_ts_r, -1, Gd(energy_emb).p, n_total, d);
                 site_base = 136; pred_bwd(ps, eneP, eneR, cfg.pitch_frame ? xr1 : xr0, dpred_r[1], gRx, SP_R);
             }
             if (cfg.pitch_frame) {
-                MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MR,
+                MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(256), stream, (const int*)p.meta, (int)META_MR,
                             (const float*)gRx.p, gRx.ts, (const int*)pidx_r, row_ts_r, -1, Gd(pitch_emb).p, n_total, d);
                 site_base = 132; pred_bwd(ps, pitP, pitR, xr0, dpred_r[0], gRx, SP_R);
             }
@@ -1564,12 +1564,12 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                     gLR.ts, (const int*)p.p_first, (const int*)p.p_count, row_ts_p, gP0.p, gP0.ts, d, 0);
         // ---- phoneme-level half of the variance adaptor ---------------------------------------------------------------------
         if (!cfg.energy_frame) {
-            MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MP,
+            MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
                         (const float*)gP0.p, gP0.ts, (const int*)eidx, row_ts_p, -1, Gd(energy_emb).p, n_total, d);
             site_base = 136; pred_bwd(ps, eneP, eneB, cfg.pitch_frame ? x0 : x1, dpred[2], gP0);
         }
         if (!cfg.pitch_frame) {
-            MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MP,
+            MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
                         (const float*)gP0.p, gP0.ts, (const int*)pidx, row_ts_p, -1, Gd(pitch_emb).p, n_total, d);
             site_base = 132; pred_bwd(ps, pitP, pitB, x0, dpred[1], gP0);
         }
@@ -1590,7 +1590,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         // word embedding (padding row 0 keeps a zero gradient); p_tok is 0 on invalid rows, and
         // gP0 is only meaningful on valid rows -> scan with the token ids masked by validity
-        MTTS_LAUNCH(table_grad_kernel, dim3(cfg.vocab, 1, nt), dim3(64), stream, (const int*)p.meta, (int)META_MP,
+        MTTS_LAUNCH(table_grad_kernel, dim3(cfg.vocab, 1, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
                     (const float*)gP0.p, gP0.ts, (const int*)p.p_tok, row_ts_p, 0, Gd(word_emb).p, n_total, d);
         return 0;
     }

@@ -711,7 +711,9 @@ __global__ void table_grad_kernel(const int* meta, int mfield, const float* dx, 
     // 64 threads: the index list is matched 64 entries at a time (one compare per lane); the 64 match bits are gathered
     // with four exact 16-bit wavefront sums and the hits are then accumulated in ascending row order — the summation
     // order of a serial scan, with a loop per HIT instead of per entry
-    const int z = blockIdx.z, v = blockIdx.x, lane = (int)threadIdx.x;
+    // blockDim.x = 64 * W wavefronts: wavefront w takes every W-th block of 64 entries (the table row that collects the padded
+    // positions has ~100 hits per task and was the kernel's tail with one wavefront); the W partial rows are folded in wavefront order
+    const int z = blockIdx.z, v = blockIdx.x, lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6, W = (int)blockDim.x >> 6;
     const int M_ = meta[z * META_STRIDE + mfield];
     const int* pi = idx + (long long)z * idx_ts;
     const float* pd = dx + (long long)z * dx_ts;
@@ -720,7 +722,7 @@ __global__ void table_grad_kernel(const int* meta, int mfield, const float* dx, 
 #pragma unroll
     for (int k = 0; k < 16; ++k) s[k] = 0.f;
     if (v != skip_row)
-        for (int base = 0; base < M_; base += 64) {
+        for (int base = wv * 64; base < M_; base += 64 * W) {
             const int m = base + lane;
             const bool hit = m < M_ && pi[m] == v;
             unsigned long long bits = 0;
@@ -752,6 +754,18 @@ __global__ void table_grad_kernel(const int* meta, int mfield, const float* dx, 
                 }
             }
         }
+    if (W > 1) {
+        __shared__ float tg_red[3][1024];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int c = lane + 64 * k; if (c < C && wv > 0 && wv < 4) tg_red[wv - 1][c] = s[k]; }
+        __syncthreads();
+        if (wv != 0) return;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) for (int w = 1; w < W && w < 4; ++w) s[k] += tg_red[w - 1][c];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) { const int c = lane + 64 * k; if (c < C) po[c] = s[k]; }
 }
