@@ -1279,7 +1279,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         const bool tf = p.has_targets;
         TS xp = x0;
         static const bool pred_batch = [] { const char* e = getenv("MTTS_PRED_BATCH"); return e ? atoi(e) != 0 : true; }();
-        if (tf && pred_batch && !any_frame_level()) {
+        if (tf && pred_batch && !any_frame_level() && p.sumMp <= 2048) {   // (measured neutral once the launches fill the chip: 8-task meta-batches)
             // teacher-forced: both embeddings come from the targets, so x1 / x2 do not wait for a predictor — embed first, then the three
             // predictors side by side
             MTTS_LAUNCH(bucket_embed_add_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP, (const float*)x0.p, x0.ts,
