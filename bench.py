@@ -423,14 +423,32 @@ def main():
     # torch.distributed's all_reduce on a zero-copy view of the same buffer and say so in the line.
     outer, ar_impl = None, None
     if n > 1:
+        # bring-up in lock step so that no rank can be left waiting inside a collective the others never enter: (1) every rank probes the
+        # library (ncclGetUniqueId is local), (2) the probes are MIN-reduced, (3) only if all succeeded is the id of rank 0 broadcast
+        # and ncclCommInitRank entered, (4) its outcome is MIN-reduced again
+        why = ""
         try:
-            ids = [eng.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            eng.comm_init(ids[0], rank, n)
-            ar_impl = "libmtts: ncclAllReduce via dlopen(librccl.so) on the engine stream"
+            uid = eng.comm_unique_id()
         except Exception as ex:  # noqa: BLE001
+            uid, why = None, str(ex)
+        flag = torch.tensor([1 if uid is not None else 0], device=f"cuda:{local_rank}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+        if ok:
+            ids = [uid if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            try:
+                eng.comm_init(ids[0], rank, n)
+            except Exception as ex:  # noqa: BLE001
+                ok, why = False, str(ex)
+            flag = torch.tensor([1 if ok else 0], device=f"cuda:{local_rank}")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item())
+        if ok:
+            ar_impl = "libmtts: ncclAllReduce via dlopen(librccl.so) on the engine stream"
+        else:
             outer = torch.as_tensor(eng.outer_grad_view(), device=f"cuda:{local_rank}")
-            ar_impl = f"torch.distributed all_reduce (library communicator failed: {ex})"
+            ar_impl = f"torch.distributed all_reduce (library communicator unavailable on some rank: {why or 'see other ranks'})"
 
     step_no = [0]
     eng.set_numerics(1 if args.numerics == "bf16x3" else 0)

@@ -337,11 +337,20 @@ class Trainer:
             self.system.engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)
             if outer_grad_tensor is None and self.system.world_size > 1:
                 # the all-reduce itself runs inside the library (mtts_allreduce_outer); torch only carries the unique id
+                # lock-step bring-up (every rank probes the library, the probes are MIN-reduced, only then is rank 0's id broadcast and
+                # ncclCommInitRank entered): a rank whose librccl cannot be loaded must not leave the others waiting in the init
                 eng = self.system.engine
-                ids = [eng.comm_unique_id() if self.dist.get_rank(self.group) == 0 else None]
-                self.dist.broadcast_object_list(ids, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
-                eng.comm_init(ids[0], self.dist.get_rank(self.group), self.system.world_size)
-                self.library_comm = True
+                try:
+                    uid = eng.comm_unique_id()
+                except Exception:  # noqa: BLE001
+                    uid = None
+                flag = torch.tensor([1 if uid is not None else 0], device=f"cuda:{dev}")
+                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+                if bool(flag.item()):
+                    ids = [uid if self.dist.get_rank(self.group) == 0 else None]
+                    self.dist.broadcast_object_list(ids, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                    eng.comm_init(ids[0], self.dist.get_rank(self.group), self.system.world_size)
+                    self.library_comm = True
 
     def _allreduce(self):
         if self.dist is None or self.system.world_size == 1:
