@@ -166,6 +166,21 @@ public:
 
     // ---------------- workspace -------------------------------------------------------
     struct LayerBuf { TS qkv, P, O, z1, st1, y1, h, z2, st2, y2; };
+    // Deferred weight gradients (under-filled launches only: single-task ranks, few-shot adaptation).  The gradients a layer's four
+    // weight-gradient GEMMs consume (dz2 / dh / dz1 / dqkv) are written into per-layer buffers instead of the shared scratch, so the
+    // GEMMs no longer have to run before the scratch is reused: they go out as ONE multi-problem launch per layer on a SIDE stream,
+    // concurrently with the backward chain of the layers below, and are joined before anything reads the parameter gradients.
+    struct LayerGrad { TS dc, gh, da, gqkv; };
+    std::vector<LayerGrad> encG, decG;
+    std::vector<TS> postG;               // per PostNet layer: gradient of the conv output (what its weight-gradient GEMM reads)
+    char* arena_defer = nullptr;
+    int defer_tasks = 0;                 // task capacity of the deferred buffers (0: not available)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_side[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_join = nullptr;
+    int ev_next = 0;
+    GemmCtx gx_side;
+    bool defer_live = false;             // side-stream work of the current backward pass is outstanding
     struct PredBuf { TS r1, st1, n1, r2, st2, n2, out; };
     struct PostBuf { TS c, a, stats, dgamma_tmp; };
     std::vector<LayerBuf> encB, decB;
@@ -477,6 +492,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         HIP_CHECK(hipMemset(grad, 0, (size_t)n_total * cap_tasks * sizeof(float)));
         fast_cur = fast; grad_dst = grad;
         if (gx.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace)"); return -1; }
+        if (init_defer() != 0) return -1;
         HIP_CHECK(hipMalloc((void**)&norm_partial, 1024 * sizeof(float)));
         HIP_CHECK(hipMalloc((void**)&norm_out, 4 * sizeof(float)));
         // frozen tables: sinusoid positions (Models.py:10-30, float64 math), linear bins
@@ -587,7 +603,46 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
     }
 
+    // buffers, stream and events of the deferred weight-gradient path (see LayerGrad)
+    int init_defer() {
+        defer_tasks = std::min(cap_tasks, 2);
+        const int d = cfg.d_model;
+        const long long per_row = 2LL * d + cfg.d_ff + 3LL * d;
+        const int post_c = std::max(cfg.postnet_dim, cfg.n_mel);
+        const size_t bytes = (size_t)defer_tasks * per_row * sizeof(float) *
+                             ((size_t)cfg.enc_layers * (capMp + 2 * G) + (size_t)cfg.dec_layers * (capMf + 2 * G)) +
+                             (size_t)defer_tasks * cfg.postnet_layers * (size_t)(capMr + 2 * G) * post_c * sizeof(float) + 4096;
+        HIP_CHECK(hipMalloc((void**)&arena_defer, bytes));
+        HIP_CHECK(hipMemset(arena_defer, 0, bytes));
+        char* cur = arena_defer;
+        auto rows_d = [&](int capM, int C) {   // [defer_tasks][G + capM + G][C], pointer at row 0 (same shape as rows())
+            const long long ts = (long long)(capM + 2 * G) * C;
+            float* p0 = (float*)cur;
+            cur += (size_t)ts * defer_tasks * sizeof(float);
+            return TS{p0 + (long long)G * C, ts};
+        };
+        auto mk = [&](std::vector<LayerGrad>& v, int n, int capM) {
+            v.resize(n);
+            for (int i = 0; i < n; ++i) { v[i].dc = rows_d(capM, d); v[i].gh = rows_d(capM, cfg.d_ff); v[i].da = rows_d(capM, d); v[i].gqkv = rows_d(capM, 3 * d); }
+        };
+        mk(encG, cfg.enc_layers, capMp);
+        mk(decG, cfg.dec_layers, capMf);
+        postG.resize(cfg.postnet_layers);
+        for (auto& t : postG) t = rows_d(capMr, post_c);
+        HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));   // (a blocking stream would serialise with the legacy default stream on every launch)
+        for (auto& e : ev_side) HIP_CHECK(hipEventCreate(&e));
+        HIP_CHECK(hipEventCreate(&ev_join));
+        gx_side.numerics = 0;
+        { const char* e = getenv("MTTS_SIDE_GLDS"); gx_side.no_glds = !(e && atoi(e) != 0); }
+        if (gx_side.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace of the side stream)"); return -1; }
+        return 0;
+    }
     void destroy() {
+        if (side) { hipStreamSynchronize(side); hipStreamDestroy(side); }
+        for (auto& e : ev_side) if (e) hipEventDestroy(e);
+        if (ev_join) hipEventDestroy(ev_join);
+        gx_side.release();
+        if (arena_defer) hipFree(arena_defer);
         for (float* p : {theta, adam_m, adam_v, outer, fast, grad, norm_partial, norm_out, pos_table, pitch_bins, energy_bins})
             if (p) hipFree(p);
         for (float* p : bn_rm) hipFree(p);
@@ -986,9 +1041,12 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                     4.0 * (alg_rows(p, s) * (cin + cout) + (double)p.tasks * cout * k * cin));
     }
     // dW[Cout][k*Cin] = dY^T * conv_k(X), db = colsum(dY)
+    // cx / st: launch context (default: the engine's own context and stream; the deferred path passes the side stream's)
     void conv_wgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS x, int cin, long long w_off, long long b_off,
-                    const unsigned char* bias_mask, int flags = 0) {
+                    const unsigned char* bias_mask, int flags = 0, GemmCtx* cx = nullptr, hipStream_t st = nullptr) {
         const Plan& p = *ps.pl;
+        GemmCtx& gcx = cx ? *cx : gx;
+        const hipStream_t gst = cx ? st : stream;
         GemmArgs g = rowgemm(p, s, GEMM_TN);
         const int pad = k / 2;
         g.A = dy.p; g.a_gs = dy.ts; g.lda = cout;
@@ -1003,14 +1061,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         // separate reduction.
         static const bool fuse_cs = [] { const char* e = getenv("MTTS_FUSE_COLSUM"); return e ? atoi(e) != 0 : true; }();
         const float* mw = mask_w(p, bias_mask);
-        const bool fused = b_off >= 0 && fuse_cs && gx.numerics == 0 && mw != nullptr;
+        const bool fused = b_off >= 0 && fuse_cs && gcx.numerics == 0 && mw != nullptr;
         if (fused) {
             TS gb = Gd(b_off);
             g.colsum = gb.p; g.colsum_gs = gb.ts; g.colsum_w = mw; g.colsum_w_gs = 4 * row_ts(s);
         }
-        gemm_launch(gx, GEMM_TN, g, cout, k * cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, (long long)cout * p.tasks,
+        gemm_launch(gcx, GEMM_TN, g, cout, k * cin, p.tasks, gst, 0, 2.0 * alg_rows(p, s) * cout * k * cin, (long long)cout * p.tasks,
                     4.0 * (alg_rows(p, s) * (cin + cout) + (double)p.tasks * cout * k * cin));
-        if (b_off >= 0 && !fused) colsum(ps, s, dy, cout, bias_mask, TS{nullptr, 0}, Gd(b_off));
+        if (b_off >= 0 && !fused) colsum(ps, s, dy, cout, bias_mask, TS{nullptr, 0}, Gd(b_off));   // (main stream: never reached on the deferred path)
     }
     // two-stage deterministic column reduction (rowops.h colpart/colfinal)
     void colreduce(const Plan& p, ColArgs a, float* out0, float* out1, long long out_ts, int maxM) {
@@ -1052,8 +1110,9 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                     row_ts(s), zout.p, zout.ts, y.p, y.ts, st.p, st.ts, C, 1e-5f, din, dout);
     }
     // dz = LayerNorm backward (masked); parameter grads into the per-task grad buffer
+    // dz_drop: second output = dropout(dz) with the forward site's mask; copy_always: written even when dropout is off (a plain copy)
     void ln_bwd(const Pass& ps, Space s, TS dy, TS z, TS st, long long g_off, long long b_off, const unsigned char* mask,
-                TS dz, int C, int relu_on_z, TS dz_drop = TS{nullptr, 0}, DropSpec dd = DropSpec()) {
+                TS dz, int C, int relu_on_z, TS dz_drop = TS{nullptr, 0}, DropSpec dd = DropSpec(), bool copy_always = false) {
         const Plan& p = *ps.pl;
         TS gm = W(ps, g_off);
         TS gg = Gd(g_off), gb = Gd(b_off);
@@ -1063,7 +1122,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         colreduce(p, a, gg.p, gb.p, gg.ts, maxM(p, s));
         MTTS_LAUNCH(layernorm_bwd_kernel, row2_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
                     (const float*)dy.p, dy.ts, (const float*)z.p, z.ts, (const float*)st.p, st.ts, (const float*)gm.p, gm.ts,
-                    mask, row_ts(s), dz.p, dz.ts, C, relu_on_z, dd.thr16 ? dz_drop.p : nullptr, dz_drop.ts, dd);
+                    mask, row_ts(s), dz.p, dz.ts, C, relu_on_z, (dd.thr16 || copy_always) ? dz_drop.p : nullptr, dz_drop.ts, dd);
     }
     void attn_gemm(const Pass& ps, Space s, int which, int form, const float* A, int lda, const float* B, int ldb,
                    float* C, int ldc, float alpha, int heads, int flags = 0) {
@@ -1109,37 +1168,41 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     }
 
     // g0 holds dL/dy2 on entry and dL/dx on exit; g1, gqkv, gh, dS are scratch
+    // lg != null: deferred weight gradients (see LayerGrad) — the four gradients the layer's weight-gradient GEMMs read go to
+    // lg's buffers, the GEMMs themselves to the side stream
     void fft_bwd(const Pass& ps, Space s, int heads, const FFTP& P, LayerBuf& b, TS xin, TS g0, TS g1, TS gqkv, TS gh,
-                 TS dS) {
+                 TS dS, LayerGrad* lg = nullptr) {
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, dk = d / heads, ff = cfg.d_ff;
         const unsigned char* vm = valid_mask(p, s);
         const unsigned char* im = inrect_mask(p, s);
+        const bool df = lg != nullptr;
+        if (df) { gh = lg->gh; gqkv = lg->gqkv; }
         // LN2 (+ row mask) backward -> g1 = dz2
         TS gm = (s == SP_P) ? gPm : gFm;                                   // masked copy feeds the conv branch, g1 the residual
         const DropSpec dd2 = drop_spec(ps, block_dropout(s), site_base + 1);
-        ln_bwd(ps, s, g0, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0, gm, dd2);
-        TS dc = dd2.thr16 ? gm : g1;
+        ln_bwd(ps, s, g0, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0, df ? lg->dc : gm, dd2, df);
+        TS dc = df ? lg->dc : (dd2.thr16 ? gm : g1);
         // conv2
         {   // wgrad and dgrad of a layer are independent: one multi-problem launch (gemm.h: gemm_f32_multi_kernel)
             GemmBatchScope pair(gx, stream);
-            conv_wgrad(ps, s, dc, d, cfg.k2, b.h, ff, P.w2, P.b2, vm);
+            if (!df) conv_wgrad(ps, s, dc, d, cfg.k2, b.h, ff, P.w2, P.b2, vm);
             conv_dgrad(ps, s, dc, d, cfg.k2, W(ps, P.w2), ff, gh, 0, im, b.h);
         }
         // conv1: g1 += dgrad -> dy1
         {
             GemmBatchScope pair(gx, stream);
-            conv_wgrad(ps, s, gh, ff, cfg.k1, b.y1, d, P.w1, P.b1, im);
+            if (!df) conv_wgrad(ps, s, gh, ff, cfg.k1, b.y1, d, P.w1, P.b1, im);
             conv_dgrad(ps, s, gh, ff, cfg.k1, W(ps, P.w1), d, g1, GEMM_ACCUM, im);
         }
         // LN1 backward -> g0 = dz1
         const DropSpec dd1 = drop_spec(ps, block_dropout(s), site_base);
-        ln_bwd(ps, s, g1, b.z1, b.st1, P.ln1g, P.ln1b, vm, g0, d, 0, gm, dd1);
-        TS da = dd1.thr16 ? gm : g0;
+        ln_bwd(ps, s, g1, b.z1, b.st1, P.ln1g, P.ln1b, vm, g0, d, 0, df ? lg->da : gm, dd1, df);
+        TS da = df ? lg->da : (dd1.thr16 ? gm : g0);
         // fc
         {
             GemmBatchScope pair(gx, stream);
-            conv_wgrad(ps, s, da, d, 1, b.O, d, P.wfc, P.bfc, vm);
+            if (!df) conv_wgrad(ps, s, da, d, 1, b.O, d, P.wfc, P.bfc, vm);
             conv_dgrad(ps, s, da, d, 1, W(ps, P.wfc), d, g1, 0, nullptr);  // g1 = dO
         }
         // attention
@@ -1162,9 +1225,39 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         // fused q/k/v projection
         {
             GemmBatchScope pair(gx, stream);
-            conv_wgrad(ps, s, gqkv, 3 * d, 1, xin, d, P.wqkv, P.bqkv, vm);
+            if (!df) conv_wgrad(ps, s, gqkv, 3 * d, 1, xin, d, P.wqkv, P.bqkv, vm);
             conv_dgrad(ps, s, gqkv, 3 * d, 1, W(ps, P.wqkv), d, g0, GEMM_ACCUM, nullptr);
         }
+        if (df) {
+            // the layer's four weight (+ bias) gradients: one multi-problem launch on the side stream, after everything above
+            hipEvent_t ev = ev_side[ev_next];
+            ev_next = (ev_next + 1) & 7;
+            hipEventRecord(ev, stream);
+            hipStreamWaitEvent(side, ev, 0);
+            {
+                GemmBatchScope batch(gx_side, side);
+                conv_wgrad(ps, s, gh, ff, cfg.k1, b.y1, d, P.w1, P.b1, im, 0, &gx_side, side);
+                conv_wgrad(ps, s, dc, d, cfg.k2, b.h, ff, P.w2, P.b2, vm, 0, &gx_side, side);
+                conv_wgrad(ps, s, gqkv, 3 * d, 1, xin, d, P.wqkv, P.bqkv, vm, 0, &gx_side, side);
+                conv_wgrad(ps, s, da, d, 1, b.O, d, P.wfc, P.bfc, vm, 0, &gx_side, side);
+            }
+            defer_live = true;
+        }
+    }
+    // weight gradients may be deferred to the side stream for this plan (under-filled launches; exact-fp32 numerics, whose bias
+    // gradient rides on the GEMM — the separate column reduction would run on the main stream)
+    bool defer_ok(const Plan& p) const {
+        static const int on = [] { const char* e = getenv("MTTS_DEFER_WGRAD"); return e ? atoi(e) : 1; }();
+        static const long long max_rows = [] { const char* e = getenv("MTTS_DEFER_MAX_ROWS"); return e ? atoll(e) : 6000LL; }();
+        static const bool fuse_cs = [] { const char* e = getenv("MTTS_FUSE_COLSUM"); return e ? atoi(e) != 0 : true; }();
+        return on && fuse_cs && defer_tasks > 0 && p.tasks <= defer_tasks && gx.numerics == 0 && p.sumMf <= max_rows && side != nullptr;
+    }
+    // the main stream waits for the side stream's weight gradients (before anything reads or overwrites what they touch)
+    void join_side() {
+        if (!defer_live) return;
+        hipEventRecord(ev_join, side);
+        hipStreamWaitEvent(stream, ev_join, 0);
+        defer_live = false;
     }
 
     // =================================================================================
@@ -1477,6 +1570,11 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // modules into grad[task][...] (fully overwritten, no accumulation across calls)
     // =================================================================================
     int backward(const Pass& ps, float scale, bool need_encoder) {
+        const int rc = backward_impl(ps, scale, need_encoder);
+        join_side();
+        return rc;
+    }
+    int backward_impl(const Pass& ps, float scale, bool need_encoder) {
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, nt = p.tasks, nm = cfg.n_mel;
         if (!ps.train) { set_error("backward needs a train-mode forward (batch statistics)"); return -1; }
@@ -1501,14 +1599,24 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             ca.mode = 3; ca.do_tanh = act; ca.mfield = META_MR;
             colreduce(p, ca, dgm.p, dbt.p, dgm.ts, p.maxMr);
             TS gm = W(ps, P.g);
-            TS dc = gR0;  // [rows][Cout] inside a scratch sized for max(postnet_dim, n_mel) channels
+            const bool dfp = defer_ok(p);
+            TS dc = dfp ? postG[i] : gR0;  // [rows][Cout] inside a scratch sized for max(postnet_dim, n_mel) channels (deferred: a buffer of the layer's own)
             MTTS_LAUNCH(bn_bwd_apply_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (const float*)cur.p,
                         cur.ts, (const float*)b.a.p, b.a.ts, (const float*)b.c.p, b.c.ts, (const float*)b.stats.p, b.stats.ts,
                         (const float*)gm.p, gm.ts, (const float*)dgm.p, (const float*)dbt.p, dgm.ts,
                         (const unsigned char*)p.r_inrect, row_ts_r, act, dc.p, dc.ts, P.cout, ysc);
             TS xin = (i == 0) ? mel : postB[i - 1].a;
+            if (dfp) {   // this layer's weight gradient on the side stream, overlapping the rest of the backward chain
+                hipEvent_t ev = ev_side[ev_next];
+                ev_next = (ev_next + 1) & 7;
+                hipEventRecord(ev, stream);
+                hipStreamWaitEvent(side, ev, 0);
+                GemmBatchScope batch(gx_side, side);
+                conv_wgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, xin, P.cin, P.w, P.b, p.r_inrect, 0, &gx_side, side);
+                defer_live = true;
+            }
             GemmBatchScope pair(gx, stream);
-            conv_wgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, xin, P.cin, P.w, P.b, p.r_inrect);
+            if (!dfp) conv_wgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, xin, P.cin, P.w, P.b, p.r_inrect);
             if (i > 0) {
                 conv_dgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, W(ps, P.w), P.cin, gR1, 0, p.r_inrect);
                 cur = gR1;
@@ -1536,7 +1644,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (int l = cfg.dec_layers - 1; l >= 0; --l) {
             TS xin = l == 0 ? dec_in : decB[l - 1].y2;
             site_base = 64 + 2 * l;
-            fft_bwd(ps, SP_F, cfg.dec_heads, decP[l], decB[l], xin, gF0, gF1, gFqkv, gFh, dSf);
+            fft_bwd(ps, SP_F, cfg.dec_heads, decP[l], decB[l], xin, gF0, gF1, gFqkv, gFh, dSf, defer_ok(p) ? &decG[l] : nullptr);
         }
         // speaker vector gradient, part 1: every valid frame
         MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(256), stream, (const int*)p.meta, (const float*)gF0.p,
@@ -1586,7 +1694,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (int l = cfg.enc_layers - 1; l >= 0; --l) {
             TS xin = l == 0 ? emb_out : encB[l - 1].y2;
             site_base = 2 * l;
-            fft_bwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], xin, gP0, gP1, gPqkv, gPh, dSp);
+            fft_bwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], xin, gP0, gP1, gPqkv, gPh, dSp, defer_ok(p) ? &encG[l] : nullptr);
         }
         // word embedding (padding row 0 keeps a zero gradient); p_tok is 0 on invalid rows, and
         // gP0 is only meaningful on valid rows -> scan with the token ids masked by validity

@@ -644,6 +644,7 @@ struct GemmCtx {
     GemmProfiler prof;
     GemmWorkspace wsp;
     int numerics = gemm_numerics_default();
+    bool no_glds = false;   // never pick the LDS-DMA kernels (48 KB of LDS per workgroup: a side-stream launch would leave no LDS for the main stream's)
     int alloc_workspace() {
         if (wsp.ws) return 0;
         if (hipMalloc((void**)&wsp.ws, kSplitWsFloats * sizeof(float)) != hipSuccess || hipMalloc((void**)&wsp.ctr, kSplitCtrs * sizeof(int)) != hipSuccess ||
@@ -808,7 +809,10 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     // pairs whose dgrad has a short K-loop (K <= 256: fc, conv2) measured ~10 % SLOWER batched than back to back — their
     // many 16-slice tiles gain nothing from a shared grid and lose the stand-alone kernels' higher occupancy
     static const int min_k = [] { const char* e = getenv("MTTS_BATCH_MIN_K"); return e ? atoi(e) : 512; }();
-    bool solo = b.q.size() == 1;
+    // a single queued problem normally takes the stand-alone launcher; in the latency regime it stays here, where the long-chain
+    // split-K rule applies (the k=9 dgrad of a single-task rank is 124 tiles x 288 slices: alone it would run at one tile per CU)
+    static const int single_multi = [] { const char* e = getenv("MTTS_SINGLE_MULTI"); return e ? atoi(e) : 1; }();
+    bool solo = b.q.size() == 1 && (!single_multi || batch_full_regime(b.q));
     for (const GemmPending& p : b.q) if (!p.g.table && p.g.K < min_k && batch_full_regime(b.q)) solo = true;
     if (solo) {
         const std::vector<GemmPending> q = b.q;
@@ -872,7 +876,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
         if (mp.g[i].taps > 1 && mp.g[i].tap_k % 32 != 0) bk32 = false;
         maxK = std::max(maxK, mp.g[i].K);
     }
-    bool glds = gemm_use_glds() && small_batch;
+    bool glds = gemm_use_glds() && small_batch && !cx.no_glds;
     for (int i = 0; i < mp.n; ++i) glds = glds && gemm_glds_ok(mp.g[i]);
 #if !defined(MTTS_EMU)
     if (glds) { gemm_glds_multi_launch(mp, grid, stream); }

@@ -59,6 +59,11 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+enum { hipStreamNonBlocking = 1 };
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)1; return 0; }   // launches execute at the call: one in-order "stream"
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)1; return 0; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipSetDevice(int) { return 0; }
