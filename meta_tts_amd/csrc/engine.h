@@ -605,7 +605,9 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
 
     // buffers, stream and events of the deferred weight-gradient path (see LayerGrad)
     int init_defer() {
-        defer_tasks = std::min(cap_tasks, 2);
+        static const int max_defer_tasks = [] { const char* e = getenv("MTTS_DEFER_TASKS"); return e ? atoi(e) : 2; }();
+        defer_tasks = std::min(cap_tasks, max_defer_tasks);
+        if (defer_tasks < 1) { defer_tasks = 0; return 0; }
         const int d = cfg.d_model;
         const long long per_row = 2LL * d + cfg.d_ff + 3LL * d;
         const int post_c = std::max(cfg.postnet_dim, cfg.n_mel);
@@ -629,7 +631,12 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         mk(decG, cfg.dec_layers, capMf);
         postG.resize(cfg.postnet_layers);
         for (auto& t : postG) t = rows_d(capMr, post_c);
-        HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));   // (a blocking stream would serialise with the legacy default stream on every launch)
+        {   // non-blocking (a blocking stream would serialise with the legacy default stream on every launch); MTTS_SIDE_PRIO=1: lowest priority
+            static const int prio = [] { const char* e = getenv("MTTS_SIDE_PRIO"); return e ? atoi(e) : 0; }();
+            int lo = 0, hi = 0;
+            if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) { HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo)); }
+            else HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        }
         for (auto& e : ev_side) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipEventCreate(&ev_join));
         gx_side.numerics = 0;
@@ -1248,7 +1255,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // gradient rides on the GEMM — the separate column reduction would run on the main stream)
     bool defer_ok(const Plan& p) const {
         static const int on = [] { const char* e = getenv("MTTS_DEFER_WGRAD"); return e ? atoi(e) : 1; }();
-        static const long long max_rows = [] { const char* e = getenv("MTTS_DEFER_MAX_ROWS"); return e ? atoll(e) : 6000LL; }();
+        static const long long max_rows = [] { const char* e = getenv("MTTS_DEFER_MAX_ROWS"); return e ? atoll(e) : 16000LL; }();
         static const bool fuse_cs = [] { const char* e = getenv("MTTS_FUSE_COLSUM"); return e ? atoi(e) != 0 : true; }();
         return on && fuse_cs && defer_tasks > 0 && p.tasks <= defer_tasks && gx.numerics == 0 && p.sumMf <= max_rows && side != nullptr;
     }

@@ -62,6 +62,8 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 enum { hipStreamNonBlocking = 1 };
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)1; return 0; }   // launches execute at the call: one in-order "stream"
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)1; return 0; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (hipStream_t)1; return 0; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return 0; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }
