@@ -170,7 +170,7 @@ public:
     // weight-gradient GEMMs consume (dz2 / dh / dz1 / dqkv) are written into per-layer buffers instead of the shared scratch, so the
     // GEMMs no longer have to run before the scratch is reused: they go out as ONE multi-problem launch per layer on a SIDE stream,
     // concurrently with the backward chain of the layers below, and are joined before anything reads the parameter gradients.
-    struct LayerGrad { TS dc, gh, da, gqkv; };
+    struct LayerGrad { TS dc, gh, da, gqkv, dy2, dy1; };   // dy2 / dy1: the gradients entering LN2 / LN1 (their gamma / beta reductions are deferred too)
     std::vector<LayerGrad> encG, decG;
     std::vector<TS> postG;               // per PostNet layer: gradient of the conv output (what its weight-gradient GEMM reads)
     char* arena_defer = nullptr;
@@ -180,6 +180,7 @@ public:
     hipEvent_t ev_join = nullptr;
     int ev_next = 0;
     GemmCtx gx_side;
+    float* col_partial_side = nullptr;   // the side stream's own scratch of the two-stage column reduction
     bool defer_live = false;             // side-stream work of the current backward pass is outstanding
     struct PredBuf { TS r1, st1, n1, r2, st2, n2, out; };
     struct PostBuf { TS c, a, stats, dgamma_tmp; };
@@ -609,7 +610,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         defer_tasks = std::min(cap_tasks, max_defer_tasks);
         if (defer_tasks < 1) { defer_tasks = 0; return 0; }
         const int d = cfg.d_model;
-        const long long per_row = 2LL * d + cfg.d_ff + 3LL * d;
+        const long long per_row = 4LL * d + cfg.d_ff + 3LL * d;
         const int post_c = std::max(cfg.postnet_dim, cfg.n_mel);
         const size_t bytes = (size_t)defer_tasks * per_row * sizeof(float) *
                              ((size_t)cfg.enc_layers * (capMp + 2 * G) + (size_t)cfg.dec_layers * (capMf + 2 * G)) +
@@ -625,7 +626,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         };
         auto mk = [&](std::vector<LayerGrad>& v, int n, int capM) {
             v.resize(n);
-            for (int i = 0; i < n; ++i) { v[i].dc = rows_d(capM, d); v[i].gh = rows_d(capM, cfg.d_ff); v[i].da = rows_d(capM, d); v[i].gqkv = rows_d(capM, 3 * d); }
+            for (int i = 0; i < n; ++i) { v[i].dc = rows_d(capM, d); v[i].gh = rows_d(capM, cfg.d_ff); v[i].da = rows_d(capM, d); v[i].gqkv = rows_d(capM, 3 * d);
+                                          v[i].dy2 = rows_d(capM, d); v[i].dy1 = rows_d(capM, d); }
         };
         mk(encG, cfg.enc_layers, capMp);
         mk(decG, cfg.dec_layers, capMf);
@@ -639,6 +641,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         for (auto& e : ev_side) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipEventCreate(&ev_join));
+        const int side_chunks = (std::max(std::max(capMp, capMf), capMr) + kRC - 1) / kRC;   // == col_max_chunks (set by layout(), later)
+        HIP_CHECK(hipMalloc((void**)&col_partial_side, (size_t)defer_tasks * side_chunks * 3 * 1024 * sizeof(float)));
         gx_side.numerics = 0;
         { const char* e = getenv("MTTS_SIDE_GLDS"); gx_side.no_glds = !(e && atoi(e) != 0); }
         if (gx_side.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace of the side stream)"); return -1; }
@@ -650,6 +654,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (ev_join) hipEventDestroy(ev_join);
         gx_side.release();
         if (arena_defer) hipFree(arena_defer);
+        if (col_partial_side) hipFree(col_partial_side);
         for (float* p : {theta, adam_m, adam_v, outer, fast, grad, norm_partial, norm_out, pos_table, pitch_bins, energy_bins})
             if (p) hipFree(p);
         for (float* p : bn_rm) hipFree(p);
@@ -1078,7 +1083,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (b_off >= 0 && !fused) colsum(ps, s, dy, cout, bias_mask, TS{nullptr, 0}, Gd(b_off));   // (main stream: never reached on the deferred path)
     }
     // two-stage deterministic column reduction (rowops.h colpart/colfinal)
-    void colreduce(const Plan& p, ColArgs a, float* out0, float* out1, long long out_ts, int maxM) {
+    void colreduce(const Plan& p, ColArgs a, float* out0, float* out1, long long out_ts, int maxM, bool on_side = false) {
+        if (on_side) {   // the deferred path's reductions: side stream, its own partial buffer, plain two-stage form
+            const int chunks_s = (maxM + kRC - 1) / kRC;
+            MTTS_LAUNCH(colpart_kernel, dim3((a.C + 127) / 128, chunks_s, p.tasks), dim3(256), side, (const int*)p.meta, a, col_partial_side, col_max_chunks);
+            MTTS_LAUNCH(colfinal_kernel, dim3((a.C + 63) / 64, 1, p.tasks), dim3(256), side, (const int*)p.meta, a.mfield, a.mode,
+                        (const float*)col_partial_side, col_max_chunks, a.C, out0, out1, out_ts, 1e-5f, a.accumulate);
+            return;
+        }
         // single-launch variant A: a workgroup per (32-column stripe, task) walks all rows (rowops.h: colstripe_kernel).  Measured
         // SLOWER (8-task step 189.5 -> 208 ms, single-task rank 44 -> 59 ms): 8-256 workgroups streaming ~70 dependent row
         // iterations each are latency-bound, the two-stage pair keeps ~1000 workgroups in flight.  Opt-in: MTTS_COL_STRIPE=<max rows>
@@ -1119,17 +1131,28 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // dz = LayerNorm backward (masked); parameter grads into the per-task grad buffer
     // dz_drop: second output = dropout(dz) with the forward site's mask; copy_always: written even when dropout is off (a plain copy)
     void ln_bwd(const Pass& ps, Space s, TS dy, TS z, TS st, long long g_off, long long b_off, const unsigned char* mask,
-                TS dz, int C, int relu_on_z, TS dz_drop = TS{nullptr, 0}, DropSpec dd = DropSpec(), bool copy_always = false) {
+                TS dz, int C, int relu_on_z, TS dz_drop = TS{nullptr, 0}, DropSpec dd = DropSpec(), bool copy_always = false,
+                TS dy_copy = TS{nullptr, 0}) {   // dy_copy set: dy is kept there and the gamma / beta reduction is left to ln_param_grads_side
         const Plan& p = *ps.pl;
         TS gm = W(ps, g_off);
         TS gg = Gd(g_off), gb = Gd(b_off);
         ColArgs a;
         a.X = dy.p; a.x_ts = dy.ts; a.Z = z.p; a.z_ts = z.ts; a.stats = st.p; a.st_ts = st.ts;
         a.mask = mask; a.mask_ts = row_ts(s); a.C = C; a.mode = 1; a.mfield = mfield(s);
-        colreduce(p, a, gg.p, gb.p, gg.ts, maxM(p, s));
+        if (!dy_copy.p) colreduce(p, a, gg.p, gb.p, gg.ts, maxM(p, s));
         MTTS_LAUNCH(layernorm_bwd_kernel, row2_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
                     (const float*)dy.p, dy.ts, (const float*)z.p, z.ts, (const float*)st.p, st.ts, (const float*)gm.p, gm.ts,
-                    mask, row_ts(s), dz.p, dz.ts, C, relu_on_z, (dd.thr16 || copy_always) ? dz_drop.p : nullptr, dz_drop.ts, dd);
+                    mask, row_ts(s), dz.p, dz.ts, C, relu_on_z, (dd.thr16 || copy_always) ? dz_drop.p : nullptr, dz_drop.ts, dd,
+                    dy_copy.p, dy_copy.ts);
+    }
+    // the LayerNorm gamma / beta gradients of a deferred layer, from the kept copy of dy, on the side stream
+    void ln_param_grads_side(const Pass& ps, Space s, TS dy_copy, TS z, TS st, long long g_off, long long b_off, const unsigned char* mask, int C) {
+        const Plan& p = *ps.pl;
+        TS gg = Gd(g_off), gb = Gd(b_off);
+        ColArgs a;
+        a.X = dy_copy.p; a.x_ts = dy_copy.ts; a.Z = z.p; a.z_ts = z.ts; a.stats = st.p; a.st_ts = st.ts;
+        a.mask = mask; a.mask_ts = row_ts(s); a.C = C; a.mode = 1; a.mfield = mfield(s);
+        colreduce(p, a, gg.p, gb.p, gg.ts, maxM(p, s), true);
     }
     void attn_gemm(const Pass& ps, Space s, int which, int form, const float* A, int lda, const float* B, int ldb,
                    float* C, int ldc, float alpha, int heads, int flags = 0) {
@@ -1188,7 +1211,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         // LN2 (+ row mask) backward -> g1 = dz2
         TS gm = (s == SP_P) ? gPm : gFm;                                   // masked copy feeds the conv branch, g1 the residual
         const DropSpec dd2 = drop_spec(ps, block_dropout(s), site_base + 1);
-        ln_bwd(ps, s, g0, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0, df ? lg->dc : gm, dd2, df);
+        ln_bwd(ps, s, g0, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0, df ? lg->dc : gm, dd2, df, df ? lg->dy2 : TS{nullptr, 0});
         TS dc = df ? lg->dc : (dd2.thr16 ? gm : g1);
         // conv2
         {   // wgrad and dgrad of a layer are independent: one multi-problem launch (gemm.h: gemm_f32_multi_kernel)
@@ -1204,7 +1227,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         // LN1 backward -> g0 = dz1
         const DropSpec dd1 = drop_spec(ps, block_dropout(s), site_base);
-        ln_bwd(ps, s, g1, b.z1, b.st1, P.ln1g, P.ln1b, vm, g0, d, 0, df ? lg->da : gm, dd1, df);
+        ln_bwd(ps, s, g1, b.z1, b.st1, P.ln1g, P.ln1b, vm, g0, d, 0, df ? lg->da : gm, dd1, df, df ? lg->dy1 : TS{nullptr, 0});
         TS da = df ? lg->da : (dd1.thr16 ? gm : g0);
         // fc
         {
@@ -1248,6 +1271,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                 conv_wgrad(ps, s, gqkv, 3 * d, 1, xin, d, P.wqkv, P.bqkv, vm, 0, &gx_side, side);
                 conv_wgrad(ps, s, da, d, 1, b.O, d, P.wfc, P.bfc, vm, 0, &gx_side, side);
             }
+            ln_param_grads_side(ps, s, lg->dy2, b.z2, b.st2, P.ln2g, P.ln2b, vm, d);
+            ln_param_grads_side(ps, s, lg->dy1, b.z1, b.st1, P.ln1g, P.ln1b, vm, d);
             defer_live = true;
         }
     }

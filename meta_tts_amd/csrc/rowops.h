@@ -153,7 +153,9 @@ __global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a
 __global__ void layernorm_bwd_kernel(const int* meta, int mfield, const float* dy, long long dy_ts, const float* zin,
                                      long long z_ts, const float* stats, long long st_ts, const float* gamma,
                                      long long par_ts, const unsigned char* mask, long long mask_ts, float* dz,
-                                     long long dz_ts, int C, int relu_on_z, float* dz_drop, long long dzd_ts, DropSpec dd) {
+                                     long long dz_ts, int C, int relu_on_z, float* dz_drop, long long dzd_ts, DropSpec dd,
+                                     float* dy_copy = nullptr, long long dyc_ts = 0) {
+    // dy_copy (optional): the incoming gradient, kept for a parameter-gradient reduction that runs later (engine.h: deferred path)
     // dz_drop (optional): dropout(dz) with the mask of the forward site — the gradient entering the dropped branch, while dz
     // itself continues along the residual path
     ROW2_PROLOGUE(mfield)
@@ -173,6 +175,7 @@ __global__ void layernorm_bwd_kernel(const int* meta, int mfield, const float* d
         int n = 0;
         for (int c = lane * 4; c < C; c += 256, ++n) {
             const float4 d = ld4(pdy + c), x = ld4(pz + c), g4 = ld4(g + c);
+            if (dy_copy && (q == 0 || live1)) st4(dy_copy + (long long)z * dyc_ts + (long long)row * C + c, d);
             gv[q][n] = make_float4(d.x * g4.x, d.y * g4.y, d.z * g4.z, d.w * g4.w);
             xh[q][n] = make_float4((x.x - mean) * rstd[q], (x.y - mean) * rstd[q], (x.z - mean) * rstd[q], (x.w - mean) * rstd[q]);
             s1[q] += (gv[q][n].x + gv[q][n].y) + (gv[q][n].z + gv[q][n].w);
