@@ -172,6 +172,8 @@ public:
     // concurrently with the backward chain of the layers below, and are joined before anything reads the parameter gradients.
     struct LayerGrad { TS dc, gh, da, gqkv, dy2, dy1; };   // dy2 / dy1: the gradients entering LN2 / LN1 (their gamma / beta reductions are deferred too)
     std::vector<LayerGrad> encG, decG;
+    struct PredGrad { TS g2a, g2b, dy2, dy1; };   // variance predictor: d(conv2 out), d(conv1 out), the gradients entering its two LayerNorms
+    PredGrad predG[3];
     std::vector<TS> postG;               // per PostNet layer: gradient of the conv output (what its weight-gradient GEMM reads)
     char* arena_defer = nullptr;
     int defer_tasks = 0;                 // task capacity of the deferred buffers (0: not available)
@@ -614,7 +616,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         const int post_c = std::max(cfg.postnet_dim, cfg.n_mel);
         const size_t bytes = (size_t)defer_tasks * per_row * sizeof(float) *
                              ((size_t)cfg.enc_layers * (capMp + 2 * G) + (size_t)cfg.dec_layers * (capMf + 2 * G)) +
-                             (size_t)defer_tasks * cfg.postnet_layers * (size_t)(capMr + 2 * G) * post_c * sizeof(float) + 4096;
+                             (size_t)defer_tasks * cfg.postnet_layers * (size_t)(capMr + 2 * G) * post_c * sizeof(float) +
+                             (size_t)defer_tasks * 3 * 4 * (size_t)(capMp + 2 * G) * cfg.vp_filter * sizeof(float) + 4096;
         HIP_CHECK(hipMalloc((void**)&arena_defer, bytes));
         HIP_CHECK(hipMemset(arena_defer, 0, bytes));
         char* cur = arena_defer;
@@ -631,6 +634,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         };
         mk(encG, cfg.enc_layers, capMp);
         mk(decG, cfg.dec_layers, capMf);
+        for (auto& pg : predG) { pg.g2a = rows_d(capMp, cfg.vp_filter); pg.g2b = rows_d(capMp, cfg.vp_filter); pg.dy2 = rows_d(capMp, cfg.vp_filter); pg.dy1 = rows_d(capMp, cfg.vp_filter); }
         postG.resize(cfg.postnet_layers);
         for (auto& t : postG) t = rows_d(capMr, post_c);
         {   // non-blocking (a blocking stream would serialise with the legacy default stream on every launch); MTTS_SIDE_PRIO=1: lowest priority
@@ -1113,12 +1117,12 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         MTTS_LAUNCH(colfinal_kernel, dim3((a.C + 63) / 64, 1, p.tasks), dim3(256), stream, (const int*)p.meta, a.mfield, a.mode,
                     (const float*)col_partial, col_max_chunks, a.C, out0, out1, out_ts, 1e-5f, a.accumulate);
     }
-    void colsum(const Pass& ps, Space s, TS x, int C, const unsigned char* mask, TS roww, TS out) {
+    void colsum(const Pass& ps, Space s, TS x, int C, const unsigned char* mask, TS roww, TS out, bool on_side = false) {
         const Plan& p = *ps.pl;
         ColArgs a;
         a.X = x.p; a.x_ts = x.ts; a.mask = mask; a.mask_ts = row_ts(s); a.roww = roww.p; a.roww_ts = roww.ts;
         a.C = C; a.mode = 0; a.mfield = mfield(s);
-        colreduce(p, a, out.p, nullptr, out.ts, maxM(p, s));
+        colreduce(p, a, out.p, nullptr, out.ts, maxM(p, s), on_side);
     }
     void ln_fwd(const Pass& ps, Space s, TS a, TS res, long long g_off, long long b_off, const unsigned char* mask,
                 TS zout, TS y, TS st, int C, DropSpec din = DropSpec(), DropSpec dout = DropSpec()) {
@@ -1336,12 +1340,40 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
     }
     // dout: [Mp] gradient of the prediction (0 on masked rows); dx accumulates the input gradient
-    void pred_bwd(const Pass& ps, const PredP& P, PredBuf& b, TS xin, TS dout, TS dx, Space s = SP_P) {
+    // pg != null (phoneme space only): deferred parameter gradients — the two weight-gradient GEMMs, the LayerNorm reductions and the
+    // output layer's column sums of this predictor run on the side stream from buffers of its own (see LayerGrad)
+    void pred_bwd(const Pass& ps, const PredP& P, PredBuf& b, TS xin, TS dout, TS dx, Space s = SP_P, PredGrad* pg = nullptr) {
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, f = cfg.vp_filter, k = cfg.vp_kernel;
         const unsigned char* im = inrect_mask(p, s);
         TS g1 = (s == SP_P) ? gPf1 : gRf1, g2 = (s == SP_P) ? gPf2 : gRf2;
         TS none{nullptr, 0};
+        if (pg) {
+            TS w = W(ps, P.lw);
+            MTTS_LAUNCH(rowdot_bwd_kernel, row_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
+                        (const float*)dout.p, dout.ts, (const float*)w.p, w.ts, g1.p, g1.ts, f);
+            drop(ps, s, g1, g1, f, cfg.vp_dropout, site_base + 1);
+            ln_bwd(ps, s, g1, b.r2, b.st2, P.l2g, P.l2b, im, pg->g2a, f, 1, none, DropSpec(), false, pg->dy2);
+            conv_dgrad(ps, s, pg->g2a, f, k, W(ps, P.c2w), f, g1, 0, im);
+            drop(ps, s, g1, g1, f, cfg.vp_dropout, site_base);
+            ln_bwd(ps, s, g1, b.r1, b.st1, P.l1g, P.l1b, im, pg->g2b, f, 1, none, DropSpec(), false, pg->dy1);
+            conv_dgrad(ps, s, pg->g2b, f, k, W(ps, P.c1w), d, dx, GEMM_ACCUM, im);
+            hipEvent_t ev = ev_side[ev_next];
+            ev_next = (ev_next + 1) & 7;
+            hipEventRecord(ev, stream);
+            hipStreamWaitEvent(side, ev, 0);
+            {
+                GemmBatchScope batch(gx_side, side);
+                conv_wgrad(ps, s, pg->g2a, f, k, b.n1, f, P.c2w, P.c2b, im, 0, &gx_side, side);
+                conv_wgrad(ps, s, pg->g2b, f, k, xin, d, P.c1w, P.c1b, im, 0, &gx_side, side);
+            }
+            ln_param_grads_side(ps, s, pg->dy2, b.r2, b.st2, P.l2g, P.l2b, im, f);
+            ln_param_grads_side(ps, s, pg->dy1, b.r1, b.st1, P.l1g, P.l1b, im, f);
+            colsum(ps, s, dout, 1, nullptr, none, Gd(P.lb), true);
+            colsum(ps, s, b.n2, f, nullptr, dout, Gd(P.lw), true);
+            defer_live = true;
+            return;
+        }
         colsum(ps, s, dout, 1, nullptr, none, Gd(P.lb));
         colsum(ps, s, b.n2, f, nullptr, dout, Gd(P.lw));
         TS w = W(ps, P.lw);
@@ -1663,13 +1695,26 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         // ---- mel_linear -------------------------------------------------------------------
         TS none{nullptr, 0};
-        colsum(ps, SP_R, gRm, nm, nullptr, none, Gd(mel_b));
+        const bool dfm = defer_ok(p);   // gRm / gMelF are final from here on: their parameter gradients can run on the side stream
+        if (!dfm) colsum(ps, SP_R, gRm, nm, nullptr, none, Gd(mel_b));
         MTTS_LAUNCH(gather_rows_kernel, row_grid(p.maxMf, nt), dim3(256), stream, (const int*)p.meta, (int)META_MF,
                     (const float*)gRm.p, gRm.ts, (const int*)p.f2r, row_ts_f, gMelF.p, gMelF.ts, nm);
         TS dec_out = cfg.dec_layers ? decB[cfg.dec_layers - 1].y2 : dec_in;
+        if (dfm) {
+            hipEvent_t ev = ev_side[ev_next];
+            ev_next = (ev_next + 1) & 7;
+            hipEventRecord(ev, stream);
+            hipStreamWaitEvent(side, ev, 0);
+            {
+                GemmBatchScope batch(gx_side, side);
+                conv_wgrad(ps, SP_F, gMelF, nm, 1, dec_out, d, mel_w, -1, nullptr, 0, &gx_side, side);
+            }
+            colsum(ps, SP_R, gRm, nm, nullptr, none, Gd(mel_b), true);
+            defer_live = true;
+        }
         {
             GemmBatchScope pair(gx, stream);
-            conv_wgrad(ps, SP_F, gMelF, nm, 1, dec_out, d, mel_w, -1, nullptr);
+            if (!dfm) conv_wgrad(ps, SP_F, gMelF, nm, 1, dec_out, d, mel_w, -1, nullptr);
             conv_dgrad(ps, SP_F, gMelF, nm, 1, W(ps, mel_w), d, gF0, 0, nullptr);
         }
         // ---- decoder ----------------------------------------------------------------------
@@ -1706,14 +1751,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (!cfg.energy_frame) {
             MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
                         (const float*)gP0.p, gP0.ts, (const int*)eidx, row_ts_p, -1, Gd(energy_emb).p, n_total, d);
-            site_base = 136; pred_bwd(ps, eneP, eneB, cfg.pitch_frame ? x0 : x1, dpred[2], gP0);
+            site_base = 136; pred_bwd(ps, eneP, eneB, cfg.pitch_frame ? x0 : x1, dpred[2], gP0, SP_P, defer_ok(p) ? &predG[2] : nullptr);
         }
         if (!cfg.pitch_frame) {
             MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
                         (const float*)gP0.p, gP0.ts, (const int*)pidx, row_ts_p, -1, Gd(pitch_emb).p, n_total, d);
-            site_base = 132; pred_bwd(ps, pitP, pitB, x0, dpred[1], gP0);
+            site_base = 132; pred_bwd(ps, pitP, pitB, x0, dpred[1], gP0, SP_P, defer_ok(p) ? &predG[1] : nullptr);
         }
-        site_base = 128; pred_bwd(ps, durP, durB, x0, dpred[0], gP0);
+        site_base = 128; pred_bwd(ps, durP, durB, x0, dpred[0], gP0, SP_P, defer_ok(p) ? &predG[0] : nullptr);
         // speaker vector gradient, part 2: every position of the phoneme rectangle
         MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(256), stream, (const int*)p.meta, (const float*)gP0.p,
                     gP0.ts, (const int*)p.p_seg_start, (const int*)p.p_seg_len, (long long)cap_B, dspk.p, dspk.ts, d, 1);
