@@ -178,7 +178,8 @@ public:
     char* arena_defer = nullptr;
     int defer_tasks = 0;                 // task capacity of the deferred buffers (0: not available)
     hipStream_t side = nullptr;
-    hipEvent_t ev_side[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int kSideEvents = 32;   // more than the forks of one backward pass (19 at base.yaml): no event is re-recorded while a wait on it can be pending
+    hipEvent_t ev_side[kSideEvents] = {};
     hipEvent_t ev_join = nullptr;
     int ev_next = 0;
     GemmCtx gx_side;
@@ -1264,10 +1265,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         if (df) {
             // the layer's four weight (+ bias) gradients: one multi-problem launch on the side stream, after everything above
-            hipEvent_t ev = ev_side[ev_next];
-            ev_next = (ev_next + 1) & 7;
-            hipEventRecord(ev, stream);
-            hipStreamWaitEvent(side, ev, 0);
+            fork_side();
             {
                 GemmBatchScope batch(gx_side, side);
                 conv_wgrad(ps, s, gh, ff, cfg.k1, b.y1, d, P.w1, P.b1, im, 0, &gx_side, side);
@@ -1287,6 +1285,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         static const long long max_rows = [] { const char* e = getenv("MTTS_DEFER_MAX_ROWS"); return e ? atoll(e) : 16000LL; }();
         static const bool fuse_cs = [] { const char* e = getenv("MTTS_FUSE_COLSUM"); return e ? atoi(e) != 0 : true; }();
         return on && fuse_cs && defer_tasks > 0 && p.tasks <= defer_tasks && gx.numerics == 0 && p.sumMf <= max_rows && side != nullptr;
+    }
+    // everything enqueued on the main stream so far happens before what is enqueued on the side stream next
+    void fork_side() {
+        hipEvent_t ev = ev_side[ev_next];
+        ev_next = (ev_next + 1) % kSideEvents;
+        hipEventRecord(ev, stream);
+        hipStreamWaitEvent(side, ev, 0);
+        defer_live = true;
     }
     // the main stream waits for the side stream's weight gradients (before anything reads or overwrites what they touch)
     void join_side() {
@@ -1358,10 +1364,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             drop(ps, s, g1, g1, f, cfg.vp_dropout, site_base);
             ln_bwd(ps, s, g1, b.r1, b.st1, P.l1g, P.l1b, im, pg->g2b, f, 1, none, DropSpec(), false, pg->dy1);
             conv_dgrad(ps, s, pg->g2b, f, k, W(ps, P.c1w), d, dx, GEMM_ACCUM, im);
-            hipEvent_t ev = ev_side[ev_next];
-            ev_next = (ev_next + 1) & 7;
-            hipEventRecord(ev, stream);
-            hipStreamWaitEvent(side, ev, 0);
+            fork_side();
             {
                 GemmBatchScope batch(gx_side, side);
                 conv_wgrad(ps, s, pg->g2a, f, k, b.n1, f, P.c2w, P.c2b, im, 0, &gx_side, side);
@@ -1671,10 +1674,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                         (const unsigned char*)p.r_inrect, row_ts_r, act, dc.p, dc.ts, P.cout, ysc);
             TS xin = (i == 0) ? mel : postB[i - 1].a;
             if (dfp) {   // this layer's weight gradient on the side stream, overlapping the rest of the backward chain
-                hipEvent_t ev = ev_side[ev_next];
-                ev_next = (ev_next + 1) & 7;
-                hipEventRecord(ev, stream);
-                hipStreamWaitEvent(side, ev, 0);
+                fork_side();
                 GemmBatchScope batch(gx_side, side);
                 conv_wgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, xin, P.cin, P.w, P.b, p.r_inrect, 0, &gx_side, side);
                 defer_live = true;
@@ -1701,10 +1701,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                     (const float*)gRm.p, gRm.ts, (const int*)p.f2r, row_ts_f, gMelF.p, gMelF.ts, nm);
         TS dec_out = cfg.dec_layers ? decB[cfg.dec_layers - 1].y2 : dec_in;
         if (dfm) {
-            hipEvent_t ev = ev_side[ev_next];
-            ev_next = (ev_next + 1) & 7;
-            hipEventRecord(ev, stream);
-            hipStreamWaitEvent(side, ev, 0);
+            fork_side();
             {
                 GemmBatchScope batch(gx_side, side);
                 conv_wgrad(ps, SP_F, gMelF, nm, 1, dec_out, d, mel_w, -1, nullptr, 0, &gx_side, side);
