@@ -184,6 +184,14 @@ public:
     int ev_next = 0;
     GemmCtx gx_side;
     float* col_partial_side = nullptr;   // the side stream's own scratch of the two-stage column reduction
+    // Encoder run-ahead (same regime): a non-adapted encoder does not depend on the fast weights, so the encoder forwards of ALL inner
+    // steps (they differ only by their dropout seeds) are enqueued on a second side stream before the inner loop and overlap it; step s
+    // waits for its event and reads the kept copy of the encoder output
+    static constexpr int kAhead = 8;
+    hipStream_t side2 = nullptr;
+    hipEvent_t ev_enc[kAhead] = {};
+    TS enc_ahead[kAhead];
+    GemmCtx gx_side2;
     bool defer_live = false;             // side-stream work of the current backward pass is outstanding
     struct PredBuf { TS r1, st1, n1, r2, st2, n2, out; };
     struct PostBuf { TS c, a, stats, dgamma_tmp; };
@@ -618,7 +626,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         const size_t bytes = (size_t)defer_tasks * per_row * sizeof(float) *
                              ((size_t)cfg.enc_layers * (capMp + 2 * G) + (size_t)cfg.dec_layers * (capMf + 2 * G)) +
                              (size_t)defer_tasks * cfg.postnet_layers * (size_t)(capMr + 2 * G) * post_c * sizeof(float) +
-                             (size_t)defer_tasks * 3 * 4 * (size_t)(capMp + 2 * G) * cfg.vp_filter * sizeof(float) + 4096;
+                             (size_t)defer_tasks * 3 * 4 * (size_t)(capMp + 2 * G) * cfg.vp_filter * sizeof(float) +
+                             (size_t)defer_tasks * kAhead * (size_t)(capMp + 2 * G) * d * sizeof(float) + 4096;
         HIP_CHECK(hipMalloc((void**)&arena_defer, bytes));
         HIP_CHECK(hipMemset(arena_defer, 0, bytes));
         char* cur = arena_defer;
@@ -635,6 +644,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         };
         mk(encG, cfg.enc_layers, capMp);
         mk(decG, cfg.dec_layers, capMf);
+        for (auto& t : enc_ahead) t = rows_d(capMp, d);
         for (auto& pg : predG) { pg.g2a = rows_d(capMp, cfg.vp_filter); pg.g2b = rows_d(capMp, cfg.vp_filter); pg.dy2 = rows_d(capMp, cfg.vp_filter); pg.dy1 = rows_d(capMp, cfg.vp_filter); }
         postG.resize(cfg.postnet_layers);
         for (auto& t : postG) t = rows_d(capMr, post_c);
@@ -646,6 +656,11 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         for (auto& e : ev_side) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipEventCreate(&ev_join));
+        HIP_CHECK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
+        for (auto& e : ev_enc) HIP_CHECK(hipEventCreate(&e));
+        gx_side2.numerics = 0;
+        gx_side2.no_glds = gx_side.no_glds;
+        if (gx_side2.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace of the run-ahead stream)"); return -1; }
         const int side_chunks = (std::max(std::max(capMp, capMf), capMr) + kRC - 1) / kRC;   // == col_max_chunks (set by layout(), later)
         HIP_CHECK(hipMalloc((void**)&col_partial_side, (size_t)defer_tasks * side_chunks * 3 * 1024 * sizeof(float)));
         gx_side.numerics = 0;
@@ -657,6 +672,9 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (side) { hipStreamSynchronize(side); hipStreamDestroy(side); }
         for (auto& e : ev_side) if (e) hipEventDestroy(e);
         if (ev_join) hipEventDestroy(ev_join);
+        if (side2) { hipStreamSynchronize(side2); hipStreamDestroy(side2); }
+        for (auto& e : ev_enc) if (e) hipEventDestroy(e);
+        gx_side2.release();
         gx_side.release();
         if (arena_defer) hipFree(arena_defer);
         if (col_partial_side) hipFree(col_partial_side);
@@ -967,6 +985,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         float p_control = 1.f, e_control = 1.f, d_control = 1.f;
         unsigned seed_override = 0;  // != 0: replay this dropout seed (second-order HVP re-runs inner step k)
         bool update_bn = true;  // momentum update of the BatchNorm running buffers (off when a pass is re-run for a HVP)
+        TS enc_out{nullptr, 0}; // set: the encoder output of this pass was computed ahead of time (run_encoder_ahead): skip embedding + encoder
     };
     enum Space { SP_P = 0, SP_F = 1, SP_R = 2 };
 
@@ -1401,26 +1420,54 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // =================================================================================
     // full forward (fastspeech2.py:40-112 / base_adaptor.py:41-95), teacher-forced
     // =================================================================================
+    unsigned next_drop_seed() {
+        unsigned sd = ((drop_base + 0x9E3779B9u) * 0x85EBCA6Bu) ^ (0x632BE5ABu * ++drop_counter);
+        sd ^= sd >> 15;
+        return sd ? sd : 1u;
+    }
+    // embedding + positions + encoder blocks (ps.pl->drop_seed already set); returns the encoder output
+    TS encoder_fwd(const Pass& ps) {
+        const Plan& p = *ps.pl;
+        TS none{nullptr, 0};
+        TS we = W(ps, word_emb);
+        MTTS_LAUNCH(embed_pos_kernel, row_grid(p.maxMp, p.tasks), dim3(256), stream, (const int*)p.meta, (int)META_MP, emb_out.p,
+                    emb_out.ts, (const float*)we.p, we.ts, (const float*)pos_table, (const int*)p.p_tok, (const int*)p.p_row_t,
+                    (const unsigned char*)p.p_valid, row_ts_p, cfg.d_model);
+        TS x = emb_out;
+        for (int l = 0; l < cfg.enc_layers; ++l) { site_base = 2 * l; fft_fwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], x, none); x = encB[l].y2; }
+        return x;
+    }
+    // Run-ahead (see kAhead): enqueue the encoder forwards of `steps` train-mode passes over plan `pl` on side2; seeds[s] / enc_ahead[s] /
+    // ev_enc[s] belong to step s.  Returns false when the regime does not qualify (the caller then runs forward() as usual).
+    bool run_encoder_ahead(Plan& pl, int steps, unsigned* seeds) {
+        static const int on = [] { const char* e = getenv("MTTS_ENC_AHEAD"); return e ? atoi(e) : 1; }();
+        if (!on || steps < 1 || steps > kAhead || encoder_adapted() || !defer_ok(pl) || side2 == nullptr || gx.prof.enabled) return false;
+        for (int s = 0; s < steps; ++s) seeds[s] = next_drop_seed();
+        hipEvent_t ev = ev_side[ev_next];
+        ev_next = (ev_next + 1) % kSideEvents;
+        hipEventRecord(ev, stream);              // the batch image / plan kernels of this plan are on the main stream
+        hipStreamWaitEvent(side2, ev, 0);
+        std::swap(stream, side2);
+        std::swap(gx, gx_side2);
+        for (int s = 0; s < steps; ++s) {
+            Pass pe{&pl, true, true};
+            pl.drop_seed = seeds[s];
+            TS x = encoder_fwd(pe);
+            MTTS_LAUNCH(copy_tasks_kernel, dim3((unsigned)std::min<long long>(((long long)pl.maxMp * cfg.d_model / 4 + 255) / 256, 1024), 1, pl.tasks), dim3(256),
+                        stream, (const float*)x.p, x.ts, enc_ahead[s].p, enc_ahead[s].ts, (long long)pl.maxMp * cfg.d_model / 4);
+            hipEventRecord(ev_enc[s], stream);
+        }
+        std::swap(gx, gx_side2);
+        std::swap(stream, side2);
+        return true;
+    }
     int forward(const Pass& ps) {
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, nt = p.tasks;
         TS none{nullptr, 0};
+        if (ps.train) ps.pl->drop_seed = ps.seed_override ? ps.seed_override : next_drop_seed();
         // encoder
-        TS we = W(ps, word_emb);
-        MTTS_LAUNCH(embed_pos_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP, emb_out.p,
-                    emb_out.ts, (const float*)we.p, we.ts, (const float*)pos_table, (const int*)p.p_tok, (const int*)p.p_row_t,
-                    (const unsigned char*)p.p_valid, row_ts_p, d);
-        if (ps.train) {
-            unsigned sd = ps.seed_override;
-            if (!sd) {
-                sd = ((drop_base + 0x9E3779B9u) * 0x85EBCA6Bu) ^ (0x632BE5ABu * ++drop_counter);
-                sd ^= sd >> 15;
-                if (!sd) sd = 1u;
-            }
-            ps.pl->drop_seed = sd;
-        }
-        TS x = emb_out;
-        for (int l = 0; l < cfg.enc_layers; ++l) { site_base = 2 * l; fft_fwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], x, none); x = encB[l].y2; }
+        TS x = ps.enc_out.p ? ps.enc_out : encoder_fwd(ps);
         // speaker vector, added on every position of the phoneme rectangle
         TS tb = W(ps, spk_table);
         if (p.ext_spk)   // the batch's own embeddings (speaker_encoder.py:71-76 computed by the d-vector encoder): rows of the image
@@ -1808,7 +1855,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             MTTS_LAUNCH(broadcast_kernel, dim3(blocks_for(n_adapt / 4), 1, nt), dim3(256), stream,
                         (const float*)(theta + adapt_start), fast, n_adapt / 4, n_adapt);
         Pass ps{&sp, true, true};
+        unsigned seeds[kAhead];
+        const bool ahead = run_encoder_ahead(sp, steps, seeds);
         for (int s = 0; s < steps; ++s) {
+            if (ahead) { hipStreamWaitEvent(stream, ev_enc[s], 0); ps.seed_override = seeds[s]; ps.enc_out = enc_ahead[s]; }
             if (forward(ps)) return -1;
             if (sup_losses_out && loss(ps, sup_losses_out + (long long)s * nt * 6)) return -1;
             if (backward(ps, 1.f, encoder_adapted())) return -1;
@@ -1833,7 +1883,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             MTTS_LAUNCH(broadcast_kernel, dim3(blocks_for(n_adapt / 4), 1, nt), dim3(256), stream,
                         (const float*)(theta + adapt_start), fast, n_adapt / 4, n_adapt);
         Pass ps{&sp, true, true};
+        unsigned seeds[kAhead];
+        const bool ahead = run_encoder_ahead(sp, steps, seeds);
         for (int s2 = 0; s2 < steps; ++s2) {
+            if (ahead) { hipStreamWaitEvent(stream, ev_enc[s2], 0); ps.seed_override = seeds[s2]; ps.enc_out = enc_ahead[s2]; }
             if (forward(ps)) return -1;
             if (sup_losses_out && loss(ps, sup_losses_out + (long long)s2 * nt * 6)) return -1;
             if (backward(ps, 1.f, encoder_adapted())) return -1;
