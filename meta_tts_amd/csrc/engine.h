@@ -1499,7 +1499,19 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             PredBuf* const BB[3] = {&durB, &pitB, &eneB};
             const TS XX[3] = {x0, x0, x1};
             const int SS[3] = {128, 132, 136};
-            pred_fwd3(ps, PP, BB, XX, SS);
+            // teacher-forced: nothing downstream in the forward reads the predictions (the decoder input uses the TARGET embeddings); with
+            // an idle side stream the predictors overlap the decoder and are joined at the end of forward()
+            static const bool pred_side = [] { const char* e = getenv("MTTS_PRED_SIDE"); return e ? atoi(e) != 0 : true; }();
+            if (pred_side && defer_ok(p) && !defer_live && !gx.prof.enabled) {
+                fork_side();
+                std::swap(stream, side);
+                std::swap(gx, gx_side);
+                pred_fwd3(ps, PP, BB, XX, SS);
+                std::swap(gx, gx_side);
+                std::swap(stream, side);
+            } else {
+                pred_fwd3(ps, PP, BB, XX, SS);
+            }
             xp = x2;
         } else {
         site_base = 128; pred_fwd(ps, durP, durB, x0);
@@ -1606,6 +1618,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             MTTS_LAUNCH(add2_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), stream, base_a, base_b,
                         base_o, n4);
         }
+        join_side();   // (the predictors of a teacher-forced pass may have run on the side stream)
         return 0;
     }
 
