@@ -8,7 +8,10 @@
  * message); nothing throws across the ABI.  A handle owns all device memory it needs (allocated in
  * mtts_create for the stated capacities; no allocation afterwards).  All work is enqueued on the
  * handle's HIP stream (mtts_set_stream) and is asynchronous w.r.t. the host unless a function
- * copies results to a host pointer, in which case it synchronises that stream.  A handle must not
+ * copies results to a host pointer, in which case it synchronises that stream.  For small plans the
+ * handle additionally uses two private non-blocking streams (parameter gradients, encoder run-ahead);
+ * they are forked from and joined back into the handle's stream with events inside the same call, so
+ * ordering against the caller's stream is exactly as if everything ran on it.  A handle must not
  * be used from two host threads at once, but DIFFERENT handles share no mutable state (launch queue,
  * profiler, split-K workspace and numerics mode are per handle) and may be driven from different host
  * threads concurrently.  "host" pointers are host memory, "dev" pointers device.
