@@ -1056,8 +1056,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         g.flags = flags;
         g.rowmask = rowmask; g.rowmask_gs = row_ts(s);
         if (relu_ref.p) { g.relu_ref = relu_ref.p; g.relu_ref_gs = relu_ref.ts; g.ld_relu = cout; }
+        // experiment (MTTS_FWD_SINGLE_MULTI=1): under-filled forward GEMMs through the multi-problem path, whose long-chain split-K rule
+        // then applies to them as it does to the single queued dgrads of the deferred backward
+        static const bool fwd_multi = [] { const char* e = getenv("MTTS_FWD_SINGLE_MULTI"); return e ? atoi(e) != 0 : false; }();
+        const bool own_scope = fwd_multi && !gx.batch.open && defer_ok(p);
+        if (own_scope) gemm_batch_begin(gx);
         gemm_launch(gx, GEMM_NT, g, maxM(p, s), cout, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s),
                     4.0 * (alg_rows(p, s) * (cin + cout) + (double)p.tasks * cout * k * cin));
+        if (own_scope) gemm_batch_end(gx, stream);
     }
     // dX[M,Cin] (+)= sum_taps dY[M +- tap, Cout] * W  (conv dgrad over the same [Cout][k][Cin] image)
     void conv_dgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS w, int cin, TS dx, int flags,
