@@ -1,0 +1,83 @@
+"""The side-stream paths of small plans (engine.h: deferred parameter gradients, encoder run-ahead, predictors on the side stream,
+batched predictor GEMMs) only re-plumb buffers and launch order: with every knob off the engine must produce the SAME outer gradient,
+losses and adapted weights, bit for bit.  The knobs are read once per process, so each arm runs in its own interpreter (SIMT emulator
+here; `-m gpu` runs the same comparison on the MI355X, where the paths really are concurrent)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import __graft_entry__ as ge
+from oracle_util import synth, tiny_dims
+from meta_tts_amd.engine import Engine
+gpu = {gpu}
+lib = None if gpu else ge.build_emulator()
+dims = tiny_dims()
+kw = dict(n_mel=dims.n_mel, vocab=dims.vocab, s_range=(5, 13), d_range=(1, 6), first_len=12)
+mods = ["speaker_emb", "variance_adaptor", "decoder", "mel_linear", "postnet"]
+eng = Engine(dims, adapt_modules=mods, max_tasks=2, max_B=3, max_S=16, max_T=96, lib_path=lib)
+eng.load_params(synth.make_params(dims, 0))
+eng.set_dropout(True, 77)
+sup = [synth.make_batch(3, 3, speaker=2, **kw), synth.make_batch(4, 2, speaker=5, **kw)]
+qry = [synth.make_batch(5, 2, speaker=2, **kw), synth.make_batch(6, 3, speaker=5, **kw)]
+out = {{}}
+for order in (1, 2):
+    eng.set_batches(0, sup)
+    eng.set_batches(1, qry, spk_from=sup, average_spk=True)
+    q, sl = eng.meta_grad(3, 0.02, 0.5, second_order=(order == 2))
+    out[f"q{{order}}"] = q
+    out[f"s{{order}}"] = sl
+    for n in ("mel_linear.weight", "decoder.layer_stack.1.pos_ffn.w_1.weight", "encoder.layer_stack.0.slf_attn.fc.weight",
+              "variance_adaptor.pitch_predictor.conv_layer.conv1d_1.conv.bias", "variance_adaptor.energy_predictor.linear_layer.weight",
+              "postnet.convolutions.2.0.conv.bias", "decoder.layer_stack.0.slf_attn.layer_norm.weight", "mel_linear.bias"):
+        out[f"g{{order}}_" + n] = eng.export(n, 1)
+eng.set_batches(0, sup)
+eng.adapt(2, 0.02, reset=True, fetch_losses=False)
+out["fast"] = eng.export("mel_linear.weight", 3, 1)
+np.savez({path!r}, **out)
+"""
+
+
+def _run(tmp_path, tag, env, gpu):
+    path = str(tmp_path / f"{tag}.npz")
+    code = WORKER.format(root=ROOT, tests=os.path.join(ROOT, "tests"), gpu=gpu, path=path)
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return dict(np.load(path))
+
+
+OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "MTTS_PRED_BATCH": "0", "MTTS_SINGLE_MULTI": "0"}
+
+
+def _compare(tmp_path, gpu):
+    a = _run(tmp_path, "on", {}, gpu)
+    b = _run(tmp_path, "off", OFF, gpu)
+    assert set(a) == set(b) and len(a) >= 15
+    for k in a:
+        assert np.isfinite(a[k]).all(), k
+        if gpu and k.startswith(("g", "fast")):
+            # on the hardware arm MTTS_SINGLE_MULTI changes the split-K factor of a few GEMMs (a different, still fixed, summation order)
+            np.testing.assert_allclose(a[k], b[k], rtol=2e-4, atol=1e-6 * max(1.0, float(np.abs(b[k]).max())), err_msg=k)
+        elif gpu:
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-5, err_msg=k)
+        else:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert np.abs(a["g1_mel_linear.weight"]).max() > 0 and np.abs(a["g2_mel_linear.weight"] - a["g1_mel_linear.weight"]).max() > 0
+
+
+def test_side_stream_paths_change_nothing_emulator(tmp_path):
+    _compare(tmp_path, False)
+
+
+@pytest.mark.gpu
+def test_side_stream_paths_change_nothing_gpu(tmp_path):
+    _compare(tmp_path, True)
