@@ -553,19 +553,33 @@ def main():
                              "frac": round(nbytes / (us * 1e-6) / 8e12, 3),
                              "bytes_model": "per parameter: 4 (grad, norm pass) + 4 (grad) + 12 (theta, m, v read) + 12 (written)"}}
     cpu = None
+    cpu_error = None
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(dims, mods)
+        try:
+            cpu = cpu_baseline(dims, mods)
+        except Exception as ex:  # noqa: BLE001
+            cpu_error = f"{type(ex).__name__}: {ex}"
     eng.close()
+    # auxiliary legs (other BASELINE configs, components beside the hot path): a failure there is reported in the line, it must not
+    # cost the headline measurement above
+    aux_errors = {}
+
+    def guarded(name, fn, *a):
+        try:
+            return fn(*a)
+        except Exception as ex:  # noqa: BLE001
+            aux_errors[name] = f"{type(ex).__name__}: {ex}"
+            return None
     infer = None
     if rank == 0 and n == 1 and not args.no_inference:
-        infer = inference_leg(dims, mods, local_rank)
-    mel_l1 = mel_l1_leg(dims, local_rank) if (rank == 0 and n == 1 and args.numerics == "fp32") else None
+        infer = guarded("inference_c5", inference_leg, dims, mods, local_rank)
+    mel_l1 = guarded("mel_l1_vs_reference", mel_l1_leg, dims, local_rank) if (rank == 0 and n == 1 and args.numerics == "fp32") else None
     c2 = None
     if rank == 0 and n == 1 and not args.no_baseline_c2:
-        c2 = baseline_c2_leg(dims, local_rank, noam_lr, trn)
+        c2 = guarded("baseline_c2", baseline_c2_leg, dims, local_rank, noam_lr, trn)
     front = None
     if rank == 0 and n == 1 and not args.no_frontend and part == n:
-        front = frontend_leg(local_rank)
+        front = guarded("frontend", frontend_leg, local_rank)
     if n > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -596,6 +610,10 @@ def main():
             line["baseline_c2"] = c2
         if front is not None:
             line["frontend"] = front
+        if cpu_error:
+            aux_errors["cpu_baseline"] = cpu_error
+        if aux_errors:
+            line["auxiliary_leg_errors"] = aux_errors
         if roof is not None:
             line["roofline"] = roof
         if hbm is not None:
