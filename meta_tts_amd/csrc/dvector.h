@@ -335,7 +335,8 @@ public:
         if (train && !train_ready) { set_error("mtts_dvector_enable_training first"); return -1; }
         if (!mels_host || !utt_off || !out_host || N < 1 || N > cap_N || B < 1 || B > cap_B) { set_error("bad d-vector arguments"); return -1; }
         if (utt_off[0] != 0 || utt_off[B] != N) { set_error("utterance offsets must cover [0, N)"); return -1; }
-        for (int b = 0; b < B; ++b) if (utt_off[b + 1] < utt_off[b]) { set_error("utterance offsets must not decrease"); return -1; }
+        for (int b = 0; b < B; ++b)   // an utterance without partials has no embedding (the reference's mean over an empty slice is NaN)
+            if (utt_off[b + 1] <= utt_off[b]) { set_error("every utterance needs at least one partial utterance (offsets must increase)"); return -1; }
         if (dirty && refresh() != 0) return -1;
         const long long rows = (long long)N * T;
         DV_CHECK(hipMemcpyAsync(mels, mels_host, (size_t)rows * n_mels * sizeof(float), hipMemcpyHostToDevice, stream));

@@ -53,6 +53,10 @@ def test_state_dict_names_and_errors():
         enc.load_state_dict(bad)
     with pytest.raises(ValueError):
         enc.embed(np.zeros((1, 6, 8), np.float32), [slice(0, 1)])            # wrong frame count
+    with pytest.raises(Exception, match="at least one partial"):
+        enc.embed(np.zeros((2, 5, 8), np.float32), [slice(0, 2), slice(2, 2)])   # an utterance without partial utterances
+    with pytest.raises(ValueError):
+        enc.embed(np.zeros((5, 5, 8), np.float32), [slice(0, 5)])            # more partials than the encoder was created for
     enc.close()
 
 

@@ -51,6 +51,26 @@ def test_stft_emulator_small():
     _run(ge.build_emulator(), 64, 16, 64, 12, 8000, 500, 1024)
 
 
+def test_stft_lengths_and_window_shorter_than_filter():
+    """Frame count = n // hop + 1 for lengths that are / are not multiples of the hop, the shortest legal waveform, and a window
+    shorter than the filter (centre-padded, stft.py:38-41)."""
+    lib = ge.build_emulator()
+    st = S.TacotronSTFT(64, 16, 48, 12, 8000, 0, None, max_samples=400, lib_path=lib)
+    for n in (33, 64, 320, 333, 400):
+        wav = _wave(n, 8000, n)
+        mel, energy = tools.get_mel_from_wav(wav, st)
+        rmel, renergy = orc.mel_spectrogram(wav, 64, 16, 48, st.mel_basis)
+        assert mel.shape == (12, n // 16 + 1) == rmel.shape
+        np.testing.assert_allclose(energy, renergy, rtol=2e-5, atol=2e-5)
+        live = rmel > np.log(2e-5)
+        np.testing.assert_allclose(mel[live], rmel[live], rtol=0, atol=2e-4)
+    with pytest.raises(Exception):
+        tools.get_mel_from_wav(_wave(401, 8000, 1), st)        # longer than max_samples
+    with pytest.raises(Exception):
+        S.TacotronSTFT(66, 16, 64, 12, 8000, 0, None, lib_path=lib)   # filter_length % 4 != 0
+    st.close()
+
+
 @pytest.mark.gpu
 def test_stft_gpu_libritts_configuration():
     ge.build_device()
