@@ -31,7 +31,7 @@ META_BATCH = 8
 INNER_STEPS = 5
 INNER_LR = 0.001
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
-KERNEL_NAMES = ["gemm_f32<NT,64>", "gemm_f32<NT,128>", "gemm_f32<NN,64>", "gemm_f32<NN,128>", "gemm_f32<TN,64>", "gemm_f32<TN,128>", "gemm_f32_multi<64>"]
+PARITY_RTOL = 2e-3  # per-task query losses of the timed configuration (dropout off) vs the oracle; the line is refused above it
 
 
 def noam_lr(step, d_model=256, warm=4000, anneal=(300000, 400000, 500000), rate=0.3):
@@ -119,7 +119,7 @@ def cpu_baseline(dims, mods, budget_s=25.0):
         sweep[nthr] = round(best, 3)
     cores = min(sweep, key=sweep.get)
     torch.set_num_threads(cores)
-    times = []
+    times, q_ref = [], []
     t_all = time.perf_counter()
     j = 0
     while j < META_BATCH and (time.perf_counter() - t_all) < budget_s:
@@ -129,12 +129,16 @@ def cpu_baseline(dims, mods, budget_s=25.0):
                                   second_order=False, modules=mods, n_head=(dims.enc_heads, dims.dec_heads))
         torch.autograd.grad(ql[0], [params[n] for n in names], allow_unused=True)
         times.append(time.perf_counter() - t0)
+        q_ref.append([float(x) for x in ql])
         j += 1
     mean_t = float(np.mean(times))
     return {"value": 1.0 / (META_BATCH * mean_t), "unit": "meta-steps/s", "cores": int(cores), "kind": "port",
+            "query_losses": q_ref,
             "host_cores": int(host_cores), "thread_sweep_s_per_inner_step": {str(k): v for k, v in sweep.items()},
             "sample": f"{len(times)} of {META_BATCH} tasks (5 inner steps + query fwd/bwd each, first-order, fp32 torch-CPU oracle) at the best of the "
-                      f"swept intra-op thread counts ({cores}); {mean_t:.2f} s/task, clip+Adam excluded (<1%)"}
+                      f"swept intra-op thread counts ({cores}); {mean_t:.2f} s/task, clip+Adam excluded (<1%)",
+            "note": "tasks run one after the other, as the reference's CPU path does; 8 concurrent task processes on this box's cores would be the "
+                    "harder same-box baseline (roughly 8x this figure if the cores scaled perfectly)"}
 
 
 def inference_leg(dims, mods, device, iters=5):
@@ -256,10 +260,9 @@ def mel_l1_leg(dims, device):
 
 def baseline_c2_leg(dims, device, noam_lr, trn, iters=8):
     """BASELINE config 2: multi-task baseline (algorithm=baseline: no inner loop, baseline.py:25-36) on ONE synthetic
-    LibriTTS-shaped batch of 16 utterances — forward + backward + clip + Adam per step, dropout on.  Timed in the exact
-    fp32 mode (the reference's arithmetic and the parity numerics: BASELINE.json's "bf16" for this config is below the reference's
-    own fp32 and misses the 1e-4 mel gate, so it is not offered) and in the optional split-bf16 mode; the bf16x3 line carries its
-    mel L1 against the fp32 forward of the same weights (eval mode) so the precision cost is visible next to the speed."""
+    LibriTTS-shaped batch of 16 utterances — forward + backward + clip + Adam per step, dropout on.  Timed in fp32 (the reference's
+    arithmetic and the parity numerics: BASELINE.json's "bf16" for this config is below the reference's own fp32 and misses the 1e-4
+    mel gate, so it is not offered)."""
     import torch
     from meta_tts_amd import synth
     from meta_tts_amd.engine import Engine
@@ -269,29 +272,17 @@ def baseline_c2_leg(dims, device, noam_lr, trn, iters=8):
     eng.load_params(synth.make_params(dims, 0))
     eng.set_batches(0, [batch])
     frames = int(np.asarray(batch[7]).sum())
-    lens = np.asarray(batch[7])
-    evals = {}
-    for mode in (0, 1):  # eval-mode forwards of the untouched weights / BatchNorm buffers, before any training step
-        eng.set_numerics(mode)
-        eng.forward(0, train=False)
-        evals[mode] = eng.outputs(0, 0)["mel_post"]
     res = {"workload": "C2: algorithm=baseline, batch 16 (sum T = %d frames), fwd + bwd + clip + Adam" % frames}
-    for name, mode in (("fp32", 0), ("bf16x3", 1)):
-        eng.set_numerics(mode)
-        eng.load_params(synth.make_params(dims, 0))
-        eng.reset_optimizer()
-        l1 = float(np.mean([np.abs(evals[mode][b, :lens[b]] - evals[0][b, :lens[b]]).mean() for b in range(16)]))
-        eng.set_dropout(True, 99)
-        for it in range(iters + 2):
-            if it == 2:
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-            eng.plain_grad(0, 1.0, fetch_losses=False)
-            eng.outer_update(lr=noam_lr(it, dims.d_model, trn["warm_up_step"], trn["anneal_steps"], trn["anneal_rate"]), betas=tuple(trn["betas"]),
-                             eps=trn["eps"], weight_decay=trn["weight_decay"], max_norm=trn["grad_clip_thresh"])
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / iters
-        res[name] = {"steps_per_sec": round(1.0 / dt, 3), "ms_per_step": round(1e3 * dt, 2), "frames_per_sec": round(frames / dt, 1),
-                     "mel_l1_vs_fp32_eval": l1}
+    eng.set_dropout(True, 99)
+    for it in range(iters + 2):
+        if it == 2:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        eng.plain_grad(0, 1.0, fetch_losses=False)
+        eng.outer_update(lr=noam_lr(it, dims.d_model, trn["warm_up_step"], trn["anneal_steps"], trn["anneal_rate"]), betas=tuple(trn["betas"]),
+                         eps=trn["eps"], weight_decay=trn["weight_decay"], max_norm=trn["grad_clip_thresh"])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    res["fp32"] = {"steps_per_sec": round(1.0 / dt, 3), "ms_per_step": round(1e3 * dt, 2), "frames_per_sec": round(frames / dt, 1)}
     eng.close()
     return res
 
@@ -303,9 +294,9 @@ def gemm_profile(eng, run):
     eng.profile_gemm(True)
     run()
     torch.cuda.synchronize()
-    rep = eng.profile_report()
+    rep = eng.profile_report()   # {kernel name as rocprofv3 prints it: [launches, ms, flops, bytes]}
     eng.profile_gemm(False)
-    return [(KERNEL_NAMES[k], rep[k][0], rep[k][1], rep[k][2], rep[k][3]) for k in range(7)]
+    return [(name, r[0], r[1], r[2], r[3]) for name, r in rep.items()]
 
 
 def roofline_of(rows, pmc_key=None):
@@ -317,11 +308,11 @@ def roofline_of(rows, pmc_key=None):
     # committed separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (profiles/).
     traffic, traffic_src, mfma_busy = None, None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r02_pmc_hbm.json", "r01_pmc_hbm.json"):
+    for name in ("r03_pmc_hbm.json", "r02_pmc_hbm.json"):
         pmc_path = os.path.join(here, "profiles", name)
         if pmc_key is not None and os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                k = json.load(f).get(pmc_key, {}).get(dom[0])
+                k = json.load(f).get(pmc_key, {}).get(dom[0].split("<")[0])
             if k:
                 traffic, traffic_src, mfma_busy = k.get("hbm_bytes_per_launch"), "profiles/" + name, k.get("mfma_busy_frac")
                 break
@@ -348,13 +339,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-inference", action="store_true")
     ap.add_argument("--no-frontend", action="store_true", help="skip the d-vector encoder / mel front-end timing")
-    ap.add_argument("--no-baseline-c2", action="store_true", help="skip the extra C2 (multi-task baseline, batch 16, fp32 + bf16x3) measurement")
+    ap.add_argument("--no-baseline-c2", action="store_true", help="skip the extra C2 (multi-task baseline, batch 16) measurement")
     ap.add_argument("--order", type=int, default=1, choices=(1, 2),
                     help="MAML order of the timed meta-step: 1 = BASELINE config C3 (first-order), 2 = the reference's training mode / config C4")
     ap.add_argument("--no-second-order", action="store_true", help="skip the extra second-order measurement")
-    ap.add_argument("--numerics", choices=("fp32", "bf16x3"), default="fp32",
-                    help="contraction numerics of the timed meta-step: exact fp32 MFMA (default, parity mode) or split-bf16")
-    ap.add_argument("--no-bf16x3-leg", action="store_true", help="skip the extra split-bf16 measurement")
     ap.add_argument("--no-dropout", action="store_true", help="parity configuration (dropout = identity) instead of train-mode dropout")
     ap.add_argument("--resident-batches", action="store_true",
                     help="upload the batches once before the timed region instead of every step (round-1 behaviour; the default re-ingests the "
@@ -451,7 +439,6 @@ def main():
             ar_impl = f"torch.distributed all_reduce (library communicator unavailable on some rank: {why or 'see other ranks'})"
 
     step_no = [0]
-    eng.set_numerics(1 if args.numerics == "bf16x3" else 0)
     ar_events = []
 
     def meta_step(order=None, timed_ar=False):
@@ -512,16 +499,6 @@ def main():
         dso = timed(so_steps, 2)
         so = {"value": round(so_steps / dso, 4), "unit": "meta-steps/s", "ms_per_step": round(1e3 * dso / so_steps, 2), "steps": so_steps,
               "workload": "same 8-task meta-step, second-order MAML (Hessian-vector recursion through the 5 inner steps)"}
-    b16 = None
-    if args.numerics == "fp32" and not args.no_bf16x3_leg:
-        # same first-order meta-step with the split-bf16 contraction numerics (3 bf16 MFMAs per product)
-        eng.set_numerics(1)
-        meta_step(1)
-        d16 = timed(args.steps, 1)
-        eng.set_numerics(0)
-        b16 = {"value": round(args.steps / d16, 4), "unit": "meta-steps/s", "ms_per_step": round(1e3 * d16 / args.steps, 2),
-               "numerics": "fp32 operands split into 2 x bf16, 3 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; "
-                           "mel L1 vs reference 1.0e-5 in eval mode (gate 1e-4), 1.6e-4 with train-mode BatchNorm"}
     q_losses = None
     roof = None
     if rank == 0:
@@ -559,6 +536,23 @@ def main():
             cpu = cpu_baseline(dims, mods)
         except Exception as ex:  # noqa: BLE001
             cpu_error = f"{type(ex).__name__}: {ex}"
+    # parity of the TIMED configuration (this rank's grouped tasks, the kernels and launch paths the clock just ran) against the
+    # oracle's per-task query losses: the line is refused when they disagree
+    parity = None
+    if cpu is not None:
+        # same handle, same grouped launches as the timed steps, dropout off (the oracle's configuration); the weights have moved by the
+        # timed Adam steps and the oracle ran on the initial ones, so they are loaded again first
+        eng.load_params(synth.make_params(dims, 0))
+        eng.set_dropout(False, 0)
+        ingest()
+        q_parity, _ = eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, fetch_losses=True)
+        ref = np.asarray(cpu["query_losses"], np.float64)
+        got = np.asarray(q_parity, np.float64)[: len(ref)]
+        rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-6)
+        parity = {"tasks_checked": int(len(ref)), "tasks_grouped_in_the_launches": len(local), "max_rel": float(rel.max()), "rtol": PARITY_RTOL,
+                  "what": "per-task query (total, mel, postnet mel, pitch, energy, duration) losses after 5 inner steps, dropout off, vs oracle/fs2_oracle.py"}
+        if not (rel.max() <= PARITY_RTOL):
+            raise SystemExit(f"bench.py: parity check of the timed configuration failed: {parity}")
     eng.close()
     # auxiliary legs (other BASELINE configs, components beside the hot path): a failure there is reported in the line, it must not
     # cost the headline measurement above
@@ -573,7 +567,7 @@ def main():
     infer = None
     if rank == 0 and n == 1 and not args.no_inference:
         infer = guarded("inference_c5", inference_leg, dims, mods, local_rank)
-    mel_l1 = guarded("mel_l1_vs_reference", mel_l1_leg, dims, local_rank) if (rank == 0 and n == 1 and args.numerics == "fp32") else None
+    mel_l1 = guarded("mel_l1_vs_reference", mel_l1_leg, dims, local_rank) if (rank == 0 and n == 1) else None
     c2 = None
     if rank == 0 and n == 1 and not args.no_baseline_c2:
         c2 = guarded("baseline_c2", baseline_c2_leg, dims, local_rank, noam_lr, trn)
@@ -587,11 +581,11 @@ def main():
         ms = 1e3 * dt / args.steps
         line = {"metric": "meta-steps/sec (8-task meta-batch, 5 inner steps)", "value": round(args.steps / dt, 4), "unit": "meta-steps/s",
                 "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
-                "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.numerics == "fp32" else "bf16x3 (split f32, fp32 accumulate)", "data": "synthetic",
+                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": ("C3: Meta-TTS MAML first-order" if args.order == 1 else "C4-style: Meta-TTS MAML second-order") + " (algorithm=meta_emb_vad, inner=5, meta-batch=8 tasks x (5 support + 5 query utts)), "
                                        "FastSpeech2 base.yaml, outer mean + clip(1.0) + Adam/Noam", "meta_batch": META_BATCH,
                            "tasks_per_gpu": META_BATCH // n, "inner_steps": INNER_STEPS, "order": "first" if args.order == 1 else "second", "parallelism": f"task-dp{n}",
-                           "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.numerics == "fp32" else "bf16x3 (split-fp32 on v_mfma_f32_32x32x16_bf16)", "dropout": "identity (parity config)" if args.no_dropout else "on (0.2 / 0.5 / 0.5, counter-based masks)",
+                           "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "dropout": "identity (parity config)" if args.no_dropout else "on (0.2 / 0.5 / 0.5, counter-based masks)",
                            "batch_ingestion": "resident (uploaded once before the timed region)" if args.resident_batches else "inside every timed step (host 12-tuples -> HBM + plans)"},
                 **({"emulated_world": part, "note": "diagnostic: rank-0 share of an emulated multi-rank run, no collective"} if part != n else {}),
                 "batch_ingest_ms_per_step": round(ingest_ms, 3),
@@ -600,8 +594,7 @@ def main():
                 "query_total_loss_mean": round(float(q_losses[:, 0].mean()), 5) if q_losses is not None else None}
         if so is not None:
             line["second_order"] = so
-        if b16 is not None:
-            line["bf16x3_numerics"] = b16
+        line["parity_check"] = parity
         if mel_l1 is not None:
             line["mel_l1_vs_reference"] = mel_l1
         if infer is not None:
@@ -619,6 +612,7 @@ def main():
         if hbm is not None:
             line["hbm_bound_kernels"] = hbm
         if cpu is not None:
+            cpu = {k: v for k, v in cpu.items() if k != "query_losses"}
             line["cpu_baseline"] = cpu
             line["speedup_vs_cpu_baseline"] = round((args.steps / dt) / cpu["value"], 1)
         print(json.dumps(line))

@@ -186,25 +186,20 @@ int mtts_get_speaker_grad(mtts_handle* h, int task, int B, float* out);
 int mtts_set_extra_grad_sumsq(mtts_handle* h, const float* sumsq_dev);
 const float* mtts_grad_norm_dev(mtts_handle* h);
 
-/* ---- numerics of the contraction kernels of this handle.  0 (default): exact fp32 MFMA, the parity reference.
- * 1: "bf16x3" — fp32 operands split into two bf16 (16 mantissa bits) at LDS-staging time, three bf16 MFMAs per
- * product, fp32 accumulation: ~1e-5 relative error per contraction; mel L1 vs the reference 1e-5 in eval mode but 1.6e-4 through
- * train-mode BatchNorm (outside the 1e-4 gate), measured 1.2x the fp32 step on MI355X (the split costs VALU work in the K-loop):
- * an optional throughput mode, never the parity or headline configuration.  Inputs, outputs, parameters and every non-GEMM kernel
- * stay fp32. */
-int mtts_set_numerics(mtts_handle* h, int mode);
-
 /* ---- measurement: per-launch HIP-event timing of this handle's GEMM launches on its stream.
- * report: out[kernel][4] = {launches, total ms, total algorithmic flops, total algorithmic bytes (every operand and the output
- * moved once, fp32)}, 7 kernels: form*2 + (tile==128) with form 0 NT / 1 NN / 2 TN, and 6 = the multi-problem launch
- * (several independent products in one grid).  (bench.py roofline leg) */
+ * report: out[kind][4] = {launches, total ms, total algorithmic flops, total algorithmic bytes (every operand and the output
+ * moved once, fp32)}; `kinds` = mtts_profile_kinds() rows, one per real kernel symbol — mtts_profile_kernel_name(kind) is the name
+ * a rocprofv3 kernel trace prints for it (csrc/gemm.h: GemmKind).  (bench.py roofline leg) */
 int mtts_profile_gemm(mtts_handle* h, int enable);
-int mtts_profile_report(mtts_handle* h, double* out28);
+int mtts_profile_kinds(void);
+const char* mtts_profile_kernel_name(int kind);
+int mtts_profile_report(mtts_handle* h, double* out, int kinds);
 
 /* ---- kernel-level entry points (parity tests; dev pointers; stream may be NULL) ----------------
  * form 0: C[M,N] = alpha*A[M,K]*B[N,K]^T + bias   1: C = A[M,K]*B[K,N]   2: C[M,N] = A[K,M]^T*B[K,N]
- * flags bit0 ReLU, bit1 accumulate, bits 8-9 contraction numerics of this call (0 fp32, 1 bf16x3);
- * tile 0 (auto) / 64 / 128, +1000 = software-pipelined variant */
+ * flags bit0 ReLU, bit1 accumulate;
+ * tile 0 (auto: the launch queue, normally the persistent work-queue kernel) / 64 / 128 (+1000 software-pipelined variant, +2000 BK = 32) /
+ * 4064 LDS-DMA kernel / 5064, 5032 work-queue kernel with BK = 16 / 32 */
 int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, float alpha, int flags, int tile, void* hip_stream);
 /* Conv1d over one zero-guarded sequence, channels-last: x [L][Cin] with >= k/2 zero rows before and

@@ -74,9 +74,10 @@ EXPORTS = {
     "mtts_outer_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_void_p]),
     "mtts_reset_optimizer": (C.c_int, [C.c_void_p]),
-    "mtts_set_numerics": (C.c_int, [C.c_void_p, C.c_int]),
     "mtts_profile_gemm": (C.c_int, [C.c_void_p, C.c_int]),
-    "mtts_profile_report": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "mtts_profile_kinds": (C.c_int, []),
+    "mtts_profile_kernel_name": (C.c_char_p, [C.c_int]),
+    "mtts_profile_report": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "mtts_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                 C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "mtts_conv1d_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

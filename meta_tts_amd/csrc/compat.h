@@ -69,11 +69,15 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 
 // cross-workgroup hand-off primitives (split-K rendezvous in gemm.h)
 #if defined(MTTS_EMU)
+#define MTTS_WAVES_PER_EU(n)
+#define MTTS_UNIFORM(x) (x)
 #define MTTS_WAIT_VMEM() ((void)0)
 #define MTTS_FENCE_RELEASE_AGENT() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define MTTS_FENCE_ACQUIRE_AGENT() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define MTTS_ATOMIC_INC_AGENT(p) atomicAdd((p), 1)
 #else
+#define MTTS_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))   // register budget: leave room for n waves per SIMD
+#define MTTS_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // a wave-uniform int held in a VGPR (an LDS read) -> SGPR
 #define MTTS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define MTTS_FENCE_RELEASE_AGENT() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
 #define MTTS_FENCE_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")

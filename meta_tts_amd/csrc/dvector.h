@@ -268,7 +268,6 @@ public:
         DV_CHECK(hipMalloc((void**)&part, (size_t)cap_N * E * sizeof(float)));
         DV_CHECK(hipMalloc((void**)&out, (size_t)cap_B * E * sizeof(float)));
         DV_CHECK(hipMalloc((void**)&off_dev, (size_t)(cap_B + 1) * sizeof(int)));
-        gx.numerics = 0;
         if (gx.alloc_workspace() != 0) { set_error("split-K workspace allocation failed"); return -1; }
         return 0;
     }

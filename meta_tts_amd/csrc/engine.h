@@ -27,8 +27,8 @@
 #include <vector>
 
 #include "gemm.h"
-#include "gemm_bf16_launch.h"
 #include "gemm_glds.h"
+#include "gemm_sk.h"
 #include "rowops.h"
 #include "plan.h"
 #include "tangent.h"
@@ -658,12 +658,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         HIP_CHECK(hipEventCreate(&ev_join));
         HIP_CHECK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
         for (auto& e : ev_enc) HIP_CHECK(hipEventCreate(&e));
-        gx_side2.numerics = 0;
         gx_side2.no_glds = gx_side.no_glds;
         if (gx_side2.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace of the run-ahead stream)"); return -1; }
         const int side_chunks = (std::max(std::max(capMp, capMf), capMr) + kRC - 1) / kRC;   // == col_max_chunks (set by layout(), later)
         HIP_CHECK(hipMalloc((void**)&col_partial_side, (size_t)defer_tasks * side_chunks * 3 * 1024 * sizeof(float)));
-        gx_side.numerics = 0;
         { const char* e = getenv("MTTS_SIDE_GLDS"); gx_side.no_glds = !(e && atoi(e) != 0); }
         if (gx_side.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace of the side stream)"); return -1; }
         return 0;
@@ -1099,11 +1097,11 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         g.K = maxM(p, s);  // upper bound of the per-task reduction length (the kernel reads the exact one through dimptr)
         g.flags = flags;
         // the bias gradient rides on the weight-gradient GEMM (GemmArgs::colsum: one extra n-tile against the mask's float image)
-        // instead of two reduction launches per layer; the split-bf16 kernels have no such arm.  MTTS_FUSE_COLSUM=0 restores the
+        // instead of two reduction launches per layer.  MTTS_FUSE_COLSUM=0 restores the
         // separate reduction.
         static const bool fuse_cs = [] { const char* e = getenv("MTTS_FUSE_COLSUM"); return e ? atoi(e) != 0 : true; }();
         const float* mw = mask_w(p, bias_mask);
-        const bool fused = b_off >= 0 && fuse_cs && gcx.numerics == 0 && mw != nullptr;
+        const bool fused = b_off >= 0 && fuse_cs && mw != nullptr;
         if (fused) {
             TS gb = Gd(b_off);
             g.colsum = gb.p; g.colsum_gs = gb.ts; g.colsum_w = mw; g.colsum_w_gs = 4 * row_ts(s);
@@ -1303,13 +1301,13 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             defer_live = true;
         }
     }
-    // weight gradients may be deferred to the side stream for this plan (under-filled launches; exact-fp32 numerics, whose bias
+    // weight gradients may be deferred to the side stream for this plan (under-filled launches; the bias
     // gradient rides on the GEMM — the separate column reduction would run on the main stream)
     bool defer_ok(const Plan& p) const {
         static const int on = [] { const char* e = getenv("MTTS_DEFER_WGRAD"); return e ? atoi(e) : 1; }();
         static const long long max_rows = [] { const char* e = getenv("MTTS_DEFER_MAX_ROWS"); return e ? atoll(e) : 16000LL; }();
         static const bool fuse_cs = [] { const char* e = getenv("MTTS_FUSE_COLSUM"); return e ? atoi(e) != 0 : true; }();
-        return on && fuse_cs && defer_tasks > 0 && p.tasks <= defer_tasks && gx.numerics == 0 && p.sumMf <= max_rows && side != nullptr;
+        return on && fuse_cs && defer_tasks > 0 && p.tasks <= defer_tasks && p.sumMf <= max_rows && side != nullptr;
     }
     // everything enqueued on the main stream so far happens before what is enqueued on the side stream next
     void fork_side() {

@@ -289,11 +289,42 @@ struct GemmSmem {
     static constexpr int FLOATS = 2 * (A_TILE + B_TILE);
 };
 
-// One workgroup's share of one problem: output tile `bxs` (times split) of group `z`.
+// A problem of a grouped launch resolved for one group z: operand bases, sizes and leading dimensions.
+struct GemmProb {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K, lda, ldb, ldc;
+};
+__device__ __forceinline__ GemmProb gemm_resolve(const GemmArgs& g, int z) {
+    GemmProb pr{g.A, g.B, g.C, g.M, g.N, g.K, g.lda, g.ldb, g.ldc};
+    if (g.table) {
+        const GemmGroupDesc d = g.table[z];
+        pr.A += d.a_off; pr.B += d.b_off; pr.C += d.c_off;
+        pr.M = d.M; pr.N = d.N; pr.K = d.K;
+        if (d.lda) pr.lda = d.lda;
+        if (d.ldb) pr.ldb = d.ldb;
+        if (d.ldc) pr.ldc = d.ldc;
+    } else {
+        pr.A += (long long)z * g.a_gs; pr.B += (long long)z * g.b_gs; pr.C += (long long)z * g.c_gs;
+        if (g.dimptr) {
+            const int v = g.dimptr[(long long)z * g.dim_stride] * g.dim_mult;
+            if (g.dim_sel == 0) pr.M = v; else pr.K = v;
+        }
+    }
+    return pr;
+}
+// n-tiles of a resolved problem: the tiles of C plus the column-sum tile (GemmArgs::colsum, TN form only)
+template <int FORM>
+__device__ __forceinline__ bool gemm_has_colsum(const GemmArgs& g) { return (FORM == GEMM_TN) && g.colsum != nullptr && !g.table; }
+
+// K-loop of one output tile (origin m0, n0) of a resolved problem over the K-chunks [c_lo, c_hi): the products are added into acc.
+// cs_tile: the tile is the column-sum tile (its B operand is GemmArgs::colsum_w).
 // ABL (diagnostic builds only, results are wrong): bit 0 drops the in-loop global loads, bit 1 the LDS stores, bit 2 the
 // in-loop fragment reads, bit 3 the barrier — timing the kernel with one stage removed shows what that stage costs.
 template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0>
-__device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs, float* smem) {
+__device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb& pr, int z, int m0, int n0, bool cs_tile, int c_lo, int c_hi,
+                                               float* smem, f32x16 (&acc)[(BM / WGM) / 32][(BN / WGN) / 32]) {
     constexpr int NTH = 64 * WGM * WGN;
     constexpr int kLDK = BK + 4;  // K-contiguous LDS row stride: 80 / 144 bytes, ds_read_b128 conflict-free
     constexpr int KQ = BK / 4;    // float4 per K-contiguous row
@@ -307,32 +338,11 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
     constexpr int A_LD4 = (BM * KQ) / NTH;  // float4 loads per thread (both layouts: BM*BK/4 float4 per tile)
     constexpr int B_LD4 = (BN * KQ) / NTH;
     constexpr int RPP = NTH / KQ;           // K-contiguous rows covered per pass
-    const float* A = g.A;
-    const float* B = g.B;
-    float* C = g.C;
-    int M = g.M, N = g.N, K = g.K;
-    int lda = g.lda, ldb = g.ldb, ldc = g.ldc;
-    if (g.table) {
-        const GemmGroupDesc d = g.table[z];
-        A += d.a_off; B += d.b_off; C += d.c_off;
-        M = d.M; N = d.N; K = d.K;
-        if (d.lda) lda = d.lda;
-        if (d.ldb) ldb = d.ldb;
-        if (d.ldc) ldc = d.ldc;
-    } else {
-        A += (long long)z * g.a_gs; B += (long long)z * g.b_gs; C += (long long)z * g.c_gs;
-        if (g.dimptr) {
-            const int v = g.dimptr[(long long)z * g.dim_stride] * g.dim_mult;
-            if (g.dim_sel == 0) M = v; else K = v;
-        }
-    }
-    const bool has_cs = (FORM == GEMM_TN) && g.colsum != nullptr && !g.table;   // one extra n-tile: GemmArgs::colsum
-    const int tiles_nc = (N + BN - 1) / BN, tiles_n = tiles_nc + (has_cs ? 1 : 0), tiles_m = (M + BM - 1) / BM;
-    const int S = g.splitk > 1 ? g.splitk : 1;
-    const int tile_lin = bxs / S, split = bxs - tile_lin * S;
-    if (tile_lin >= tiles_m * tiles_n || K <= 0) return;
-    const int m0 = (tile_lin / tiles_n) * BM, n0 = (tile_lin % tiles_n) * BN;
-    const bool cs_tile = has_cs && n0 == tiles_nc * BN;
+    const float* A = pr.A;
+    const float* B = pr.B;
+    const int M = pr.M, N = pr.N, K = pr.K;
+    const int lda = pr.lda;
+    int ldb = pr.ldb;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
@@ -436,17 +446,8 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
         }
     };
 
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nch_all = (K + BK - 1) / BK, cps = (nch_all + S - 1) / S;
-    const int c_lo = split * cps, c_hi = (c_lo + cps < nch_all) ? c_lo + cps : nch_all;
-    const int nchunks = c_hi > c_lo ? c_hi - c_lo : 0;  // this workgroup's run of K-chunks (all of them when S == 1)
+    const int nchunks = c_hi > c_lo ? c_hi - c_lo : 0;  // this workgroup's run of K-chunks
+    if (nchunks == 0) return;
     const int kb0 = c_lo * BK;
     load_a(kb0);
     load_b(kb0);
@@ -490,6 +491,13 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
         }
     }
 
+}
+
+// What follows the K-loop: the column sums of the extra n-tile, or the fused epilogue.
+template <int TM, int TN, int WGM, int WGN>
+__device__ __forceinline__ void gemm_finish(const GemmArgs& g, const GemmProb& pr, int z, int m0, int n0, bool cs_tile, f32x16 (&acc)[TM][TN]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WGN) * (32 * TM), wn0 = (wave % WGN) * (32 * TN);
     if (cs_tile) {  // column 0 of the extra n-tile = masked column sums of A
         if (wn0 == 0 && (lane & 31) == 0) {
 #pragma unroll
@@ -497,13 +505,39 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < M) g.colsum[(long long)z * g.colsum_gs + row] = acc[i][0][r];
+                    if (row < pr.M) g.colsum[(long long)z * g.colsum_gs + row] = acc[i][0][r];
                 }
         }
         return;
     }
+    gemm_epilogue<TM, TN>(g, z, acc, pr.C, pr.ldc, pr.M, pr.N, m0 + wm0, n0 + wn0, lane);
+}
+
+// One workgroup's share of one problem: output tile `bxs` (times split) of group `z`.
+template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0>
+__device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs, float* smem) {
+    constexpr int NTH = 64 * WGM * WGN;
+    constexpr int TM = (BM / WGM) / 32, TN = (BN / WGN) / 32;
+    const GemmProb pr = gemm_resolve(g, z);
+    const bool has_cs = gemm_has_colsum<FORM>(g);
+    const int tiles_nc = (pr.N + BN - 1) / BN, tiles_n = tiles_nc + (has_cs ? 1 : 0), tiles_m = (pr.M + BM - 1) / BM;
+    const int S = g.splitk > 1 ? g.splitk : 1;
+    const int tile_lin = bxs / S, split = bxs - tile_lin * S;
+    if (tile_lin >= tiles_m * tiles_n || pr.K <= 0) return;
+    const int m0 = (tile_lin / tiles_n) * BM, n0 = (tile_lin % tiles_n) * BN;
+    const bool cs_tile = has_cs && n0 == tiles_nc * BN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nch_all = (pr.K + BK - 1) / BK, cps = (nch_all + S - 1) / S;
+    const int c_lo = split * cps, c_hi = (c_lo + cps < nch_all) ? c_lo + cps : nch_all;   // (all chunks when S == 1)
+    gemm_f32_kloop<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL>(g, pr, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
     if (S > 1 && !splitk_combine<TM, TN, NTH>(g, z, tile_lin, split, S, acc)) return;
-    gemm_epilogue<TM, TN>(g, z, acc, C, ldc, M, N, m0 + wm0, n0 + wn0, lane);
+    gemm_finish<TM, TN, WGM, WGN>(g, pr, z, m0, n0, cs_tile, acc);
 }
 
 template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0>
@@ -519,8 +553,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
 // [start[p], start[p+1]) of every z-slice belong to problem p.  The chip then never drains between two under-filled or
 // badly quantised grids — the tail of one problem is filled by the next — and it costs no stream / event traffic.
 constexpr int kGemmMultiMax = 6;
+// parameters of the persistent work-queue kernel (gemm_sk.h)
+struct GemmSk {
+    int ent_start[kGemmMultiMax + 1] = {0};  // first (problem, group) entry of each problem
+    int s_max = 4, min_chunks = 16, tol_div = 16;  // a late tile is cut into <= s_max pieces of >= min_chunks K-chunks; tolerated lateness = work / tol_div
+    int slabs = 0;                           // capacity of the partial-tile workspace (16 KB slabs, one arrival counter each)
+    float* ws = nullptr;
+    int* ctr = nullptr;
+    int* head = nullptr;                     // item queue head of THIS launch (zero on entry)
+    int* head_next = nullptr;                // the other head, zeroed for the next launch
+};
 struct GemmMulti {
     int n = 0;
+    GemmSk sk;
     int start[kGemmMultiMax + 1] = {0};
     int form[kGemmMultiMax] = {0};
     int groups[kGemmMultiMax] = {0};
@@ -563,8 +608,27 @@ __global__ __launch_bounds__(256) void gemm_f32_multi_kernel(GemmMulti mp) {
     else gemm_f32_body<GEMM_TN, BM, BN, BK, true>(mp.g[p], z, bx, smem);
 }
 
+// Kernel kinds of the launcher: one per real kernel symbol, so that a profiler line can be matched to a rocprofv3 kernel-trace row.
+enum GemmKind {
+    GK_F32_64_BK16 = 0,   // + form: gemm_f32_kernel<F, 64, 64, 16, true, 2, 2, 0>
+    GK_F32_64_BK32 = 3,   // + form: gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0>
+    GK_F32_128 = 6,       // + form: gemm_f32_kernel<F, 128, 128, *, *>
+    GK_GLDS = 9,          // + form: gemm_glds_kernel<F>
+    GK_MULTI16 = 12, GK_MULTI32 = 13, GK_GLDS_MULTI = 14, GK_SK16 = 15, GK_SK32 = 16, GK_OTHER = 17, GK_COUNT = 18
+};
+inline const char* gemm_kind_name(int k) {
+    static const char* names[GK_COUNT] = {
+        "gemm_f32_kernel<0, 64, 64, 16, true, 2, 2, 0>", "gemm_f32_kernel<1, 64, 64, 16, true, 2, 2, 0>", "gemm_f32_kernel<2, 64, 64, 16, true, 2, 2, 0>",
+        "gemm_f32_kernel<0, 64, 64, 32, true, 2, 2, 0>", "gemm_f32_kernel<1, 64, 64, 32, true, 2, 2, 0>", "gemm_f32_kernel<2, 64, 64, 32, true, 2, 2, 0>",
+        "gemm_f32_kernel<0, 128, 128, ...>", "gemm_f32_kernel<1, 128, 128, ...>", "gemm_f32_kernel<2, 128, 128, ...>",
+        "gemm_glds_kernel<0>", "gemm_glds_kernel<1>", "gemm_glds_kernel<2>",
+        "gemm_f32_multi_kernel<64, 64, 16>", "gemm_f32_multi_kernel<64, 64, 32>", "gemm_glds_multi_kernel", "gemm_sk_kernel<16, *>", "gemm_sk_kernel<32, *>",
+        "gemm_f32_kernel<other>"};
+    return (k >= 0 && k < GK_COUNT) ? names[k] : "?";
+}
+
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg):
-// one record per launch, aggregated per (form, tile) kernel instantiation.
+// one record per launch, aggregated per kernel kind.
 struct GemmProfiler {
     struct Rec { int kernel; double flops; hipEvent_t e0, e1; int form = 0, tile = 0, N = 0, K = 0, groups = 0, splitk = 1; double rows = 0, bytes = 0; };
     std::vector<Rec> recs;
@@ -577,17 +641,17 @@ struct GemmProfiler {
     }
     void reset() { recs.clear(); used = 0; }
     void destroy() { for (hipEvent_t e : pool) hipEventDestroy(e); pool.clear(); recs.clear(); used = 0; }
-    // out[kernel][4] = launches, total ms, total algorithmic flops, total algorithmic bytes; kernel = form * 2 + (tile == 128), 6 = multi-problem launch
-    void report(double out[7][4]) {
-        for (int k = 0; k < 7; ++k) out[k][0] = out[k][1] = out[k][2] = out[k][3] = 0.0;
+    // out[kind][4] = launches, total ms, total algorithmic flops, total algorithmic bytes
+    void report(double out[GK_COUNT][4]) {
+        for (int k = 0; k < GK_COUNT; ++k) out[k][0] = out[k][1] = out[k][2] = out[k][3] = 0.0;
         FILE* dump = getenv("MTTS_GEMM_DUMP") ? fopen(getenv("MTTS_GEMM_DUMP"), "w") : nullptr;  // per-launch CSV (tools/gemm_sites.py)
-        if (dump) fprintf(dump, "form,tile,N,K,rows,groups,splitk,us,gflop\n");
+        if (dump) fprintf(dump, "kind,form,tile,N,K,rows,groups,splitk,us,gflop\n");
         for (auto& r : recs) {
             hipEventSynchronize(r.e1);
             float ms = 0.f;
             hipEventElapsedTime(&ms, r.e0, r.e1);
             out[r.kernel][0] += 1.0; out[r.kernel][1] += ms; out[r.kernel][2] += r.flops; out[r.kernel][3] += r.bytes;
-            if (dump) fprintf(dump, "%d,%d,%d,%d,%.0f,%d,%d,%.2f,%.4f\n", r.form, r.tile, r.N, r.K, r.rows, r.groups, r.splitk, 1e3 * ms, r.flops * 1e-9);
+            if (dump) fprintf(dump, "%d,%d,%d,%d,%d,%.0f,%d,%d,%.2f,%.4f\n", r.kernel, r.form, r.tile, r.N, r.K, r.rows, r.groups, r.splitk, 1e3 * ms, r.flops * 1e-9);
         }
         if (dump) fclose(dump);
     }
@@ -596,12 +660,6 @@ inline int& gemm_xcd_swizzle() {
     static int v = [] { const char* e = getenv("MTTS_XCD_GROUP"); return e ? (atoi(e) != 0) : 1; }();
     return v;
 }
-inline int gemm_numerics_default() {  // 0: exact fp32 MFMA (default), 1: split-bf16 "bf16x3" (gemm_bf16.h); MTTS_NUMERICS sets the initial mode of every context
-    static const int v = [] { const char* e = getenv("MTTS_NUMERICS"); return (e && atoi(e) == 1) ? 1 : 0; }();
-    return v;
-}
-inline bool gemm_launch_bf16x3(int form, const GemmArgs& g, int max_M, int max_N, int groups, hipStream_t stream, int tile,
-                               double rows);  // gemm_bf16_launch.h
 inline int& gemm_default_bk() {  // MTTS_GEMM_BK=16/32
     static int v = [] { const char* e = getenv("MTTS_GEMM_BK"); return (e && atoi(e) == 32) ? 32 : 16; }();
     return v;
@@ -611,7 +669,8 @@ inline bool& gemm_default_pipe() {  // MTTS_GEMM_PIPE=0/1 overrides the built-in
     return v;
 }
 
-// Split-K workspace (partial tiles + tile counters): owned by a GemmCtx, allocated once by its owner's create.
+// Split-K / work-queue workspace (partial tiles + tile counters + the two queue heads): owned by a GemmCtx, allocated once by its
+// owner's create.
 struct GemmWorkspace { float* ws = nullptr; int* ctr = nullptr; };
 constexpr long long kSplitWsFloats = 16ll << 20;  // 64 MB of partial tiles
 constexpr int kSplitCtrs = 1 << 16;
@@ -625,8 +684,9 @@ inline int& gemm_splitk_minchunks() {  // K-chunks every split must keep (MTTS_S
     return v;
 }
 
-// Launch batching: between gemm_batch_begin() and gemm_batch_end() every eligible gemm_launch (auto tile resolving to
-// 64x64, fp32 numerics) is queued instead of launched; gemm_batch_end() issues the queue as ONE gemm_f32_multi_kernel.
+// Launch batching: between gemm_batch_begin() and gemm_batch_end() every eligible gemm_launch (automatic tile choice) is queued
+// instead of launched; gemm_batch_end() issues the queue as ONE launch (the persistent work-queue kernel of gemm_sk.h, or
+// gemm_f32_multi_kernel / gemm_glds_multi_kernel for small batches).
 // The caller guarantees the queued problems are mutually independent and that nothing launched before gemm_batch_end()
 // reads their outputs (engine: the wgrad / dgrad pair of a layer, dQ / dK / dV of an attention block).
 struct GemmPending { int form; GemmArgs g; int max_M, max_N, groups; double flops, rows, bytes; };
@@ -636,30 +696,37 @@ inline bool& gemm_batch_enabled() {  // MTTS_GEMM_BATCH=0 launches every problem
     return v;
 }
 
-// Every piece of MUTABLE launcher state — the launch-batching queue, the per-launch profiler, the split-K workspace and the
-// contraction numerics mode — lives in a context owned by one handle (Engine / Vocoder), so two handles on two host threads
-// share nothing (include/mtts.h conventions).  The workspace is allocated by the owner's create, never lazily.
+// Every piece of MUTABLE launcher state — the launch-batching queue, the per-launch profiler, the split-K / work-queue workspace —
+// lives in a context owned by one handle (Engine / Vocoder / ...), so two handles on two host threads share nothing
+// (include/mtts.h conventions).  The workspace is allocated by the owner's create, never lazily.  One context = one stream
+// (the queue heads alternate between consecutive launches of a context).
 struct GemmCtx {
     GemmBatch batch;
     GemmProfiler prof;
     GemmWorkspace wsp;
-    int numerics = gemm_numerics_default();
+    int* sk_heads = nullptr;   // two queue heads (gemm_sk.h), inside the counter allocation
+    int sk_parity = 0;
+    int last_kind = GK_OTHER;  // kernel kind of the last launch (profiler)
+    bool flushing = false;     // gemm_batch_end is issuing the queue
     bool no_glds = false;   // never pick the LDS-DMA kernels (48 KB of LDS per workgroup: a side-stream launch would leave no LDS for the main stream's)
     int alloc_workspace() {
         if (wsp.ws) return 0;
-        if (hipMalloc((void**)&wsp.ws, kSplitWsFloats * sizeof(float)) != hipSuccess || hipMalloc((void**)&wsp.ctr, kSplitCtrs * sizeof(int)) != hipSuccess ||
-            hipMemset(wsp.ctr, 0, kSplitCtrs * sizeof(int)) != hipSuccess) { release(); return -1; }
+        if (hipMalloc((void**)&wsp.ws, kSplitWsFloats * sizeof(float)) != hipSuccess || hipMalloc((void**)&wsp.ctr, (kSplitCtrs + 2) * sizeof(int)) != hipSuccess ||
+            hipMemset(wsp.ctr, 0, (kSplitCtrs + 2) * sizeof(int)) != hipSuccess) { release(); return -1; }
+        sk_heads = wsp.ctr + kSplitCtrs;
         return 0;
     }
     void release() {
         if (wsp.ws) hipFree(wsp.ws);
         if (wsp.ctr) hipFree(wsp.ctr);
-        wsp.ws = nullptr; wsp.ctr = nullptr;
+        wsp.ws = nullptr; wsp.ctr = nullptr; sk_heads = nullptr;
         prof.destroy();
     }
 };
 inline void gemm_batch_begin(GemmCtx& cx) { if (gemm_batch_enabled()) cx.batch.open = true; }
 inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream);
+inline bool gemm_sk_launch(GemmCtx& cx, GemmMulti& mp, const std::vector<GemmPending>& q, hipStream_t stream, bool force);  // gemm_sk.h
+inline int& gemm_sk_enabled();
 
 // LDS-DMA kernel family (gemm_glds.h, device builds only).  MTTS_GLDS=0 keeps the register-staged kernels (A/B runs).
 inline bool& gemm_use_glds() {
@@ -682,40 +749,33 @@ inline void gemm_glds_launch(int form, const GemmArgs& g, dim3 grid, hipStream_t
 inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t stream);
 #endif
 
-// Host launcher.  max_M / max_N bound the tile grid over all groups.  tile = 0 picks the tile by a
-// wave-quantisation model (128x128 rated 0.85x the 64x64 tile, measured on the model shapes; MTTS_TILE128_EFF): one 4-wave workgroup saturates a CU's four MFMA pipes, so B workgroups
-// on 256 CUs take ceil(B/256) rounds; the 64x64 tile quarters the quantum at ~0.97x the per-tile
-// efficiency of 128x128 (software-pipelined variants, measured with tools/gemm_bench.py).  total_M = sum of the groups' row counts
-// (0: max_M * groups).  alg_flops: algorithmic (unpadded) flops of this launch, profiler only.
+// Host launcher.  max_M / max_N bound the tile grid over all groups.  tile = 0: automatic — the problem goes through the launch
+// queue (alone if no batch is open), i.e. normally to the persistent work-queue kernel; small launches fall back to a plain
+// 64x64 grid (LDS-DMA kernels in the latency regime).  An explicit tile code picks one kernel: 64 / 128 (+1000 software pipeline,
+// +2000 BK = 32), 4064 LDS-DMA, 5064 / 5032 work-queue kernel with BK = 16 / 32 (kernel tests, micro-benchmarks).
+// total_M = sum of the groups' row counts (0: max_M * groups).  alg_flops / alg_bytes: algorithmic (unpadded) work of this launch,
+// profiler only.
 inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, int max_N, int groups, hipStream_t stream,
                         int tile = 0, double alg_flops = 0.0, long long total_M = 0, double alg_bytes = 0.0) {
     if (max_M <= 0 || max_N <= 0 || groups <= 0) return;
     GemmArgs g = g_in;
     g.swizzle = gemm_xcd_swizzle();
     const int user_tile = tile;
+    const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
     auto ntiles = [&](int t) { return (long)((max_M + t - 1) / t) * gemm_tiles_n(g, max_N, t); };
-    if (tile == 0) {
-        const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
-        auto eff = [&](int t, double base) {
-            const double b = std::ceil(rows / t) * gemm_tiles_n(g, max_N, t) / 256.0;
-            return base * b / std::ceil(b);
-        };
-        static const double eff128 = [] { const char* e = getenv("MTTS_TILE128_EFF"); return e ? atof(e) : 0.85; }();
-        tile = eff(128, eff128) >= eff(64, 1.0) ? 128 : 64;
-    }
-    GemmProfiler& prof0 = cx.prof;
-    if (cx.numerics >= 1 && tile < 1000 && !(g.taps > 1 && g.tap_k % 32 != 0) && g.a_tap_rows == 0) {  // (the split-bf16 kernels have no dilated-tap walk)
-        hipEvent_t b0 = nullptr, b1 = nullptr;
-        if (prof0.enabled) { b0 = prof0.get(); b1 = prof0.get(); hipEventRecord(b0, stream); }
-        const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
-        const bool big = gemm_launch_bf16x3(form, g, max_M, max_N, groups, stream, user_tile, rows);
-        if (prof0.enabled) { hipEventRecord(b1, stream); GemmProfiler::Rec rec{form * 2 + (big ? 1 : 0), alg_flops, b0, b1}; rec.bytes = alg_bytes; prof0.recs.push_back(rec); }
-        return;
-    }
-    if (cx.batch.open && user_tile == 0 && tile == 64) {
-        cx.batch.q.push_back(GemmPending{form, g, max_M, max_N, groups, alg_flops, total_M > 0 ? (double)total_M : (double)max_M * groups, alg_bytes});
-        if ((int)cx.batch.q.size() == kGemmMultiMax) { gemm_batch_end(cx, stream); cx.batch.open = true; }
-        return;
+    if (user_tile == 0 || user_tile == 5064 || user_tile == 5032) {
+        if (!cx.flushing) {
+            // through the queue: with the batch's other problems, or alone
+            cx.batch.q.push_back(GemmPending{form, g, max_M, max_N, groups, alg_flops, rows, alg_bytes});
+            if (!cx.batch.open || user_tile != 0) {
+                const bool was_open = cx.batch.open;
+                if (user_tile != 0) cx.batch.q.back().g.swizzle = user_tile;   // (flag for gemm_batch_end: forced work-queue kernel)
+                gemm_batch_end(cx, stream);
+                cx.batch.open = was_open;
+            } else if ((int)cx.batch.q.size() == kGemmMultiMax) { gemm_batch_end(cx, stream); cx.batch.open = true; }
+            return;
+        }
+        tile = 64;
     }
     // tile code: 64 / 128 (+1000 software pipeline, +2000 BK=32); plain 64 / 128 take the defaults
     bool pipe = gemm_default_pipe();
@@ -724,14 +784,13 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
 #if !defined(MTTS_EMU)
     if (tile == 4064) { glds = gemm_glds_ok(g); tile = 64; }            // explicit request (kernel tests, microbenchmarks)
     else if (user_tile == 0 && tile == 64) {
-        const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
         const long wgs = (long)std::ceil(rows / 64.0) * gemm_tiles_n(g, max_N, 64);
-        glds = gemm_use_glds() && gemm_glds_ok(g) && wgs <= gemm_glds_max_wgs();
+        glds = gemm_use_glds() && gemm_glds_ok(g) && wgs <= gemm_glds_max_wgs() && !cx.no_glds;
     }
 #else
     if (tile == 4064) tile = 64;
 #endif
-    const int ablate = tile / 10000;  // diagnostic stage ablation (NT 64x64 pipelined BK=16 only), see gemm_f32_body
+    const int ablate = tile / 10000;  // diagnostic stage ablation (NT 64x64 pipelined BK=16 only), see gemm_f32_kloop
     tile %= 10000;
     if (tile >= 1000) { pipe = (tile / 1000) & 1; bk = (tile / 2000) ? 32 : 16; tile %= 1000; }
     if (user_tile == 0 && !g.table && g.K >= 1024 && (form == GEMM_NT || form == GEMM_TN)) bk = 32;  // long K-contiguous panels: full 128-B lines per row
@@ -740,7 +799,6 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     // ~4 per CU, each still reducing >= 4 K-chunks
     int S = 1;
     if (!g.table && gemm_splitk_target() > 0 && !g.colsum) {  // stand-alone launches: opt-in (measured neutral on the model's forward shapes)
-        const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
         const long wgs = (long)std::ceil(rows / tile) * gemm_tiles_n(g, max_N, tile);
         const int nch = (g.K + bk - 1) / bk;
         S = (int)std::min<long>(std::min<long>(gemm_splitk_target() / std::max<long>(wgs, 1), nch / gemm_splitk_minchunks()), 8);
@@ -757,41 +815,39 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     GemmProfiler& prof = cx.prof;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
+    int kind = GK_OTHER;
 #define MTTS_GEMM_CASE(F, T)                                                                              \
     if (form == F && tile == T) {                                                                         \
-        if (bk == 32 && pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 32, true>), grid, block, stream, g); }   \
-        else if (bk == 32) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 32, false>), grid, block, stream, g); }     \
-        else if (pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, true>), grid, block, stream, g); }          \
-        else { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, false>), grid, block, stream, g); }                   \
+        if (bk == 32 && pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 32, true>), grid, block, stream, g); kind = (T == 64 ? GK_F32_64_BK32 : GK_F32_128) + F; }   \
+        else if (bk == 32) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 32, false>), grid, block, stream, g); kind = T == 64 ? GK_OTHER : GK_F32_128 + F; }     \
+        else if (pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, true>), grid, block, stream, g); kind = (T == 64 ? GK_F32_64_BK16 : GK_F32_128) + F; }          \
+        else { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, false>), grid, block, stream, g); kind = T == 64 ? GK_OTHER : GK_F32_128 + F; }                   \
     }
 #if !defined(MTTS_EMU)
     if (glds) {
         gemm_glds_launch(form, g, grid, stream);
-        if (prof.enabled) {
-            hipEventRecord(e1, stream);
-            GemmProfiler::Rec rec{form * 2, alg_flops, e0, e1};
-            rec.form = form; rec.tile = 4064; rec.N = max_N; rec.K = g.K; rec.groups = groups; rec.splitk = S;
-            rec.rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
-            rec.bytes = alg_bytes;
-            prof.recs.push_back(rec);
-        }
-        return;
-    }
+        kind = GK_GLDS + form;
+    } else
 #endif
+    {
 #if defined(MTTS_GEMM_ABLATION)
 #define MTTS_ABL(A) if (ablate == A && form == GEMM_NT) { MTTS_LAUNCH((gemm_f32_kernel<GEMM_NT, 64, 64, 16, true, 2, 2, A>), grid, block, stream, g); return; }
-    MTTS_ABL(1) MTTS_ABL(2) MTTS_ABL(3) MTTS_ABL(4) MTTS_ABL(7) MTTS_ABL(8) MTTS_ABL(15) MTTS_ABL(6) MTTS_ABL(14)
+        MTTS_ABL(1) MTTS_ABL(2) MTTS_ABL(3) MTTS_ABL(4) MTTS_ABL(7) MTTS_ABL(8) MTTS_ABL(15) MTTS_ABL(6) MTTS_ABL(14)
 #undef MTTS_ABL
+#else
+        (void)ablate;
 #endif
-    MTTS_GEMM_CASE(GEMM_NT, 128) MTTS_GEMM_CASE(GEMM_NT, 64)
-    MTTS_GEMM_CASE(GEMM_NN, 128) MTTS_GEMM_CASE(GEMM_NN, 64)
-    MTTS_GEMM_CASE(GEMM_TN, 128) MTTS_GEMM_CASE(GEMM_TN, 64)
+        MTTS_GEMM_CASE(GEMM_NT, 128) MTTS_GEMM_CASE(GEMM_NT, 64)
+        MTTS_GEMM_CASE(GEMM_NN, 128) MTTS_GEMM_CASE(GEMM_NN, 64)
+        MTTS_GEMM_CASE(GEMM_TN, 128) MTTS_GEMM_CASE(GEMM_TN, 64)
+    }
 #undef MTTS_GEMM_CASE
+    cx.last_kind = kind;
     if (prof.enabled) {
         hipEventRecord(e1, stream);
-        GemmProfiler::Rec rec{form * 2 + (tile == 128 ? 1 : 0), alg_flops, e0, e1};
-        rec.form = form; rec.tile = tile; rec.N = max_N; rec.K = g.K; rec.groups = groups; rec.splitk = S;
-        rec.rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
+        GemmProfiler::Rec rec{kind, alg_flops, e0, e1};
+        rec.form = form; rec.tile = glds ? 4064 : tile; rec.N = max_N; rec.K = g.K; rec.groups = groups; rec.splitk = S;
+        rec.rows = rows;
         rec.bytes = alg_bytes;
         prof.recs.push_back(rec);
     }
@@ -806,6 +862,36 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     GemmBatch& b = cx.batch;
     b.open = false;
     if (b.q.empty()) return;
+    struct Flush { GemmCtx& c; Flush(GemmCtx& x) : c(x) { c.flushing = true; } ~Flush() { c.flushing = false; } } guard(cx);
+    std::stable_sort(b.q.begin(), b.q.end(), [](const GemmPending& x, const GemmPending& y) { return x.g.K > y.g.K; });
+    GemmProfiler& prof = cx.prof;
+    // ---- the persistent work-queue kernel (gemm_sk.h) whenever the launch carries enough work ----
+    int forced = 0;
+    for (GemmPending& p : b.q) if (p.g.swizzle == 5064 || p.g.swizzle == 5032) { forced = p.g.swizzle; p.g.swizzle = 0; }
+    if (gemm_sk_enabled() || forced) {
+        GemmMulti mp;
+        mp.n = (int)b.q.size();
+        double flops = 0.0, rows = 0.0, bytes = 0.0;
+        int maxK = 0;
+        for (int i = 0; i < mp.n; ++i) {
+            const GemmPending& p = b.q[i];
+            mp.form[i] = p.form; mp.groups[i] = p.groups; mp.g[i] = p.g;
+            flops += p.flops; rows += p.rows; bytes += p.bytes; maxK = std::max(maxK, p.g.K);
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
+        if (gemm_sk_launch(cx, mp, b.q, stream, forced != 0)) {
+            if (prof.enabled) {
+                hipEventRecord(e1, stream);
+                GemmProfiler::Rec rec{cx.last_kind, flops, e0, e1};
+                rec.form = 3; rec.tile = 5064; rec.N = mp.n; rec.K = maxK; rec.groups = 0; rec.splitk = 1; rec.rows = rows; rec.bytes = bytes;
+                prof.recs.push_back(rec);
+            }
+            b.q.clear();
+            return;
+        }
+        if (prof.enabled) prof.used -= 2;   // (events not used)
+    }
     // pairs whose dgrad has a short K-loop (K <= 256: fc, conv2) measured ~10 % SLOWER batched than back to back — their
     // many 16-slice tiles gain nothing from a shared grid and lose the stand-alone kernels' higher occupancy
     static const int min_k = [] { const char* e = getenv("MTTS_BATCH_MIN_K"); return e ? atoi(e) : 512; }();
@@ -820,7 +906,6 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
         for (const GemmPending& p : q) gemm_launch(cx, p.form, p.g, p.max_M, p.max_N, p.groups, stream, 0, p.flops, (long long)p.rows, p.bytes);
         return;
     }
-    std::stable_sort(b.q.begin(), b.q.end(), [](const GemmPending& x, const GemmPending& y) { return x.g.K > y.g.K; });
     GemmMulti mp;
     mp.n = (int)b.q.size();
     int max_groups = 0;
@@ -863,7 +948,6 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
         max_groups = std::max(max_groups, p.groups);
         flops += p.flops; rows += p.rows; bytes += p.bytes;
     }
-    GemmProfiler& prof = cx.prof;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
     dim3 block(256), grid((unsigned)mp.start[mp.n], 1, 1);
@@ -878,15 +962,17 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     }
     bool glds = gemm_use_glds() && small_batch && !cx.no_glds;
     for (int i = 0; i < mp.n; ++i) glds = glds && gemm_glds_ok(mp.g[i]);
+    int kind = GK_MULTI16;
 #if !defined(MTTS_EMU)
-    if (glds) { gemm_glds_multi_launch(mp, grid, stream); }
+    if (glds) { gemm_glds_multi_launch(mp, grid, stream); kind = GK_GLDS_MULTI; }
     else
 #endif
-    if (bk32 && maxK >= 1024) { MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32>), grid, block, stream, mp); }
+    if (bk32 && maxK >= 1024) { MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32>), grid, block, stream, mp); kind = GK_MULTI32; }
     else { MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 16>), grid, block, stream, mp); }
+    cx.last_kind = kind;
     if (prof.enabled) {
         hipEventRecord(e1, stream);
-        GemmProfiler::Rec rec{6, flops, e0, e1};
+        GemmProfiler::Rec rec{kind, flops, e0, e1};
         rec.form = 3; rec.tile = glds ? 4064 : 64; rec.N = mp.n; rec.K = maxK; rec.groups = mp.start[mp.n]; rec.splitk = 1; rec.rows = rows; rec.bytes = bytes;  // multi: N = problems, K = longest K, groups = workgroups
         prof.recs.push_back(rec);
     }

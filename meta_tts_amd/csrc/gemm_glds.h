@@ -37,37 +37,19 @@ constexpr int kGldsTile = 64 * kGldsBK;         // floats per operand tile
 constexpr int kGldsStage = 2 * kGldsTile;       // floats per ring stage (A + B)
 constexpr int kGldsSmemFloats = kGldsStages * kGldsStage;
 
+// K-loop of one 64x64 output tile over the BK=32 K-chunks [c_lo, c_hi) (see gemm.h: gemm_f32_kloop); the products are ADDED into acc.
 template <int FORM>
-__device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs, float* smem) {
-    constexpr int BM = 64, BN = 64, BK = kGldsBK, R = kGldsStages;
+__device__ __forceinline__ void gemm_glds_kloop(const GemmArgs& g, const GemmProb& pr, int z, int m0, int n0, bool cs_tile, int c_lo, int c_hi,
+                                                float* smem, f32x16 (&acc)[1][1]) {
+    constexpr int BK = kGldsBK, R = kGldsStages;
     constexpr bool A_KC = (FORM != GEMM_TN);
     constexpr bool B_KC = (FORM == GEMM_NT);
-    const float* A = g.A;
-    const float* B = g.B;
-    float* C = g.C;
-    int M = g.M, N = g.N, K = g.K;
-    int lda = g.lda, ldb = g.ldb, ldc = g.ldc;
-    if (g.table) {
-        const GemmGroupDesc d = g.table[z];
-        A += d.a_off; B += d.b_off; C += d.c_off;
-        M = d.M; N = d.N; K = d.K;
-        if (d.lda) lda = d.lda;
-        if (d.ldb) ldb = d.ldb;
-        if (d.ldc) ldc = d.ldc;
-    } else {
-        A += (long long)z * g.a_gs; B += (long long)z * g.b_gs; C += (long long)z * g.c_gs;
-        if (g.dimptr) {
-            const int v = g.dimptr[(long long)z * g.dim_stride] * g.dim_mult;
-            if (g.dim_sel == 0) M = v; else K = v;
-        }
-    }
-    const bool has_cs = (FORM == GEMM_TN) && g.colsum != nullptr && !g.table;   // one extra n-tile: GemmArgs::colsum
-    const int tiles_nc = (N + BN - 1) / BN, tiles_n = tiles_nc + (has_cs ? 1 : 0), tiles_m = (M + BM - 1) / BM;
-    const int S = g.splitk > 1 ? g.splitk : 1;
-    const int tile_lin = bxs / S, split = bxs - tile_lin * S;
-    if (tile_lin >= tiles_m * tiles_n || K <= 0) return;
-    const int m0 = (tile_lin / tiles_n) * BM, n0 = (tile_lin % tiles_n) * BN;
-    const bool cs_tile = has_cs && n0 == tiles_nc * BN;
+    const float* A = pr.A;
+    const float* B = pr.B;
+    const int M = pr.M, N = pr.N, K = pr.K;
+    const int lda = pr.lda;
+    int ldb = pr.ldb;
+    (void)R;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,9 +87,8 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
         }
     }
 
-    const int nch_all = (K + BK - 1) / BK, cps = (nch_all + S - 1) / S;
-    const int c_lo = split * cps, c_hi = (c_lo + cps < nch_all) ? c_lo + cps : nch_all;
     const int nchunks = c_hi > c_lo ? c_hi - c_lo : 0;
+    if (nchunks == 0) return;
     const int kb0 = c_lo * BK;
 
     auto is_full = [&](int c) { return kb0 + (c + 1) * BK <= K; };
@@ -226,21 +207,29 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
         st = (st == 2) ? 0 : st + 1;
     }
 
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += acc0[r] + acc1[r];
+}
+
+template <int FORM>
+__device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs, float* smem) {
+    constexpr int BM = 64, BN = 64, BK = kGldsBK;
+    const GemmProb pr = gemm_resolve(g, z);
+    const bool has_cs = gemm_has_colsum<FORM>(g);
+    const int tiles_nc = (pr.N + BN - 1) / BN, tiles_n = tiles_nc + (has_cs ? 1 : 0), tiles_m = (pr.M + BM - 1) / BM;
+    const int S = g.splitk > 1 ? g.splitk : 1;
+    const int tile_lin = bxs / S, split = bxs - tile_lin * S;
+    if (tile_lin >= tiles_m * tiles_n || pr.K <= 0) return;
+    const int m0 = (tile_lin / tiles_n) * BM, n0 = (tile_lin % tiles_n) * BN;
+    const bool cs_tile = has_cs && n0 == tiles_nc * BN;
     f32x16 acc[1][1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][0][r] = acc0[r] + acc1[r];
-    if (cs_tile) {  // column 0 of the extra n-tile = masked column sums of A
-        if (wn0 == 0 && l31 == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row < M) g.colsum[(long long)z * g.colsum_gs + row] = acc[0][0][r];
-            }
-        }
-        return;
-    }
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    const int nch_all = (pr.K + BK - 1) / BK, cps = (nch_all + S - 1) / S;
+    const int c_lo = split * cps, c_hi = (c_lo + cps < nch_all) ? c_lo + cps : nch_all;
+    gemm_glds_kloop<FORM>(g, pr, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
     if (S > 1 && !splitk_combine<1, 1, 256>(g, z, tile_lin, split, S, acc)) return;
-    gemm_epilogue<1, 1>(g, z, acc, C, ldc, M, N, m0 + wm0, n0 + wn0, lane);
+    gemm_finish<1, 1, 2, 2>(g, pr, z, m0, n0, cs_tile, acc);
 }
 
 template <int FORM>

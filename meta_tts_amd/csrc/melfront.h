@@ -92,7 +92,6 @@ public:
         MF_CHECK(hipMalloc((void**)&mag, ((size_t)cap_T * ld_mag + 64) * sizeof(float)));
         MF_CHECK(hipMalloc((void**)&mel, ((size_t)cap_T * n_mel + 64) * sizeof(float)));
         MF_CHECK(hipMalloc((void**)&energy, (size_t)cap_T * sizeof(float)));
-        gx.numerics = 0;
         if (gx.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace)"); return -1; }
         return 0;
     }

@@ -341,13 +341,6 @@ int mtts_reset_optimizer(mtts_handle* h) {
     return 0;
 }
 
-int mtts_set_numerics(mtts_handle* h, int mode) {
-    if (!h) return -1;
-    if (mode < 0 || mode > 1) { h->eng.set_error("numerics mode must be 0 (exact fp32 MFMA) or 1 (bf16x3)"); return -1; }
-    h->eng.gx.numerics = mode;
-    return 0;
-}
-
 int mtts_profile_gemm(mtts_handle* h, int enable) {
     if (!h) return -1;
     GemmProfiler& p = h->eng.gx.prof;
@@ -356,35 +349,41 @@ int mtts_profile_gemm(mtts_handle* h, int enable) {
     return 0;
 }
 
-int mtts_profile_report(mtts_handle* h, double* out28) {
-    if (!h || !out28) return -1;
-    double r[7][4];
+int mtts_profile_kinds(void) { return GK_COUNT; }
+const char* mtts_profile_kernel_name(int kind) { return gemm_kind_name(kind); }
+int mtts_profile_report(mtts_handle* h, double* out, int kinds) {
+    if (!h || !out || kinds < GK_COUNT) return -1;
+    double r[GK_COUNT][4];
     h->eng.gx.prof.report(r);
-    for (int k = 0; k < 7; ++k) for (int j = 0; j < 4; ++j) out28[k * 4 + j] = r[k][j];
+    for (int k = 0; k < GK_COUNT; ++k) for (int j = 0; j < 4; ++j) out[k * 4 + j] = r[k][j];
     return 0;
 }
 
-// launcher state of the handle-less kernel-level entry points: one context per host thread, no split-K workspace (stand-alone
-// launches never split), fp32 numerics unless MTTS_NUMERICS says otherwise
-static GemmCtx& kernel_ctx() { static thread_local GemmCtx cx; return cx; }
+// launcher state of the handle-less kernel-level entry points: one context per host thread; the work-queue workspace is allocated
+// on the first call of a thread (64 MB, kept for the life of the thread)
+static GemmCtx& kernel_ctx() {
+    static thread_local GemmCtx cx;
+    if (!cx.wsp.ws) cx.alloc_workspace();
+    return cx;
+}
+static bool tile_code_ok(int tile) {
+    return tile == 0 || tile == 4064 || tile == 5064 || tile == 5032 || ((tile % 1000 == 64 || tile % 1000 == 128) && tile % 10000 < 4000);
+}
 
 int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, float alpha, int flags, int tile, void* stream) {
-    if (form < 0 || form > 2 || (tile != 0 && tile != 4064 && ((tile % 1000 != 64 && tile % 1000 != 128) || tile % 10000 >= 4000))) return -1;
+    if (form < 0 || form > 2 || !tile_code_ok(tile)) return -1;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.alpha = alpha; g.flags = flags & 0xff;
-    GemmCtx& cx = kernel_ctx();
-    cx.numerics = (flags >> 8) & 3;
-    if (cx.numerics > 1) return -1;
-    gemm_launch(cx, form, g, M, N, 1, (hipStream_t)stream, tile);
-    cx.numerics = gemm_numerics_default();
+    if (flags & ~0xff) return -1;
+    gemm_launch(kernel_ctx(), form, g, M, N, 1, (hipStream_t)stream, tile);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* a, const float* b, float* out, const float* bias,
                     int tile, void* stream) {
-    if (mode < 0 || mode > 2 || (k & 1) == 0 || k / 2 > G) return -1;
+    if (mode < 0 || mode > 2 || (k & 1) == 0 || k / 2 > G || !tile_code_ok(tile)) return -1;
     const int pad = k / 2;
     GemmArgs g;
     if (mode == 0) {         // y[L][Cout] = conv(x) + bias

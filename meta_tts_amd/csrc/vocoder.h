@@ -99,7 +99,7 @@ public:
     int hop = 1;
     // per-stage scratch (element offsets into the arena, per-utterance strides)
     struct Buf { long long off, gs; };
-    GemmCtx gx;  // this handle's launcher state (gemm.h); fp32 numerics always
+    GemmCtx gx;  // this handle's launcher state (gemm.h)
     Buf b_x[2], b_pad, b_h;
 
     void set_error(const std::string& s) { last_error = s; }
@@ -128,7 +128,6 @@ public:
             }
         }
         add("conv_out.w", 7LL * ch(cfg.n_ratios)); add("conv_out.b", 1);
-        gx.numerics = 0;
         if (gx.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace)"); return -1; }
         VOC_CHECK(hipMalloc((void**)&params, (size_t)n_params * sizeof(float)));
         VOC_CHECK(hipMemset(params, 0, (size_t)n_params * sizeof(float)));

@@ -99,18 +99,17 @@ class Engine:
     def synchronize(self):
         self._ck(self.lib.mtts_synchronize(self.h))
 
-    def set_numerics(self, mode: int):
-        """Contraction numerics of THIS handle: 0 exact fp32 MFMA (parity mode), 1 bf16x3, 2 bf16 operands."""
-        self._ck(self.lib.mtts_set_numerics(self.h, int(mode)))
-
     def profile_gemm(self, enable: bool):
         self._ck(self.lib.mtts_profile_gemm(self.h, int(enable)))
 
-    def profile_report(self) -> np.ndarray:
-        """[7][4] = launches, ms, algorithmic flops, algorithmic bytes per GEMM kernel of this handle (include/mtts.h)."""
-        rep = (C.c_double * 28)()
-        self._ck(self.lib.mtts_profile_report(self.h, rep))
-        return np.array(list(rep), np.float64).reshape(7, 4)
+    def profile_report(self) -> Dict[str, np.ndarray]:
+        """{kernel name as a rocprofv3 kernel trace prints it: [launches, ms, algorithmic flops, algorithmic bytes]} for the GEMM
+        kernels this handle launched since profile_gemm(True) (include/mtts.h)."""
+        kinds = int(self.lib.mtts_profile_kinds())
+        rep = (C.c_double * (4 * kinds))()
+        self._ck(self.lib.mtts_profile_report(self.h, rep, kinds))
+        arr = np.array(list(rep), np.float64).reshape(kinds, 4)
+        return {self.lib.mtts_profile_kernel_name(k).decode(): arr[k] for k in range(kinds) if arr[k, 0] > 0}
 
     # ---- parameters --------------------------------------------------------------
     def load_params(self, params: Dict[str, np.ndarray], strict: bool = True):

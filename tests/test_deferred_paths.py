@@ -59,13 +59,16 @@ OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "M
 
 
 def _compare(tmp_path, gpu):
-    a = _run(tmp_path, "on", {}, gpu)
-    b = _run(tmp_path, "off", OFF, gpu)
+    # emulator arm: whole tiles only (MTTS_SK_SMAX=1) — the work-queue kernel cuts the late tiles of a launch into pieces, and which
+    # tiles are late depends on what shares the launch, i.e. on the very batching the knobs change; without pieces the comparison is exact
+    common = {} if gpu else {"MTTS_SK_SMAX": "1"}
+    a = _run(tmp_path, "on", dict(common), gpu)
+    b = _run(tmp_path, "off", dict(OFF, **common), gpu)
     assert set(a) == set(b) and len(a) >= 15
     for k in a:
         assert np.isfinite(a[k]).all(), k
         if gpu and k.startswith(("g", "fast")):
-            # on the hardware arm MTTS_SINGLE_MULTI changes the split-K factor of a few GEMMs (a different, still fixed, summation order)
+            # on the hardware arm the knobs change the split-K factors / split tails of a few GEMMs (a different, still fixed, summation order)
             np.testing.assert_allclose(a[k], b[k], rtol=2e-4, atol=1e-6 * max(1.0, float(np.abs(b[k]).max())), err_msg=k)
         elif gpu:
             np.testing.assert_allclose(a[k], b[k], rtol=1e-5, err_msg=k)

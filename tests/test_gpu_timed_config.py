@@ -1,0 +1,139 @@
+"""-m gpu: the configuration bench.py times — BASELINE C3, 8 full-size tasks grouped in the same launches (the grouped,
+non-deferred, work-queue paths that plans of <= 2 tasks never reach) — against the oracle, plus the single-stream arm of the
+small-plan tests against the REFERENCE fixtures.
+
+Reference rows: base_adaptor.py:98-131 (adapt / meta_learn), meta.py:68-80 (training_step), base_adaptor.py:107 (second order)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle_util import O, heads, synth, torch_buffers, torch_params
+from meta_tts_amd.config import ModelDims, default_algorithm_config
+from meta_tts_amd.engine import Engine
+
+pytestmark = pytest.mark.gpu
+DIMS = ModelDims()
+MODS = default_algorithm_config()["adapt"]["modules"]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCALE = 0.5      # contractive at the reference's inner lr 1e-3 (support loss falls over the 5 steps), as the lr-1e-3 fixture
+LR = 0.001
+SAMPLED = ["mel_linear.weight", "decoder.layer_stack.5.pos_ffn.w_2.weight", "decoder.layer_stack.0.slf_attn.w_qs.weight",
+           "postnet.convolutions.2.0.conv.weight", "variance_adaptor.pitch_predictor.conv_layer.conv1d_1.conv.weight",
+           "decoder.layer_stack.3.pos_ffn.w_1.weight", "variance_adaptor.duration_predictor.linear_layer.weight"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    import __graft_entry__ as ge
+    ge.build_device()
+
+
+@pytest.fixture(scope="module")
+def tasks():
+    return [synth.make_task(j) for j in range(8)]
+
+
+def _engine(n_tasks, tasks):
+    max_T = max(max(s[8], q[8]) for s, q in tasks)
+    eng = Engine(DIMS, adapt_modules=MODS, max_tasks=n_tasks, max_B=5, max_S=80, max_T=max_T)
+    eng.load_params(synth.make_params(DIMS, 0, weight_scale=SCALE))
+    return eng
+
+
+def _set(eng, tasks):
+    sup, qry = [t[0] for t in tasks], [t[1] for t in tasks]
+    eng.set_batches(0, sup)
+    eng.set_batches(1, qry, spk_from=sup, average_spk=True)
+
+
+def test_eight_grouped_tasks_first_order_vs_oracle(tasks):
+    """One C3 meta-gradient exactly as bench.py issues it (8 tasks in every launch, grad_scale 1/8, dropout off): per-task query
+    6-tuples and support losses against O.maml_task, and sampled tensors of the outer gradient against the mean of the oracle's
+    per-task autograd gradients."""
+    eng = _engine(8, tasks)
+    _set(eng, tasks)
+    q, s = eng.meta_grad(5, LR, 1.0 / 8)
+    p = torch_params(DIMS, requires_grad=True, weight_scale=SCALE)
+    buf = torch_buffers(DIMS)
+    ref_g = {n: np.zeros_like(p[n].detach().numpy()) for n in SAMPLED}
+    for j, (sup, qry) in enumerate(tasks):
+        ql, sl, _, _ = O.maml_task(p, buf, O.to_torch_batch(sup), O.to_torch_batch(qry), steps=5, lr=LR, second_order=False, modules=MODS,
+                                   n_head=heads(DIMS))
+        np.testing.assert_allclose(q[j], [float(x) for x in ql], rtol=2e-3, err_msg=f"query losses of task {j}")
+        ref_s = np.array([[float(x) for x in l] for l in sl])
+        np.testing.assert_allclose(s[:, j, :], ref_s, rtol=2e-3, err_msg=f"support losses of task {j}")
+        assert ref_s[-1, 0] < ref_s[0, 0]
+        gs = torch.autograd.grad(ql[0], [p[n] for n in SAMPLED])
+        for n, g in zip(SAMPLED, gs):
+            ref_g[n] += g.numpy() / 8.0
+    for n in SAMPLED:
+        got = eng.export(n, 1)
+        assert np.abs(got - ref_g[n]).max() <= 3e-3 * np.abs(ref_g[n]).max(), n
+    eng.close()
+
+
+@pytest.mark.parametrize("order", ["fo", "so"])
+def test_grouped_tasks_equal_the_same_tasks_alone(tasks, order):
+    """Grouping is a scheduling decision: task j's losses and its contribution to the outer gradient must not depend on what else
+    shares its launches.  8 grouped tasks vs tasks 2 and 5 run alone on a single-task handle (which takes the deferred / side-stream /
+    LDS-DMA paths instead), first and second order; the summation orders differ (split points of the work queue), hence 1e-5 / 1e-4
+    instead of bit equality."""
+    so = order == "so"
+    pick = (2, 5)
+    eng = _engine(8, tasks)
+    _set(eng, tasks)
+    q8, s8 = eng.meta_grad(5, LR, 1.0, second_order=so)
+    per_task = {j: {n: eng.export(n, 2, j).copy() for n in SAMPLED} for j in pick}   # which = 2: the per-task gradient buffer
+    eng.close()
+    for j in pick:
+        e1 = _engine(1, [tasks[j]])
+        _set(e1, [tasks[j]])
+        q1, s1 = e1.meta_grad(5, LR, 1.0, second_order=so)
+        np.testing.assert_allclose(q8[j], q1[0], rtol=1e-5)
+        np.testing.assert_allclose(s8[:, j, :], s1[:, 0, :], rtol=1e-5)
+        for n in SAMPLED:
+            a, b = per_task[j][n], e1.export(n, 2, 0)
+            assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max() + 1e-9, (j, n)
+        e1.close()
+
+
+def test_second_order_two_of_eight_vs_oracle(tasks):
+    """Second-order MAML (the reference's training mode) on the grouped path against the oracle for two of the eight tasks (the oracle's
+    double backward costs ~20 s per full-size task on host cores)."""
+    eng = _engine(8, tasks)
+    _set(eng, tasks)
+    q, _ = eng.meta_grad(5, LR, 1.0, second_order=True)
+    p = torch_params(DIMS, requires_grad=True, weight_scale=SCALE)
+    buf = torch_buffers(DIMS)
+    names = SAMPLED + ["encoder.layer_stack.0.slf_attn.w_qs.weight"]   # second order reaches the (non-adapted) encoder through the fast weights
+    for j in (1, 6):
+        sup, qry = tasks[j]
+        ql, _, _, _ = O.maml_task(p, buf, O.to_torch_batch(sup), O.to_torch_batch(qry), steps=5, lr=LR, second_order=True, modules=MODS,
+                                  n_head=heads(DIMS))
+        np.testing.assert_allclose(q[j], [float(x) for x in ql], rtol=2e-3)
+        gs = torch.autograd.grad(ql[0], [p[n] for n in names])
+        for n, g in zip(names, gs):
+            got = eng.export(n, 2, j)
+            assert np.abs(got - g.numpy()).max() <= 5e-3 * np.abs(g.numpy()).max(), (j, n)
+    eng.close()
+
+
+@pytest.mark.parametrize("knobs", ["MTTS_DEFER_WGRAD=0 MTTS_ENC_AHEAD=0 MTTS_PRED_SIDE=0", "MTTS_SK=0", "MTTS_SK_MIN_UNITS=0 MTTS_SK_MIN_TILE=0"])
+def test_reference_fixtures_on_the_other_launch_paths(knobs):
+    """The small-plan tests against the REFERENCE fixtures (small-batch gradients, the contractive lr-1e-3 MAML fixture first and
+    second order, two ragged tasks) once more with (a) the single-stream order — no deferred weight gradients, no encoder run-ahead,
+    no side-stream predictors —, (b) the plain grids instead of the work-queue kernel, (c) the work-queue kernel forced onto every
+    launch.  The switches are read once per process, hence the child."""
+    env = dict(os.environ)
+    for kv in knobs.split():
+        k, v = kv.split("=")
+        env[k] = v
+    sel = "small_batch_gradients or contractive_fixture or two_ragged_tasks"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-k", sel, os.path.join(ROOT, "tests", "test_gpu_model.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_c5_training.py")], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "4 passed" in r.stdout, r.stdout[-500:]
