@@ -69,17 +69,22 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 
 // cross-workgroup hand-off primitives (split-K rendezvous in gemm.h)
 #if defined(MTTS_EMU)
-#define MTTS_WAVES_PER_EU(n)
 #define MTTS_UNIFORM(x) (x)
+#define MTTS_OPAQUE_TID() ((int)threadIdx.x)
 #define MTTS_WAIT_VMEM() ((void)0)
 #define MTTS_FENCE_RELEASE_AGENT() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define MTTS_FENCE_ACQUIRE_AGENT() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define MTTS_ATOMIC_INC_AGENT(p) atomicAdd((p), 1)
+#define MTTS_ATOMIC_LOAD_AGENT(p) __atomic_load_n((p), __ATOMIC_RELAXED)
 #else
-#define MTTS_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))   // register budget: leave room for n waves per SIMD
 #define MTTS_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // a wave-uniform int held in a VGPR (an LDS read) -> SGPR
+// threadIdx.x as a value the optimiser cannot see through: inside a persistent loop this keeps the per-thread address arithmetic of
+// the loop body from being hoisted above the loop (where the three operand forms' worth of it would be live at once)
+__device__ __forceinline__ int mtts_opaque_tid() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+#define MTTS_OPAQUE_TID() mtts_opaque_tid()
 #define MTTS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define MTTS_FENCE_RELEASE_AGENT() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
 #define MTTS_FENCE_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define MTTS_ATOMIC_INC_AGENT(p) __hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MTTS_ATOMIC_LOAD_AGENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #endif

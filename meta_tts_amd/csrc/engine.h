@@ -1152,7 +1152,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                 TS zout, TS y, TS st, int C, DropSpec din = DropSpec(), DropSpec dout = DropSpec()) {
         const Plan& p = *ps.pl;
         TS gm = W(ps, g_off), bt = W(ps, b_off);
-        MTTS_LAUNCH(layernorm_fwd_kernel, row2_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
+        MTTS_LAUNCH_LN(layernorm_fwd_kernel, C, row2_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
                     (const float*)a.p, a.ts, (const float*)res.p, res.ts, (const float*)gm.p, (const float*)bt.p, gm.ts, mask,
                     row_ts(s), zout.p, zout.ts, y.p, y.ts, st.p, st.ts, C, 1e-5f, din, dout);
     }
@@ -1168,7 +1168,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         a.X = dy.p; a.x_ts = dy.ts; a.Z = z.p; a.z_ts = z.ts; a.stats = st.p; a.st_ts = st.ts;
         a.mask = mask; a.mask_ts = row_ts(s); a.C = C; a.mode = 1; a.mfield = mfield(s);
         if (!dy_copy.p) colreduce(p, a, gg.p, gb.p, gg.ts, maxM(p, s));
-        MTTS_LAUNCH(layernorm_bwd_kernel, row2_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
+        MTTS_LAUNCH_LN(layernorm_bwd_kernel, C, row2_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
                     (const float*)dy.p, dy.ts, (const float*)z.p, z.ts, (const float*)st.p, st.ts, (const float*)gm.p, gm.ts,
                     mask, row_ts(s), dz.p, dz.ts, C, relu_on_z, (dd.thr16 || copy_always) ? dz_drop.p : nullptr, dz_drop.ts, dd,
                     dy_copy.p, dy_copy.ts);

@@ -228,15 +228,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int z, f32x16 (
         }
 }
 
-// Split-K rendezvous: park this workgroup's partial tile in the workspace; the last of the S workgroups of a tile to
-// arrive reloads all S partials in split order (its own included, so the sum is order-independent) and returns true to
-// run the epilogue; it also re-arms the tile counter for the next launch.
+// Partial-tile slab stores.  The slab is written THROUGH the XCD's L2 (sc1), so publishing it needs no release fence — a
+// fence(release, agent) writes back every dirty line of that L2, which between GEMM epilogues costs far more than the slab itself
+// (cdna_hip_programming.md, Guideline 16 form R1: write-through payload, every storing wave drains, one relaxed agent-scope
+// counter increment, ONE acquire on the reducing workgroup, plain loads).
+__device__ __forceinline__ void st4_through(float* p, float4 v) {
+#if defined(MTTS_EMU)
+    st4(p, v);
+#else
+    f32x4 x; x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+#endif
+}
+
+// Rendezvous of the S workgroups that share one output tile: each parks its partial tile in a slab (`base` + split * slab size); the
+// last to arrive (`ctr`) reloads all S partials in split order (its own included, so the sum does not depend on the arrival order)
+// and returns true to run the epilogue; it also re-arms the counter for the next launch.
 template <int TM, int TN, int NTH>
-__device__ __forceinline__ bool splitk_combine(const GemmArgs& g, int z, int tile_lin, int split, int S, f32x16 (&acc)[TM][TN]) {
+__device__ __forceinline__ bool slab_combine(float* base, int* ctr, int split, int S, f32x16 (&acc)[TM][TN]) {
     constexpr int PART = NTH * 16 * TM * TN;  // floats per partial tile
     const int tid = threadIdx.x;
-    const long long slot = (long long)z * g.tiles_pg + tile_lin;
-    float* base = g.ws + slot * S * PART;
     float* mine = base + (long long)split * PART;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -246,19 +257,13 @@ __device__ __forceinline__ bool splitk_combine(const GemmArgs& g, int z, int til
             for (int r4 = 0; r4 < 4; ++r4) {
                 float4 v;
                 v.x = acc[i][j][4 * r4]; v.y = acc[i][j][4 * r4 + 1]; v.z = acc[i][j][4 * r4 + 2]; v.w = acc[i][j][4 * r4 + 3];
-                st4(mine + (((i * TN + j) * 4 + r4) * NTH + tid) * 4, v);
+                st4_through(mine + (((i * TN + j) * 4 + r4) * NTH + tid) * 4, v);
             }
-    // hand-off (cdna_hip_programming.md, in-launch split-K): every wave drains its own stores, ONE agent-scope release by
-    // lane 0 publishes the workgroup's slab, a relaxed agent-scope counter elects the reducer, ONE acquire by its lane 0
-    // precedes the slab reads.  (A __threadfence() by all 256 threads on both sides writes back / invalidates the XCD's
-    // L2 hundreds of times per tile and made split-K a net loss.)
     __shared__ int s_last;
-    MTTS_WAIT_VMEM();
+    MTTS_WAIT_VMEM();      // every storing wave drains its write-through stores
     __syncthreads();
     if (tid == 0) {
-        MTTS_FENCE_RELEASE_AGENT();
-        MTTS_WAIT_VMEM();
-        s_last = (MTTS_ATOMIC_INC_AGENT(g.tile_ctr + slot) == S - 1) ? 1 : 0;
+        s_last = (MTTS_ATOMIC_INC_AGENT(ctr) == S - 1) ? 1 : 0;
         if (s_last) MTTS_FENCE_ACQUIRE_AGENT();
     }
     __syncthreads();
@@ -276,8 +281,14 @@ __device__ __forceinline__ bool splitk_combine(const GemmArgs& g, int z, int til
                 }
                 acc[i][j][4 * r4] = sum.x; acc[i][j][4 * r4 + 1] = sum.y; acc[i][j][4 * r4 + 2] = sum.z; acc[i][j][4 * r4 + 3] = sum.w;
             }
-    if (tid == 0) g.tile_ctr[slot] = 0;
+    if (tid == 0) *ctr = 0;
     return true;
+}
+// split-K of a plain grid: slab / counter of output tile `tile_lin` of group z
+template <int TM, int TN, int NTH>
+__device__ __forceinline__ bool splitk_combine(const GemmArgs& g, int z, int tile_lin, int split, int S, f32x16 (&acc)[TM][TN]) {
+    const long long slot = (long long)z * g.tiles_pg + tile_lin;
+    return slab_combine<TM, TN, NTH>(g.ws + slot * S * (NTH * 16 * TM * TN), g.tile_ctr + slot, split, S, acc);
 }
 
 // WGM x WGN waves per workgroup (64 threads each); the wave tile is (BM/WGM) x (BN/WGN) = TM x TN MFMA tiles.
@@ -344,7 +355,7 @@ __device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb
     const int lda = pr.lda;
     int ldb = pr.ldb;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = MTTS_OPAQUE_TID(), lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
     const int M4 = (M + 3) & ~3, N4 = (N + 3) & ~3, K4 = (K + 3) & ~3;
     int n0b = n0, N4b = N4;   // column window of the B operand
@@ -496,7 +507,7 @@ __device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb
 // What follows the K-loop: the column sums of the extra n-tile, or the fused epilogue.
 template <int TM, int TN, int WGM, int WGN>
 __device__ __forceinline__ void gemm_finish(const GemmArgs& g, const GemmProb& pr, int z, int m0, int n0, bool cs_tile, f32x16 (&acc)[TM][TN]) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = MTTS_OPAQUE_TID(), lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / WGN) * (32 * TM), wn0 = (wave % WGN) * (32 * TN);
     if (cs_tile) {  // column 0 of the extra n-tile = masked column sums of A
         if (wn0 == 0 && (lane & 31) == 0) {
@@ -560,8 +571,9 @@ struct GemmSk {
     int slabs = 0;                           // capacity of the partial-tile workspace (16 KB slabs, one arrival counter each)
     float* ws = nullptr;
     int* ctr = nullptr;
-    int* head = nullptr;                     // item queue head of THIS launch (zero on entry)
-    int* head_next = nullptr;                // the other head, zeroed for the next launch
+    int run = 16;                            // consecutive items dealt to one XCD's queue
+    int* head = nullptr;                     // the eight item-queue heads of THIS launch (zero on entry)
+    int* head_next = nullptr;                // the other set, zeroed for the next launch
 };
 struct GemmMulti {
     int n = 0;
@@ -622,7 +634,7 @@ inline const char* gemm_kind_name(int k) {
         "gemm_f32_kernel<0, 64, 64, 32, true, 2, 2, 0>", "gemm_f32_kernel<1, 64, 64, 32, true, 2, 2, 0>", "gemm_f32_kernel<2, 64, 64, 32, true, 2, 2, 0>",
         "gemm_f32_kernel<0, 128, 128, ...>", "gemm_f32_kernel<1, 128, 128, ...>", "gemm_f32_kernel<2, 128, 128, ...>",
         "gemm_glds_kernel<0>", "gemm_glds_kernel<1>", "gemm_glds_kernel<2>",
-        "gemm_f32_multi_kernel<64, 64, 16>", "gemm_f32_multi_kernel<64, 64, 32>", "gemm_glds_multi_kernel", "gemm_sk_kernel<16, *>", "gemm_sk_kernel<32, *>",
+        "gemm_f32_multi_kernel<64, 64, 16>", "gemm_f32_multi_kernel<64, 64, 32>", "gemm_glds_multi_kernel", "gemm_sk_kernel<16>", "gemm_sk_kernel<32>",
         "gemm_f32_kernel<other>"};
     return (k >= 0 && k < GK_COUNT) ? names[k] : "?";
 }
@@ -685,8 +697,8 @@ inline int& gemm_splitk_minchunks() {  // K-chunks every split must keep (MTTS_S
 }
 
 // Launch batching: between gemm_batch_begin() and gemm_batch_end() every eligible gemm_launch (automatic tile choice) is queued
-// instead of launched; gemm_batch_end() issues the queue as ONE launch (the persistent work-queue kernel of gemm_sk.h, or
-// gemm_f32_multi_kernel / gemm_glds_multi_kernel for small batches).
+// instead of launched; gemm_batch_end() issues the queue as ONE launch (gemm_f32_multi_kernel / gemm_glds_multi_kernel, or the
+// persistent work-queue kernel of gemm_sk.h when enabled).
 // The caller guarantees the queued problems are mutually independent and that nothing launched before gemm_batch_end()
 // reads their outputs (engine: the wgrad / dgrad pair of a layer, dQ / dK / dV of an attention block).
 struct GemmPending { int form; GemmArgs g; int max_M, max_N, groups; double flops, rows, bytes; };
@@ -704,15 +716,15 @@ struct GemmCtx {
     GemmBatch batch;
     GemmProfiler prof;
     GemmWorkspace wsp;
-    int* sk_heads = nullptr;   // two queue heads (gemm_sk.h), inside the counter allocation
+    int* sk_heads = nullptr;   // two sets of eight queue heads (gemm_sk.h), inside the counter allocation
     int sk_parity = 0;
     int last_kind = GK_OTHER;  // kernel kind of the last launch (profiler)
     bool flushing = false;     // gemm_batch_end is issuing the queue
     bool no_glds = false;   // never pick the LDS-DMA kernels (48 KB of LDS per workgroup: a side-stream launch would leave no LDS for the main stream's)
     int alloc_workspace() {
         if (wsp.ws) return 0;
-        if (hipMalloc((void**)&wsp.ws, kSplitWsFloats * sizeof(float)) != hipSuccess || hipMalloc((void**)&wsp.ctr, (kSplitCtrs + 2) * sizeof(int)) != hipSuccess ||
-            hipMemset(wsp.ctr, 0, (kSplitCtrs + 2) * sizeof(int)) != hipSuccess) { release(); return -1; }
+        if (hipMalloc((void**)&wsp.ws, kSplitWsFloats * sizeof(float)) != hipSuccess || hipMalloc((void**)&wsp.ctr, (kSplitCtrs + 16) * sizeof(int)) != hipSuccess ||
+            hipMemset(wsp.ctr, 0, (kSplitCtrs + 16) * sizeof(int)) != hipSuccess) { release(); return -1; }
         sk_heads = wsp.ctr + kSplitCtrs;
         return 0;
     }
@@ -750,8 +762,8 @@ inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t s
 #endif
 
 // Host launcher.  max_M / max_N bound the tile grid over all groups.  tile = 0: automatic — the problem goes through the launch
-// queue (alone if no batch is open), i.e. normally to the persistent work-queue kernel; small launches fall back to a plain
-// 64x64 grid (LDS-DMA kernels in the latency regime).  An explicit tile code picks one kernel: 64 / 128 (+1000 software pipeline,
+// queue (alone if no batch is open): a plain 64x64 grid (LDS-DMA kernels in the latency regime, a multi-problem grid for a batch), or
+// the persistent work-queue kernel when that is switched on (gemm_sk.h).  An explicit tile code picks one kernel: 64 / 128 (+1000 software pipeline,
 // +2000 BK = 32), 4064 LDS-DMA, 5064 / 5032 work-queue kernel with BK = 16 / 32 (kernel tests, micro-benchmarks).
 // total_M = sum of the groups' row counts (0: max_M * groups).  alg_flops / alg_bytes: algorithmic (unpadded) work of this launch,
 // profiler only.

@@ -7,7 +7,7 @@
 // is the schedule.
 //
 // What: ONE grid of G persistent workgroups (G <= the resident capacity of the chip) pulls ITEMS from a device queue (one
-// returning atomic per item, fetched one item ahead so its latency hides behind the K-loop).  The item list is every output
+// returning atomic per item, issued between the item's K-loop and its epilogue so that its round trip hides behind the epilogue).  The item list is every output
 // tile of every (problem, group) of the launch in problem-major order (the launcher sorts problems longest K-loop first), so
 // equal-length tiles run in lock-step and keep sharing their operand panels through the L2 exactly as a plain grid does.
 // Only tiles that would START too late to finish with the rest are cut: a round of G tiles of c K-chunks each that starts with R
@@ -24,7 +24,7 @@
 
 namespace mtts {
 
-constexpr int kSkMaxEntries = 192;   // (problem, group) pairs of one launch (C3: 8 tasks x 5 utterances x 2 heads x 2 problems = 160)
+constexpr int kSkMaxEntries = 160;   // (problem, group) pairs of one launch (C3: 8 tasks x 5 utterances x 2 heads x 2 problems = 160)
 
 // inclusive scan of a[1..n] (a[0] = 0 is the caller's), n <= 256, all 256 threads call
 __device__ __forceinline__ void sk_scan2(int* a, int* b, int n) {
@@ -61,54 +61,23 @@ __device__ __forceinline__ void sk_scan2(int* a, int* b, int n) {
 // Model: list scheduling on G workgroups.  The entry's tiles start in rounds of G ("waves"): wave w starts when P + w * G * c chunks
 // of work are done, i.e. with R_w = W - P - w * G * c chunks left in the launch; whole tiles started then end c chunk-times later,
 // on time iff c * G <= R_w (+ tol).  Otherwise the wave's tiles are cut into ceil(c * G / R_w) pieces each.  Returns the number of
-// tiles (a prefix of the entry's tile list, whole waves) whose level is <= s.
-__device__ __forceinline__ int sk_cnt_le(int s, int T, int c, long long P, long long W, long long tol, int G) {
-    const long long cg = (long long)c * G;
-    const long long need = (cg + s - 1) / s;                   // R_w >= need  <=>  level <= s
-    const long long room = W + tol - P - need;                 // w * c * G <= room
+// tiles (a prefix of the entry's tile list, whole waves) whose level is <= s.  32-bit arithmetic: the launcher keeps W below 2^30.
+__device__ __forceinline__ int sk_cnt_le(int s, int T, int c, int P, int W, int tol, int G) {
+    const unsigned cg = (unsigned)c * (unsigned)G;
+    const unsigned need = (cg + (unsigned)s - 1u) / (unsigned)s;   // R_w >= need  <=>  level <= s
+    const int room = W + tol - P - (int)need;                     // w * c * G <= room
     if (room < 0) return 0;
-    const long long t = (room / cg + 1) * G;
-    return t < T ? (int)t : T;
+    const unsigned waves = (unsigned)room / cg + 1u;
+    const unsigned full = ((unsigned)T + (unsigned)G - 1u) / (unsigned)G;
+    return waves >= full ? T : (int)(waves * (unsigned)G);
 }
 
-// The pieces of one split tile: `S` slabs starting at `base`, arrival counter `ctr`.  Same hand-off as splitk_combine (gemm.h).
-template <int NTH>
-__device__ __forceinline__ bool sk_combine(float* base, int* ctr, int split, int S, f32x16 (&acc)[1][1]) {
-    constexpr int PART = NTH * 16;
-    const int tid = threadIdx.x;
-    float* mine = base + (long long)split * PART;
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-        float4 v;
-        v.x = acc[0][0][4 * r4]; v.y = acc[0][0][4 * r4 + 1]; v.z = acc[0][0][4 * r4 + 2]; v.w = acc[0][0][4 * r4 + 3];
-        st4(mine + (r4 * NTH + tid) * 4, v);
-    }
-    __shared__ int s_last;
-    MTTS_WAIT_VMEM();
-    __syncthreads();
-    if (tid == 0) {
-        MTTS_FENCE_RELEASE_AGENT();
-        MTTS_WAIT_VMEM();
-        s_last = (MTTS_ATOMIC_INC_AGENT(ctr) == S - 1) ? 1 : 0;
-        if (s_last) MTTS_FENCE_ACQUIRE_AGENT();
-    }
-    __syncthreads();
-    if (!s_last) return false;
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-        float4 sum = zero4();
-        for (int sp = 0; sp < S; ++sp) {
-            const float4 v = ld4(base + (long long)sp * PART + (r4 * NTH + tid) * 4);
-            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-        }
-        acc[0][0][4 * r4] = sum.x; acc[0][0][4 * r4 + 1] = sum.y; acc[0][0][4 * r4 + 2] = sum.z; acc[0][0][4 * r4 + 3] = sum.w;
-    }
-    if (tid == 0) *ctr = 0;   // re-armed for the next launch
-    return true;
-}
-
+// One item.  The NEXT item is claimed here, between the K-loop and the epilogue: early enough for the atomic's round trip to hide behind
+// the epilogue, late enough that a workgroup never sits on a second item while another workgroup has none (claiming it before the
+// K-loop doubled the time of every launch with about one item per workgroup).
 template <int FORM, int BK>
-__device__ __forceinline__ void sk_tile(const GemmMulti& mp, int p, int z, int tile, int tn, int spt, int split, int S, int slab, float* smem) {
+__device__ __forceinline__ void sk_tile(const GemmMulti& mp, int p, int z, int tile, int tn, int spt, int split, int S, int slab, float* smem,
+                                        int* head, int& nxt) {
     const GemmArgs& g = mp.g[p];
     const GemmProb pr = gemm_resolve(g, z);
     const bool has_cs = gemm_has_colsum<FORM>(g);
@@ -121,13 +90,19 @@ __device__ __forceinline__ void sk_tile(const GemmMulti& mp, int p, int z, int t
     const int cps = (spt + S - 1) / S;
     const int c_lo = split * cps, c_hi = (c_lo + cps < spt) ? c_lo + cps : spt;
     gemm_f32_kloop<FORM, 64, 64, BK, true>(g, pr, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
-    if (S > 1 && !sk_combine<256>(mp.sk.ws + (long long)slab * 4096, mp.sk.ctr + slab, split, S, acc)) return;
+    if (threadIdx.x == 0) nxt = MTTS_ATOMIC_INC_AGENT(head);
+    if (S > 1 && !slab_combine<1, 1, 256>(mp.sk.ws + (long long)slab * 4096, mp.sk.ctr + slab, split, S, acc)) return;
     gemm_finish<1, 1, 2, 2>(g, pr, z, m0, n0, cs_tile, acc);
 }
 
-// WPE: waves per SIMD the register allocation must leave room for (= resident workgroups per CU)
-template <int BK, int WPE>
-__global__ __launch_bounds__(256) MTTS_WAVES_PER_EU(WPE) void gemm_sk_kernel(GemmMulti mp) {
+// Item queues: eight heads, one per XCD (workgroup b runs on XCD b % 8 — an observation used for speed only: any placement gives
+// the same results).  The global item list is dealt to the queues in runs of `run` consecutive items (the n-tiles of an m-tile, which
+// read the same operand panel, then meet in one L2), round-robin — queue x holds the runs x, x + 8, x + 16, ...  A workgroup
+// drains the queue of its XCD, then helps the others.
+__device__ __forceinline__ int sk_item_of(int j, int q, int run) { return ((j / run) * 8 + q) * run + (j % run); }
+
+template <int BK>
+__global__ __launch_bounds__(256) void gemm_sk_kernel(GemmMulti mp) {
     constexpr int F0 = GemmSmem<GEMM_NT, 64, 64, BK>::FLOATS, F1 = GemmSmem<GEMM_NN, 64, 64, BK>::FLOATS, F2 = GemmSmem<GEMM_TN, 64, 64, BK>::FLOATS;
     constexpr int FL = F0 > F1 ? (F0 > F2 ? F0 : F2) : (F1 > F2 ? F1 : F2);
     __shared__ __attribute__((aligned(16))) float smem[FL];
@@ -135,7 +110,8 @@ __global__ __launch_bounds__(256) MTTS_WAVES_PER_EU(WPE) void gemm_sk_kernel(Gem
     __shared__ int s_ipref[kSkMaxEntries + 1];   // items before entry e
     __shared__ int s_spref[kSkMaxEntries + 1];   // pieces of split tiles before entry e (slab index)
     __shared__ int s_tn[kSkMaxEntries], s_spt[kSkMaxEntries], s_tiles[kSkMaxEntries];
-    __shared__ int s_item, s_state[4];
+    __shared__ int s_le[3][kSkMaxEntries];       // tiles of entry e with split level <= 1, 2, 3
+    __shared__ int s_item, s_state[8];
     const int tid = threadIdx.x;
     const GemmSk& sk = mp.sk;
     const int E = sk.ent_start[mp.n], G = (int)gridDim.x;
@@ -161,25 +137,27 @@ __global__ __launch_bounds__(256) MTTS_WAVES_PER_EU(WPE) void gemm_sk_kernel(Gem
     }
     if (tid == 0) { s_upref[0] = 0; s_ipref[0] = 0; s_spref[0] = 0; }
     sk_scan2(s_upref, nullptr, E);
-    const long long W = MTTS_UNIFORM(s_upref[E]);
+    const int W = MTTS_UNIFORM(s_upref[E]);
     if (W == 0) return;
-    const long long tol = W / sk.tol_div;
-    const int s_cap = (my_spt / sk.min_chunks < sk.s_max) ? (my_spt / sk.min_chunks > 1 ? my_spt / sk.min_chunks : 1) : sk.s_max;
+    const int tol = W / sk.tol_div;
     if (tid < E) {
-        int items = my_tiles, pieces = 0;
-        if (s_cap > 1 && my_tiles > 0) {
-            const long long P = s_upref[tid];
-            int prev = sk_cnt_le(1, my_tiles, my_spt, P, W, tol, G);
-            items = prev;
-            for (int s = 2; s < s_cap; ++s) {
-                const int le = sk_cnt_le(s, my_tiles, my_spt, P, W, tol, G);
-                items += (le - prev) * s;
-                prev = le;
+        const int cap = (my_spt / sk.min_chunks < sk.s_max) ? (my_spt / sk.min_chunks > 1 ? my_spt / sk.min_chunks : 1) : sk.s_max;
+        int le[3] = {my_tiles, my_tiles, my_tiles};
+        int items = my_tiles;
+        if (cap > 1 && my_tiles > 0) {
+            const int P = s_upref[tid];
+            int prev = 0;
+            items = 0;
+            for (int s = 1; s < cap; ++s) {     // cap <= 4
+                le[s - 1] = sk_cnt_le(s, my_tiles, my_spt, P, W, tol, G);
+                items += (le[s - 1] - prev) * s;
+                prev = le[s - 1];
             }
-            items += (my_tiles - prev) * s_cap;
-            pieces = items - sk_cnt_le(1, my_tiles, my_spt, P, W, tol, G);
+            for (int s = cap; s <= 3; ++s) le[s - 1] = prev;
+            items += (my_tiles - prev) * cap;
         }
-        s_ipref[tid + 1] = items; s_spref[tid + 1] = pieces;
+        s_le[0][tid] = le[0]; s_le[1][tid] = le[1]; s_le[2][tid] = le[2];
+        s_ipref[tid + 1] = items; s_spref[tid + 1] = items - le[0];
     }
     sk_scan2(s_ipref, s_spref, E);
     bool nosplit = false;
@@ -189,57 +167,71 @@ __global__ __launch_bounds__(256) MTTS_WAVES_PER_EU(WPE) void gemm_sk_kernel(Gem
         if (tid < E) s_ipref[tid + 1] = my_tiles;
         sk_scan2(s_ipref, nullptr, E);
     }
-    // ---- queue ----
+
+    // ---- queues ----
     // Loop state lives in LDS (s_state), not in registers: the K-loop below is register-tight (occupancy), and everything the
     // scheduler needs between two items is re-read after the item's closing barrier.
+    // s_state: 0 items of this launch, 1 entry of the previous item (the search resumes there), 2 no-split flag, 3 queue
     if (tid == 0) {
-        s_state[0] = s_ipref[E];                          // items of this launch
-        s_state[1] = 0;                                   // entry of the previous item (the search resumes there)
+        s_state[0] = s_ipref[E];
+        s_state[1] = 0;
         s_state[2] = nosplit ? 1 : 0;
-        if (blockIdx.x == 0) *sk.head_next = 0;           // the next launch of this context uses the other head
-        s_item = MTTS_ATOMIC_INC_AGENT(sk.head);
+        s_state[3] = (int)(blockIdx.x & 7);
+        s_item = MTTS_ATOMIC_INC_AGENT(sk.head + (blockIdx.x & 7));
     }
+    if (blockIdx.x == 0 && tid < 8) sk.head_next[tid] = 0;   // the next launch of this context uses the other set of heads
     __syncthreads();
     for (;;) {
-        const int item = MTTS_UNIFORM(s_item);
-        if (item >= MTTS_UNIFORM(s_state[0])) break;
+        const int total = MTTS_UNIFORM(s_state[0]);
+        int q = MTTS_UNIFORM(s_state[3]);
+        int item = sk_item_of(MTTS_UNIFORM(s_item), q, sk.run);
+        if (item >= total) {
+            // this queue is drained: help the one with the most items left (one look at the eight heads, one returning atomic)
+            __syncthreads();
+            if (tid == 0) {
+                const int run = sk.run, runs = (total + run - 1) / run, deficit = runs * run - total;
+                int best = -1, best_rem = 0;
+                for (int k = 1; k < 8; ++k) {
+                    const int qq = (q + k) & 7;
+                    int len = runs > qq ? ((runs - qq + 7) / 8) * run : 0;
+                    if (len > 0 && ((runs - 1) & 7) == qq) len -= deficit;
+                    const int rem = len - MTTS_ATOMIC_LOAD_AGENT(sk.head + qq);
+                    if (rem > best_rem) { best = qq; best_rem = rem; }
+                }
+                s_state[3] = best;
+                if (best >= 0) { s_state[1] = 0; s_item = MTTS_ATOMIC_INC_AGENT(sk.head + best); }
+            }
+            __syncthreads();
+            if (MTTS_UNIFORM(s_state[3]) < 0) break;
+            continue;
+        }
         int nxt = 0;
-        if (tid == 0) nxt = MTTS_ATOMIC_INC_AGENT(sk.head);   // one item ahead: the round trip hides behind this item's K-loop
         int e = MTTS_UNIFORM(s_state[1]);
         while (MTTS_UNIFORM(s_ipref[e + 1]) <= item) ++e;
-        const int j = item - MTTS_UNIFORM(s_ipref[e]), c = MTTS_UNIFORM(s_spt[e]), T = MTTS_UNIFORM(s_tiles[e]), tn = MTTS_UNIFORM(s_tn[e]);
+        const int j = item - MTTS_UNIFORM(s_ipref[e]), c = MTTS_UNIFORM(s_spt[e]), tn = MTTS_UNIFORM(s_tn[e]);
         int tile = j, split = 0, S = 1, slab = 0;
-        if (!MTTS_UNIFORM(s_state[2])) {
+        const int le1 = MTTS_UNIFORM(s_le[0][e]);
+        if (!MTTS_UNIFORM(s_state[2]) && j >= le1) {
             const int cap = (c / sk.min_chunks < sk.s_max) ? (c / sk.min_chunks > 1 ? c / sk.min_chunks : 1) : sk.s_max;
-            if (cap > 1) {
-                const long long Wl = MTTS_UNIFORM(s_upref[E]), tl = Wl / sk.tol_div;
-                const long long P = MTTS_UNIFORM(s_upref[e]);
-                const int le1 = sk_cnt_le(1, T, c, P, Wl, tl, G);
-                if (j >= le1) {
-                    int jj = j - le1, prev = le1;
-                    S = cap;
-                    for (int s = 2; s < cap; ++s) {
-                        const int le = sk_cnt_le(s, T, c, P, Wl, tl, G);
-                        if (jj < (le - prev) * s) { S = s; break; }
-                        jj -= (le - prev) * s; prev = le;
-                    }
-                    tile = prev + jj / S; split = jj - (jj / S) * S;
-                    slab = MTTS_UNIFORM(s_spref[e]) + (j - le1) - split;   // slab of the tile's first piece
-                }
+            int jj = j - le1, prev = le1;
+            S = cap;
+            for (int s = 2; s < cap; ++s) {
+                const int le = MTTS_UNIFORM(s_le[s - 1][e]);
+                if (jj < (le - prev) * s) { S = s; break; }
+                jj -= (le - prev) * s; prev = le;
             }
+            tile = prev + jj / S; split = jj - (jj / S) * S;
+            slab = MTTS_UNIFORM(s_spref[e]) + (j - le1) - split;   // slab of the tile's first piece
         }
-        // (the 64-bit divisions above run on the vector ALU: tell the compiler their results are wave-uniform, or the whole K-loop
-        // below is compiled with exec-masked control flow)
-        tile = MTTS_UNIFORM(tile); split = MTTS_UNIFORM(split); S = MTTS_UNIFORM(S); slab = MTTS_UNIFORM(slab);
         if (tid == 0) s_state[1] = e;
         int p = 0;
         while (p + 1 < mp.n && e >= sk.ent_start[p + 1]) ++p;
         p = MTTS_UNIFORM(p);
         const int z = MTTS_UNIFORM(e - sk.ent_start[p]);
         const int form = mp.form[p];
-        if (form == GEMM_NT) sk_tile<GEMM_NT, BK>(mp, p, z, tile, tn, c, split, S, slab, smem);
-        else if (form == GEMM_NN) sk_tile<GEMM_NN, BK>(mp, p, z, tile, tn, c, split, S, slab, smem);
-        else sk_tile<GEMM_TN, BK>(mp, p, z, tile, tn, c, split, S, slab, smem);
+        if (form == GEMM_NT) sk_tile<GEMM_NT, BK>(mp, p, z, tile, tn, c, split, S, slab, smem, sk.head + q, nxt);
+        else if (form == GEMM_NN) sk_tile<GEMM_NN, BK>(mp, p, z, tile, tn, c, split, S, slab, smem, sk.head + q, nxt);
+        else sk_tile<GEMM_TN, BK>(mp, p, z, tile, tn, c, split, S, slab, smem, sk.head + q, nxt);
         __syncthreads();          // every wave is done with the LDS tiles (and with s_item)
         if (tid == 0) s_item = nxt;
         __syncthreads();
@@ -247,18 +239,20 @@ __global__ __launch_bounds__(256) MTTS_WAVES_PER_EU(WPE) void gemm_sk_kernel(Gem
 }
 
 // ---- host side ----
-inline int& gemm_sk_enabled() {   // MTTS_SK=0: the plain grids of gemm.h everywhere (A/B runs)
+// OPT-IN (MTTS_SK=1; the emulator build defaults to on so that the CPU tests exercise it).  Measured on MI355X (profiles/r03_sk_queue.md):
+// on single launches the queue recovers the tail (conv1 forward BK16: 90 -> 100 TFLOP/s) but its tiles run ~10 % slower than the same
+// K-loop in a plain grid (PostNet 64x64 BK16: 113 -> 99-104 TFLOP/s; VGPR- and AGPR-form accumulators, 4-6 workgroups per CU alike),
+// and the whole 8-task meta-step is 6-9 % slower (171 -> 183-190 ms); the plain grids stay the default.
+inline int& gemm_sk_enabled() {
+#if defined(MTTS_EMU)
     static int v = [] { const char* e = getenv("MTTS_SK"); return e ? atoi(e) : 1; }();
+#else
+    static int v = [] { const char* e = getenv("MTTS_SK"); return e ? atoi(e) : 0; }();
+#endif
     return v;
 }
 inline int gemm_sk_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 // resident capacity of the chip for the persistent kernel, in workgroups
-// kernel variants: BK = 16 compiled for 5 (default) or 4 resident workgroups per CU, BK = 32 for 4 or 3 (MTTS_SK_WPE)
-inline int gemm_sk_wpe(int bk) {
-    static const int e = gemm_sk_env("MTTS_SK_WPE", 0);
-    if (bk == 32) return e == 3 ? 3 : 4;
-    return e == 4 ? 4 : 5;
-}
 inline int gemm_sk_capacity(int bk) {
 #if defined(MTTS_EMU)
     (void)bk;
@@ -271,12 +265,11 @@ inline int gemm_sk_capacity(int bk) {
         int dev = 0, cus = 256, per_cu = 0;
         hipGetDevice(&dev);
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const int wpe = gemm_sk_wpe(bk);
-        if (bk == 32) { if (wpe == 3) hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_sk_kernel<32, 3>, 256, 0); else hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_sk_kernel<32, 4>, 256, 0); }
-        else { if (wpe == 4) hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_sk_kernel<16, 4>, 256, 0); else hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_sk_kernel<16, 5>, 256, 0); }
-        // never more workgroups than are resident at once (a queued workgroup would start when the others are done): the API's answer,
-        // capped by what the variant was compiled for
-        per_cu = std::max(1, std::min(per_cu, gemm_sk_env("MTTS_SK_OCC", wpe)));
+        if (bk == 32) hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_sk_kernel<32>, 256, 0);
+        else hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_sk_kernel<16>, 256, 0);
+        // never more workgroups than are resident at once (a queued workgroup would only start when the others are done): the API's
+        // answer, capped at 5 (it over-reports by one for SGPR-heavy kernels, MI355X_MICROARCH.md: residency)
+        per_cu = std::max(1, std::min(per_cu, gemm_sk_env("MTTS_SK_OCC", 5)));
         c = gemm_sk_env("MTTS_SK_WGS", cus * per_cu);
     }
     return c;
@@ -316,25 +309,24 @@ inline bool gemm_sk_launch(GemmCtx& cx, GemmMulti& mp, const std::vector<GemmPen
     static const int min_tile = gemm_sk_env("MTTS_SK_MIN_TILE", kMinTile);      // ... and the launch's longest K-loop, in chunks of 16
     const double unit = bk / 16.0;
     if (!force && (work * unit < (double)min_units * cap || max_chunks * unit < min_tile)) return false;
+    if (work > 1.0e9) return false;   // the in-kernel schedule is 32-bit
     int G = (int)std::min<double>(cap, std::max(1.0, tiles));
     mp.sk.s_max = gemm_sk_env("MTTS_SK_SMAX", 4);
     mp.sk.min_chunks = std::max(1, gemm_sk_env("MTTS_SK_MINCH", 16) * 16 / bk);
     mp.sk.tol_div = std::max(1, gemm_sk_env("MTTS_SK_TOL", 16));
     mp.sk.slabs = (int)std::min<long long>(kSplitWsFloats / 4096, kSplitCtrs);
     mp.sk.ws = cx.wsp.ws; mp.sk.ctr = cx.wsp.ctr;
-    mp.sk.head = cx.sk_heads + (cx.sk_parity & 1);
-    mp.sk.head_next = cx.sk_heads + ((cx.sk_parity + 1) & 1);
+    mp.sk.head = cx.sk_heads + 8 * (cx.sk_parity & 1);
+    mp.sk.head_next = cx.sk_heads + 8 * ((cx.sk_parity + 1) & 1);
     cx.sk_parity ^= 1;
+    // a run = the n-tiles of an m-tile of the first (longest) problem, at least 4 and at most 32 items
+    mp.sk.run = std::max(4, std::min(32, gemm_tiles_n(q[0].g, q[0].max_N, 64)));
+    static const int run_env = gemm_sk_env("MTTS_SK_RUN", 0);
+    if (run_env > 0) mp.sk.run = run_env;
     for (int i = 0; i < mp.n; ++i) { mp.g[i].splitk = 1; mp.g[i].swizzle = 0; }
     dim3 block(256), grid((unsigned)G, 1, 1);
-    const int wpe = gemm_sk_wpe(bk);
-    if (bk == 32) {
-        if (wpe == 3) { MTTS_LAUNCH((gemm_sk_kernel<32, 3>), grid, block, stream, mp); }
-        else { MTTS_LAUNCH((gemm_sk_kernel<32, 4>), grid, block, stream, mp); }
-    } else {
-        if (wpe == 4) { MTTS_LAUNCH((gemm_sk_kernel<16, 4>), grid, block, stream, mp); }
-        else { MTTS_LAUNCH((gemm_sk_kernel<16, 5>), grid, block, stream, mp); }
-    }
+    if (bk == 32) { MTTS_LAUNCH((gemm_sk_kernel<32>), grid, block, stream, mp); }
+    else { MTTS_LAUNCH((gemm_sk_kernel<16>), grid, block, stream, mp); }
     cx.last_kind = bk == 32 ? GK_SK32 : GK_SK16;
     return true;
 }

@@ -80,8 +80,18 @@ __device__ __forceinline__ float4 drop4(const DropSpec& d, int z, int row, int C
     const int rows_[2] = {row0, row0 + 1 < M_ ? row0 + 1 : row0};                               \
     const bool live1 = row0 + 1 < M_;
 
+// LayerNorm-family launch: the kernel instantiation that holds a row of C channels in registers (NV = 1 or 4 float4 per lane)
+#define MTTS_LAUNCH_LN(kernel, C_, grid, block, stream, ...)                                           \
+    do {                                                                                               \
+        if ((C_) <= 256) { MTTS_LAUNCH((kernel<1>), grid, block, stream, __VA_ARGS__); }               \
+        else { MTTS_LAUNCH((kernel<4>), grid, block, stream, __VA_ARGS__); }                           \
+    } while (0)
+
 inline dim3 row2_grid(int max_rows, int tasks) { return dim3((unsigned)((max_rows + 7) / 8), 1, (unsigned)tasks); }
 
+// NV = float4 a lane holds per row (1: C <= 256, 4: C <= 1024): a compile-time bound keeps the row in VGPRs (with a runtime
+// trip count the arrays below are indexed dynamically and live in scratch memory)
+template <int NV>
 __global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a, long long a_ts, const float* res,
                                      long long res_ts, const float* gamma, const float* beta, long long par_ts,
                                      const unsigned char* mask, long long mask_ts, float* z_out, long long z_ts,
@@ -90,7 +100,7 @@ __global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a
     // din: dropout applied to `a` before the residual add (self.dropout(sublayer(x)) + residual, SubLayers.py:54-55,90-91);
     // dout: dropout applied to the normalised output (LayerNorm -> Dropout of the variance predictors, modules.py:222-235)
     ROW2_PROLOGUE(mfield)
-    float4 v[2][4];
+    float4 v[2][NV];
     float s[2] = {0.f, 0.f};
     bool keep[2];
 #pragma unroll
@@ -99,24 +109,30 @@ __global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a
         const float* pa = a + (long long)z * a_ts + (long long)row * C;
         const float* pr = res ? res + (long long)z * res_ts + (long long)row * C : nullptr;
         keep[q] = mask ? (mask[(long long)z * mask_ts + row] != 0) : true;
-        int n = 0;
-        for (int c = lane * 4; c < C; c += 256, ++n) {
-            float4 x = ld4(pa + c);
-            if (din.thr16) x = drop4(din, z, row, C, c, x);
-            if (pr) { const float4 r4 = ld4(pr + c); x = make_float4(x.x + r4.x, x.y + r4.y, x.z + r4.z, x.w + r4.w); }
-            v[q][n] = x;
-            s[q] += (x.x + x.y) + (x.z + x.w);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int c = lane * 4 + 256 * n;
+            v[q][n] = zero4();
+            if (c < C) {
+                float4 x = ld4(pa + c);
+                if (din.thr16) x = drop4(din, z, row, C, c, x);
+                if (pr) { const float4 r4 = ld4(pr + c); x = make_float4(x.x + r4.x, x.y + r4.y, x.z + r4.z, x.w + r4.w); }
+                v[q][n] = x;
+                s[q] += (x.x + x.y) + (x.z + x.w);
+            }
         }
     }
-    const int nv = (C - lane * 4 + 255) / 256 > 0 ? (C - lane * 4 + 255) / 256 : 0;  // float4 this lane holds per row
     float mean[2], rstd[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         mean[q] = wave_sum(s[q]) / (float)C;
         float t = 0.f;
-        for (int i = 0; i < nv; ++i) {
-            const float dx = v[q][i].x - mean[q], dy = v[q][i].y - mean[q], dz = v[q][i].z - mean[q], dw = v[q][i].w - mean[q];
-            t += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (lane * 4 + 256 * i < C) {
+                const float dx = v[q][i].x - mean[q], dy = v[q][i].y - mean[q], dz = v[q][i].z - mean[q], dw = v[q][i].w - mean[q];
+                t += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
         }
         rstd[q] = rsqrtf(wave_sum(t) / (float)C + eps);
     }
@@ -128,8 +144,10 @@ __global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a
         const int row = rows_[q];
         float* py = y + (long long)z * y_ts + (long long)row * C;
         float* pz = z_out ? z_out + (long long)z * z_ts + (long long)row * C : nullptr;
-        int i = 0;
-        for (int c = lane * 4; c < C; c += 256, ++i) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c >= C) continue;
             if (pz) st4(pz + c, v[q][i]);
             float4 o = zero4();
             if (keep[q]) {
@@ -150,17 +168,18 @@ __global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a
 
 // dz = mask ? rstd * (g - mean(g) - xhat * mean(g * xhat)) : 0, g = dy * gamma
 // (relu_on_z additionally multiplies by [z > 0]: z = ReLU(conv) in the variance predictors)
+template <int NV>
 __global__ void layernorm_bwd_kernel(const int* meta, int mfield, const float* dy, long long dy_ts, const float* zin,
                                      long long z_ts, const float* stats, long long st_ts, const float* gamma,
                                      long long par_ts, const unsigned char* mask, long long mask_ts, float* dz,
                                      long long dz_ts, int C, int relu_on_z, float* dz_drop, long long dzd_ts, DropSpec dd,
-                                     float* dy_copy = nullptr, long long dyc_ts = 0) {
+                                     float* dy_copy, long long dyc_ts) {
     // dy_copy (optional): the incoming gradient, kept for a parameter-gradient reduction that runs later (engine.h: deferred path)
     // dz_drop (optional): dropout(dz) with the mask of the forward site — the gradient entering the dropped branch, while dz
     // itself continues along the residual path
     ROW2_PROLOGUE(mfield)
     const float* g = gamma + (long long)z * par_ts;
-    float4 gv[2][4], xh[2][4];
+    float4 gv[2][NV], xh[2][NV];
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rstd[2];
     bool keep[2];
 #pragma unroll
@@ -172,8 +191,11 @@ __global__ void layernorm_bwd_kernel(const int* meta, int mfield, const float* d
         const float* st = stats + (long long)z * st_ts + (long long)row * 2;
         const float mean = st[0];
         rstd[q] = st[1];
-        int n = 0;
-        for (int c = lane * 4; c < C; c += 256, ++n) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int c = lane * 4 + 256 * n;
+            gv[q][n] = zero4(); xh[q][n] = zero4();
+            if (c >= C) continue;
             const float4 d = ld4(pdy + c), x = ld4(pz + c), g4 = ld4(g + c);
             if (dy_copy && (q == 0 || live1)) st4(dy_copy + (long long)z * dyc_ts + (long long)row * C + c, d);
             gv[q][n] = make_float4(d.x * g4.x, d.y * g4.y, d.z * g4.z, d.w * g4.w);
@@ -189,8 +211,10 @@ __global__ void layernorm_bwd_kernel(const int* meta, int mfield, const float* d
         const int row = rows_[q];
         float* pd = dz + (long long)z * dz_ts + (long long)row * C;
         const float* pz = zin + (long long)z * z_ts + (long long)row * C;
-        int i = 0;
-        for (int c = lane * 4; c < C; c += 256, ++i) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c >= C) continue;
             float4 o = make_float4(rstd[q] * (gv[q][i].x - m1 - xh[q][i].x * m2), rstd[q] * (gv[q][i].y - m1 - xh[q][i].y * m2),
                                    rstd[q] * (gv[q][i].z - m1 - xh[q][i].z * m2), rstd[q] * (gv[q][i].w - m1 - xh[q][i].w * m2));
             if (relu_on_z) {  // z is a ReLU output: pass the gradient only where the pre-activation was > 0

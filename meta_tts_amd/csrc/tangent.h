@@ -18,6 +18,7 @@ __device__ __forceinline__ float4 f4(float a, float b, float c, float d) { retur
 // ---- LayerNorm --------------------------------------------------------------------------------
 // forward tangent: tz = ta (+ tres); m1 = mean(tz), m2 = mean(xhat tz); t_xhat = r (tz - m1 - xhat m2);
 // ty = mask ? tgamma*xhat + gamma*t_xhat + tbeta : 0.   tstats = (m1, m2) per row.
+template <int NV>   // float4 per lane and row, see layernorm_fwd_kernel
 __global__ void ln_jvp_fwd_kernel(const int* meta, int mfield, const float* ta, long long ta_ts, const float* tres,
                                   long long tres_ts, const float* zin, long long z_ts, const float* stats, long long st_ts,
                                   const float* gamma, long long par_ts, const float* tgamma, const float* tbeta,
@@ -29,10 +30,13 @@ __global__ void ln_jvp_fwd_kernel(const int* meta, int mfield, const float* ta, 
     const float* pz = zin + (long long)z * z_ts + (long long)row * C;
     const float* st = stats + (long long)z * st_ts + (long long)row * 2;
     const float mean = st[0], rstd = st[1];
-    float4 tv[4], xh[4];
+    float4 tv[NV], xh[NV];
     float s1 = 0.f, s2 = 0.f;
-    int n = 0;
-    for (int c = lane * 4; c < C; c += 256, ++n) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int c = lane * 4 + 256 * n;
+        tv[n] = zero4(); xh[n] = zero4();
+        if (c >= C) continue;
         float4 t = ld4(pa + c);
         if (pr) { const float4 r4 = ld4(pr + c); t = f4(t.x + r4.x, t.y + r4.y, t.z + r4.z, t.w + r4.w); }
         const float4 x = ld4(pz + c);
@@ -48,8 +52,10 @@ __global__ void ln_jvp_fwd_kernel(const int* meta, int mfield, const float* ta, 
     const float* tb = tbeta ? tbeta + (long long)z * tpar_ts : nullptr;
     float* po = ty + (long long)z * ty_ts + (long long)row * C;
     float* ptz = tz_out ? tz_out + (long long)z * tz_ts + (long long)row * C : nullptr;
-    int i = 0;
-    for (int c = lane * 4; c < C; c += 256, ++i) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c >= C) continue;
         if (ptz) st4(ptz + c, tv[i]);
         float4 o = zero4();
         if (keep) {
@@ -75,6 +81,7 @@ __global__ void ln_jvp_fwd_kernel(const int* meta, int mfield, const float* ta, 
 //   tg = tg_y*gamma + dy*tgamma, t_xhat = r (tz - m1 - xhat m2), rdot/r = -r m2:
 //   tg_z = -r m2 dz + r (tg - mean(tg) - t_xhat a2 - xhat (mean(tg xhat) + mean(g t_xhat)))
 // masked rows give 0 for both; relu_on_z multiplies both by [z > 0].
+template <int NV>
 __global__ void ln_jvp_bwd_kernel(const int* meta, int mfield, const float* dy, long long dy_ts, const float* tgy,
                                   long long tgy_ts, const float* zin, long long z_ts, const float* stats, long long st_ts,
                                   const float* tz, long long tz_ts, const float* tstats, long long tst_ts, const float* gamma,
@@ -98,14 +105,17 @@ __global__ void ln_jvp_bwd_kernel(const int* meta, int mfield, const float* dy, 
     const float mean = st[0], rstd = st[1], m1 = ts[0], m2 = ts[1];
     const float* g = gamma + (long long)z * par_ts;
     const float* tgm = tgamma ? tgamma + (long long)z * tpar_ts : nullptr;
-    float gv[4][4], tgv[4][4], xh[4][4], txh[4][4], zz[4][4];
+    float gv[NV][4], tgv[NV][4], xh[NV][4], txh[NV][4], zz[NV][4];
     float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
-    int n = 0;
-    for (int c = lane * 4; c < C; c += 256, ++n) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int c = lane * 4 + 256 * n;
+        if (c >= C) continue;
         const float4 d4 = ld4(pdy + c), t4 = ld4(ptgy + c), x4 = ld4(pz + c), tz4 = ld4(ptz + c), g4 = ld4(g + c);
         const float4 tg4 = tgm ? ld4(tgm + c) : zero4();
         const float d_[4] = {d4.x, d4.y, d4.z, d4.w}, t_[4] = {t4.x, t4.y, t4.z, t4.w}, x_[4] = {x4.x, x4.y, x4.z, x4.w};
         const float tz_[4] = {tz4.x, tz4.y, tz4.z, tz4.w}, g_[4] = {g4.x, g4.y, g4.z, g4.w}, tgm_[4] = {tg4.x, tg4.y, tg4.z, tg4.w};
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
             zz[n][k] = x_[k];
             xh[n][k] = (x_[k] - mean) * rstd;
@@ -120,9 +130,12 @@ __global__ void ln_jvp_bwd_kernel(const int* meta, int mfield, const float* dy, 
     }
     const float invC = 1.f / (float)C;
     a1 = wave_sum(a1) * invC; a2 = wave_sum(a2) * invC; b1 = wave_sum(b1) * invC; b2 = wave_sum(b2) * invC;
-    int i = 0;
-    for (int c = lane * 4; c < C; c += 256, ++i) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c >= C) continue;
         float o1[4], o2[4];
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float dzk = rstd * (gv[i][k] - a1 - xh[i][k] * a2);
             float tk = -rstd * m2 * dzk + rstd * (tgv[i][k] - b1 - txh[i][k] * a2 - xh[i][k] * b2);

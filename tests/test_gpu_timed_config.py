@@ -80,7 +80,7 @@ def test_eight_grouped_tasks_first_order_vs_oracle(tasks):
 def test_grouped_tasks_equal_the_same_tasks_alone(tasks, order):
     """Grouping is a scheduling decision: task j's losses and its contribution to the outer gradient must not depend on what else
     shares its launches.  8 grouped tasks vs tasks 2 and 5 run alone on a single-task handle (which takes the deferred / side-stream /
-    LDS-DMA paths instead), first and second order; the summation orders differ (split points of the work queue), hence 1e-5 / 1e-4
+    LDS-DMA paths instead), first and second order; the summation orders differ (split-K factors), hence 1e-5 / 1e-4
     instead of bit equality."""
     so = order == "so"
     pick = (2, 5)
@@ -122,12 +122,12 @@ def test_second_order_two_of_eight_vs_oracle(tasks):
     eng.close()
 
 
-@pytest.mark.parametrize("knobs", ["MTTS_DEFER_WGRAD=0 MTTS_ENC_AHEAD=0 MTTS_PRED_SIDE=0", "MTTS_SK=0", "MTTS_SK_MIN_UNITS=0 MTTS_SK_MIN_TILE=0"])
+@pytest.mark.parametrize("knobs", ["MTTS_DEFER_WGRAD=0 MTTS_ENC_AHEAD=0 MTTS_PRED_SIDE=0", "MTTS_SK=1 MTTS_SK_MIN_UNITS=0 MTTS_SK_MIN_TILE=0"])
 def test_reference_fixtures_on_the_other_launch_paths(knobs):
     """The small-plan tests against the REFERENCE fixtures (small-batch gradients, the contractive lr-1e-3 MAML fixture first and
     second order, two ragged tasks) once more with (a) the single-stream order — no deferred weight gradients, no encoder run-ahead,
-    no side-stream predictors —, (b) the plain grids instead of the work-queue kernel, (c) the work-queue kernel forced onto every
-    launch.  The switches are read once per process, hence the child."""
+    no side-stream predictors —, (b) the opt-in persistent work-queue kernel (csrc/gemm_sk.h) forced onto every queued launch.  The
+    switches are read once per process, hence the child."""
     env = dict(os.environ)
     for kv in knobs.split():
         k, v = kv.split("=")
