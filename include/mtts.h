@@ -73,6 +73,11 @@ int mtts_create(const mtts_model_cfg* cfg, int device, int max_tasks, int max_B,
 void mtts_destroy(mtts_handle* h);
 const char* mtts_last_error(mtts_handle* h); /* h may be NULL: error of the last failed mtts_create */
 int mtts_set_stream(mtts_handle* h, void* hip_stream);
+/* ---- gradient accumulation (main.py:62 `accumulate_grad_batches=grad_acc_step`): with accumulate != 0 the next mtts_meta_grad /
+ * mtts_plain_grad calls ADD their (already grad_scale-d) result to the outer-gradient buffer instead of overwriting it; the caller
+ * passes grad_scale / grad_acc_step, all-reduces and steps the optimizer once per grad_acc_step batches (systems.Trainer). */
+int mtts_set_grad_accumulation(mtts_handle* h, int accumulate);
+
 /* Train-mode dropout (nn.Dropout / F.dropout sites of SubLayers.py:54,90, modules.py:223,235, Layers.py:133-134).
  * Off by default — the parity configuration (SURVEY.md Appendix B.5 patches dropout to identity).  When on, masks are a
  * counter-based function of (seed, pass, site, element) regenerated in backward and in the second-order replay. */

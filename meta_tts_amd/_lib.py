@@ -74,6 +74,7 @@ EXPORTS = {
     "mtts_outer_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_void_p]),
     "mtts_reset_optimizer": (C.c_int, [C.c_void_p]),
+    "mtts_set_grad_accumulation": (C.c_int, [C.c_void_p, C.c_int]),
     "mtts_profile_gemm": (C.c_int, [C.c_void_p, C.c_int]),
     "mtts_profile_kinds": (C.c_int, []),
     "mtts_profile_kernel_name": (C.c_char_p, [C.c_int]),

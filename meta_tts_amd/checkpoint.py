@@ -162,7 +162,22 @@ def load_checkpoint(system, path: str, strict: bool = False):
         else:
             import warnings
             warnings.warn("unrecognised optimizer_states layout: Adam moments reset (the step count restarts the bias correction)")
-            system.engine.reset_optimizer()
+            _reset_optimizer(system)
     else:
-        system.engine.reset_optimizer()  # system.py:191-192 drops the optimizer state when the loader changed anything
+        _reset_optimizer(system)  # system.py:191-192 drops the optimizer state when the loader changed anything
     return changes
+
+
+def _reset_optimizer(system):
+    """Fresh Adam state for EVERY trained parameter: the engine's moments and, for speaker_emb: encoder / scratch_encoder, the LSTM
+    speaker encoder's moments and step count (left as they were they would resume with stale moments under a restarted bias
+    correction, and a later save would write moments inconsistent with the recorded step)."""
+    system.engine.reset_optimizer()
+    enc = getattr(system.model, "speaker_encoder", None)
+    if enc is not None and getattr(system.model, "spk_mode", "dvec") in ("encoder", "scratch_encoder"):
+        from .speaker_encoder import tensor_shapes
+        for name, shape in tensor_shapes(**enc.cfg).items():
+            zeros = np.zeros(shape, np.float32)
+            enc.import_state(name, 2, zeros)
+            enc.import_state(name, 3, zeros)
+        enc.set_optimizer_step(0)

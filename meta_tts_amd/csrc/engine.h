@@ -228,6 +228,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     ~GemmBatchScope() { gemm_batch_end(cx, s); }
 };
     // dropout (off by default: parity runs patch it to identity)
+    // gradient accumulation (main.py:62 accumulate_grad_batches): meta_grad / plain_grad ADD their result to the outer buffer
+    bool outer_accumulate = false;
     bool dropout_on = false;
     unsigned drop_base = 0x1234567u, drop_counter = 0;
     int site_base = 0;  // set by the caller of fft_* / pred_*: identifies the layer for the mask stream
@@ -1886,7 +1888,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (loss(pq, losses_out ? losses_out : losses)) return -1;
         if (backward(pq, grad_scale, true)) return -1;
         MTTS_LAUNCH(sum_tasks_kernel, dim3(blocks_for(n_total / 4)), dim3(256), stream, (const float*)grad, n_total, nt, 1.f, outer,
-                    n_total / 4);
+                    n_total / 4, (int)outer_accumulate);
         return 0;
     }
 
@@ -1921,7 +1923,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (loss(ps, losses_out ? losses_out : losses)) return -1;
         if (backward(ps, grad_scale, true)) return -1;
         MTTS_LAUNCH(sum_tasks_kernel, dim3(blocks_for(n_total / 4)), dim3(256), stream, (const float*)grad, n_total, p.tasks, 1.f,
-                    outer, n_total / 4);
+                    outer, n_total / 4, (int)outer_accumulate);
         return 0;
     }
 

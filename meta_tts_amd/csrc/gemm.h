@@ -39,7 +39,7 @@
 namespace mtts {
 
 enum GemmForm { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
-enum GemmFlags { GEMM_RELU = 1, GEMM_ACCUM = 2, GEMM_LRELU = 4 };  // LRELU: v < 0 -> act_slope * v (MelGAN generator)
+enum GemmFlags { GEMM_RELU = 1, GEMM_ACCUM = 2, GEMM_LRELU = 4, GEMM_SLAB_FENCE = 8 };   // SLAB_FENCE: split-K slabs published with plain stores + a release fence (A/B arm)  // LRELU: v < 0 -> act_slope * v (MelGAN generator)
 
 struct GemmGroupDesc {
     long long a_off, b_off, c_off;  // element offsets added to A / B / C
@@ -237,7 +237,9 @@ __device__ __forceinline__ void st4_through(float* p, float4 v) {
     st4(p, v);
 #else
     f32x4 x; x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+    // (s_nop: a store of more than 8 bytes must not have its data VGPRs overwritten by the very next VALU instruction — a hazard hipcc
+    // pads for its own stores but cannot see inside an asm; without it the slab held garbage whenever the register allocation reused x)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(x) : "memory");
 #endif
 }
 
@@ -245,7 +247,7 @@ __device__ __forceinline__ void st4_through(float* p, float4 v) {
 // last to arrive (`ctr`) reloads all S partials in split order (its own included, so the sum does not depend on the arrival order)
 // and returns true to run the epilogue; it also re-arms the counter for the next launch.
 template <int TM, int TN, int NTH>
-__device__ __forceinline__ bool slab_combine(float* base, int* ctr, int split, int S, f32x16 (&acc)[TM][TN]) {
+__device__ __forceinline__ bool slab_combine(float* base, int* ctr, int split, int S, f32x16 (&acc)[TM][TN], bool fence = false) {
     constexpr int PART = NTH * 16 * TM * TN;  // floats per partial tile
     const int tid = threadIdx.x;
     float* mine = base + (long long)split * PART;
@@ -257,12 +259,14 @@ __device__ __forceinline__ bool slab_combine(float* base, int* ctr, int split, i
             for (int r4 = 0; r4 < 4; ++r4) {
                 float4 v;
                 v.x = acc[i][j][4 * r4]; v.y = acc[i][j][4 * r4 + 1]; v.z = acc[i][j][4 * r4 + 2]; v.w = acc[i][j][4 * r4 + 3];
-                st4_through(mine + (((i * TN + j) * 4 + r4) * NTH + tid) * 4, v);
+                if (fence) st4(mine + (((i * TN + j) * 4 + r4) * NTH + tid) * 4, v);
+                else st4_through(mine + (((i * TN + j) * 4 + r4) * NTH + tid) * 4, v);
             }
     __shared__ int s_last;
     MTTS_WAIT_VMEM();      // every storing wave drains its write-through stores
     __syncthreads();
     if (tid == 0) {
+        if (fence) { MTTS_FENCE_RELEASE_AGENT(); MTTS_WAIT_VMEM(); }   // A/B arm (MTTS_SLAB_FENCE=1): plain stores + agent-scope release
         s_last = (MTTS_ATOMIC_INC_AGENT(ctr) == S - 1) ? 1 : 0;
         if (s_last) MTTS_FENCE_ACQUIRE_AGENT();
     }
@@ -288,7 +292,7 @@ __device__ __forceinline__ bool slab_combine(float* base, int* ctr, int split, i
 template <int TM, int TN, int NTH>
 __device__ __forceinline__ bool splitk_combine(const GemmArgs& g, int z, int tile_lin, int split, int S, f32x16 (&acc)[TM][TN]) {
     const long long slot = (long long)z * g.tiles_pg + tile_lin;
-    return slab_combine<TM, TN, NTH>(g.ws + slot * S * (NTH * 16 * TM * TN), g.tile_ctr + slot, split, S, acc);
+    return slab_combine<TM, TN, NTH>(g.ws + slot * S * (NTH * 16 * TM * TN), g.tile_ctr + slot, split, S, acc, (g.flags & GEMM_SLAB_FENCE) != 0);
 }
 
 // WGM x WGN waves per workgroup (64 threads each); the wave tile is (BM/WGM) x (BN/WGN) = TM x TN MFMA tiles.
@@ -772,6 +776,8 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     if (max_M <= 0 || max_N <= 0 || groups <= 0) return;
     GemmArgs g = g_in;
     g.swizzle = gemm_xcd_swizzle();
+    static const bool slab_fence = [] { const char* e = getenv("MTTS_SLAB_FENCE"); return e && atoi(e) != 0; }();
+    if (slab_fence) g.flags |= GEMM_SLAB_FENCE;
     const int user_tile = tile;
     const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
     auto ntiles = [&](int t) { return (long)((max_M + t - 1) / t) * gemm_tiles_n(g, max_N, t); };

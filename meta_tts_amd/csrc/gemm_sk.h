@@ -91,7 +91,7 @@ __device__ __forceinline__ void sk_tile(const GemmMulti& mp, int p, int z, int t
     const int c_lo = split * cps, c_hi = (c_lo + cps < spt) ? c_lo + cps : spt;
     gemm_f32_kloop<FORM, 64, 64, BK, true>(g, pr, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
     if (threadIdx.x == 0) nxt = MTTS_ATOMIC_INC_AGENT(head);
-    if (S > 1 && !slab_combine<1, 1, 256>(mp.sk.ws + (long long)slab * 4096, mp.sk.ctr + slab, split, S, acc)) return;
+    if (S > 1 && !slab_combine<1, 1, 256>(mp.sk.ws + (long long)slab * 4096, mp.sk.ctr + slab, split, S, acc, (g.flags & GEMM_SLAB_FENCE) != 0)) return;
     gemm_finish<1, 1, 2, 2>(g, pr, z, m0, n0, cs_tile, acc);
 }
 

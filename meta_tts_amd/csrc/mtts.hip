@@ -84,6 +84,12 @@ void mtts_destroy(mtts_handle* h) {
 const char* mtts_last_error(mtts_handle* h) { return h ? h->eng.last_error.c_str() : g_create_error.c_str(); }
 
 int mtts_set_stream(mtts_handle* h, void* s) { h->eng.stream = (hipStream_t)s; return 0; }
+int mtts_set_grad_accumulation(mtts_handle* h, int accumulate) {
+    if (!h) return -1;
+    h->eng.outer_accumulate = accumulate != 0;
+    return 0;
+}
+
 int mtts_set_dropout(mtts_handle* h, int enable, unsigned seed) {
     Engine& e = h->eng;
     for (float p : {e.cfg.enc_dropout, e.cfg.dec_dropout, e.cfg.vp_dropout})

@@ -989,15 +989,17 @@ __global__ void sgd_update_kernel(float* w, const float* g, long long n4, float 
     }
 }
 
-// out[i] = scale * sum_t g[t][i]   (fixed task order)
-__global__ void sum_tasks_kernel(const float* g, long long g_ts, int tasks, float scale, float* out, long long n4) {
+// out[i] (+)= scale * sum_t g[t][i]   (fixed task order; accumulate: gradient accumulation over several batches, main.py:62)
+__global__ void sum_tasks_kernel(const float* g, long long g_ts, int tasks, float scale, float* out, long long n4, int accumulate) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         float4 s = zero4();
         for (int t = 0; t < tasks; ++t) {
             const float4 x = ld4(g + (long long)t * g_ts + i * 4);
             s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
         }
-        st4(out + i * 4, make_float4(s.x * scale, s.y * scale, s.z * scale, s.w * scale));
+        float4 o = make_float4(s.x * scale, s.y * scale, s.z * scale, s.w * scale);
+        if (accumulate) { const float4 p = ld4(out + i * 4); o = make_float4(o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w); }
+        st4(out + i * 4, o);
     }
 }
 

@@ -96,6 +96,10 @@ class Engine:
         """Train-mode dropout on/off (off = parity configuration)."""
         self._ck(self.lib.mtts_set_dropout(self.h, int(enable), int(seed) & 0xFFFFFFFF))
 
+    def set_grad_accumulation(self, accumulate: bool):
+        """meta_grad / plain_grad add to the outer-gradient buffer instead of overwriting it (gradient accumulation, main.py:62)."""
+        self._ck(self.lib.mtts_set_grad_accumulation(self.h, int(bool(accumulate))))
+
     def synchronize(self):
         self._ck(self.lib.mtts_synchronize(self.h))
 

@@ -64,6 +64,7 @@ class System:
         if enc is not None:   # back-propagate dLoss/d(speaker embedding) through the LSTM encoder (autograd does this in the reference)
             assert self.world_size == 1, "a trained speaker encoder is single-rank here (its gradients are not all-reduced)"
             enc.backward(self.engine.speaker_grad(0, int(np.shape(batch[3])[0])))
+            self._enc_grads_fresh = True
         return {"loss": losses[0][0], "losses": losses[0], "_batch": batch}
 
     def _trained_speaker_encoder(self):
@@ -80,6 +81,11 @@ class System:
         lr = noam_lr(self.global_step, self.model.dims.d_model, self.train_config)
         enc = self._trained_speaker_encoder()
         if enc is not None:   # clip_grad_norm_ over ALL parameters (main.py:61): the encoder's sum of squares joins the engine's norm
+            if not getattr(self, "_enc_grads_fresh", False):
+                raise RuntimeError("optimizer_step with a trained speaker encoder but no encoder backward since the last step "
+                                   "(only System.training_step back-propagates through it): its stale gradients would be applied "
+                                   "and would skew the joint clip norm")
+            self._enc_grads_fresh = False
             self.engine.set_extra_grad_sumsq(enc.grad_sumsq_ptr())
         self.engine.outer_update(lr=lr, betas=tuple(o["betas"]), eps=o["eps"], weight_decay=o["weight_decay"],
                                  max_norm=o["grad_clip_thresh"], grad_ptr=grad_ptr)
@@ -329,6 +335,13 @@ class Trainer:
         self.system.world_size = self.dist.get_world_size(self.group) if self.dist else 1
         self.outer = outer_grad_tensor  # torch view of engine.outer_grad_ptr() (zero copy on GPU)
         self.library_comm = False
+        # accumulate_grad_batches (main.py:62; config/train/base.yaml: optimizer.grad_acc_step): gradients of N consecutive batches are
+        # summed (each scaled by 1/N, as PL divides the loss), the ranks reduce and the optimizer steps on the N-th — DDP's no_sync
+        # behaviour: no collective on the accumulating batches
+        self.grad_acc = int(system.train_config["optimizer"].get("grad_acc_step", 1))
+        if self.grad_acc < 1:
+            raise ValueError(f"optimizer.grad_acc_step must be >= 1, got {self.grad_acc}")
+        self._acc_i = 0
         if self.dist is not None and self.dist.get_backend(self.group) == "nccl":
             # RCCL orders its collective after torch's CURRENT stream of the engine's device: put the engine's launches on that
             # stream so the all-reduce sees the finished outer gradient and the clip + Adam after it sees the reduced one
@@ -363,21 +376,43 @@ class Trainer:
             self.outer = torch.as_tensor(self.system.engine.outer_grad_view(), device=f"cuda:{self.system.engine.device}")
         self.dist.all_reduce(self.outer, op=self.dist.ReduceOp.SUM, group=self.group)
 
+    def _accumulating(self) -> bool:
+        """Arms the engine for this batch; True when the optimizer must NOT step yet."""
+        self.system.engine.set_grad_accumulation(self._acc_i > 0)
+        self._acc_i += 1
+        if self._acc_i < self.grad_acc:
+            return True
+        self._acc_i = 0
+        return False
+
     def meta_step(self, local_tasks: Sequence[tuple], total_tasks: int):
-        q, s = self.system.meta_learn_tasks(local_tasks, total_tasks=total_tasks)
+        """One batch.  With grad_acc_step = N the optimizer steps on every N-th call (returned lr is None in between)."""
+        hold = self._accumulating()
+        q, s = self.system.meta_learn_tasks(local_tasks, total_tasks=total_tasks * self.grad_acc)
+        if hold:
+            return q, s, None
         self._allreduce()
         lr = self.system.optimizer_step()
         return q, s, lr
 
     def imaml_step(self, batch, total_tasks: int):
         """IMAMLSystem.meta_learn(train=True) on this rank's task, mean over ranks (imaml.py:132 `reduce`), manual optimizer step."""
+        if self.grad_acc != 1:
+            raise NotImplementedError("optimizer.grad_acc_step != 1 with the iMAML system (its hypergradient overwrites the outer buffer per task)")
         q = self.system.meta_learn(batch, 0, train=True, total_tasks=total_tasks)
         self._allreduce()
         lr = self.system.optimizer_step()
         return q, lr
 
     def plain_step(self, local_batches: Sequence[tuple], total_batches: int):
-        losses = self.system.engine_plain_grad(local_batches, total_batches)
+        if self.system._trained_speaker_encoder() is not None:
+            # the LSTM speaker encoder's backward lives in System.training_step (one batch, one rank): stepping the optimizer from here
+            # would update it from stale gradients and skew the joint clip norm
+            raise NotImplementedError("speaker_emb: encoder / scratch_encoder train through System.training_step (single batch, single rank)")
+        hold = self._accumulating()
+        losses = self.system.engine_plain_grad(local_batches, total_batches * self.grad_acc)
+        if hold:
+            return losses, None
         self._allreduce()
         lr = self.system.optimizer_step()
         return losses, lr

@@ -1,12 +1,13 @@
 """TEST INFRASTRUCTURE ONLY — torch restatement of the reference's mel front-end, the checker of meta_tts_amd/csrc/melfront.h.
 
-PARITY UNPINNED: audio/stft.py cannot be run here to make fixtures — `STFT.transform` moves its operands with hard-coded
-`.cuda()` calls (stft.py:67-68; there is no GPU in the build container, and torch on the GPU box is not the reference) and the module
-imports librosa (absent).  Restated line by line instead: STFT.__init__ (stft.py:27-46: np.fft.fft(np.eye(n)) -> real | imaginary
-rows -> FloatTensor -> times the padded periodic Hann window), STFT.transform (:52-77: reflect pad n/2, F.conv1d with stride hop,
-sqrt(re^2 + im^2)), TacotronSTFT.mel_spectrogram (:159-178: matmul with the mel basis, log(clamp(., 1e-5)), torch.norm over
-frequency) and audio/tools.py:8-15 (clip).  The mel basis is an input here (librosa.filters.mel in the reference).  Only tests/,
-__graft_entry__.smoke() and bench.py may import it."""
+PINNED (round 3) by tests/golden/stft.npz — outputs of the REFERENCE's own audio/stft.py + audio/tools.py run in the build container by
+tests/golden/make_stft_golden.py (librosa's three padding helpers shimmed, `.cuda()` made the identity): the windowed Fourier basis,
+mel and energy at a small, a short-window and the LibriTTS configuration (tests/test_stft.py).  What stays unpinned is the mel FILTER
+BANK only: the reference takes it from librosa.filters.mel, which is absent here, so the basis is an input of this oracle and of the
+fixture.  Restated: STFT.__init__ (stft.py:27-46: np.fft.fft(np.eye(n)) -> real | imaginary rows -> FloatTensor -> times the padded
+periodic Hann window), STFT.transform (:52-77: reflect pad n/2, F.conv1d with stride hop, sqrt(re^2 + im^2)),
+TacotronSTFT.mel_spectrogram (:159-178: matmul with the mel basis, log(clamp(., 1e-5)), torch.norm over frequency) and
+audio/tools.py:8-15 (clip).  Only tests/, __graft_entry__.smoke() and bench.py may import it."""
 import numpy as np
 import torch
 import torch.nn.functional as F

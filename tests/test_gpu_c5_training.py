@@ -437,24 +437,3 @@ def test_frame_level_full_size_matches_reference_fixture(golden_dir):
     np.testing.assert_array_equal(out["d_rounded"], g["ff_fr_d_rounded"])
     np.testing.assert_array_equal(out["mel_lens"], g["ff_fr_mel_len"])
     eng.close()
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# f4: the LSTM speaker-encoder modes (dvec frozen, scratch_encoder trained) through the whole host layer on the hardware arm:
-# baseline-system step vs the oracle, BPTT vs torch autograd, joint clip + Adam, checkpoint positions, average_spk_emb
-# ---------------------------------------------------------------------------------------------------------------------
-def _host_tests():
-    import test_host_api as H
-    return [H.test_dvec_speaker_mode_baseline_system, H.test_dvec_few_shot_test_step_averages_support_embeddings]
-
-
-@pytest.mark.parametrize("fn", _host_tests(), ids=lambda f: f.__name__)
-def test_speaker_encoder_modes_on_device(fn, tmp_path):
-    import test_host_api as H
-    fn(H.make_cfgs(tmp_path), None)
-
-
-def test_trained_speaker_encoder_on_device(tmp_path):
-    import test_host_api as H
-    H.test_trained_speaker_encoder_baseline_step_and_checkpoint(H.make_cfgs(tmp_path), None, tmp_path)
-

@@ -1,6 +1,8 @@
-"""Reference-shaped host layer (model.py / systems.py / checkpoint.py) driven on CPU through the SIMT
-emulator build: registry, hook names, 12-tuple / 10-tuple layouts, state_dict + checkpoint key layout,
-loader surgery (system.py:115-192), Noam schedule."""
+"""Reference-shaped host layer (model.py / systems.py / checkpoint.py): registry, hook names, 12-tuple / 10-tuple layouts,
+state_dict + checkpoint key layout incl. the torch-Adam / LambdaLR state, loader surgery (system.py:115-192), 1-shot test mode,
+avg_train_spk_emb, the Saver's result tree, Noam schedule.  Every test runs twice: through the SIMT emulator build on CPU and,
+marked gpu, through libmtts.so on the MI355X (checkpoint import / export, optimizer-step restore and the test loop then move real
+device state)."""
 import json
 import os
 
@@ -15,8 +17,12 @@ from meta_tts_amd.config import default_algorithm_config, default_train_config
 from meta_tts_amd.systems import Trainer, get_system, noam_lr
 
 
-@pytest.fixture(scope="module")
-def emu_lib():
+@pytest.fixture(scope="module", params=[pytest.param("emu", id="emu"), pytest.param("gpu", id="gpu", marks=pytest.mark.gpu)])
+def emu_lib(request):
+    """Library the systems load: the emulator build, or None = meta_tts_amd/libmtts.so (the HIP build) on the GPU arm."""
+    if request.param == "gpu":
+        ge.build_device()
+        return None
     return ge.build_emulator()
 
 
@@ -642,3 +648,45 @@ def test_dvec_few_shot_test_step_averages_support_embeddings(cfgs, emu_lib):
     with torch.no_grad():
         lo = O.fs2_loss(tuple(tb), O.fs2_forward(prm, torch_buffers(dims), *tb[2:], n_head=heads(dims), max_seq_len=dims.max_seq_len, training=False))
     assert abs(got - float(lo[0])) < 2e-4 * max(1.0, abs(float(lo[0])))
+
+
+def test_gradient_accumulation_matches_one_step_on_the_joint_batch(cfgs, emu_lib):
+    """optimizer.grad_acc_step = 2 (main.py:62 accumulate_grad_batches): two meta-batches of one task each, ONE optimizer step on the sum
+    of their halved gradients — the same parameters as one step on a meta-batch holding both tasks; the optimizer must not move between
+    the two calls.  iMAML and the trained speaker encoders refuse the combination instead of ignoring it."""
+    pre, mc, tc, ac = cfgs
+    import copy
+    tc2 = copy.deepcopy(tc)
+    tc2["optimizer"]["grad_acc_step"] = 2
+    ac = copy.deepcopy(ac)
+    ac["adapt"]["first_order"] = True
+    dims = tiny_dims()
+    kw = _kw(dims.n_mel)
+    t1 = (synth.make_batch(5, 3, speaker=2, vocab=dims.vocab, **kw), synth.make_batch(6, 2, speaker=2, vocab=dims.vocab, **kw))
+    t2 = (synth.make_batch(7, 2, speaker=4, vocab=dims.vocab, **kw), synth.make_batch(8, 3, speaker=4, vocab=dims.vocab, **kw))
+    acc = get_system("meta")(pre, mc, tc2, ac, max_tasks=2, max_batch=3, max_src_len=16, max_mel_len=96, lib_path=emu_lib)
+    tr = Trainer(acc)
+    assert tr.grad_acc == 2
+    before = acc.state_dict()["model.mel_linear.weight"].copy()
+    _, _, lr = tr.meta_step([t1], total_tasks=1)
+    assert lr is None and acc.global_step == 0
+    np.testing.assert_array_equal(acc.state_dict()["model.mel_linear.weight"], before)   # nothing stepped yet
+    _, _, lr = tr.meta_step([t2], total_tasks=1)
+    assert lr is not None and acc.global_step == 1
+    ref = get_system("meta")(pre, mc, tc, ac, max_tasks=2, max_batch=3, max_src_len=16, max_mel_len=96, lib_path=emu_lib)
+    Trainer(ref).meta_step([t1, t2], total_tasks=2)
+    for k in ("model.mel_linear.weight", "model.decoder.layer_stack.1.pos_ffn.w_1.weight", "model.encoder.layer_stack.0.slf_attn.fc.weight",
+              "model.postnet.convolutions.2.0.conv.bias"):
+        a, b = acc.state_dict()[k], ref.state_dict()[k]
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-7, err_msg=k)
+        assert np.abs(a - (before if k == "model.mel_linear.weight" else a * 0 + 1e9)).max() > 0
+    tc0 = copy.deepcopy(tc)
+    tc0["optimizer"]["grad_acc_step"] = 0
+    with pytest.raises(ValueError):
+        Trainer(get_system("meta")(pre, mc, tc0, ac, max_tasks=1, max_batch=3, max_src_len=16, max_mel_len=96, lib_path=emu_lib))
+    alg = default_algorithm_config()
+    alg["type"] = "imaml"
+    alg["adapt"]["imaml"] = {"K": 2, "reg_param": 1.0, "batch_size": 2, "stochastic": True}
+    im = get_system("imaml")(pre, mc, tc2, alg, max_tasks=1, max_batch=3, max_src_len=16, max_mel_len=96, lib_path=emu_lib)
+    with pytest.raises(NotImplementedError):
+        Trainer(im).imaml_step([([t1[0]], [t1[1]])], total_tasks=1)

@@ -1,6 +1,8 @@
 """Waveform -> log-mel + energy (csrc/melfront.h through include/mtts.h: mtts_stft_*) against oracle/stft_oracle.py (torch
-restatement of audio/stft.py:15-77,128-178 and audio/tools.py:8-15).  Small transform through the SIMT emulator, the reference's
+restatement of audio/stft.py:15-77,128-178 and audio/tools.py:8-15) AND against tests/golden/stft.npz — outputs of the reference's own
+TacotronSTFT / get_mel_from_wav (tests/golden/make_stft_golden.py).  Small transforms through the SIMT emulator, the reference's
 LibriTTS configuration (1024 / 256 / 1024, 80 mels, 22050 Hz) on the MI355X."""
+import os
 import numpy as np
 import pytest
 
@@ -75,3 +77,48 @@ def test_stft_lengths_and_window_shorter_than_filter():
 def test_stft_gpu_libritts_configuration():
     ge.build_device()
     _run(None, 1024, 256, 1024, 80, 22050, 22050 * 3 + 77, 22050 * 4)
+
+
+# ---- the reference's own outputs (tests/golden/stft.npz) ----------------------------------------------------------------------
+def _golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stft.npz"))
+
+
+@pytest.mark.parametrize("tag", ["small", "short_window", "libritts"])
+def test_oracle_matches_reference_fixture(tag):
+    """Pins oracle/stft_oracle.py: same waveform, same mel basis -> the reference's mel / energy; the windowed Fourier basis bit for bit."""
+    g = _golden()
+    n_fft, hop, win, n_mel, sr, n = (int(x) for x in g[tag + "_cfg"])
+    mel, energy = orc.mel_spectrogram(g[tag + "_wav"], n_fft, hop, win, g[tag + "_mel_basis"])
+    np.testing.assert_allclose(energy, g[tag + "_energy"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(mel, g[tag + "_mel"], rtol=0, atol=5e-5)
+    if tag != "libritts":
+        np.testing.assert_array_equal(orc.forward_basis(n_fft, win).numpy(), g[tag + "_forward_basis"])
+        np.testing.assert_array_equal(S.forward_basis(n_fft, win), g[tag + "_forward_basis"][:, 0, :])
+
+
+def _device_vs_fixture(lib_path, tag):
+    g = _golden()
+    n_fft, hop, win, n_mel, sr, n = (int(x) for x in g[tag + "_cfg"])
+    st = S.TacotronSTFT(n_fft, hop, win, n_mel, sr, 0, None, max_samples=n + 64, lib_path=lib_path)
+    np.testing.assert_array_equal(st.mel_basis, g[tag + "_mel_basis"])     # the shim of the generating script IS this filter bank
+    mel, energy = tools.get_mel_from_wav(g[tag + "_wav"], st)
+    rmel, renergy = g[tag + "_mel"], g[tag + "_energy"]
+    assert mel.shape == rmel.shape
+    np.testing.assert_allclose(energy, renergy, rtol=2e-5, atol=2e-5)
+    live = rmel > np.log(2e-5)
+    np.testing.assert_allclose(mel[live], rmel[live], rtol=0, atol=2e-4)
+    assert np.all(mel[~live] <= np.log(3e-5))
+    st.close()
+
+
+@pytest.mark.parametrize("tag", ["small", "short_window"])
+def test_stft_emulator_vs_reference_fixture(tag):
+    _device_vs_fixture(ge.build_emulator(), tag)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["small", "short_window", "libritts"])
+def test_stft_gpu_vs_reference_fixture(tag):
+    ge.build_device()
+    _device_vs_fixture(None, tag)
