@@ -250,6 +250,7 @@ template <int TM, int TN, int NTH>
 __device__ __forceinline__ bool slab_combine(float* base, int* ctr, int split, int S, f32x16 (&acc)[TM][TN], bool fence = false) {
     constexpr int PART = NTH * 16 * TM * TN;  // floats per partial tile
     const int tid = threadIdx.x;
+    const bool act = tid < NTH;   // (workgroups larger than the tile's NTH threads only take part in the barriers)
     float* mine = base + (long long)split * PART;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -257,6 +258,7 @@ __device__ __forceinline__ bool slab_combine(float* base, int* ctr, int split, i
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
+                if (!act) continue;
                 float4 v;
                 v.x = acc[i][j][4 * r4]; v.y = acc[i][j][4 * r4 + 1]; v.z = acc[i][j][4 * r4 + 2]; v.w = acc[i][j][4 * r4 + 3];
                 if (fence) st4(mine + (((i * TN + j) * 4 + r4) * NTH + tid) * 4, v);
@@ -278,6 +280,7 @@ __device__ __forceinline__ bool slab_combine(float* base, int* ctr, int split, i
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
+                if (!act) continue;
                 float4 sum = zero4();
                 for (int sp = 0; sp < S; ++sp) {
                     const float4 v = ld4(base + (long long)sp * PART + (((i * TN + j) * 4 + r4) * NTH + tid) * 4);

@@ -27,7 +27,7 @@ def _rand(g, *shape):
 
 @pytest.mark.parametrize("tile", [0, 64, 128, 1064, 1128, 2064, 3064, 3128, 4064, 5064, 5032])
 @pytest.mark.parametrize("form", [0, 1, 2])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 80, 256), (300, 768, 48), (33, 130, 100), (5, 7, 20)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 80, 256), (300, 768, 48), (33, 130, 100), (5, 7, 20), (200, 256, 1100), (190, 70, 517)])
 def test_gemm_forms(lib, form, tile, M, N, K):
     g = np.random.RandomState(M * 7 + N * 3 + K + form)
     pad4 = lambda x: (x + 3) & ~3
