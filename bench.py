@@ -192,6 +192,9 @@ def inference_leg(dims, mods, device, iters=5):
     res["note"] = ("5 query utterances per iteration; host->device batch upload, the duration read-back and (vocoder legs) the mel download, "
                    "waveform int16 conversion and download are inside the timed loop (the mel itself stays in HBM); MelGAN generator with synthetic weights "
                    "(~90 MFLOP per mel frame)")
+    res["parity"] = {"acoustic_model": "pinned (tests/golden/c5_synth.npz, reference outputs)",
+                     "vocoder_legs": "UNPINNED: the MelGAN generator is a torch.hub dependency absent from the reference tree; its published architecture is "
+                                     "restated (oracle/melgan_oracle.py) and timed with synthetic weights — a throughput figure, not a parity claim"}
     return res
 
 

@@ -176,6 +176,7 @@ float* mtts_outer_grad_ptr(mtts_handle* h);
  * ncclAllReduce(SUM, fp32, in place) of the whole outer-gradient buffer on the handle's stream: ordered after the meta-gradient
  * kernels and before the following mtts_outer_update, no host synchronisation.  Each rank scales its contribution by
  * 1 / total_tasks through grad_scale, so the sum is the mean the reference takes.  librccl.so is resolved with dlopen on first use. */
+int mtts_comm_available(mtts_handle* h);   /* 0 when librccl can be loaded in this process (every rank probes before rank 0 makes the id) */
 int mtts_comm_unique_id(mtts_handle* h, void* id128);
 int mtts_comm_init(mtts_handle* h, const void* id128, int rank, int world_size);
 int mtts_allreduce_outer(mtts_handle* h);
@@ -289,6 +290,9 @@ int mtts_vocoder_infer_device(mtts_vocoder* h, const float* mel_dev, int64_t mel
 typedef struct mtts_dvector mtts_dvector;
 int mtts_dvector_create(int n_mels, int hidden, int layers, int emb, int max_partials, int frames, int max_utts, int device, mtts_dvector** out);
 void mtts_dvector_destroy(mtts_dvector* h);
+/* HIP stream of this handle's launches (default: the null stream).  A trained encoder exchanges device scalars with the engine (its
+ * gradient's sum of squares -> mtts_set_extra_grad_sumsq, the joint norm <- mtts_grad_norm_dev): put both handles on ONE stream. */
+int mtts_dvector_set_stream(mtts_dvector* h, void* hip_stream);
 const char* mtts_dvector_last_error(mtts_dvector* h);
 int mtts_dvector_load(mtts_dvector* h, const char* name, const float* data, int64_t numel);
 int mtts_dvector_embed(mtts_dvector* h, const float* mels, int n_partials, const int* utt_offsets, int n_utts, float* out, float* partial_out);
@@ -321,6 +325,7 @@ int mtts_dvector_import(mtts_dvector* h, const char* name, int which, const floa
 typedef struct mtts_stft mtts_stft;
 int mtts_stft_create(int filter_length, int hop_length, int n_mel, int max_samples, int device, mtts_stft** out);
 void mtts_stft_destroy(mtts_stft* h);
+int mtts_stft_set_stream(mtts_stft* h, void* hip_stream);
 const char* mtts_stft_last_error(mtts_stft* h);
 int mtts_stft_load(mtts_stft* h, const float* forward_basis, const float* mel_basis);
 int mtts_stft_mel_spectrogram(mtts_stft* h, const float* wav, int n_samples, float* mel, float* energy);

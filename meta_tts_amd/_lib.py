@@ -68,6 +68,7 @@ EXPORTS = {
     "mtts_imaml_finish": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mtts_plain_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "mtts_outer_grad_ptr": (C.c_void_p, [C.c_void_p]),
+    "mtts_comm_available": (C.c_int, [C.c_void_p]),
     "mtts_comm_unique_id": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mtts_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "mtts_allreduce_outer": (C.c_int, [C.c_void_p]),
@@ -100,6 +101,7 @@ EXPORTS = {
     "mtts_softmax_jvp": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_dvector_create": (C.c_int, [C.c_int] * 8 + [C.POINTER(C.c_void_p)]),
     "mtts_dvector_destroy": (None, [C.c_void_p]),
+    "mtts_dvector_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mtts_dvector_last_error": (C.c_char_p, [C.c_void_p]),
     "mtts_dvector_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     "mtts_dvector_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -116,6 +118,7 @@ EXPORTS = {
     "mtts_grad_norm_dev": (C.c_void_p, [C.c_void_p]),
     "mtts_stft_create": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_void_p)]),
     "mtts_stft_destroy": (None, [C.c_void_p]),
+    "mtts_stft_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mtts_stft_last_error": (C.c_char_p, [C.c_void_p]),
     "mtts_stft_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mtts_stft_mel_spectrogram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

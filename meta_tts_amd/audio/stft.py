@@ -78,6 +78,10 @@ class TacotronSTFT:
             raise MttsError(self.lib.mtts_stft_last_error(self.h).decode())
         return rc
 
+    def set_stream(self, stream_ptr: int):
+        if self.lib.mtts_stft_set_stream(self.h, C.c_void_p(stream_ptr)) != 0:
+            raise RuntimeError("mtts_stft_set_stream failed")
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.mtts_stft_destroy(self.h)

@@ -973,8 +973,10 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
     dim3 block(256), grid((unsigned)mp.start[mp.n], 1, 1);
     // BK = 32 stages K-contiguous operands in full 128-byte lines (half the load instructions, TA transactions and barriers
-    // per flop); needs every tapped problem's tap length to be a multiple of 32 and pays off only for long K
-    static const int multi_bk = [] { const char* e = getenv("MTTS_MULTI_BK"); return e ? atoi(e) : 0; }();
+    // per flop); needs every tapped problem's tap length to be a multiple of 32 and pays off only for long K.  Default since round 3
+    // (profiles/r03_sk_queue.md: the multi-problem launches with K >= 1024 run at 0.676 instead of 0.646 of the fp32 matrix peak, the
+    // whole step is unchanged, a single-task rank gains 1.7 %); MTTS_MULTI_BK=16 restores BK = 16 everywhere.
+    static const int multi_bk = [] { const char* e = getenv("MTTS_MULTI_BK"); return e ? atoi(e) : 32; }();
     bool bk32 = multi_bk == 32;
     int maxK = 0;
     for (int i = 0; i < mp.n; ++i) {

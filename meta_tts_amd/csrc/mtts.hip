@@ -312,6 +312,11 @@ int mtts_plain_grad(mtts_handle* h, int slot, float grad_scale, float* losses_ho
 
 float* mtts_outer_grad_ptr(mtts_handle* h) { return h->eng.outer; }
 
+int mtts_comm_available(mtts_handle* h) {
+    if (!h) return -1;
+    if (h->comm.load()) { h->eng.set_error(h->comm.err); return -1; }
+    return 0;
+}
 int mtts_comm_unique_id(mtts_handle* h, void* id128) {
     if (!id128) { h->eng.set_error("null id buffer"); return -1; }
     if (h->comm.unique_id((NcclUniqueId*)id128)) { h->eng.set_error(h->comm.err); return -1; }
@@ -457,6 +462,7 @@ int mtts_dvector_create(int n_mels, int hidden, int layers, int emb, int max_par
     *out = h;
     return 0;
 }
+int mtts_dvector_set_stream(mtts_dvector* h, void* s) { if (!h) return -1; h->d.stream = (hipStream_t)s; return 0; }
 void mtts_dvector_destroy(mtts_dvector* h) {
     if (!h) return;
     hipDeviceSynchronize();
@@ -490,6 +496,7 @@ int mtts_stft_create(int filter_length, int hop_length, int n_mel, int max_sampl
     *out = h;
     return 0;
 }
+int mtts_stft_set_stream(mtts_stft* h, void* s) { if (!h) return -1; h->m.stream = (hipStream_t)s; return 0; }
 void mtts_stft_destroy(mtts_stft* h) {
     if (!h) return;
     hipDeviceSynchronize();

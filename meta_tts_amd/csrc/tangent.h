@@ -328,16 +328,29 @@ __global__ void rowdot_jvp_bwd_kernel(const int* meta, int mfield, const float* 
 // ---- loss: tangent of the prediction gradients (MSE terms; the L1 terms have zero second derivative) ----
 __global__ void loss_tangent_kernel(const int* meta, const float* tpp, const float* tep, const float* tlogd, long long pred_ts,
                                     const unsigned char* pvalid, long long prow_ts, float scale, float* tgpp, float* tgep,
-                                    float* tglogd) {
+                                    float* tglogd, int pitch_frame, int energy_frame) {
     const int z = blockIdx.z, Mp = meta[z * META_STRIDE + META_MP];
     const float wP = 2.f * scale / (float)meta[z * META_STRIDE + META_NP];
     const unsigned char* pv = pvalid + (long long)z * prow_ts;
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < Mp; r += gridDim.x * blockDim.x) {
         const long long q = (long long)z * pred_ts + r;
         const bool v = pv[r] != 0;
-        tgpp[q] = v ? wP * tpp[q] : 0.f;
-        tgep[q] = v ? wP * tep[q] : 0.f;
+        tgpp[q] = (v && !pitch_frame) ? wP * tpp[q] : 0.f;      // (a frame-level feature has no phoneme-level loss term)
+        tgep[q] = (v && !energy_frame) ? wP * tep[q] : 0.f;
         tglogd[q] = v ? wP * tlogd[q] : 0.f;
+    }
+}
+// the same for frame-level pitch / energy predictions (rows of the mel rectangle, normalised by the number of valid frames)
+__global__ void loss_tangent_r_kernel(const int* meta, const float* tpp_r, const float* tep_r, long long pred_r_ts,
+                                      const unsigned char* rvalid, long long rrow_ts, float scale, float* tgpp_r, float* tgep_r,
+                                      int pitch_frame, int energy_frame) {
+    const int z = blockIdx.z, Mr = meta[z * META_STRIDE + META_MR];
+    const float wR = 2.f * scale / (float)meta[z * META_STRIDE + META_NF];
+    const unsigned char* rv = rvalid + (long long)z * rrow_ts;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < Mr; r += gridDim.x * blockDim.x) {
+        const long long q = (long long)z * pred_r_ts + r;
+        if (pitch_frame) tgpp_r[q] = rv[r] ? wR * tpp_r[q] : 0.f;
+        if (energy_frame) tgep_r[q] = rv[r] ? wR * tep_r[q] : 0.f;
     }
 }
 

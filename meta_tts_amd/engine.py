@@ -376,6 +376,10 @@ class Engine:
         return _DevView(self.outer_grad_ptr(), self.n_total)
 
     # ---- RCCL inside the library (include/mtts.h: mtts_comm_*) -------------------
+    def comm_available(self) -> bool:
+        """True when librccl can be loaded by this process (a local probe, no communication)."""
+        return self.lib.mtts_comm_available(self.h) == 0
+
     def comm_unique_id(self) -> bytes:
         buf = C.create_string_buffer(128)
         self._ck(self.lib.mtts_comm_unique_id(self.h, buf))

@@ -57,6 +57,10 @@ class DVectorEncoder:
         self.h = h
         self.load_state_dict(state_dict if state_dict is not None else synthetic_state_dict(**self.cfg))
 
+    def set_stream(self, stream_ptr: int):
+        """HIP stream of this encoder's launches — the engine's, when the encoder is trained with it (shared device scalars)."""
+        self._check(self.lib.mtts_dvector_set_stream(self.h, C.c_void_p(stream_ptr)))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.mtts_dvector_destroy(self.h)

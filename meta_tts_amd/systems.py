@@ -348,22 +348,35 @@ class Trainer:
             import torch
             dev = self.system.engine.device
             self.system.engine.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            enc = self.system._trained_speaker_encoder()
+            if enc is not None:   # the encoder and the engine exchange device scalars (joint clip norm): same stream, same order
+                enc.set_stream(torch.cuda.current_stream(dev).cuda_stream)
             if outer_grad_tensor is None and self.system.world_size > 1:
                 # the all-reduce itself runs inside the library (mtts_allreduce_outer); torch only carries the unique id
                 # lock-step bring-up (every rank probes the library, the probes are MIN-reduced, only then is rank 0's id broadcast and
                 # ncclCommInitRank entered): a rank whose librccl cannot be loaded must not leave the others waiting in the init
                 eng = self.system.engine
+                rank = self.dist.get_rank(self.group)
                 try:
-                    uid = eng.comm_unique_id()
+                    ok = eng.comm_available()            # every rank: can librccl be loaded here?
+                    uid = eng.comm_unique_id() if (ok and rank == 0) else None   # the id itself is rank 0's alone
+                    ok = ok and (rank != 0 or uid is not None)
                 except Exception:  # noqa: BLE001
-                    uid = None
-                flag = torch.tensor([1 if uid is not None else 0], device=f"cuda:{dev}")
+                    ok, uid = False, None
+                flag = torch.tensor([1 if ok else 0], device=f"cuda:{dev}")
                 self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
                 if bool(flag.item()):
-                    ids = [uid if self.dist.get_rank(self.group) == 0 else None]
+                    ids = [uid]
                     self.dist.broadcast_object_list(ids, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
-                    eng.comm_init(ids[0], self.dist.get_rank(self.group), self.system.world_size)
-                    self.library_comm = True
+                    try:
+                        eng.comm_init(ids[0], rank, self.system.world_size)
+                        ok = True
+                    except Exception:  # noqa: BLE001
+                        ok = False
+                    # a rank whose ncclCommInitRank failed must not leave the others blocked in the first ncclAllReduce: agree on the outcome
+                    flag = torch.tensor([1 if ok else 0], device=f"cuda:{dev}")
+                    self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+                    self.library_comm = bool(flag.item())   # False: torch.distributed's all_reduce on the zero-copy view (_allreduce)
 
     def _allreduce(self):
         if self.dist is None or self.system.world_size == 1:

@@ -195,11 +195,24 @@ def test_free_running_synthesis_matches_oracle(emu_lib):
     eng.close()
 
 
+ENC_MODS = ["encoder"] + MODS   # config/algorithm/dev.yaml:28-33 adapts the encoder too
+
+
 def test_hessian_vector_product_matches_double_backward(emu_lib):
+    _check_hvp(emu_lib, MODS)
+
+
+def test_hessian_vector_product_with_adapted_encoder(emu_lib):
+    _check_hvp(emu_lib, ENC_MODS)
+
+
+def _check_hvp(emu_lib, mods):
     """The forward-over-reverse HVP (csrc/engine_so.inc) against torch's create_graph double backward, every tensor,
-    two ragged tasks; direction v = the support gradient itself (adapted slice)."""
+    two ragged tasks; direction v = the support gradient itself (adapted slice).  With the encoder among the adapted modules the
+    tangents start at the word-embedding table instead of at the encoder output."""
+    MODS = mods
     dims = tiny_dims()
-    eng = _engine(dims, emu_lib)
+    eng = _engine(dims, emu_lib, mods=mods)
     b0 = synth.make_batch(3, 3, speaker=2, **_kw(dims)); b1 = synth.make_batch(4, 2, speaker=5, **_kw(dims))
     eng.set_batches(0, [b0, b1])
     eng.adapt(0, 0.0, reset=True)  # fast weights := theta
@@ -224,9 +237,18 @@ def test_hessian_vector_product_matches_double_backward(emu_lib):
 
 
 def test_second_order_maml_matches_oracle(emu_lib):
+    _check_second_order(emu_lib, MODS)
+
+
+def test_second_order_maml_with_adapted_encoder(emu_lib):
+    _check_second_order(emu_lib, ENC_MODS)
+
+
+def _check_second_order(emu_lib, mods):
     """Training mode of the reference (first_order = not train, base_adaptor.py:107): outer gradient through 3 inner steps."""
+    MODS = mods
     dims = tiny_dims()
-    eng = _engine(dims, emu_lib)
+    eng = _engine(dims, emu_lib, mods=mods)
     tasks = [(synth.make_batch(10 + 2 * j, 3, speaker=2 + j, **_kw(dims)), synth.make_batch(11 + 2 * j, 2, speaker=2 + j, **_kw(dims)))
              for j in range(2)]
     eng.set_batches(0, [t[0] for t in tasks])
@@ -382,8 +404,7 @@ def test_adapted_encoder_moves_in_the_inner_loop(emu_lib):
     eng.adapt(2, 0.05, reset=True)
     n = "encoder.layer_stack.0.slf_attn.fc.weight"
     assert np.abs(eng.export(n, 3, 0) - fast[n].detach().numpy()).max() <= 2e-5 * np.abs(fast[n].detach().numpy()).max()
-    with pytest.raises(Exception):
-        eng.meta_grad(2, 0.05, 1.0, second_order=True)  # rejected loudly, not silently wrong
+    eng.meta_grad(2, 0.05, 1.0, second_order=True)  # supported since round 3 (checked against the oracle in test_second_order_maml_with_adapted_encoder)
     eng.close()
 
 
@@ -604,7 +625,66 @@ def test_external_speaker_embeddings_match_a_table_of_the_same_rows(emu_lib):
             ref = gr.numpy() if gr is not None else np.zeros(eng.params[n][0], np.float32)
             assert np.abs(eng.export(n, 2, ti) - ref).max() <= 1e-3 * np.abs(ref).max() + 2e-7, (ti, n)
         assert not eng.export("speaker_emb.model.weight", 2, ti).any()
-    # mixing embedded and id batches in one call, or asking for Hessian-vector products, is rejected loudly
+    # Hessian-vector products with external embeddings (round 3): the embeddings carry no tangent, the table receives none
+    eng.adapt(0, 0.0, reset=True)
+    eng.forward(0, use_fast=True, train=True)
+    eng.backward(0, use_fast=True, scale=1.0, need_encoder=True)
+    eng.hvp_support()
+    for ti, (b, e) in enumerate(zip(bs, embs)):
+        p = torch_params(dims, requires_grad=True)
+        p["speaker_emb.model.weight"] = torch.from_numpy(e.copy())
+        tb = list(O.to_torch_batch(b))
+        tb[2] = torch.arange(e.shape[0])
+        lo = O.fs2_loss(tuple(tb), O.fs2_forward(p, torch_buffers(dims), *tb[2:], n_head=heads(dims), max_seq_len=dims.max_seq_len, training=True))
+        an = [n for n in O.adapted_names(p, MODS) if n != "speaker_emb.model.weight"]
+        gsup = torch.autograd.grad(lo[0], [p[n] for n in an], create_graph=True)
+        dot = sum((gi * gi.detach()).sum() for gi in gsup)
+        names = [n for n in eng.params if n != "speaker_emb.model.weight"]
+        hv = torch.autograd.grad(dot, [p[n] for n in names], allow_unused=True)
+        scale = max(float(h.abs().max()) for h in hv if h is not None)
+        for n, h in zip(names, hv):
+            ref = h.numpy() if h is not None else np.zeros(eng.params[n][0], np.float32)
+            assert np.abs(eng.export(n, 6, ti) - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7 * scale, (ti, n)
+    # mixing embedded and id batches in one call is rejected loudly
     with pytest.raises(Exception, match="every task or none"):
         eng.set_batches(0, [ext[0], bs[1]])
+    eng.close()
+
+
+@pytest.mark.parametrize("pl,el,mods", [("frame_level", "frame_level", MODS), ("phoneme_level", "frame_level", MODS),
+                                        ("frame_level", "phoneme_level", ENC_MODS)],
+                         ids=["both_frame", "energy_frame", "pitch_frame_adapted_encoder"])
+def test_frame_level_hessian_vector_product(emu_lib, pl, el, mods):
+    """Second order with frame-level pitch / energy (modules.py:139-148 under create_graph=True): the forward-over-reverse HVP with the
+    variance adaptor's second half on the frame rectangle, against torch's double backward, every tensor, two ragged tasks — incl. the
+    combination with an adapted encoder (primal input gradients through the rectangle)."""
+    dims = tiny_dims(pitch_level=pl, energy_level=el)
+    eng = _engine(dims, emu_lib, mods=mods)
+    kw = dict(pitch_level=pl, energy_level=el, **_kw(dims))
+    b0 = synth.make_batch(3, 3, speaker=2, **kw); b1 = synth.make_batch(4, 2, speaker=5, **kw)
+    eng.set_batches(0, [b0, b1])
+    eng.adapt(0, 0.0, reset=True)  # fast weights := theta
+    eng.forward(0, use_fast=True, train=True)
+    eng.backward(0, use_fast=True, scale=1.0, need_encoder=True)
+    eng.hvp_support()
+    okw = dict(n_head=heads(dims), max_seq_len=dims.max_seq_len, pitch_level=pl, energy_level=el)
+    for ti, b in enumerate([b0, b1]):
+        p = torch_params(dims, requires_grad=True)
+        tb = O.to_torch_batch(b)
+        lo = O.fs2_loss(tb, O.fs2_forward(p, torch_buffers(dims), *tb[2:], training=True, **okw), pl, el)
+        an = O.adapted_names(p, mods)
+        g = torch.autograd.grad(lo[0], [p[n] for n in an], create_graph=True)
+        dot = sum((gi * gi.detach()).sum() for gi in g)
+        names = list(eng.params)
+        hv = torch.autograd.grad(dot, [p[n] for n in names], allow_unused=True)
+        scale = max(float(h.abs().max()) for h in hv if h is not None)
+        for n, h in zip(names, hv):
+            ref = h.numpy() if h is not None else np.zeros(eng.params[n][0], np.float32)
+            got = eng.export(n, 6, ti)
+            assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7 * scale, (ti, n)
+    # and the whole second-order meta-gradient runs on it
+    q0 = synth.make_batch(13, 2, speaker=2, **kw); q1 = synth.make_batch(14, 2, speaker=5, **kw)
+    eng.set_batches(1, [q0, q1], spk_from=[b0, b1], average_spk=True)
+    q, _ = eng.meta_grad(2, 0.01, 0.5, second_order=True)
+    assert np.isfinite(q).all()
     eng.close()

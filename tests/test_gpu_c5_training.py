@@ -143,6 +143,7 @@ def _emu_tests():
     import test_emu_engine as E
     return [E.test_dropout_masks_are_replayed_and_gradients_consistent, E.test_second_order_with_dropout_replays_inner_step_masks,
             E.test_hessian_vector_product_matches_double_backward, E.test_second_order_maml_matches_oracle,
+            E.test_hessian_vector_product_with_adapted_encoder, E.test_second_order_maml_with_adapted_encoder,
             E.test_free_running_synthesis_matches_oracle, E.test_adapted_encoder_moves_in_the_inner_loop,
             E.test_forward_loss_backward_two_ragged_tasks, E.test_first_order_maml_and_outer_update,
             E.test_imaml_hypergradient_matches_oracle, E.test_two_handles_on_two_host_threads_do_not_interfere,
