@@ -146,7 +146,7 @@ def _emu_tests():
             E.test_hessian_vector_product_with_adapted_encoder, E.test_second_order_maml_with_adapted_encoder,
             E.test_free_running_synthesis_matches_oracle, E.test_adapted_encoder_moves_in_the_inner_loop,
             E.test_forward_loss_backward_two_ragged_tasks, E.test_first_order_maml_and_outer_update,
-            E.test_imaml_hypergradient_matches_oracle, E.test_two_handles_on_two_host_threads_do_not_interfere,
+            E.test_imaml_hypergradient_matches_oracle, E.test_imaml_hypergradient_with_adapted_encoder, E.test_two_handles_on_two_host_threads_do_not_interfere,
             E.test_external_speaker_embeddings_match_a_table_of_the_same_rows]
 
 
@@ -400,6 +400,13 @@ def test_in_library_rccl_allreduce_world_size_one():
 def test_frame_level_tiny_on_device(pl, el):
     import test_emu_engine as E
     E.test_frame_level_pitch_energy_matches_oracle(None, pl, el)
+
+
+@pytest.mark.parametrize("pl,el,enc", [("frame_level", "frame_level", False), ("phoneme_level", "frame_level", False), ("frame_level", "phoneme_level", True)])
+def test_frame_level_hessian_vector_product_on_device(pl, el, enc):
+    """Second order with frame-level features (and, third case, an adapted encoder) on the hardware arm."""
+    import test_emu_engine as E
+    E.test_frame_level_hessian_vector_product(None, pl, el, E.ENC_MODS if enc else E.MODS)
 
 
 def test_frame_level_full_size_matches_reference_fixture(golden_dir):
