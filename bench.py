@@ -315,7 +315,8 @@ def roofline_of(rows, pmc_key=None):
         pmc_path = os.path.join(here, "profiles", name)
         if pmc_key is not None and os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                k = json.load(f).get(pmc_key, {}).get(dom[0].split("<")[0])
+                table = json.load(f).get(pmc_key, {})
+            k = table.get(dom[0]) or table.get(dom[0].split("<")[0])
             if k:
                 traffic, traffic_src, mfma_busy = k.get("hbm_bytes_per_launch"), "profiles/" + name, k.get("mfma_busy_frac")
                 break

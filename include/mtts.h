@@ -208,6 +208,11 @@ int mtts_profile_report(mtts_handle* h, double* out, int kinds);
  * 4064 LDS-DMA kernel / 5064, 5032 work-queue kernel with BK = 16 / 32 */
 int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, float alpha, int flags, int tile, void* hip_stream);
+/* Dual-source product in one accumulator chain: C = alpha * (op(A, B) + op(A2, B2)) + bias, same form / sizes / leading dimensions for
+ * both pairs — the shape of every tangent product of second-order MAML, t(X W) = tX W + X tW (csrc/gemm.h: GemmArgs::A2;
+ * reference: the double backward that `higher` records for lightning/systems/base_adaptor.py:107). */
+int mtts_gemm_f32_dual(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* A2, const float* B2,
+                       float* C, int ldc, const float* bias, float alpha, int flags, int tile, void* hip_stream);
 /* Conv1d over one zero-guarded sequence, channels-last: x [L][Cin] with >= k/2 zero rows before and
  * after, w [Cout][k][Cin].  mode 0: y = conv(x) + bias; 1: dx = dgrad(dy); 2: dw = wgrad(dy, x) */
 int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* x_or_dy, const float* w_or_x, float* out,

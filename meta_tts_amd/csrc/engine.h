@@ -218,6 +218,9 @@ public:
 
     char* arena = nullptr;
     size_t arena_bytes = 0;
+    size_t act_bytes = 0;             // leading part of the arena: the activation set (layout_act)
+    std::vector<char*> act_sets;      // extra activation sets (second-order MAML: one per inner step); set 0 is the arena's own
+    int act_bound = 0;
 
     struct Pass;
     GemmCtx gx;  // this handle's launcher state: batching queue, profiler, split-K workspace, numerics mode (gemm.h)
@@ -396,9 +399,36 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
 
     static long long attn_elems(int B, int H, int L) { return (long long)B * H * L * ((L + 3) & ~3); }
 
+    // The arena starts with everything a forward pass writes and a later backward (or tangent) pass reads — the activation set —
+    // followed by the backward scratch and the plan arrays.  Second-order MAML binds the activation set to one buffer per inner
+    // step (bind_act) so that the reverse sweep finds the activations of step s where the first sweep left them.
     void layout() {
-        const int d = cfg.d_model, f = cfg.vp_filter, nt = cap_tasks;
-        (void)nt;
+        layout_act();
+        act_bytes = (arena_off + 255) & ~(size_t)255;
+        layout_rest();
+    }
+    // point every activation buffer at set k (0 = the arena's own; k >= 1 = act_sets[k - 1]); host-side only
+    void bind_act(int k) {
+        if (k == act_bound) return;
+        char* save_arena = arena; const size_t save_off = arena_off; const bool save_dry = arena_dry;
+        if (k > 0) arena = act_sets[k - 1];
+        arena_dry = false; arena_off = 0;
+        layout_act();
+        arena = save_arena; arena_off = save_off; arena_dry = save_dry;
+        act_bound = k;
+    }
+    // n extra activation sets (zeroed: the guard rows of every row buffer stay zero); false when the device cannot hold them
+    bool ensure_act_sets(int n) {
+        while ((int)act_sets.size() < n) {
+            char* a = nullptr;
+            if (hipMalloc((void**)&a, act_bytes + 256) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (hipMemset(a, 0, act_bytes + 256) != hipSuccess) { hipFree(a); (void)hipGetLastError(); return false; }
+            act_sets.push_back(a);
+        }
+        return true;
+    }
+    void layout_act() {
+        const int d = cfg.d_model, f = cfg.vp_filter;
         S_ts_p = attn_elems(cap_B, cfg.enc_heads, cap_S);
         S_ts_f = attn_elems(cap_B, cfg.dec_heads, cap_Tc);
         auto layer = [&](int capM, long long S_ts, std::vector<LayerBuf>& v, int n) {
@@ -440,6 +470,9 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             postB[i].c = rows(capMr, c); postB[i].a = rows(capMr, c); postB[i].stats = flat(3LL * c);
             postB[i].dgamma_tmp = flat(2LL * c);
         }
+    }
+    void layout_rest() {
+        const int d = cfg.d_model, f = cfg.vp_filter;
         // backward scratch
         gPm = rows(capMp, d); gFm = rows(capMf, d);
         gP0 = rows(capMp, d); gP1 = rows(capMp, d); gPqkv = rows(capMp, 3 * d); gPh = rows(capMp, cfg.d_ff);
@@ -686,6 +719,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         destroy_imaml();
         destroy_images();
         if (arena) hipFree(arena);
+        for (char* a : act_sets) if (a) hipFree(a);
         if (arena_so) hipFree(arena_so);
         if (hv) hipFree(hv);
         if (fast_hist) hipFree(fast_hist);
@@ -1043,13 +1077,16 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     }
 
     // Y[M,N] = conv_k(X)[M, k*Cin] * W[N][k*Cin]^T + b   (k = 1: Linear)
+    // (x2, w2): second source of a dual-source launch, y = conv(x; w) + conv(x2; w2) (GemmArgs::A2 — the tangent pairs of engine_so.inc)
     void conv_fwd(const Pass& ps, Space s, TS x, int cin, int k, TS w, TS b, int cout, TS y, int flags,
-                  const unsigned char* rowmask, TS relu_ref = TS{nullptr, 0}) {
+                  const unsigned char* rowmask, TS relu_ref = TS{nullptr, 0}, TS x2 = TS{nullptr, 0}, TS w2 = TS{nullptr, 0}) {
         const Plan& p = *ps.pl;
         GemmArgs g = rowgemm(p, s, GEMM_NT);
         const int pad = k / 2;
+        const double nsrc = x2.p ? 2.0 : 1.0;
         g.A = x.p - (long long)pad * cin; g.a_gs = x.ts; g.lda = cin;
         g.B = w.p; g.b_gs = w.ts; g.ldb = k * cin;
+        if (x2.p) { g.A2 = x2.p - (long long)pad * cin; g.a2_gs = x2.ts; g.B2 = w2.p; g.b2_gs = w2.ts; }
         g.C = y.p; g.c_gs = y.ts; g.ldc = cout;
         g.N = cout; g.K = k * cin;
         g.bias = b.p; g.bias_gs = b.ts;
@@ -1061,31 +1098,34 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         static const bool fwd_multi = [] { const char* e = getenv("MTTS_FWD_SINGLE_MULTI"); return e ? atoi(e) != 0 : false; }();
         const bool own_scope = fwd_multi && !gx.batch.open && defer_ok(p);
         if (own_scope) gemm_batch_begin(gx);
-        gemm_launch(gx, GEMM_NT, g, maxM(p, s), cout, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s),
-                    4.0 * (alg_rows(p, s) * (cin + cout) + (double)p.tasks * cout * k * cin));
+        gemm_launch(gx, GEMM_NT, g, maxM(p, s), cout, p.tasks, stream, 0, nsrc * 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s),
+                    4.0 * (alg_rows(p, s) * (nsrc * cin + cout) + nsrc * (double)p.tasks * cout * k * cin));
         if (own_scope) gemm_batch_end(gx, stream);
     }
     // dX[M,Cin] (+)= sum_taps dY[M +- tap, Cout] * W  (conv dgrad over the same [Cout][k][Cin] image)
     void conv_dgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS w, int cin, TS dx, int flags,
-                    const unsigned char* rowmask, TS relu_ref = TS{nullptr, 0}) {
+                    const unsigned char* rowmask, TS relu_ref = TS{nullptr, 0}, TS dy2 = TS{nullptr, 0}, TS w2 = TS{nullptr, 0}) {
         const Plan& p = *ps.pl;
         GemmArgs g = rowgemm(p, s, GEMM_NN);
         const int pad = k / 2;
+        const double nsrc = dy2.p ? 2.0 : 1.0;
         g.A = dy.p - (long long)pad * cout; g.a_gs = dy.ts; g.lda = cout;
         g.B = w.p; g.b_gs = w.ts; g.ldb = k * cin;
+        if (dy2.p) { g.A2 = dy2.p - (long long)pad * cout; g.a2_gs = dy2.ts; g.B2 = w2.p; g.b2_gs = w2.ts; }
         g.C = dx.p; g.c_gs = dx.ts; g.ldc = cin;
         g.N = cin; g.K = k * cout;
         g.taps = k; g.tap_k = cout; g.tap_bstride = cin;
         g.flags = flags;
         g.rowmask = rowmask; g.rowmask_gs = row_ts(s);
         if (relu_ref.p) { g.relu_ref = relu_ref.p; g.relu_ref_gs = relu_ref.ts; g.ld_relu = cin; }
-        gemm_launch(gx, GEMM_NN, g, maxM(p, s), cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s),
-                    4.0 * (alg_rows(p, s) * (cin + cout) + (double)p.tasks * cout * k * cin));
+        gemm_launch(gx, GEMM_NN, g, maxM(p, s), cin, p.tasks, stream, 0, nsrc * 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s),
+                    4.0 * (alg_rows(p, s) * (cin + nsrc * cout) + nsrc * (double)p.tasks * cout * k * cin));
     }
     // dW[Cout][k*Cin] = dY^T * conv_k(X), db = colsum(dY)
     // cx / st: launch context (default: the engine's own context and stream; the deferred path passes the side stream's)
     void conv_wgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS x, int cin, long long w_off, long long b_off,
-                    const unsigned char* bias_mask, int flags = 0, GemmCtx* cx = nullptr, hipStream_t st = nullptr) {
+                    const unsigned char* bias_mask, int flags = 0, GemmCtx* cx = nullptr, hipStream_t st = nullptr,
+                    TS dy2 = TS{nullptr, 0}, TS x2 = TS{nullptr, 0}) {
         const Plan& p = *ps.pl;
         GemmCtx& gcx = cx ? *cx : gx;
         const hipStream_t gst = cx ? st : stream;
@@ -1093,6 +1133,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         const int pad = k / 2;
         g.A = dy.p; g.a_gs = dy.ts; g.lda = cout;
         g.B = x.p - (long long)pad * cin; g.b_gs = x.ts; g.ldb = cin;
+        const double nsrc = dy2.p ? 2.0 : 1.0;
+        if (dy2.p) { g.A2 = dy2.p; g.a2_gs = dy2.ts; g.B2 = x2.p - (long long)pad * cin; g.b2_gs = x2.ts; }   // dW = dy^T x + dy2^T x2 (the bias sum: dy only)
         TS gw = Gd(w_off);
         g.C = gw.p; g.c_gs = gw.ts; g.ldc = k * cin;
         g.M = cout; g.N = k * cin;
@@ -1108,8 +1150,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             TS gb = Gd(b_off);
             g.colsum = gb.p; g.colsum_gs = gb.ts; g.colsum_w = mw; g.colsum_w_gs = 4 * row_ts(s);
         }
-        gemm_launch(gcx, GEMM_TN, g, cout, k * cin, p.tasks, gst, 0, 2.0 * alg_rows(p, s) * cout * k * cin, (long long)cout * p.tasks,
-                    4.0 * (alg_rows(p, s) * (cin + cout) + (double)p.tasks * cout * k * cin));
+        gemm_launch(gcx, GEMM_TN, g, cout, k * cin, p.tasks, gst, 0, nsrc * 2.0 * alg_rows(p, s) * cout * k * cin, (long long)cout * p.tasks,
+                    4.0 * (nsrc * alg_rows(p, s) * (cin + cout) + (double)p.tasks * cout * k * cin));
         if (b_off >= 0 && !fused) colsum(ps, s, dy, cout, bias_mask, TS{nullptr, 0}, Gd(b_off));   // (main stream: never reached on the deferred path)
     }
     // two-stage deterministic column reduction (rowops.h colpart/colfinal)
@@ -1185,11 +1227,13 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         colreduce(p, a, gg.p, gb.p, gg.ts, maxM(p, s), true);
     }
     void attn_gemm(const Pass& ps, Space s, int which, int form, const float* A, int lda, const float* B, int ldb,
-                   float* C, int ldc, float alpha, int heads, int flags = 0) {
+                   float* C, int ldc, float alpha, int heads, int flags = 0, const float* A2 = nullptr, const float* B2 = nullptr) {
         const Plan& p = *ps.pl;
         GemmArgs g;
         g.table = (s == SP_P) ? p.enc_tab[which] : p.dec_tab[which];
         g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha; g.flags = flags;
+        g.A2 = A2; g.B2 = B2;   // dual source: the same per-(sequence, head) offsets into a second pair of buffers
+        const double nsrc = A2 ? 2.0 : 1.0;
         const int L = (s == SP_P) ? p.enc_maxL : p.dec_maxL, dk = cfg.d_model / heads;
         const int groups = (s == SP_P) ? p.n_enc_groups : p.n_dec_groups;
         int mM = L, mN = L;
@@ -1197,8 +1241,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         g.K = (which == TAB_QK || which == TAB_DP) ? dk : L;  // cost hint for launch batching (the table carries the real K)
         // per (sequence, head): two L x dk operands and one L x L matrix, each moved once
         const double sumL2 = (s == SP_P) ? p.sum_attn_p : p.sum_attn_f, sumL = (double)((s == SP_P) ? p.sumLp : p.sumLf);
-        gemm_launch(gx, form, g, mM, mN, groups, stream, 0, 2.0 * sumL2 * dk, (s == SP_P) ? p.sumLp : p.sumLf,
-                    4.0 * (sumL2 + 2.0 * sumL * dk));
+        gemm_launch(gx, form, g, mM, mN, groups, stream, 0, nsrc * 2.0 * sumL2 * dk, (s == SP_P) ? p.sumLp : p.sumLf,
+                    4.0 * nsrc * (sumL2 + 2.0 * sumL * dk));
     }
 
     // =================================================================================
@@ -1445,7 +1489,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     }
     // Run-ahead (see kAhead): enqueue the encoder forwards of `steps` train-mode passes over plan `pl` on side2; seeds[s] / enc_ahead[s] /
     // ev_enc[s] belong to step s.  Returns false when the regime does not qualify (the caller then runs forward() as usual).
-    bool run_encoder_ahead(Plan& pl, int steps, unsigned* seeds) {
+    // per_step_sets: step s writes the encoder's activations into activation set s + 1 (second-order MAML keeps them for its reverse sweep)
+    bool run_encoder_ahead(Plan& pl, int steps, unsigned* seeds, bool per_step_sets = false) {
         static const int on = [] { const char* e = getenv("MTTS_ENC_AHEAD"); return e ? atoi(e) : 1; }();
         if (!on || steps < 1 || steps > kAhead || encoder_adapted() || !defer_ok(pl) || side2 == nullptr || gx.prof.enabled) return false;
         for (int s = 0; s < steps; ++s) seeds[s] = next_drop_seed();
@@ -1458,11 +1503,13 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (int s = 0; s < steps; ++s) {
             Pass pe{&pl, true, true};
             pl.drop_seed = seeds[s];
+            if (per_step_sets) bind_act(s + 1);
             TS x = encoder_fwd(pe);
             MTTS_LAUNCH(copy_tasks_kernel, dim3((unsigned)std::min<long long>(((long long)pl.maxMp * cfg.d_model / 4 + 255) / 256, 1024), 1, pl.tasks), dim3(256),
                         stream, (const float*)x.p, x.ts, enc_ahead[s].p, enc_ahead[s].ts, (long long)pl.maxMp * cfg.d_model / 4);
             hipEventRecord(ev_enc[s], stream);
         }
+        if (per_step_sets) bind_act(0);
         std::swap(gx, gx_side2);
         std::swap(stream, side2);
         return true;

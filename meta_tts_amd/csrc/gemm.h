@@ -91,7 +91,17 @@ struct GemmArgs {
     long long colsum_gs = 0;
     const float* colsum_w = nullptr;
     long long colsum_w_gs = 0;
+    // Dual source: C = epilogue(A·B + A2·B2) in ONE accumulator chain — the K-loop runs over (A, B) and then over (A2, B2), which share
+    // every size, leading dimension, tap walk and (TABLE mode) per-group offset with the first pair; only the bases and the TASK-mode
+    // group strides differ.  The tangent products of second-order MAML come in such pairs (t(XW) = tX·W + X·tW): one launch, one
+    // epilogue and no read-modify-write of C instead of a plain launch followed by an accumulating one.  The column-sum tile
+    // (colsum) belongs to the first pair only.
+    const float* A2 = nullptr;
+    const float* B2 = nullptr;
+    long long a2_gs = 0, b2_gs = 0;
 };
+// K-loop length of a problem for the launch heuristics (both sources of a dual-source problem)
+inline int gemm_keff(const GemmArgs& g) { return g.A2 ? 2 * g.K : g.K; }
 
 
 // XCD-aware tile order (speed only, never correctness).  The dispatcher deals consecutive workgroups round-robin to the 8
@@ -332,6 +342,17 @@ __device__ __forceinline__ GemmProb gemm_resolve(const GemmArgs& g, int z) {
     }
     return pr;
 }
+// second source of a dual-source problem (GemmArgs::A2 / B2) for group z: everything but the operand bases is the first source's
+__device__ __forceinline__ GemmProb gemm_resolve2(const GemmArgs& g, int z, const GemmProb& pr) {
+    GemmProb q = pr;
+    if (g.table) {
+        const GemmGroupDesc d = g.table[z];
+        q.A = g.A2 + d.a_off; q.B = g.B2 + d.b_off;
+    } else {
+        q.A = g.A2 + (long long)z * g.a2_gs; q.B = g.B2 + (long long)z * g.b2_gs;
+    }
+    return q;
+}
 // n-tiles of a resolved problem: the tiles of C plus the column-sum tile (GemmArgs::colsum, TN form only)
 template <int FORM>
 __device__ __forceinline__ bool gemm_has_colsum(const GemmArgs& g) { return (FORM == GEMM_TN) && g.colsum != nullptr && !g.table; }
@@ -532,7 +553,10 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& g, const GemmProb& p
 }
 
 // One workgroup's share of one problem: output tile `bxs` (times split) of group `z`.
-template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0>
+// DUAL: the kernel also runs the second source of dual-source problems (GemmArgs::A2) — a second, separately inlined K-loop into the
+// same accumulators.  (A runtime loop over the sources around ONE inlined K-loop costs every kernel ~10 VGPRs of spilled SGPR state
+// — the multi-problem BK = 32 kernel drops from 4 to 3 workgroups per CU — so only the kernels that may be handed such problems pay for it.)
+template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0, bool DUAL = false>
 __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs, float* smem) {
     constexpr int NTH = 64 * WGM * WGN;
     constexpr int TM = (BM / WGM) / 32, TN = (BN / WGN) / 32;
@@ -554,6 +578,13 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
     const int nch_all = (pr.K + BK - 1) / BK, cps = (nch_all + S - 1) / S;
     const int c_lo = split * cps, c_hi = (c_lo + cps < nch_all) ? c_lo + cps : nch_all;   // (all chunks when S == 1)
     gemm_f32_kloop<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL>(g, pr, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
+    if (DUAL) {
+        if (g.A2 != nullptr && !cs_tile) {
+            __syncthreads();   // every wave is done with the first source's LDS tiles
+            const GemmProb p2 = gemm_resolve2(g, z, pr);
+            gemm_f32_kloop<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL>(g, p2, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
+        }
+    }
     if (S > 1 && !splitk_combine<TM, TN, NTH>(g, z, tile_lin, split, S, acc)) return;
     gemm_finish<TM, TN, WGM, WGN>(g, pr, z, m0, n0, cs_tile, acc);
 }
@@ -627,13 +658,28 @@ __global__ __launch_bounds__(256) void gemm_f32_multi_kernel(GemmMulti mp) {
     else gemm_f32_body<GEMM_TN, BM, BN, BK, true>(mp.g[p], z, bx, smem);
 }
 
+// the same grid for launches that carry dual-source problems (GemmArgs::A2)
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void gemm_f32_multi_dual_kernel(GemmMulti mp) {
+    constexpr int F0 = GemmSmem<GEMM_NT, BM, BN, BK>::FLOATS, F1 = GemmSmem<GEMM_NN, BM, BN, BK>::FLOATS, F2 = GemmSmem<GEMM_TN, BM, BN, BK>::FLOATS;
+    constexpr int FL = F0 > F1 ? (F0 > F2 ? F0 : F2) : (F1 > F2 ? F1 : F2);
+    __shared__ __attribute__((aligned(16))) float smem[FL];
+    int p, z, bx;
+    gemm_multi_locate(mp, p, z, bx);
+    const int form = mp.form[p];
+    if (form == GEMM_NT) gemm_f32_body<GEMM_NT, BM, BN, BK, true, 2, 2, 0, true>(mp.g[p], z, bx, smem);
+    else if (form == GEMM_NN) gemm_f32_body<GEMM_NN, BM, BN, BK, true, 2, 2, 0, true>(mp.g[p], z, bx, smem);
+    else gemm_f32_body<GEMM_TN, BM, BN, BK, true, 2, 2, 0, true>(mp.g[p], z, bx, smem);
+}
+
 // Kernel kinds of the launcher: one per real kernel symbol, so that a profiler line can be matched to a rocprofv3 kernel-trace row.
 enum GemmKind {
     GK_F32_64_BK16 = 0,   // + form: gemm_f32_kernel<F, 64, 64, 16, true, 2, 2, 0>
     GK_F32_64_BK32 = 3,   // + form: gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0>
     GK_F32_128 = 6,       // + form: gemm_f32_kernel<F, 128, 128, *, *>
     GK_GLDS = 9,          // + form: gemm_glds_kernel<F>
-    GK_MULTI16 = 12, GK_MULTI32 = 13, GK_GLDS_MULTI = 14, GK_SK16 = 15, GK_SK32 = 16, GK_OTHER = 17, GK_COUNT = 18
+    GK_MULTI16 = 12, GK_MULTI32 = 13, GK_GLDS_MULTI = 14, GK_SK16 = 15, GK_SK32 = 16, GK_OTHER = 17,
+    GK_MULTI16_DUAL = 18, GK_MULTI32_DUAL = 19, GK_GLDS_MULTI_DUAL = 20, GK_COUNT = 21
 };
 inline const char* gemm_kind_name(int k) {
     static const char* names[GK_COUNT] = {
@@ -642,7 +688,7 @@ inline const char* gemm_kind_name(int k) {
         "gemm_f32_kernel<0, 128, 128, ...>", "gemm_f32_kernel<1, 128, 128, ...>", "gemm_f32_kernel<2, 128, 128, ...>",
         "gemm_glds_kernel<0>", "gemm_glds_kernel<1>", "gemm_glds_kernel<2>",
         "gemm_f32_multi_kernel<64, 64, 16>", "gemm_f32_multi_kernel<64, 64, 32>", "gemm_glds_multi_kernel", "gemm_sk_kernel<16>", "gemm_sk_kernel<32>",
-        "gemm_f32_kernel<other>"};
+        "gemm_f32_kernel<other>", "gemm_f32_multi_dual_kernel<64, 64, 16>", "gemm_f32_multi_dual_kernel<64, 64, 32>", "gemm_glds_multi_dual_kernel"};
     return (k >= 0 && k < GK_COUNT) ? names[k] : "?";
 }
 
@@ -709,7 +755,7 @@ inline int& gemm_splitk_minchunks() {  // K-chunks every split must keep (MTTS_S
 // The caller guarantees the queued problems are mutually independent and that nothing launched before gemm_batch_end()
 // reads their outputs (engine: the wgrad / dgrad pair of a layer, dQ / dK / dV of an attention block).
 struct GemmPending { int form; GemmArgs g; int max_M, max_N, groups; double flops, rows, bytes; };
-struct GemmBatch { bool open = false; std::vector<GemmPending> q; };
+struct GemmBatch { bool open = false; std::vector<GemmPending> q; int force_family = 0; };   // force_family: 16 / 32 (BK of the register-staged multi-problem kernel) or 4064 (LDS-DMA) for the next flush (explicit tile codes of dual-source problems)
 inline bool& gemm_batch_enabled() {  // MTTS_GEMM_BATCH=0 launches every problem on its own (A/B runs)
     static bool v = [] { const char* e = getenv("MTTS_GEMM_BATCH"); return e ? atoi(e) != 0 : true; }();
     return v;
@@ -765,7 +811,7 @@ inline long& gemm_glds_max_wgs() {
 }
 #if !defined(MTTS_EMU)
 inline void gemm_glds_launch(int form, const GemmArgs& g, dim3 grid, hipStream_t stream);
-inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t stream);
+inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t stream, bool dual = false);
 #endif
 
 // Host launcher.  max_M / max_N bound the tile grid over all groups.  tile = 0: automatic — the problem goes through the launch
@@ -784,6 +830,15 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     const int user_tile = tile;
     const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
     auto ntiles = [&](int t) { return (long)((max_M + t - 1) / t) * gemm_tiles_n(g, max_N, t); };
+    if (g.A2 && user_tile != 0 && user_tile != 5064 && user_tile != 5032 && !cx.flushing && !cx.batch.open) {
+        // dual-source problems exist in the multi-problem kernels only: an explicit tile code picks the family (kernel tests)
+        const int code = user_tile % 10000;
+        cx.batch.force_family = code == 4064 ? 4064 : (code / 2000 ? 32 : 16);
+        cx.batch.q.push_back(GemmPending{form, g, max_M, max_N, groups, alg_flops, rows, alg_bytes});
+        gemm_batch_end(cx, stream);
+        cx.batch.force_family = 0;
+        return;
+    }
     if (user_tile == 0 || user_tile == 5064 || user_tile == 5032) {
         if (!cx.flushing) {
             // through the queue: with the batch's other problems, or alone
@@ -797,6 +852,10 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
             return;
         }
         tile = 64;
+    }
+    if (g.A2) {   // (unreachable from the engine: gemm_batch_end never sends a dual-source problem to the stand-alone kernels)
+        fprintf(stderr, "mtts: dual-source GEMM handed to a stand-alone kernel (explicit tile code inside an open batch)\n");
+        abort();
     }
     // tile code: 64 / 128 (+1000 software pipeline, +2000 BK=32); plain 64 / 128 take the defaults
     bool pipe = gemm_default_pipe();
@@ -814,14 +873,14 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     const int ablate = tile / 10000;  // diagnostic stage ablation (NT 64x64 pipelined BK=16 only), see gemm_f32_kloop
     tile %= 10000;
     if (tile >= 1000) { pipe = (tile / 1000) & 1; bk = (tile / 2000) ? 32 : 16; tile %= 1000; }
-    if (user_tile == 0 && !g.table && g.K >= 1024 && (form == GEMM_NT || form == GEMM_TN)) bk = 32;  // long K-contiguous panels: full 128-B lines per row
+    if (user_tile == 0 && !g.table && gemm_keff(g) >= 1024 && (form == GEMM_NT || form == GEMM_TN)) bk = 32;  // long K-contiguous panels: full 128-B lines per row
     if (g.taps > 1 && g.tap_k % 32 != 0) bk = 16;  // a K-slice must not straddle two conv taps
     // split-K for under-filled grids (single-task ranks, the phoneme-side GEMMs, small wgrads): enough workgroups for
     // ~4 per CU, each still reducing >= 4 K-chunks
     int S = 1;
     if (!g.table && gemm_splitk_target() > 0 && !g.colsum) {  // stand-alone launches: opt-in (measured neutral on the model's forward shapes)
         const long wgs = (long)std::ceil(rows / tile) * gemm_tiles_n(g, max_N, tile);
-        const int nch = (g.K + bk - 1) / bk;
+        const int nch = (gemm_keff(g) + bk - 1) / bk;
         S = (int)std::min<long>(std::min<long>(gemm_splitk_target() / std::max<long>(wgs, 1), nch / gemm_splitk_minchunks()), 8);
         const long long slots = (long long)ntiles(tile) * groups;
         if (S >= 2 && (slots * S * tile * tile > kSplitWsFloats || slots > kSplitCtrs)) S = 1;
@@ -867,7 +926,7 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     if (prof.enabled) {
         hipEventRecord(e1, stream);
         GemmProfiler::Rec rec{kind, alg_flops, e0, e1};
-        rec.form = form; rec.tile = glds ? 4064 : tile; rec.N = max_N; rec.K = g.K; rec.groups = groups; rec.splitk = S;
+        rec.form = form; rec.tile = glds ? 4064 : tile; rec.N = max_N; rec.K = gemm_keff(g); rec.groups = groups; rec.splitk = S;
         rec.rows = rows;
         rec.bytes = alg_bytes;
         prof.recs.push_back(rec);
@@ -884,12 +943,12 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     b.open = false;
     if (b.q.empty()) return;
     struct Flush { GemmCtx& c; Flush(GemmCtx& x) : c(x) { c.flushing = true; } ~Flush() { c.flushing = false; } } guard(cx);
-    std::stable_sort(b.q.begin(), b.q.end(), [](const GemmPending& x, const GemmPending& y) { return x.g.K > y.g.K; });
+    std::stable_sort(b.q.begin(), b.q.end(), [](const GemmPending& x, const GemmPending& y) { return gemm_keff(x.g) > gemm_keff(y.g); });
     GemmProfiler& prof = cx.prof;
     // ---- the persistent work-queue kernel (gemm_sk.h) whenever the launch carries enough work ----
     int forced = 0;
     for (GemmPending& p : b.q) if (p.g.swizzle == 5064 || p.g.swizzle == 5032) { forced = p.g.swizzle; p.g.swizzle = 0; }
-    if (gemm_sk_enabled() || forced) {
+    if ((gemm_sk_enabled() || forced) && !b.force_family) {
         GemmMulti mp;
         mp.n = (int)b.q.size();
         double flops = 0.0, rows = 0.0, bytes = 0.0;
@@ -897,7 +956,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
         for (int i = 0; i < mp.n; ++i) {
             const GemmPending& p = b.q[i];
             mp.form[i] = p.form; mp.groups[i] = p.groups; mp.g[i] = p.g;
-            flops += p.flops; rows += p.rows; bytes += p.bytes; maxK = std::max(maxK, p.g.K);
+            flops += p.flops; rows += p.rows; bytes += p.bytes; maxK = std::max(maxK, gemm_keff(p.g));
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
@@ -920,7 +979,10 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     // split-K rule applies (the k=9 dgrad of a single-task rank is 124 tiles x 288 slices: alone it would run at one tile per CU)
     static const int single_multi = [] { const char* e = getenv("MTTS_SINGLE_MULTI"); return e ? atoi(e) : 1; }();
     bool solo = b.q.size() == 1 && (!single_multi || batch_full_regime(b.q));
-    for (const GemmPending& p : b.q) if (!p.g.table && p.g.K < min_k && batch_full_regime(b.q)) solo = true;
+    for (const GemmPending& p : b.q) if (!p.g.table && gemm_keff(p.g) < min_k && batch_full_regime(b.q)) solo = true;
+    bool any_dual = false;   // dual-source problems (GemmArgs::A2) exist in the multi-problem kernels only
+    for (const GemmPending& p : b.q) any_dual = any_dual || p.g.A2 != nullptr;
+    if (any_dual) solo = false;
     if (solo) {
         const std::vector<GemmPending> q = b.q;
         b.q.clear();
@@ -935,7 +997,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     // swept: 1.25-1.5 best) of the whole batch's per-CU work would finish last on its own (single-task ranks: the k=9 dgrad tile, 576 slices, beside a
     // batch that is worth ~590 slices per CU), so it is cut into S workgroups (rendezvous in splitk_combine)
     double work = 0.0;
-    for (const GemmPending& p : b.q) work += std::ceil(p.rows / 64.0) * gemm_tiles_n(p.g, p.max_N, 64) * std::max(1, (p.g.K + 15) / 16);
+    for (const GemmPending& p : b.q) work += std::ceil(p.rows / 64.0) * gemm_tiles_n(p.g, p.max_N, 64) * std::max(1, (gemm_keff(p.g) + 15) / 16);
     const double per_cu = work / 256.0;
     double batch_wgs = 0.0;
     for (const GemmPending& p : b.q) batch_wgs += std::ceil(p.rows / 64.0) * gemm_tiles_n(p.g, p.max_N, 64);
@@ -948,7 +1010,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
         mp.g[i].swizzle = 0; mp.g[i].splitk = 1;
         const int tiles = ((p.max_M + 63) / 64) * gemm_tiles_n(p.g, p.max_N, 64);
         int S = 1;
-        const int nch = (p.g.K + 15) / 16;
+        const int nch = (gemm_keff(p.g) + 15) / 16;
         static const double ratio = [] { const char* e = getenv("MTTS_SPLIT_RATIO"); return e ? atof(e) : 1.5; }();
         if (small_batch && !p.g.table && !p.g.colsum && gemm_splitk_target() != 0 && nch > per_cu / ratio) {
             S = (int)std::min<double>(std::min<double>(std::ceil(nch / std::max(per_cu / ratio, 1.0)), nch / 16), 8);
@@ -981,16 +1043,20 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     int maxK = 0;
     for (int i = 0; i < mp.n; ++i) {
         if (mp.g[i].taps > 1 && mp.g[i].tap_k % 32 != 0) bk32 = false;
-        maxK = std::max(maxK, mp.g[i].K);
+        maxK = std::max(maxK, gemm_keff(mp.g[i]));
     }
     bool glds = gemm_use_glds() && small_batch && !cx.no_glds;
+    if (b.force_family) { glds = b.force_family == 4064; bk32 = bk32 && b.force_family == 32; if (bk32) maxK = std::max(maxK, 1024); }
     for (int i = 0; i < mp.n; ++i) glds = glds && gemm_glds_ok(mp.g[i]);
     int kind = GK_MULTI16;
 #if !defined(MTTS_EMU)
-    if (glds) { gemm_glds_multi_launch(mp, grid, stream); kind = GK_GLDS_MULTI; }
+    if (glds) { gemm_glds_multi_launch(mp, grid, stream, any_dual); kind = any_dual ? GK_GLDS_MULTI_DUAL : GK_GLDS_MULTI; }
     else
 #endif
-    if (bk32 && maxK >= 1024) { MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32>), grid, block, stream, mp); kind = GK_MULTI32; }
+    if (bk32 && maxK >= 1024) {
+        if (any_dual) { MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32>), grid, block, stream, mp); kind = GK_MULTI32_DUAL; }
+        else { MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32>), grid, block, stream, mp); kind = GK_MULTI32; }
+    } else if (any_dual) { MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 16>), grid, block, stream, mp); kind = GK_MULTI16_DUAL; }
     else { MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 16>), grid, block, stream, mp); }
     cx.last_kind = kind;
     if (prof.enabled) {

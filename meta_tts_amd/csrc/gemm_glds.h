@@ -211,7 +211,7 @@ __device__ __forceinline__ void gemm_glds_kloop(const GemmArgs& g, const GemmPro
     for (int r = 0; r < 16; ++r) acc[0][0][r] += acc0[r] + acc1[r];
 }
 
-template <int FORM>
+template <int FORM, bool DUAL = false>
 __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs, float* smem) {
     constexpr int BM = 64, BN = 64, BK = kGldsBK;
     const GemmProb pr = gemm_resolve(g, z);
@@ -228,6 +228,13 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
     const int nch_all = (pr.K + BK - 1) / BK, cps = (nch_all + S - 1) / S;
     const int c_lo = split * cps, c_hi = (c_lo + cps < nch_all) ? c_lo + cps : nch_all;
     gemm_glds_kloop<FORM>(g, pr, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
+    if (DUAL) {   // second source of a dual-source problem (gemm.h: gemm_f32_body)
+        if (g.A2 != nullptr && !cs_tile) {
+            __syncthreads();   // every wave is done with the ring slots of the first source
+            const GemmProb p2 = gemm_resolve2(g, z, pr);
+            gemm_glds_kloop<FORM>(g, p2, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
+        }
+    }
     if (S > 1 && !splitk_combine<1, 1, 256>(g, z, tile_lin, split, S, acc)) return;
     gemm_finish<1, 1, 2, 2>(g, pr, z, m0, n0, cs_tile, acc);
 }
@@ -250,13 +257,24 @@ __global__ __launch_bounds__(256) void gemm_glds_multi_kernel(GemmMulti mp) {
     else gemm_glds_body<GEMM_TN>(mp.g[p], z, bx, smem);
 }
 
+__global__ __launch_bounds__(256) void gemm_glds_multi_dual_kernel(GemmMulti mp) {
+    __shared__ __attribute__((aligned(16))) float smem[kGldsSmemFloats];
+    int p, z, bx;
+    gemm_multi_locate(mp, p, z, bx);
+    const int form = mp.form[p];
+    if (form == GEMM_NT) gemm_glds_body<GEMM_NT, true>(mp.g[p], z, bx, smem);
+    else if (form == GEMM_NN) gemm_glds_body<GEMM_NN, true>(mp.g[p], z, bx, smem);
+    else gemm_glds_body<GEMM_TN, true>(mp.g[p], z, bx, smem);
+}
+
 inline void gemm_glds_launch(int form, const GemmArgs& g, dim3 grid, hipStream_t stream) {
     if (form == GEMM_NT) hipLaunchKernelGGL((gemm_glds_kernel<GEMM_NT>), grid, dim3(256), 0, stream, g);
     else if (form == GEMM_NN) hipLaunchKernelGGL((gemm_glds_kernel<GEMM_NN>), grid, dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((gemm_glds_kernel<GEMM_TN>), grid, dim3(256), 0, stream, g);
 }
-inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t stream) {
-    hipLaunchKernelGGL(gemm_glds_multi_kernel, grid, dim3(256), 0, stream, mp);
+inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t stream, bool dual) {
+    if (dual) hipLaunchKernelGGL(gemm_glds_multi_dual_kernel, grid, dim3(256), 0, stream, mp);
+    else hipLaunchKernelGGL(gemm_glds_multi_kernel, grid, dim3(256), 0, stream, mp);
 }
 
 }  // namespace mtts

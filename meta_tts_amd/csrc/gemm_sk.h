@@ -89,7 +89,13 @@ __device__ __forceinline__ void sk_tile(const GemmMulti& mp, int p, int z, int t
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
     const int cps = (spt + S - 1) / S;
     const int c_lo = split * cps, c_hi = (c_lo + cps < spt) ? c_lo + cps : spt;
-    gemm_f32_kloop<FORM, 64, 64, BK, true>(g, pr, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
+    const int nsrc = (g.A2 != nullptr && !cs_tile) ? 2 : 1;   // dual-source problems: both K-loops over the piece's chunk range
+    GemmProb src = pr;
+#pragma nounroll
+    for (int s = 0; s < nsrc; ++s) {
+        if (s) { __syncthreads(); src = gemm_resolve2(g, z, pr); }
+        gemm_f32_kloop<FORM, 64, 64, BK, true>(g, src, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
+    }
     if (threadIdx.x == 0) nxt = MTTS_ATOMIC_INC_AGENT(head);
     if (S > 1 && !slab_combine<1, 1, 256>(mp.sk.ws + (long long)slab * 4096, mp.sk.ctr + slab, split, S, acc, (g.flags & GEMM_SLAB_FENCE) != 0)) return;
     gemm_finish<1, 1, 2, 2>(g, pr, z, m0, n0, cs_tile, acc);
@@ -296,7 +302,7 @@ inline bool gemm_sk_launch(GemmCtx& cx, GemmMulti& mp, const std::vector<GemmPen
     for (int i = 0; i < mp.n; ++i) {
         const GemmPending& p = q[i];
         const double t = std::ceil(p.rows / 64.0) * gemm_tiles_n(p.g, p.max_N, 64);
-        const int ch = std::max(1, (p.g.K + bk - 1) / bk);
+        const int ch = std::max(1, (gemm_keff(p.g) + bk - 1) / bk);
         tiles += t; work += t * ch; max_chunks = std::max(max_chunks, ch);
     }
     const int cap = gemm_sk_capacity(bk);

@@ -392,6 +392,16 @@ int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+int mtts_gemm_f32_dual(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* A2, const float* B2,
+                       float* C, int ldc, const float* bias, float alpha, int flags, int tile, void* stream) {
+    if (form < 0 || form > 2 || !tile_code_ok(tile) || !A2 || !B2 || (flags & ~0xff)) return -1;
+    GemmArgs g;
+    g.A = A; g.B = B; g.A2 = A2; g.B2 = B2; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.alpha = alpha; g.flags = flags & 0xff;
+    gemm_launch(kernel_ctx(), form, g, M, N, 1, (hipStream_t)stream, tile);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* a, const float* b, float* out, const float* bias,
                     int tile, void* stream) {
     if (mode < 0 || mode > 2 || (k & 1) == 0 || k / 2 > G || !tile_code_ok(tile)) return -1;

@@ -1,5 +1,5 @@
 """The side-stream paths of small plans (engine.h: deferred parameter gradients, encoder run-ahead, predictors on the side stream,
-batched predictor GEMMs) only re-plumb buffers and launch order: with every knob off the engine must produce the SAME outer gradient,
+batched predictor GEMMs) and the per-step activation sets of second-order MAML only re-plumb buffers and launch order: with every knob off the engine must produce the SAME outer gradient,
 losses and adapted weights, bit for bit.  The knobs are read once per process, so each arm runs in its own interpreter (SIMT emulator
 here; `-m gpu` runs the same comparison on the MI355X, where the paths really are concurrent)."""
 import os
@@ -55,7 +55,10 @@ def _run(tmp_path, tag, env, gpu):
     return dict(np.load(path))
 
 
-OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "MTTS_PRED_BATCH": "0", "MTTS_SINGLE_MULTI": "0"}
+# (MTTS_SO_KEEP_ACT=0: second-order MAML replays the forward of every inner step in its reverse sweep instead of keeping one activation
+# set per step — the same kernels on the same data either way)
+OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "MTTS_PRED_BATCH": "0", "MTTS_SINGLE_MULTI": "0",
+       "MTTS_SO_KEEP_ACT": "0"}
 
 
 def _compare(tmp_path, gpu):

@@ -60,6 +60,43 @@ def test_gemm_forms(lib, form, tile, M, N, K):
     assert (C2[:, :N].double() - want2).abs().max().item() < 2e-5 * max(1.0, want2.abs().max().item())
 
 
+@pytest.mark.parametrize("tile", [0, 64, 1064, 3064, 4064, 5064, 5032])
+@pytest.mark.parametrize("form", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 80, 256), (33, 130, 100), (200, 256, 1100), (190, 70, 517), (2100, 256, 2304)])
+def test_gemm_dual_source(lib, form, tile, M, N, K):
+    """C = alpha (A B + A2 B2) + bias in one K-loop chain (the tangent pairs of second-order MAML): every kernel family, the
+    split-K path of under-filled launches included, against float64."""
+    g = np.random.RandomState(M * 5 + N * 11 + K + form)
+    pad4 = lambda x: (x + 3) & ~3
+
+    def operands():
+        if form == 0:
+            A = _rand(g, M, pad4(K)); B = _rand(g, N, pad4(K)); A[:, K:] = 0; B[:, K:] = 0
+            return A, B, A[:, :K].double() @ B[:, :K].double().T, pad4(K), pad4(K)
+        if form == 1:
+            A = _rand(g, M, pad4(K)); B = _rand(g, K, pad4(N)); A[:, K:] = 0
+            return A, B, A[:, :K].double() @ B[:, :N].double(), pad4(K), pad4(N)
+        A = _rand(g, K, pad4(M)); B = _rand(g, K, pad4(N))
+        return A, B, A[:, :M].double().T @ B[:, :N].double(), pad4(M), pad4(N)
+
+    A, B, r1, lda, ldb = operands()
+    A2, B2, r2, _, _ = operands()
+    bias = _rand(g, N)
+    Cm = torch.full((M, pad4(N)), 7.0, device="cuda")
+    assert lib.mtts_gemm_f32_dual(form, M, N, K, P(A), lda, P(B), ldb, P(A2), P(B2), P(Cm), pad4(N), P(bias), 0.5, 0, tile, None) == 0
+    torch.cuda.synchronize()
+    want = 0.5 * (r1 + r2) + bias.double()[None, :]
+    err = (Cm[:, :N].double() - want).abs().max().item()
+    assert err < 3e-5 * max(1.0, want.abs().max().item()), err
+    assert torch.all(Cm[:, N:] == 7.0)
+    # against the two-launch form it replaces (plain, then accumulate): same value up to the order of summation
+    C2 = torch.zeros((M, pad4(N)), device="cuda")
+    assert lib.mtts_gemm_f32(form, M, N, K, P(A), lda, P(B), ldb, P(C2), pad4(N), P(bias), 0.5, 0, tile, None) == 0
+    assert lib.mtts_gemm_f32(form, M, N, K, P(A2), lda, P(B2), ldb, P(C2), pad4(N), None, 0.5, 2, tile, None) == 0
+    torch.cuda.synchronize()
+    assert (C2[:, :N] - Cm[:, :N]).abs().max().item() < 3e-5 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize("tile", [0, 64, 128, 1064, 1128, 3064, 3128, 4064, 5064, 5032])
 @pytest.mark.parametrize("L,Cin,Cout,k", [(97, 32, 48, 3), (300, 256, 1024, 9), (211, 80, 512, 5), (150, 1024, 256, 1), (64, 512, 80, 5)])
 def test_conv1d_fwd_dgrad_wgrad(lib, tile, L, Cin, Cout, k):

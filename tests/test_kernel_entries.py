@@ -251,3 +251,40 @@ def test_layernorm_and_softmax_jvp(dev, rows, Cc, full):
     assert dev.lib.mtts_softmax_jvp(n_mat, L, P(dS), P(dtS), P(ws2), None) == 0
     _, ref = torch.func.jvp(lambda s: torch.softmax(s, -1), (torch.from_numpy(S0),), (torch.from_numpy(tS0),))
     np.testing.assert_allclose(dev.get(dtS)[:, :, :L], ref.numpy(), rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("tile", [0, 64, 5064])
+@pytest.mark.parametrize("form", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(70, 40, 36), (33, 130, 100), (129, 64, 530)])
+def test_gemm_dual_source(dev, form, tile, M, N, K):
+    """mtts_gemm_f32_dual: C = alpha (A B + A2 B2) + bias in ONE accumulator chain (csrc/gemm.h: GemmArgs::A2 — the shape of every tangent
+    product of second-order MAML, base_adaptor.py:107) against float64, for the three operand forms, through the launch queue (tile 0),
+    a plain 64x64 grid and the work-queue kernel."""
+    g = np.random.RandomState(M + 3 * N + 7 * K + form)
+    pad4 = lambda x: (x + 3) & ~3
+
+    def operands():
+        if form == 0:
+            A, B = np.zeros((M, pad4(K)), np.float32), np.zeros((N, pad4(K)), np.float32)
+            A[:, :K], B[:, :K] = g.standard_normal((M, K)), g.standard_normal((N, K))
+            return A, B, A[:, :K].astype(np.float64) @ B[:, :K].astype(np.float64).T, pad4(K), pad4(K)
+        if form == 1:
+            A, B = np.zeros((M, pad4(K)), np.float32), g.standard_normal((K, pad4(N))).astype(np.float32)
+            A[:, :K] = g.standard_normal((M, K))
+            return A, B, A[:, :K].astype(np.float64) @ B[:, :N].astype(np.float64), pad4(K), pad4(N)
+        A, B = g.standard_normal((K, pad4(M))).astype(np.float32), g.standard_normal((K, pad4(N))).astype(np.float32)
+        return A, B, A[:, :M].astype(np.float64).T @ B[:, :N].astype(np.float64), pad4(M), pad4(N)
+
+    A, B, r1, lda, ldb = operands()
+    A2, B2, r2, _, _ = operands()
+    bias = g.standard_normal(N).astype(np.float32)
+    dA, dB, dA2, dB2, dbias = (dev.put(x) for x in (A, B, A2, B2, bias))
+    out = dev.empty((M, pad4(N)), fill=7.0)
+    P = dev.ptr
+    assert dev.lib.mtts_gemm_f32_dual(form, M, N, K, P(dA), lda, P(dB), ldb, P(dA2), P(dB2), P(out), pad4(N), P(dbias), 0.5, 0, tile, None) == 0
+    got = dev.get(out)
+    want = 0.5 * (r1 + r2) + bias[None, :].astype(np.float64)
+    assert np.abs(got[:, :N] - want).max() < 3e-5 * max(1.0, np.abs(want).max())
+    assert np.all(got[:, N:] == 7.0)
+    # a missing second source is an error, not a silent single product
+    assert dev.lib.mtts_gemm_f32_dual(form, M, N, K, P(dA), lda, P(dB), ldb, None, None, P(out), pad4(N), None, 1.0, 0, tile, None) != 0

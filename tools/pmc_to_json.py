@@ -13,36 +13,36 @@ import re
 import sqlite3
 import sys
 
-FORMS = {"0": "NT", "1": "NN", "2": "TN"}
+def categories(sym):
+    """Keys a dispatch is accumulated under: the kernel's name as rocprofv3 --stats prints it (template arguments included, what
+    bench.py's roofline.kernel holds) and the bare template name (all instantiations together)."""
+    m = re.search(r"(gemm_\w+_kernel)(<[^>(]*>)?", sym)
+    if not m:
+        return []
+    return [m.group(1) + (m.group(2) or ""), m.group(1)] if m.group(2) else [m.group(1)]
 
 
-def category(sym):
-    m = re.search(r"gemm_f32_kernelILi(\d)ELi(\d+)E", sym)
-    if m:
-        return f"gemm_f32<{FORMS[m.group(1)]},{m.group(2)}>"
-    m = re.search(r"gemm_glds_kernelILi(\d)E", sym)
-    if m:
-        return f"gemm_f32<{FORMS[m.group(1)]},64>"
-    if "gemm_f32_multi_kernel" in sym or "gemm_glds_multi_kernel" in sym:
-        return "gemm_f32_multi<64>"
-    return None
+def name_column(c):
+    cols = [r[1] for r in c.execute("pragma table_info(rocpd_info_kernel_symbol)")]
+    for want in ("demangled_kernel_name", "display_name", "formatted_kernel_name", "kernel_name"):
+        if want in cols:
+            return want
+    return "kernel_name"
 
 
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))  # cat -> counter -> [sum, dispatches]
 for path in sys.argv[2:]:
     c = sqlite3.connect(path)
-    rows = c.execute("""select s.kernel_name, p.name, d.id, sum(e.value) from rocpd_pmc_event e
+    rows = c.execute(f"""select s.{name_column(c)}, p.name, d.id, sum(e.value) from rocpd_pmc_event e
         join rocpd_info_pmc p on e.pmc_id = p.id
         join rocpd_kernel_dispatch d on e.event_id = d.event_id
         join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by 1, 2, 3""").fetchall()
     for sym, ctr, _disp, val in rows:
-        cat = category(sym)
-        if cat is None:
-            continue
-        a = acc[cat][ctr]
-        a[0] += val
-        a[1] += 1
-out = {"source": "rocprofv3 --pmc passes (one counter group per pass: FETCH_SIZE | WRITE_SIZE | SQ_BUSY_CYCLES + SQ_VALU_MFMA_BUSY_CYCLES) over `bench.py --steps 1 --warmup 0` (fp32, dropout on; `--order 2` for kernels_second_order), 1x MI355X",
+        for cat in categories(sym):
+            a = acc[cat][ctr]
+            a[0] += val
+            a[1] += 1
+out = {"source": "rocprofv3 --pmc passes (one counter group per pass: FETCH_SIZE | WRITE_SIZE | SQ_BUSY_CYCLES + SQ_VALU_MFMA_BUSY_CYCLES) over `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference --no-frontend --no-baseline-c2 --no-roofline` (fp32, dropout on; `--order 2` for kernels_second_order), 1x MI355X",
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B/lane loads -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported; both KB",
        "kernels": {}}
 for cat, d in sorted(acc.items()):
