@@ -218,6 +218,18 @@ public:
 
     char* arena = nullptr;
     size_t arena_bytes = 0;
+    // Gradients of a backward pass that second-order MAML reads again in its reverse sweep (engine_so.inc): per decoder layer the
+    // gradient leaving the layer (g0) and dh, dy1, dO, dqkv; the gradient reaching every PostNet layer's output; the final mel gradient.
+    // By default (gs_alias) every field aliases the shared backward scratch — one layer alive at a time, as a first-order pass needs —;
+    // meta_grad_so gives the backward of inner step s a set of its own (gs_steps[s]), so that step's tangent backward finds the primal
+    // gradients instead of recomputing them (one forward-equivalent of GEMMs per step).
+    struct LayerKeep { TS g0, gh, dy1, dO, gqkv; };
+    struct GradSet { std::vector<LayerKeep> dec; TS dec_top{nullptr, 0}; std::vector<TS> post_cur; TS gRm{nullptr, 0}; };
+    GradSet gs_alias;
+    std::vector<GradSet> gs_steps;
+    std::vector<char*> gs_mem;
+    int gs_bound = -1;                // -1: gs_alias
+    GradSet& GK() { return gs_bound < 0 ? gs_alias : gs_steps[gs_bound]; }
     size_t act_bytes = 0;             // leading part of the arena: the activation set (layout_act)
     std::vector<char*> act_sets;      // extra activation sets (second-order MAML: one per inner step); set 0 is the arena's own
     int act_bound = 0;
@@ -406,6 +418,39 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         layout_act();
         act_bytes = (arena_off + 255) & ~(size_t)255;
         layout_rest();
+        gs_alias.dec.assign(cfg.dec_layers, LayerKeep{gF0, gFh, gF1, gF1, gFqkv});
+        gs_alias.dec_top = gF0;
+        gs_alias.post_cur.assign(std::max(cfg.postnet_layers - 1, 0), gR1);
+        gs_alias.gRm = gRm;
+    }
+    void layout_gradset(GradSet& g) {
+        const int d = cfg.d_model;
+        g.dec.resize(cfg.dec_layers);
+        for (LayerKeep& k : g.dec) {
+            k.g0 = rows(capMf, d); k.gh = rows(capMf, cfg.d_ff); k.dy1 = rows(capMf, d); k.dO = rows(capMf, d); k.gqkv = rows(capMf, 3 * d);
+        }
+        g.dec_top = rows(capMf, d);
+        g.post_cur.resize(std::max(cfg.postnet_layers - 1, 0));
+        for (TS& t : g.post_cur) t = rows(capMr, std::max(cfg.postnet_dim, cfg.n_mel));
+        g.gRm = rows(capMr, cfg.n_mel);
+    }
+    // n gradient sets of their own memory (zeroed, like the arena: guard rows stay zero); false when the device cannot hold them
+    bool ensure_grad_sets(int n) {
+        while ((int)gs_steps.size() < n) {
+            char* save_arena = arena; const size_t save_off = arena_off; const bool save_dry = arena_dry;
+            GradSet g;
+            arena_dry = true; arena_off = 0; layout_gradset(g);
+            const size_t bytes = arena_off + 256;
+            char* mem = nullptr;
+            bool ok = hipMalloc((void**)&mem, bytes) == hipSuccess;
+            if (ok && hipMemset(mem, 0, bytes) != hipSuccess) { hipFree(mem); ok = false; }
+            if (ok) { arena = mem; arena_dry = false; arena_off = 0; layout_gradset(g); }
+            arena = save_arena; arena_off = save_off; arena_dry = save_dry;
+            if (!ok) { (void)hipGetLastError(); return false; }
+            gs_mem.push_back(mem);
+            gs_steps.push_back(g);
+        }
+        return true;
     }
     // point every activation buffer at set k (0 = the arena's own; k >= 1 = act_sets[k - 1]); host-side only
     void bind_act(int k) {
@@ -720,6 +765,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         destroy_images();
         if (arena) hipFree(arena);
         for (char* a : act_sets) if (a) hipFree(a);
+        for (char* a : gs_mem) if (a) hipFree(a);
         if (arena_so) hipFree(arena_so);
         if (hv) hipFree(hv);
         if (fast_hist) hipFree(fast_hist);
@@ -1271,21 +1317,23 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         ln_fwd(ps, s, b.z2, b.y1, P.ln2g, P.ln2b, vm, b.z2, b.y2, b.st2, d, drop_spec(ps, block_dropout(s), site_base + 1));
     }
 
-    // g0 holds dL/dy2 on entry and dL/dx on exit; g1, gqkv, gh, dS are scratch
+    // g0_in holds dL/dy2; K.g0 receives dL/dx, K.gh / K.dy1 / K.dO / K.gqkv the gradients in between (LayerKeep: by default aliases of
+    // the shared scratch, with g0_in == K.g0 and K.dy1 == K.dO); dS is scratch
     // lg != null: deferred weight gradients (see LayerGrad) — the four gradients the layer's weight-gradient GEMMs read go to
     // lg's buffers, the GEMMs themselves to the side stream
-    void fft_bwd(const Pass& ps, Space s, int heads, const FFTP& P, LayerBuf& b, TS xin, TS g0, TS g1, TS gqkv, TS gh,
+    void fft_bwd(const Pass& ps, Space s, int heads, const FFTP& P, LayerBuf& b, TS xin, TS g0_in, const LayerKeep& K,
                  TS dS, LayerGrad* lg = nullptr) {
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, dk = d / heads, ff = cfg.d_ff;
         const unsigned char* vm = valid_mask(p, s);
         const unsigned char* im = inrect_mask(p, s);
         const bool df = lg != nullptr;
-        if (df) { gh = lg->gh; gqkv = lg->gqkv; }
+        TS g0 = K.g0, g1 = K.dy1, gqkv = K.gqkv, gh = K.gh;
+        if (df && K.dy1.p == K.dO.p) { gh = lg->gh; gqkv = lg->gqkv; }   // (a set of its own already has a buffer per layer)
         // LN2 (+ row mask) backward -> g1 = dz2
         TS gm = (s == SP_P) ? gPm : gFm;                                   // masked copy feeds the conv branch, g1 the residual
         const DropSpec dd2 = drop_spec(ps, block_dropout(s), site_base + 1);
-        ln_bwd(ps, s, g0, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0, df ? lg->dc : gm, dd2, df, df ? lg->dy2 : TS{nullptr, 0});
+        ln_bwd(ps, s, g0_in, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0, df ? lg->dc : gm, dd2, df, df ? lg->dy2 : TS{nullptr, 0});
         TS dc = df ? lg->dc : (dd2.thr16 ? gm : g1);
         // conv2
         {   // wgrad and dgrad of a layer are independent: one multi-problem launch (gemm.h: gemm_f32_multi_kernel)
@@ -1307,8 +1355,9 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         {
             GemmBatchScope pair(gx, stream);
             if (!df) conv_wgrad(ps, s, da, d, 1, b.O, d, P.wfc, P.bfc, vm);
-            conv_dgrad(ps, s, da, d, 1, W(ps, P.wfc), d, g1, 0, nullptr);  // g1 = dO
+            conv_dgrad(ps, s, da, d, 1, W(ps, P.wfc), d, K.dO, 0, nullptr);
         }
+        g1 = K.dO;
         // attention
         const int groups = (s == SP_P) ? p.n_enc_groups : p.n_dec_groups;
         const int L = (s == SP_P) ? p.enc_maxL : p.dec_maxL;
@@ -1760,6 +1809,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (!ps.train) { set_error("backward needs a train-mode forward (batch statistics)"); return -1; }
         if (!p.has_targets) { set_error("backward needs a teacher-forced batch (targets)"); return -1; }
         LossArgs a = loss_args(p);
+        GradSet& K = GK();   // where the gradients a second-order reverse sweep reads again go (default: the shared scratch)
+        const TS gRm = K.gRm;
         // prediction strides in the phoneme space: the [Mp] vectors were allocated as rows(capMp, 1)
         MTTS_LAUNCH(loss_grad_kernel, dim3(kLossBlocks, 1, nt), dim3(256), stream, (const int*)p.meta, a, scale, gRm.p, gRp.p,
                     dpred[1].p, dpred[2].p, dpred[0].p, dpred_r[0].p, dpred_r[1].p);
@@ -1795,8 +1846,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             GemmBatchScope pair(gx, stream);
             if (!dfp) conv_wgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, xin, P.cin, P.w, P.b, p.r_inrect);
             if (i > 0) {
-                conv_dgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, W(ps, P.w), P.cin, gR1, 0, p.r_inrect);
-                cur = gR1;
+                conv_dgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, W(ps, P.w), P.cin, K.post_cur[i - 1], 0, p.r_inrect);
+                cur = K.post_cur[i - 1];
             } else {
                 // dL/d(mel) total = direct L1 term + residual path + PostNet input gradient
                 const long long n4 = (gRm.ts * nt) / 4;
@@ -1825,14 +1876,16 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         {
             GemmBatchScope pair(gx, stream);
             if (!dfm) conv_wgrad(ps, SP_F, gMelF, nm, 1, dec_out, d, mel_w, -1, nullptr);
-            conv_dgrad(ps, SP_F, gMelF, nm, 1, W(ps, mel_w), d, gF0, 0, nullptr);
+            conv_dgrad(ps, SP_F, gMelF, nm, 1, W(ps, mel_w), d, K.dec_top, 0, nullptr);
         }
         // ---- decoder ----------------------------------------------------------------------
         for (int l = cfg.dec_layers - 1; l >= 0; --l) {
             TS xin = l == 0 ? dec_in : decB[l - 1].y2;
             site_base = 64 + 2 * l;
-            fft_bwd(ps, SP_F, cfg.dec_heads, decP[l], decB[l], xin, gF0, gF1, gFqkv, gFh, dSf, defer_ok(p) ? &decG[l] : nullptr);
+            fft_bwd(ps, SP_F, cfg.dec_heads, decP[l], decB[l], xin, l == cfg.dec_layers - 1 ? K.dec_top : K.dec[l + 1].g0, K.dec[l], dSf,
+                    defer_ok(p) ? &decG[l] : nullptr);
         }
+        const TS gF0 = cfg.dec_layers ? K.dec[0].g0 : K.dec_top;   // gradient of the decoder input
         // speaker vector gradient, part 1: every valid frame
         MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(256), stream, (const int*)p.meta, (const float*)gF0.p,
                     gF0.ts, (const int*)p.f_seg_start, (const int*)p.f_seg_len, (long long)cap_B, dspk.p, dspk.ts, d, 0);
@@ -1881,7 +1934,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (int l = cfg.enc_layers - 1; l >= 0; --l) {
             TS xin = l == 0 ? emb_out : encB[l - 1].y2;
             site_base = 2 * l;
-            fft_bwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], xin, gP0, gP1, gPqkv, gPh, dSp, defer_ok(p) ? &encG[l] : nullptr);
+            fft_bwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], xin, gP0, LayerKeep{gP0, gPh, gP1, gP1, gPqkv}, dSp, defer_ok(p) ? &encG[l] : nullptr);
         }
         // word embedding (padding row 0 keeps a zero gradient); p_tok is 0 on invalid rows, and
         // gP0 is only meaningful on valid rows -> scan with the token ids masked by validity

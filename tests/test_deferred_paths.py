@@ -64,9 +64,18 @@ OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "M
 def _compare(tmp_path, gpu):
     # emulator arm: whole tiles only (MTTS_SK_SMAX=1) — the work-queue kernel cuts the late tiles of a launch into pieces, and which
     # tiles are late depends on what shares the launch, i.e. on the very batching the knobs change; without pieces the comparison is exact
-    common = {} if gpu else {"MTTS_SK_SMAX": "1"}
+    # (MTTS_SO_KEEP_GRAD=0 in both arms: with kept primal gradients the reverse sweep reads the dz of the first sweep's LayerNorm backward
+    # instead of the tangent kernel's own — equal up to rounding, compared separately below)
+    common = {"MTTS_SO_KEEP_GRAD": "0"} if gpu else {"MTTS_SK_SMAX": "1", "MTTS_SO_KEEP_GRAD": "0"}
     a = _run(tmp_path, "on", dict(common), gpu)
     b = _run(tmp_path, "off", dict(OFF, **common), gpu)
+    c = _run(tmp_path, "keepgrad", {k: v for k, v in common.items() if k != "MTTS_SO_KEEP_GRAD"}, gpu)   # the default configuration
+    scale = max(float(np.abs(a[k]).max()) for k in a if k.startswith("g2_"))   # (a conv bias in front of a BatchNorm has a zero gradient: pure rounding noise)
+    for k in a:
+        if k.startswith("g2_"):   # second-order outer gradient: kept vs recomputed primal gradients
+            np.testing.assert_allclose(c[k], a[k], rtol=2e-3, atol=max(2e-5 * float(np.abs(a[k]).max()), 1e-6 * scale), err_msg=k)
+        elif not gpu:
+            np.testing.assert_array_equal(c[k], a[k], err_msg=k)
     assert set(a) == set(b) and len(a) >= 15
     for k in a:
         assert np.isfinite(a[k]).all(), k
