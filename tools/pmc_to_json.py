@@ -42,7 +42,7 @@ for path in sys.argv[2:]:
             a = acc[cat][ctr]
             a[0] += val
             a[1] += 1
-out = {"source": "rocprofv3 --pmc passes (one counter group per pass: FETCH_SIZE | WRITE_SIZE | SQ_BUSY_CYCLES + SQ_VALU_MFMA_BUSY_CYCLES) over `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-inference --no-frontend --no-baseline-c2 --no-roofline` (fp32, dropout on; `--order 2` for kernels_second_order), 1x MI355X",
+out = {"source": "rocprofv3 --pmc passes (one counter group per pass: FETCH_SIZE | WRITE_SIZE | SQ_BUSY_CYCLES + SQ_VALU_MFMA_BUSY_CYCLES) over `bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-inference --no-frontend --no-baseline-c2 --no-roofline` (fp32, dropout on; `--order 2` for kernels_second_order), 1x MI355X",
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B/lane loads -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported; both KB",
        "kernels": {}}
 for cat, d in sorted(acc.items()):
