@@ -1119,6 +1119,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         g.dimptr = p.meta + mfield(s);
         g.dim_stride = META_STRIDE;
         g.dim_sel = (form == GEMM_TN) ? 2 : 0;
+        g.host_dims = (s == SP_P) ? p.hMp.data() : (s == SP_F) ? p.hMf.data() : p.hMr.data();   // (8-task launches: task-per-XCD schedule, gemm.h)
         return g;
     }
 

@@ -47,6 +47,72 @@ struct GemmGroupDesc {
     int lda, ldb, ldc;              // per-group leading dimensions (0: use GemmArgs')
 };
 
+// Task-per-XCD schedule of a launch of exactly 8 groups (the 8 tasks of a meta-batch on the 8 XCDs of the part).  The dispatcher deals
+// consecutive workgroups round-robin to the XCDs, each with a private 4 MB L2; with the plain order every XCD touches every task and
+// streams every task's operands (the weight image of a dgrad, the activation panels of a wgrad) from the Infinity Cache / HBM: ~6x the
+// algorithmic bytes on the 8-task meta-step.  Here workgroup slot 8 j + x belongs to XCD x, which first runs its OWN task's units
+// (own[x] of them, from unit 0) and then a contiguous piece [ps[x], ps[x+1]) of the POOL — the surplus units of the tasks that carry
+// more than an eighth of the launch's work (task z's units own[z] .., pool positions [P[z], P[z+1])), so the ragged tasks do not
+// unbalance the XCDs.  A unit is an m-tile (all its n-tiles; M-ragged problems: forward, dgrad) or a tile (K-ragged: wgrad).
+// Built on the host per launch (xcd_sched_build), speed only: any placement gives the same results.
+struct XcdSched {
+    int on = 0;          // 1: units are m-tiles of `tn` tiles; 2: units are tiles
+    int tn = 1;
+    int maxlen = 0;      // longest per-XCD list, in units (grid = 8 * maxlen * (on == 1 ? tn : 1))
+    int own[8] = {0};
+    int ps[9] = {0};
+    int P[9] = {0};
+};
+// workgroup slot -> (group z, tile index inside the group); false: the slot is padding
+__host__ __device__ __forceinline__ bool xcd_sched_locate(const XcdSched& s, int lin, int& z, int& tile) {
+    const int x = lin & 7, j = lin >> 3;
+    const int ju = s.on == 1 ? j / s.tn : j, n = s.on == 1 ? j - ju * s.tn : 0;
+    int u;
+    if (ju < s.own[x]) { z = x; u = ju; }
+    else {
+        const int idx = s.ps[x] + (ju - s.own[x]);
+        if (idx >= s.ps[x + 1]) return false;
+        z = 0;
+        while (z < 7 && idx >= s.P[z + 1]) ++z;
+        u = s.own[z] + (idx - s.P[z]);
+    }
+    tile = s.on == 1 ? u * s.tn + n : u;
+    return true;
+}
+// dims[z]: rows of task z (M of an M-ragged problem, K of a K-ragged one).  cls 1: units = m-tiles of tile_m rows, tn tiles each;
+// cls 2: units = tiles, units_per_group of them in every group, cost proportional to dims[z].
+inline void xcd_sched_build(XcdSched& s, const int* dims, int cls, int tn, int units_per_group, int tile_m = 64) {
+    long long cnt[8], w[8], W = 0;
+    for (int z = 0; z < 8; ++z) {
+        cnt[z] = cls == 1 ? (dims[z] + tile_m - 1) / tile_m : units_per_group;
+        w[z] = cls == 1 ? 1 : (dims[z] > 0 ? dims[z] : 1);
+        if (dims[z] <= 0) cnt[z] = 0;
+        W += cnt[z] * w[z];
+    }
+    const long long Q = (W + 7) / 8;
+    s.on = cls; s.tn = cls == 1 ? tn : 1;
+    s.P[0] = 0;
+    for (int z = 0; z < 8; ++z) {
+        s.own[z] = (int)std::min<long long>(cnt[z], Q / w[z]);
+        s.P[z + 1] = s.P[z] + (int)(cnt[z] - s.own[z]);
+    }
+    const int pool = s.P[8];
+    int idx = 0, zt = 0;   // next pool position and the task it belongs to
+    s.maxlen = 0;
+    for (int x = 0; x < 8; ++x) {
+        s.ps[x] = idx;
+        long long load = (long long)s.own[x] * w[x];
+        while (idx < pool) {
+            while (zt < 7 && idx >= s.P[zt + 1]) ++zt;
+            if (x < 7 && load + w[zt] / 2 + (w[zt] & 1) > Q) break;   // (the last XCD takes what is left)
+            load += w[zt];
+            ++idx;
+        }
+        s.maxlen = std::max(s.maxlen, s.own[x] + idx - s.ps[x]);
+    }
+    s.ps[8] = idx;
+}
+
 struct GemmArgs {
     const float* A = nullptr;
     const float* B = nullptr;
@@ -99,6 +165,10 @@ struct GemmArgs {
     const float* A2 = nullptr;
     const float* B2 = nullptr;
     long long a2_gs = 0, b2_gs = 0;
+    // task-per-XCD schedule (8-group launches).  host_dims: HOST array of the 8 groups' dimptr values, read by the launcher to build
+    // `xs`; never dereferenced on the device.
+    const int* host_dims = nullptr;
+    XcdSched xs;
 };
 // K-loop length of a problem for the launch heuristics (both sources of a dual-source problem)
 inline int gemm_keff(const GemmArgs& g) { return g.A2 ? 2 * g.K : g.K; }
@@ -592,9 +662,10 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
 template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[GemmSmem<FORM, BM, BN, BK>::FLOATS];
-    const int z = blockIdx.z;
+    int z = blockIdx.z;
     int bxs = blockIdx.x;
-    if (g.swizzle) bxs = xcd_group_remap(bxs, (int)gridDim.x, xcd_group_size((g.N + BN - 1) / BN, g.splitk));
+    if (g.xs.on) { if (!xcd_sched_locate(g.xs, bxs, z, bxs)) return; }   // 1-D grid, task-per-XCD order
+    else if (g.swizzle) bxs = xcd_group_remap(bxs, (int)gridDim.x, xcd_group_size((g.N + BN - 1) / BN, g.splitk));
     gemm_f32_body<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL>(g, z, bxs, smem);
 }
 
@@ -619,31 +690,35 @@ struct GemmMulti {
     int start[kGemmMultiMax + 1] = {0};
     int form[kGemmMultiMax] = {0};
     int groups[kGemmMultiMax] = {0};
-    int xcd_group[kGemmMultiMax] = {0};  // > 1: this many consecutive tile slots share an XCD (gemm_multi_locate)
+    int xcd_group[kGemmMultiMax] = {0};  // > 1: this many consecutive tile slots share an XCD (gemm_multi_locate); -1: task z on XCD z; -2: GemmArgs::xs
+    int tiles_pg[kGemmMultiMax] = {0};   // tile slots per group (start[p + 1] - start[p] may be padded up to a multiple of 8)
     GemmArgs g[kGemmMultiMax];
 };
 
 // Problem / group / tile of a workgroup of a multi-problem launch.  Problems are sorted by per-tile cost (longest first) and
 // laid out problem-major over a 1-D grid, so the long tiles all start in the first dispatch round and the short ones fill
 // the tail; within a problem the tile order is XCD-grouped (xcd_group_remap).
-__device__ __forceinline__ void gemm_multi_locate(const GemmMulti& mp, int& p, int& z, int& bx) {
+__device__ __forceinline__ bool gemm_multi_locate(const GemmMulti& mp, int& p, int& z, int& bx) {
     p = 0;
     int lin = (int)blockIdx.x;
     while (p + 1 < mp.n && lin >= mp.start[p + 1]) ++p;
     lin -= mp.start[p];
-    const int total = mp.start[p + 1] - mp.start[p];
-    const int tiles = total / mp.groups[p];
+    if (mp.xcd_group[p] == -2) return xcd_sched_locate(mp.g[p].xs, lin, z, bx);   // (starts are multiples of 8 then)
+    const int total = mp.tiles_pg[p] * mp.groups[p];
+    if (lin >= total) return false;   // padding up to the next multiple of 8
+    const int tiles = mp.tiles_pg[p];
     if (mp.xcd_group[p] < 0) {
         // group-per-XCD order (8 | groups): workgroup slot lin belongs to group lin % groups, so the dispatcher's round-robin puts ALL
         // tiles of a group (a task) on one XCD and the operand every tile of that task streams (the weight image of a dgrad) is fetched
         // into one L2 instead of eight.  Unbalanced by the raggedness of the tasks.
         z = lin % mp.groups[p];
         bx = lin / mp.groups[p];
-        return;
+        return true;
     }
     lin = xcd_group_remap(lin, total, mp.xcd_group[p]);
     z = lin / tiles;
     bx = lin - z * tiles;
+    return true;
 }
 template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_multi_kernel(GemmMulti mp) {
@@ -651,7 +726,7 @@ __global__ __launch_bounds__(256) void gemm_f32_multi_kernel(GemmMulti mp) {
     constexpr int FL = F0 > F1 ? (F0 > F2 ? F0 : F2) : (F1 > F2 ? F1 : F2);
     __shared__ __attribute__((aligned(16))) float smem[FL];
     int p, z, bx;
-    gemm_multi_locate(mp, p, z, bx);
+    if (!gemm_multi_locate(mp, p, z, bx)) return;
     const int form = mp.form[p];
     if (form == GEMM_NT) gemm_f32_body<GEMM_NT, BM, BN, BK, true>(mp.g[p], z, bx, smem);
     else if (form == GEMM_NN) gemm_f32_body<GEMM_NN, BM, BN, BK, true>(mp.g[p], z, bx, smem);
@@ -665,7 +740,7 @@ __global__ __launch_bounds__(256) void gemm_f32_multi_dual_kernel(GemmMulti mp) 
     constexpr int FL = F0 > F1 ? (F0 > F2 ? F0 : F2) : (F1 > F2 ? F1 : F2);
     __shared__ __attribute__((aligned(16))) float smem[FL];
     int p, z, bx;
-    gemm_multi_locate(mp, p, z, bx);
+    if (!gemm_multi_locate(mp, p, z, bx)) return;
     const int form = mp.form[p];
     if (form == GEMM_NT) gemm_f32_body<GEMM_NT, BM, BN, BK, true, 2, 2, 0, true>(mp.g[p], z, bx, smem);
     else if (form == GEMM_NN) gemm_f32_body<GEMM_NN, BM, BN, BK, true, 2, 2, 0, true>(mp.g[p], z, bx, smem);
@@ -814,6 +889,23 @@ inline void gemm_glds_launch(int form, const GemmArgs& g, dim3 grid, hipStream_t
 inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t stream, bool dual = false);
 #endif
 
+// Task-per-XCD schedule (XcdSched) of a problem: exactly 8 groups whose sizes the caller knows on the host, whole tiles.  MTTS_XCD_SCHED=0: off.
+inline bool gemm_xcd_sched_for(GemmArgs& g, int max_M, int max_N, int groups, int S, int tile) {
+    static const bool on = [] { const char* e = getenv("MTTS_XCD_SCHED"); return e ? atoi(e) != 0 : true; }();
+    g.xs.on = 0;
+    if (!on || groups != 8 || !g.host_dims || !g.dimptr || g.table || S != 1) return false;
+    int dims[8];
+    for (int z = 0; z < 8; ++z) dims[z] = g.host_dims[z] * g.dim_mult;
+    const int tn = gemm_tiles_n(g, max_N, tile);
+    if (g.dim_sel == 0) xcd_sched_build(g.xs, dims, 1, tn, 0, tile);
+    else xcd_sched_build(g.xs, dims, 2, 1, ((max_M + tile - 1) / tile) * tn);
+    if (g.xs.maxlen <= 0) g.xs.on = 0;
+    static const bool dbg = getenv("MTTS_XCD_SCHED_DEBUG") != nullptr;   // one line per scheduled problem (tests: the schedule really is in use)
+    if (dbg && g.xs.on) fprintf(stderr, "xcd_sched cls %d tn %d maxlen %d pool %d\n", g.xs.on, g.xs.tn, g.xs.maxlen, g.xs.P[8]);
+    return g.xs.on != 0;
+}
+inline long gemm_xcd_sched_slots(const XcdSched& s) { return 8L * s.maxlen * (s.on == 1 ? s.tn : 1); }
+
 // Host launcher.  max_M / max_N bound the tile grid over all groups.  tile = 0: automatic — the problem goes through the launch
 // queue (alone if no batch is open): a plain 64x64 grid (LDS-DMA kernels in the latency regime, a multi-problem grid for a batch), or
 // the persistent work-queue kernel when that is switched on (gemm_sk.h).  An explicit tile code picks one kernel: 64 / 128 (+1000 software pipeline,
@@ -892,6 +984,7 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     const int nth = 256;
     const long grid_tiles = ntiles(tile);
     dim3 block(nth), grid((unsigned)(grid_tiles * S), 1, (unsigned)groups);
+    if (gemm_xcd_sched_for(g, max_M, max_N, groups, S, tile)) grid = dim3((unsigned)gemm_xcd_sched_slots(g.xs), 1, 1);   // 1-D, task-per-XCD order
     GemmProfiler& prof = cx.prof;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
@@ -1027,7 +1120,10 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
         mp.xcd_group[i] = gemm_xcd_swizzle() ? std::min(gemm_tiles_n(p.g, p.max_N, 64) * S, 64) : 0;
         static const int task_xcd = [] { const char* e = getenv("MTTS_XCD_TASK"); return e ? atoi(e) : 0; }();   // experiment: 1 = NN problems, 2 = all
         if (task_xcd && !p.g.table && p.groups % 8 == 0 && (mp.start[i] & 7) == 0 && (task_xcd >= 2 || p.form == GEMM_NN)) mp.xcd_group[i] = -1;
-        mp.start[i + 1] = mp.start[i] + tiles * S * p.groups;
+        mp.tiles_pg[i] = tiles * S;
+        long slots = (long)tiles * S * p.groups;
+        if (!task_xcd && gemm_xcd_sched_for(mp.g[i], p.max_M, p.max_N, p.groups, S, 64)) { mp.xcd_group[i] = -2; slots = gemm_xcd_sched_slots(mp.g[i].xs); }
+        mp.start[i + 1] = mp.start[i] + (int)((slots + 7) & ~7L);   // (every problem starts on a multiple of 8: workgroup slot % 8 = XCD)
         max_groups = std::max(max_groups, p.groups);
         flops += p.flops; rows += p.rows; bytes += p.bytes;
     }

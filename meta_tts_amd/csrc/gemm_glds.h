@@ -242,15 +242,16 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g, int z, int bxs
 template <int FORM>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[kGldsSmemFloats];
-    int bx = blockIdx.x;
-    if (g.swizzle) bx = xcd_group_remap(bx, (int)gridDim.x, xcd_group_size((g.N + 63) / 64, g.splitk));
-    gemm_glds_body<FORM>(g, blockIdx.z, bx, smem);
+    int bx = blockIdx.x, z = blockIdx.z;
+    if (g.xs.on) { if (!xcd_sched_locate(g.xs, bx, z, bx)) return; }
+    else if (g.swizzle) bx = xcd_group_remap(bx, (int)gridDim.x, xcd_group_size((g.N + 63) / 64, g.splitk));
+    gemm_glds_body<FORM>(g, z, bx, smem);
 }
 
 __global__ __launch_bounds__(256) void gemm_glds_multi_kernel(GemmMulti mp) {
     __shared__ __attribute__((aligned(16))) float smem[kGldsSmemFloats];
     int p, z, bx;
-    gemm_multi_locate(mp, p, z, bx);
+    if (!gemm_multi_locate(mp, p, z, bx)) return;
     const int form = mp.form[p];
     if (form == GEMM_NT) gemm_glds_body<GEMM_NT>(mp.g[p], z, bx, smem);
     else if (form == GEMM_NN) gemm_glds_body<GEMM_NN>(mp.g[p], z, bx, smem);
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm_glds_multi_kernel(GemmMulti mp) {
 __global__ __launch_bounds__(256) void gemm_glds_multi_dual_kernel(GemmMulti mp) {
     __shared__ __attribute__((aligned(16))) float smem[kGldsSmemFloats];
     int p, z, bx;
-    gemm_multi_locate(mp, p, z, bx);
+    if (!gemm_multi_locate(mp, p, z, bx)) return;
     const int form = mp.form[p];
     if (form == GEMM_NT) gemm_glds_body<GEMM_NT, true>(mp.g[p], z, bx, smem);
     else if (form == GEMM_NN) gemm_glds_body<GEMM_NN, true>(mp.g[p], z, bx, smem);

@@ -392,6 +392,34 @@ int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+int mtts_xcd_schedule_check(const int* dims, int cls, int tn, int units_per_group, int* max_load_permille) {
+    if (!dims || (cls != 1 && cls != 2) || tn < 1) return -1;
+    XcdSched s;
+    xcd_sched_build(s, dims, cls, tn, units_per_group);
+    std::vector<std::vector<int>> seen(8);
+    long long total = 0, work[8] = {0};
+    for (int z = 0; z < 8; ++z) {
+        const int tiles = dims[z] <= 0 ? 0 : (cls == 1 ? ((dims[z] + 63) / 64) * tn : units_per_group);
+        seen[z].assign(tiles, 0);
+        total += (long long)tiles * (cls == 1 ? 1 : std::max(dims[z], 1));
+    }
+    const long slots = gemm_xcd_sched_slots(s);
+    for (long lin = 0; lin < slots; ++lin) {
+        int z = -1, tile = -1;
+        if (!xcd_sched_locate(s, (int)lin, z, tile)) continue;
+        if (z < 0 || z > 7 || tile < 0 || tile >= (int)seen[z].size() || seen[z][tile]++) return -1;
+        work[lin & 7] += cls == 1 ? 1 : std::max(dims[z], 1);
+    }
+    for (int z = 0; z < 8; ++z)
+        for (int v : seen[z]) if (v != 1) return -1;
+    if (max_load_permille) {
+        long long mx = 0;
+        for (int x = 0; x < 8; ++x) mx = std::max(mx, work[x]);
+        *max_load_permille = total > 0 ? (int)(mx * 8000 / total) : 0;
+    }
+    return (int)slots;
+}
+
 int mtts_gemm_f32_dual(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* A2, const float* B2,
                        float* C, int ldc, const float* bias, float alpha, int flags, int tile, void* stream) {
     if (form < 0 || form > 2 || !tile_code_ok(tile) || !A2 || !B2 || (flags & ~0xff)) return -1;
