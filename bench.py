@@ -514,7 +514,7 @@ def main():
             rows2 = gemm_profile(eng, lambda: eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=True, fetch_losses=False))
             r2 = roofline_of(rows2, "kernels_second_order")
             so["roofline"] = {k: r2[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launches", "avg_launch_us", "alg_gflop_per_launch",
-                                                 "alg_bytes_per_launch", "traffic", "traffic_source")}
+                                                 "alg_bytes_per_launch", "traffic", "traffic_source", "traffic_over_alg_bytes", "mfma_pipe_busy_frac_pmc")}
             so["roofline"]["all_gemm"] = {k: r2["all_gemm"][k] for k in ("ms_per_meta_step", "alg_tflop_per_meta_step", "achieved", "frac")}
             so["whole_step_tflops"] = round(r2["all_gemm"]["alg_tflop_per_meta_step"] / (so["ms_per_step"] * 1e-3), 2)
             # SURVEY.md section 8(d) prices a second-order meta-step at 35.5 TFLOP (reverse sweep = 2 x (fwd + bwd) per inner step); the
