@@ -1065,9 +1065,10 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
         }
         if (prof.enabled) prof.used -= 2;   // (events not used)
     }
-    // pairs whose dgrad has a short K-loop (K <= 256: fc, conv2) measured ~10 % SLOWER batched than back to back — their
-    // many 16-slice tiles gain nothing from a shared grid and lose the stand-alone kernels' higher occupancy
-    static const int min_k = [] { const char* e = getenv("MTTS_BATCH_MIN_K"); return e ? atoi(e) : 512; }();
+    // MTTS_BATCH_MIN_K=n: pairs with a problem whose K-loop is shorter than n go out back to back instead of batched.  Round 2 measured
+    // the K <= 256 pairs (fc, conv2) ~10 % slower batched in the BK = 16 multi-problem kernel (n was 512); with the BK = 32 kernel and the
+    // task-per-XCD schedule batching them wins: 8-task step 170.9 -> 166.9 ms, second order 442 -> 436, 4-task rank 97.5 -> 95.2 (round 3) — 0 now.
+    static const int min_k = [] { const char* e = getenv("MTTS_BATCH_MIN_K"); return e ? atoi(e) : 0; }();
     // a single queued problem normally takes the stand-alone launcher; in the latency regime it stays here, where the long-chain
     // split-K rule applies (the k=9 dgrad of a single-task rank is 124 tiles x 288 slices: alone it would run at one tile per CU)
     static const int single_multi = [] { const char* e = getenv("MTTS_SINGLE_MULTI"); return e ? atoi(e) : 1; }();
