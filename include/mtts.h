@@ -213,11 +213,11 @@ int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const 
  * reference: the double backward that `higher` records for lightning/systems/base_adaptor.py:107). */
 int mtts_gemm_f32_dual(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* A2, const float* B2,
                        float* C, int ldc, const float* bias, float alpha, int flags, int tile, void* hip_stream);
-/* Host-only self check of the task-per-XCD workgroup schedule of 8-group launches (csrc/gemm.h: XcdSched): builds the schedule for
- * the 8 group sizes `dims` (cls 1: M-ragged, units = m-tiles of 64 rows with tn tiles each; cls 2: K-ragged, units_per_group tiles per
- * group whose cost is dims[z]) and walks every workgroup slot.  Returns the number of slots when every (group, tile) is visited exactly
- * once, -1 otherwise; *max_load_permille (optional) = heaviest XCD's work in 1/1000 of a perfect eighth. */
-int mtts_xcd_schedule_check(const int* dims, int cls, int tn, int units_per_group, int* max_load_permille);
+/* Host-only self check of the task-per-XCD workgroup schedule of 8- / 4- / 2-group launches (csrc/gemm.h: XcdSched): builds the schedule
+ * for the `groups` group sizes `dims` (cls 1: M-ragged, units = m-tiles of 64 rows with tn tiles each; cls 2: K-ragged, units_per_group
+ * tiles per group whose cost is dims[z]) and walks every workgroup slot.  Returns the number of slots when every (group, tile) is visited
+ * exactly once, -1 otherwise; *max_load_permille (optional) = heaviest XCD's work in 1/1000 of a perfect eighth. */
+int mtts_xcd_schedule_check(const int* dims, int groups, int cls, int tn, int units_per_group, int* max_load_permille);
 /* Conv1d over one zero-guarded sequence, channels-last: x [L][Cin] with >= k/2 zero rows before and
  * after, w [Cout][k][Cin].  mode 0: y = conv(x) + bias; 1: dx = dgrad(dy); 2: dw = wgrad(dy, x) */
 int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* x_or_dy, const float* w_or_x, float* out,

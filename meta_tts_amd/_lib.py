@@ -82,7 +82,7 @@ EXPORTS = {
     "mtts_profile_report": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "mtts_gemm_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                 C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
-    "mtts_xcd_schedule_check": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "mtts_xcd_schedule_check": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "mtts_gemm_f32_dual": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "mtts_conv1d_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -59,7 +59,9 @@ struct XcdSched {
     int on = 0;          // 1: units are m-tiles of `tn` tiles; 2: units are tiles
     int tn = 1;
     int maxlen = 0;      // longest per-XCD list, in units (grid = 8 * maxlen * (on == 1 ? tn : 1))
+    int shift = 0;       // launches of 4 / 2 groups: every group is cut into 2 / 4 contiguous parts, one per XCD (part x of group x >> shift)
     int own[8] = {0};
+    int base[8] = {0};   // first unit of part x inside its group
     int ps[9] = {0};
     int P[9] = {0};
 };
@@ -67,27 +69,35 @@ struct XcdSched {
 __host__ __device__ __forceinline__ bool xcd_sched_locate(const XcdSched& s, int lin, int& z, int& tile) {
     const int x = lin & 7, j = lin >> 3;
     const int ju = s.on == 1 ? j / s.tn : j, n = s.on == 1 ? j - ju * s.tn : 0;
-    int u;
-    if (ju < s.own[x]) { z = x; u = ju; }
+    int u, part;
+    if (ju < s.own[x]) { part = x; u = s.base[x] + ju; }
     else {
         const int idx = s.ps[x] + (ju - s.own[x]);
         if (idx >= s.ps[x + 1]) return false;
-        z = 0;
-        while (z < 7 && idx >= s.P[z + 1]) ++z;
-        u = s.own[z] + (idx - s.P[z]);
+        part = 0;
+        while (part < 7 && idx >= s.P[part + 1]) ++part;
+        u = s.base[part] + s.own[part] + (idx - s.P[part]);
     }
+    z = part >> s.shift;
     tile = s.on == 1 ? u * s.tn + n : u;
     return true;
 }
 // dims[z]: rows of task z (M of an M-ragged problem, K of a K-ragged one).  cls 1: units = m-tiles of tile_m rows, tn tiles each;
 // cls 2: units = tiles, units_per_group of them in every group, cost proportional to dims[z].
-inline void xcd_sched_build(XcdSched& s, const int* dims, int cls, int tn, int units_per_group, int tile_m = 64) {
+// groups = 8, 4 or 2: with fewer than 8 groups every group is cut into 8 / groups contiguous parts and the parts play the role of the tasks
+// (a task's operands are then streamed into 2 or 4 L2s instead of 8).
+inline void xcd_sched_build(XcdSched& s, const int* dims, int cls, int tn, int units_per_group, int tile_m = 64, int groups = 8) {
     long long cnt[8], w[8], W = 0;
-    for (int z = 0; z < 8; ++z) {
-        cnt[z] = cls == 1 ? (dims[z] + tile_m - 1) / tile_m : units_per_group;
-        w[z] = cls == 1 ? 1 : (dims[z] > 0 ? dims[z] : 1);
-        if (dims[z] <= 0) cnt[z] = 0;
-        W += cnt[z] * w[z];
+    s.shift = groups == 8 ? 0 : (groups == 4 ? 1 : 2);
+    const int v = 1 << s.shift;
+    for (int x = 0; x < 8; ++x) {
+        const int z = x >> s.shift, part = x & (v - 1);
+        const long long units = dims[z] <= 0 ? 0 : (cls == 1 ? (dims[z] + tile_m - 1) / tile_m : units_per_group);
+        const long long lo = units * part / v, hi = units * (part + 1) / v;
+        s.base[x] = (int)lo;
+        cnt[x] = hi - lo;
+        w[x] = cls == 1 ? 1 : (dims[z] > 0 ? dims[z] : 1);
+        W += cnt[x] * w[x];
     }
     const long long Q = (W + 7) / 8;
     s.on = cls; s.tn = cls == 1 ? tn : 1;
@@ -893,12 +903,13 @@ inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t s
 inline bool gemm_xcd_sched_for(GemmArgs& g, int max_M, int max_N, int groups, int S, int tile) {
     static const bool on = [] { const char* e = getenv("MTTS_XCD_SCHED"); return e ? atoi(e) != 0 : true; }();
     g.xs.on = 0;
-    if (!on || groups != 8 || !g.host_dims || !g.dimptr || g.table || S != 1) return false;
-    int dims[8];
-    for (int z = 0; z < 8; ++z) dims[z] = g.host_dims[z] * g.dim_mult;
+    static const int min_groups = [] { const char* e = getenv("MTTS_XCD_SCHED_MIN_GROUPS"); return e ? atoi(e) : 8; }();   // 2 / 4: also the launches of a 4- / 2-rank job's ranks
+    if (!on || (groups != 8 && groups != 4 && groups != 2) || groups < min_groups || !g.host_dims || !g.dimptr || g.table || S != 1) return false;
+    int dims[8] = {0};
+    for (int z = 0; z < groups; ++z) dims[z] = g.host_dims[z] * g.dim_mult;
     const int tn = gemm_tiles_n(g, max_N, tile);
-    if (g.dim_sel == 0) xcd_sched_build(g.xs, dims, 1, tn, 0, tile);
-    else xcd_sched_build(g.xs, dims, 2, 1, ((max_M + tile - 1) / tile) * tn);
+    if (g.dim_sel == 0) xcd_sched_build(g.xs, dims, 1, tn, 0, tile, groups);
+    else xcd_sched_build(g.xs, dims, 2, 1, ((max_M + tile - 1) / tile) * tn, 64, groups);
     if (g.xs.maxlen <= 0) g.xs.on = 0;
     static const bool dbg = getenv("MTTS_XCD_SCHED_DEBUG") != nullptr;   // one line per scheduled problem (tests: the schedule really is in use)
     if (dbg && g.xs.on) fprintf(stderr, "xcd_sched cls %d tn %d maxlen %d pool %d\n", g.xs.on, g.xs.tn, g.xs.maxlen, g.xs.P[8]);

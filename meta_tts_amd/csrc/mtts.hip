@@ -392,13 +392,15 @@ int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int mtts_xcd_schedule_check(const int* dims, int cls, int tn, int units_per_group, int* max_load_permille) {
-    if (!dims || (cls != 1 && cls != 2) || tn < 1) return -1;
+int mtts_xcd_schedule_check(const int* dims_in, int groups, int cls, int tn, int units_per_group, int* max_load_permille) {
+    if (!dims_in || (groups != 8 && groups != 4 && groups != 2) || (cls != 1 && cls != 2) || tn < 1) return -1;
+    int dims[8] = {0};
+    for (int z = 0; z < groups; ++z) dims[z] = dims_in[z];
     XcdSched s;
-    xcd_sched_build(s, dims, cls, tn, units_per_group);
-    std::vector<std::vector<int>> seen(8);
+    xcd_sched_build(s, dims, cls, tn, units_per_group, 64, groups);
+    std::vector<std::vector<int>> seen(groups);
     long long total = 0, work[8] = {0};
-    for (int z = 0; z < 8; ++z) {
+    for (int z = 0; z < groups; ++z) {
         const int tiles = dims[z] <= 0 ? 0 : (cls == 1 ? ((dims[z] + 63) / 64) * tn : units_per_group);
         seen[z].assign(tiles, 0);
         total += (long long)tiles * (cls == 1 ? 1 : std::max(dims[z], 1));
@@ -407,10 +409,10 @@ int mtts_xcd_schedule_check(const int* dims, int cls, int tn, int units_per_grou
     for (long lin = 0; lin < slots; ++lin) {
         int z = -1, tile = -1;
         if (!xcd_sched_locate(s, (int)lin, z, tile)) continue;
-        if (z < 0 || z > 7 || tile < 0 || tile >= (int)seen[z].size() || seen[z][tile]++) return -1;
+        if (z < 0 || z >= groups || tile < 0 || tile >= (int)seen[z].size() || seen[z][tile]++) return -1;
         work[lin & 7] += cls == 1 ? 1 : std::max(dims[z], 1);
     }
-    for (int z = 0; z < 8; ++z)
+    for (int z = 0; z < groups; ++z)
         for (int v : seen[z]) if (v != 1) return -1;
     if (max_load_permille) {
         long long mx = 0;

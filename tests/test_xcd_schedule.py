@@ -22,16 +22,19 @@ def test_schedule_visits_every_tile_once_and_balances():
     cases = [[2100, 1700, 2600, 1900, 2300, 2050, 1800, 2500], [64] * 8, [1, 1, 1, 1, 1, 1, 1, 5000], [300, 0, 310, 290, 305, 0, 280, 330],
              [63, 65, 127, 129, 1, 2, 640, 641]]
     cases += [list(g.randint(1, 3000, 8)) for _ in range(200)]
-    for dims in cases:
-        arr = (C.c_int * 8)(*[int(v) for v in dims])
-        for cls, tn, upg in ((1, 4, 0), (1, 1, 0), (1, 17, 0), (2, 1, 576), (2, 1, 37), (2, 1, 1)):
-            load = C.c_int(0)
-            slots = lib.mtts_xcd_schedule_check(arr, cls, tn, upg, C.byref(load))
-            assert slots >= 0, (dims, cls, tn, upg)
-            units = sum((d + 63) // 64 for d in dims) if cls == 1 else upg * sum(1 for d in dims if d > 0)
-            if units >= 64 and min(dims) > 0:   # enough units to balance: the heaviest XCD stays within 15 % of a perfect eighth
-                assert load.value <= 1150, (dims, cls, tn, upg, load.value)
-    assert lib.mtts_xcd_schedule_check(None, 1, 1, 0, None) == -1
+    for dims8 in cases:
+        for groups in (8, 4, 2):   # 4 / 2 groups (the ranks of a 2- / 4-rank job): every group cut into 2 / 4 parts, one per XCD
+            dims = dims8[:groups]
+            arr = (C.c_int * groups)(*[int(v) for v in dims])
+            for cls, tn, upg in ((1, 4, 0), (1, 1, 0), (1, 17, 0), (2, 1, 576), (2, 1, 37), (2, 1, 1)):
+                load = C.c_int(0)
+                slots = lib.mtts_xcd_schedule_check(arr, groups, cls, tn, upg, C.byref(load))
+                assert slots >= 0, (dims, cls, tn, upg)
+                units = sum((d + 63) // 64 for d in dims) if cls == 1 else upg * sum(1 for d in dims if d > 0)
+                if units >= 256 and min(dims) > 0:   # enough units to balance: the heaviest XCD stays within 15 % of a perfect eighth
+                    assert load.value <= 1150, (dims, groups, cls, tn, upg, load.value)
+    assert lib.mtts_xcd_schedule_check(None, 8, 1, 1, 0, None) == -1
+    assert lib.mtts_xcd_schedule_check((C.c_int * 3)(5, 6, 7), 3, 1, 1, 0, None) == -1   # only 8, 4 or 2 groups
 
 
 WORKER = r"""
@@ -45,15 +48,16 @@ lib = None if gpu else ge.build_emulator()
 dims = tiny_dims()
 kw = dict(n_mel=dims.n_mel, vocab=dims.vocab, s_range=(4, 15), d_range=(1, 7), first_len=12)
 mods = ["variance_adaptor", "decoder", "mel_linear", "postnet"]
-eng = Engine(dims, adapt_modules=mods, max_tasks=8, max_B=3, max_S=16, max_T=112, lib_path=lib)
+NT = {nt}
+eng = Engine(dims, adapt_modules=mods, max_tasks=NT, max_B=3, max_S=16, max_T=112, lib_path=lib)
 eng.load_params(synth.make_params(dims, 0))
-sup = [synth.make_batch(10 + j, 1 + j % 3, speaker=j, **kw) for j in range(8)]      # ragged: 1-3 utterances per task
-qry = [synth.make_batch(30 + j, 1 + (j + 1) % 3, speaker=j, **kw) for j in range(8)]
+sup = [synth.make_batch(10 + j, 1 + j % 3, speaker=j, **kw) for j in range(NT)]      # ragged: 1-3 utterances per task
+qry = [synth.make_batch(30 + j, 1 + (j + 1) % 3, speaker=j, **kw) for j in range(NT)]
 out = {{}}
 for order in (1, 2):
     eng.set_batches(0, sup)
     eng.set_batches(1, qry, spk_from=sup, average_spk=True)
-    q, sl = eng.meta_grad(2, 0.02, 0.125, second_order=(order == 2))
+    q, sl = eng.meta_grad(2, 0.02, 1.0 / NT, second_order=(order == 2))
     out[f"q{{order}}"] = q
     out[f"s{{order}}"] = sl
     for n in ("mel_linear.weight", "decoder.layer_stack.1.pos_ffn.w_1.weight", "encoder.layer_stack.0.slf_attn.fc.weight",
@@ -64,9 +68,9 @@ np.savez({path!r}, **out)
 """
 
 
-def _run(tmp_path, tag, env, gpu):
+def _run(tmp_path, tag, env, gpu, nt=8):
     path = str(tmp_path / f"{tag}.npz")
-    code = WORKER.format(root=ROOT, tests=os.path.join(ROOT, "tests"), gpu=gpu, path=path)
+    code = WORKER.format(root=ROOT, tests=os.path.join(ROOT, "tests"), gpu=gpu, path=path, nt=nt)
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=1200)
@@ -76,11 +80,14 @@ def _run(tmp_path, tag, env, gpu):
     return dict(np.load(path))
 
 
-def _compare(tmp_path, gpu):
-    # (emulator: MTTS_SK=0 — its default, the work-queue kernel, has a schedule of its own and would bypass this one)
-    common = {"MTTS_XCD_SCHED_DEBUG": "1"} if gpu else {"MTTS_SK": "0", "MTTS_XCD_SCHED_DEBUG": "1"}
-    a = _run(tmp_path, "on", dict(common, MTTS_XCD_SCHED="1"), gpu)
-    b = _run(tmp_path, "off", dict(common, MTTS_XCD_SCHED="0"), gpu)
+def _compare(tmp_path, gpu, nt=8):
+    # (emulator: MTTS_SK=0 — its default, the work-queue kernel, has a schedule of its own and would bypass this one;
+    #  MTTS_XCD_SCHED_MIN_GROUPS=2: the opt-in schedules of 4- and 2-task launches too)
+    common = {"MTTS_XCD_SCHED_DEBUG": "1", "MTTS_XCD_SCHED_MIN_GROUPS": "2"}
+    if not gpu:
+        common["MTTS_SK"] = "0"
+    a = _run(tmp_path, "on", dict(common, MTTS_XCD_SCHED="1"), gpu, nt)
+    b = _run(tmp_path, "off", dict(common, MTTS_XCD_SCHED="0"), gpu, nt)
     assert set(a) == set(b) and len(a) >= 16
     for k in a:
         assert np.isfinite(a[k]).all(), k
@@ -88,11 +95,13 @@ def _compare(tmp_path, gpu):
     assert np.abs(a["g1_mel_linear.weight"]).max() > 0 and np.abs(a["g2_mel_linear.weight"] - a["g1_mel_linear.weight"]).max() > 0
 
 
-def test_schedule_changes_nothing_emulator(tmp_path):
-    _compare(tmp_path, False)
+@pytest.mark.parametrize("nt", [8, 4, 2])
+def test_schedule_changes_nothing_emulator(tmp_path, nt):
+    _compare(tmp_path, False, nt)
 
 
 @pytest.mark.gpu
-def test_schedule_changes_nothing_gpu(tmp_path):
+@pytest.mark.parametrize("nt", [8, 4])
+def test_schedule_changes_nothing_gpu(tmp_path, nt):
     ge.build_device()
-    _compare(tmp_path, True)
+    _compare(tmp_path, True, nt)
