@@ -47,7 +47,8 @@ struct GemmGroupDesc {
     int lda, ldb, ldc;              // per-group leading dimensions (0: use GemmArgs')
 };
 
-// Task-per-XCD schedule of a launch of exactly 8 groups (the 8 tasks of a meta-batch on the 8 XCDs of the part).  The dispatcher deals
+// Task-per-XCD schedule of a launch of 8 groups (the 8 tasks of a meta-batch on the 8 XCDs of the part; opt-in also for 4 / 2 groups,
+// whose tasks are cut into 2 / 4 parts that play the role of the tasks below).  The dispatcher deals
 // consecutive workgroups round-robin to the XCDs, each with a private 4 MB L2; with the plain order every XCD touches every task and
 // streams every task's operands (the weight image of a dgrad, the activation panels of a wgrad) from the Infinity Cache / HBM: ~6x the
 // algorithmic bytes on the 8-task meta-step.  Here workgroup slot 8 j + x belongs to XCD x, which first runs its OWN task's units
@@ -175,8 +176,8 @@ struct GemmArgs {
     const float* A2 = nullptr;
     const float* B2 = nullptr;
     long long a2_gs = 0, b2_gs = 0;
-    // task-per-XCD schedule (8-group launches).  host_dims: HOST array of the 8 groups' dimptr values, read by the launcher to build
-    // `xs`; never dereferenced on the device.
+    // task-per-XCD schedule (launches of 8 — opt-in 4 / 2 — groups).  host_dims: HOST array of the groups' dimptr values, read by the
+    // launcher to build `xs`; never dereferenced on the device.
     const int* host_dims = nullptr;
     XcdSched xs;
 };
