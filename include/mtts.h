@@ -45,7 +45,7 @@ typedef struct mtts_model_cfg {
     float enc_dropout, dec_dropout, vp_dropout;
     /* preprocess_config["preprocessing"]["pitch" | "energy"]["feature"] == "frame_level" (lightning/model/modules.py:28-33,139-148,
      * loss.py:54-63): that feature's targets are [B][T_max] (one value per mel frame) and its predictor / embedding / loss run on
-     * the frame rectangle after the length regulator.  0 = phoneme_level (config/preprocess/LibriTTS.yaml).  First-order only. */
+     * the frame rectangle after the length regulator.  0 = phoneme_level (config/preprocess/LibriTTS.yaml).  First- and second-order. */
     int pitch_frame_level, energy_frame_level;
 } mtts_model_cfg;
 
@@ -63,7 +63,7 @@ typedef struct mtts_batch {
     const int64_t* durations; /* [B][S_max]          batch[11] */
     /* NULL, or [B][d_model] speaker embeddings used INSTEAD of the table lookup — `speaker_emb: dvec`, where batch[2] is
      * (ref_mels, ref_slices) and the embedding is the d-vector encoder's output (speaker_encoder.py:71-76; mtts_dvector_embed).
-     * `speakers` is ignored then; no speaker-table gradient; first-order / baseline passes only. */
+     * `speakers` is ignored then; no speaker-table gradient (the embeddings are inputs: no tangent in second-order passes either). */
     const float* spk_emb;
 } mtts_batch;
 
@@ -77,6 +77,17 @@ int mtts_set_stream(mtts_handle* h, void* hip_stream);
  * mtts_plain_grad calls ADD their (already grad_scale-d) result to the outer-gradient buffer instead of overwriting it; the caller
  * passes grad_scale / grad_acc_step, all-reduces and steps the optimizer once per grad_acc_step batches (systems.Trainer). */
 int mtts_set_grad_accumulation(mtts_handle* h, int accumulate);
+
+/* Numerics mode of the handle's contractions (every Linear / Conv1d / attention product, forward and backward; csrc/gemm_bf16.h).
+ * 0 (default): fp32 operands on the fp32-input MFMA — the reference's own arithmetic (main.py:110-112 passes no `precision=`), the
+ *    mode every parity gate (mel L1 <= 1e-4) is stated in.
+ * 1: bf16 operands (rounded to nearest even once, on the way into LDS), exact products, fp32 accumulation — BASELINE.json configs[1]
+ *    ("multi-task baseline bf16 on 1xMI355X"; what `Trainer(precision="bf16")` / torch.autocast(bfloat16) would make of the Linear /
+ *    Conv1d / bmm ops).  Parameters, optimizer state, LayerNorm / BatchNorm / softmax / losses and every tensor in HBM stay fp32.
+ *    The few problems whose conv taps do not cover whole 32-element K-slices (the PostNet's 80-channel output layer in its
+ *    input-gradient form) keep the fp32 kernels.  May be switched between calls; applies to the handle's three streams. */
+int mtts_set_numerics(mtts_handle* h, int mode);
+int mtts_get_numerics(mtts_handle* h);
 
 /* Train-mode dropout (nn.Dropout / F.dropout sites of SubLayers.py:54,90, modules.py:223,235, Layers.py:133-134).
  * Off by default — the parity configuration (SURVEY.md Appendix B.5 patches dropout to identity).  When on, masks are a
@@ -204,8 +215,8 @@ int mtts_profile_report(mtts_handle* h, double* out, int kinds);
 /* ---- kernel-level entry points (parity tests; dev pointers; stream may be NULL) ----------------
  * form 0: C[M,N] = alpha*A[M,K]*B[N,K]^T + bias   1: C = A[M,K]*B[K,N]   2: C[M,N] = A[K,M]^T*B[K,N]
  * flags bit0 ReLU, bit1 accumulate;
- * tile 0 (auto: the launch queue, normally the persistent work-queue kernel) / 64 / 128 (+1000 software-pipelined variant, +2000 BK = 32) /
- * 4064 LDS-DMA kernel / 5064, 5032 work-queue kernel with BK = 16 / 32 */
+ * tile 0 (auto: the launch queue — a plain 64x64 grid, the LDS-DMA kernels for under-filled launches) / 64 / 128 (+1000 software-pipelined
+ * variant, +2000 BK = 32) / 4064 LDS-DMA kernel.  These handle-less entries never split K (no hidden workspace). */
 int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, float alpha, int flags, int tile, void* hip_stream);
 /* Dual-source product in one accumulator chain: C = alpha * (op(A, B) + op(A2, B2)) + bias, same form / sizes / leading dimensions for
@@ -213,6 +224,10 @@ int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const 
  * reference: the double backward that `higher` records for lightning/systems/base_adaptor.py:107). */
 int mtts_gemm_f32_dual(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* A2, const float* B2,
                        float* C, int ldc, const float* bias, float alpha, int flags, int tile, void* hip_stream);
+/* The bf16 operand family on one problem (csrc/gemm_bf16.h): C = alpha * (op(A, B) [+ op(A2, B2)]) + bias with fp32 A / B in memory,
+ * rounded to bf16 on the way into LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation.  A2 / B2 both NULL or both set.  tile 0 (auto) / 64 / 128. */
+int mtts_gemm_bf16(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* A2, const float* B2,
+                   float* C, int ldc, const float* bias, float alpha, int flags, int tile, void* hip_stream);
 /* Host-only self check of the task-per-XCD workgroup schedule of 8- / 4- / 2-group launches (csrc/gemm.h: XcdSched): builds the schedule
  * for the `groups` group sizes `dims` (cls 1: M-ragged, units = m-tiles of 64 rows with tn tiles each; cls 2: K-ragged, units_per_group
  * tiles per group whose cost is dims[z]) and walks every workgroup slot.  Returns the number of slots when every (group, tile) is visited
@@ -290,8 +305,8 @@ int mtts_vocoder_infer_device(mtts_vocoder* h, const float* mel_dev, int64_t mel
  * resemblyzer `VoiceEncoder` (un-vendored; architecture restated by the reference's own GE2E class, :11-31: LSTM(n_mels -> hidden,
  * `layers` layers, batch_first) + Linear(hidden -> emb) + ReLU), applied to the partial utterances of the batch
  * (`spk_ref_mel_slices`, lightning/collate.py:29-43): partial embedding = L2-normalised ReLU(Linear(final hidden state of the last
- * layer)); utterance embedding = F.normalize(mean of its partials).  The trained variants ("encoder", "scratch_encoder") need the
- * LSTM backward and are not built.
+ * layer)); utterance embedding = F.normalize(mean of its partials).  The trained variants ("encoder", "scratch_encoder") are the
+ * mtts_dvector_enable_training / embed_train / backward / adam_step entries further down.
  * Tensors (torch names and layouts): lstm.weight_ih_l{k} [4*hidden][in], lstm.weight_hh_l{k} [4*hidden][hidden],
  * lstm.bias_ih_l{k}, lstm.bias_hh_l{k} [4*hidden] (gate order i, f, g, o), linear.weight [emb][hidden], linear.bias [emb].
  * embed: mels [n_partials][frames][n_mels] (host), utt_offsets [n_utts + 1] (partials of utterance b = [off[b], off[b+1]),

@@ -38,6 +38,8 @@ EXPORTS = {
     "mtts_last_error": (C.c_char_p, [C.c_void_p]),
     "mtts_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mtts_set_dropout": (C.c_int, [C.c_void_p, C.c_int, C.c_uint]),
+    "mtts_set_numerics": (C.c_int, [C.c_void_p, C.c_int]),
+    "mtts_get_numerics": (C.c_int, [C.c_void_p]),
     "mtts_synchronize": (C.c_int, [C.c_void_p]),
     "mtts_param_count": (C.c_int, [C.c_void_p]),
     "mtts_param_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int * 4),
@@ -85,6 +87,8 @@ EXPORTS = {
     "mtts_xcd_schedule_check": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "mtts_gemm_f32_dual": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "mtts_gemm_bf16": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "mtts_conv1d_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_void_p]),
     "mtts_kernel_ws_bytes": (C.c_int64, [C.c_int, C.c_int]),

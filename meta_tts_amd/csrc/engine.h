@@ -28,7 +28,7 @@
 
 #include "gemm.h"
 #include "gemm_glds.h"
-#include "gemm_sk.h"
+#include "gemm_bf16.h"
 #include "rowops.h"
 #include "plan.h"
 #include "tangent.h"
@@ -1542,7 +1542,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // per_step_sets: step s writes the encoder's activations into activation set s + 1 (second-order MAML keeps them for its reverse sweep)
     bool run_encoder_ahead(Plan& pl, int steps, unsigned* seeds, bool per_step_sets = false) {
         static const int on = [] { const char* e = getenv("MTTS_ENC_AHEAD"); return e ? atoi(e) : 1; }();
-        if (!on || steps < 1 || steps > kAhead || encoder_adapted() || !defer_ok(pl) || side2 == nullptr || gx.prof.enabled) return false;
+        if (!on || steps < 1 || steps > kAhead || encoder_adapted() || !defer_ok(pl) || side2 == nullptr) return false;
         for (int s = 0; s < steps; ++s) seeds[s] = next_drop_seed();
         hipEvent_t ev = ev_side[ev_next];
         ev_next = (ev_next + 1) % kSideEvents;
@@ -1605,7 +1605,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             // teacher-forced: nothing downstream in the forward reads the predictions (the decoder input uses the TARGET embeddings); with
             // an idle side stream the predictors overlap the decoder and are joined at the end of forward()
             static const bool pred_side = [] { const char* e = getenv("MTTS_PRED_SIDE"); return e ? atoi(e) != 0 : true; }();
-            if (pred_side && defer_ok(p) && !defer_live && !gx.prof.enabled) {
+            if (pred_side && defer_ok(p) && !defer_live) {
                 fork_side();
                 std::swap(stream, side);
                 std::swap(gx, gx_side);

@@ -19,12 +19,14 @@
 //  * grouped launch: blockIdx.z = group (task of the meta-batch, or (task, sequence, head) via a
 //    descriptor table), so the 8 MAML tasks — each with its own fast weights — fill the 256 CUs
 //    in one launch;
-//  * 256 threads = 4 waves (2x2), block tile 128x128 (wave 64x64 = 2x2 MFMA tiles, 64
-//    accumulator VGPRs) or 64x64; BK = 16; global -> registers -> LDS double buffering with one
-//    barrier per K-chunk.  K-contiguous operands live in LDS as [row][16+4] (80-byte rows:
-//    ds_read_b128 conflict-free), reduction-major operands as [16][cols].  Each lane half h
-//    feeds k = 8j+4h+e into MFMA step (j,e) for both operands, which lets a K-contiguous operand
-//    be fetched with two ds_read_b128 per 32-row subtile per chunk;
+//  * 256 threads = 4 waves (2x2); the block tile the engine uses is 64x64 (wave 32x32 = one MFMA tile, 16 accumulator VGPRs; 4-6
+//    workgroups per CU), K-slices of BK = 32 for long K-contiguous panels (full 128-byte lines per row) and 16 otherwise;
+//    128x128 (wave 64x64 = 2x2 MFMA tiles) exists for explicit tile codes.  global -> registers -> LDS double buffering with one
+//    barrier per K-slice, software-pipelined (the LDS store, the barrier and the fragment reads of slice c+1 sit between the two MFMA
+//    halves of slice c).  K-contiguous operands live in LDS as [row][BK+4] (ds_read_b128 conflict-free), reduction-major operands
+//    as [BK][cols].  Each lane half h feeds k = 8j+4h+e into MFMA step (j,e) of both operands, which lets a K-contiguous operand
+//    be fetched with two ds_read_b128 per 32-row subtile per slice.  The LDS-DMA family (gemm_glds.h) takes the under-filled launches;
+//    the bf16 operand family (gemm_bf16.h) is the optional reduced-precision mode (mtts_set_numerics);
 //  * fused epilogue: alpha, bias, ReLU, ReLU-mask of a saved activation (dgrad through ReLU),
 //    row mask (guard / padded rows), output row remap, accumulate.
 #pragma once
@@ -684,20 +686,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
 // [start[p], start[p+1]) of every z-slice belong to problem p.  The chip then never drains between two under-filled or
 // badly quantised grids — the tail of one problem is filled by the next — and it costs no stream / event traffic.
 constexpr int kGemmMultiMax = 6;
-// parameters of the persistent work-queue kernel (gemm_sk.h)
-struct GemmSk {
-    int ent_start[kGemmMultiMax + 1] = {0};  // first (problem, group) entry of each problem
-    int s_max = 4, min_chunks = 16, tol_div = 16;  // a late tile is cut into <= s_max pieces of >= min_chunks K-chunks; tolerated lateness = work / tol_div
-    int slabs = 0;                           // capacity of the partial-tile workspace (16 KB slabs, one arrival counter each)
-    float* ws = nullptr;
-    int* ctr = nullptr;
-    int run = 16;                            // consecutive items dealt to one XCD's queue
-    int* head = nullptr;                     // the eight item-queue heads of THIS launch (zero on entry)
-    int* head_next = nullptr;                // the other set, zeroed for the next launch
-};
 struct GemmMulti {
     int n = 0;
-    GemmSk sk;
     int start[kGemmMultiMax + 1] = {0};
     int form[kGemmMultiMax] = {0};
     int groups[kGemmMultiMax] = {0};
@@ -764,8 +754,11 @@ enum GemmKind {
     GK_F32_64_BK32 = 3,   // + form: gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0>
     GK_F32_128 = 6,       // + form: gemm_f32_kernel<F, 128, 128, *, *>
     GK_GLDS = 9,          // + form: gemm_glds_kernel<F>
-    GK_MULTI16 = 12, GK_MULTI32 = 13, GK_GLDS_MULTI = 14, GK_SK16 = 15, GK_SK32 = 16, GK_OTHER = 17,
-    GK_MULTI16_DUAL = 18, GK_MULTI32_DUAL = 19, GK_GLDS_MULTI_DUAL = 20, GK_COUNT = 21
+    GK_MULTI16 = 12, GK_MULTI32 = 13, GK_GLDS_MULTI = 14, GK_OTHER = 15,
+    GK_MULTI16_DUAL = 16, GK_MULTI32_DUAL = 17, GK_GLDS_MULTI_DUAL = 18,
+    GK_BF16_64 = 19,      // + form: gemm_bf16_kernel<F, 64, 64, 32>
+    GK_BF16_128 = 22,     // + form: gemm_bf16_kernel<F, 128, 128, 32>
+    GK_BF16_MULTI64 = 25, GK_BF16_MULTI128 = 26, GK_BF16_MULTI64_DUAL = 27, GK_BF16_MULTI128_DUAL = 28, GK_COUNT = 29
 };
 inline const char* gemm_kind_name(int k) {
     static const char* names[GK_COUNT] = {
@@ -773,8 +766,12 @@ inline const char* gemm_kind_name(int k) {
         "gemm_f32_kernel<0, 64, 64, 32, true, 2, 2, 0>", "gemm_f32_kernel<1, 64, 64, 32, true, 2, 2, 0>", "gemm_f32_kernel<2, 64, 64, 32, true, 2, 2, 0>",
         "gemm_f32_kernel<0, 128, 128, ...>", "gemm_f32_kernel<1, 128, 128, ...>", "gemm_f32_kernel<2, 128, 128, ...>",
         "gemm_glds_kernel<0>", "gemm_glds_kernel<1>", "gemm_glds_kernel<2>",
-        "gemm_f32_multi_kernel<64, 64, 16>", "gemm_f32_multi_kernel<64, 64, 32>", "gemm_glds_multi_kernel", "gemm_sk_kernel<16>", "gemm_sk_kernel<32>",
-        "gemm_f32_kernel<other>", "gemm_f32_multi_dual_kernel<64, 64, 16>", "gemm_f32_multi_dual_kernel<64, 64, 32>", "gemm_glds_multi_dual_kernel"};
+        "gemm_f32_multi_kernel<64, 64, 16>", "gemm_f32_multi_kernel<64, 64, 32>", "gemm_glds_multi_kernel",
+        "gemm_f32_kernel<other>", "gemm_f32_multi_dual_kernel<64, 64, 16>", "gemm_f32_multi_dual_kernel<64, 64, 32>", "gemm_glds_multi_dual_kernel",
+        "gemm_bf16_kernel<0, 64, 64, 32>", "gemm_bf16_kernel<1, 64, 64, 32>", "gemm_bf16_kernel<2, 64, 64, 32>",
+        "gemm_bf16_kernel<0, 128, 128, 32>", "gemm_bf16_kernel<1, 128, 128, 32>", "gemm_bf16_kernel<2, 128, 128, 32>",
+        "gemm_bf16_multi_kernel<64, 64, 32, false>", "gemm_bf16_multi_kernel<128, 128, 32, false>",
+        "gemm_bf16_multi_kernel<64, 64, 32, true>", "gemm_bf16_multi_kernel<128, 128, 32, true>"};
     return (k >= 0 && k < GK_COUNT) ? names[k] : "?";
 }
 
@@ -820,8 +817,7 @@ inline bool& gemm_default_pipe() {  // MTTS_GEMM_PIPE=0/1 overrides the built-in
     return v;
 }
 
-// Split-K / work-queue workspace (partial tiles + tile counters + the two queue heads): owned by a GemmCtx, allocated once by its
-// owner's create.
+// Split-K workspace (partial tiles + tile counters): owned by a GemmCtx, allocated once by its owner's create.
 struct GemmWorkspace { float* ws = nullptr; int* ctr = nullptr; };
 constexpr long long kSplitWsFloats = 16ll << 20;  // 64 MB of partial tiles
 constexpr int kSplitCtrs = 1 << 16;
@@ -836,48 +832,45 @@ inline int& gemm_splitk_minchunks() {  // K-chunks every split must keep (MTTS_S
 }
 
 // Launch batching: between gemm_batch_begin() and gemm_batch_end() every eligible gemm_launch (automatic tile choice) is queued
-// instead of launched; gemm_batch_end() issues the queue as ONE launch (gemm_f32_multi_kernel / gemm_glds_multi_kernel, or the
-// persistent work-queue kernel of gemm_sk.h when enabled).
+// instead of launched; gemm_batch_end() issues the queue as ONE launch (gemm_f32_multi_kernel / gemm_glds_multi_kernel).
 // The caller guarantees the queued problems are mutually independent and that nothing launched before gemm_batch_end()
 // reads their outputs (engine: the wgrad / dgrad pair of a layer, dQ / dK / dV of an attention block).
 struct GemmPending { int form; GemmArgs g; int max_M, max_N, groups; double flops, rows, bytes; };
-struct GemmBatch { bool open = false; std::vector<GemmPending> q; int force_family = 0; };   // force_family: 16 / 32 (BK of the register-staged multi-problem kernel) or 4064 (LDS-DMA) for the next flush (explicit tile codes of dual-source problems)
+struct GemmBatch { bool open = false; std::vector<GemmPending> q; int force_family = 0; int force_tile = 0; };   // force_family: 16 / 32 (BK of the register-staged multi-problem kernel) or 4064 (LDS-DMA) for the next flush (explicit tile codes of dual-source problems)
 inline bool& gemm_batch_enabled() {  // MTTS_GEMM_BATCH=0 launches every problem on its own (A/B runs)
     static bool v = [] { const char* e = getenv("MTTS_GEMM_BATCH"); return e ? atoi(e) != 0 : true; }();
     return v;
 }
 
-// Every piece of MUTABLE launcher state — the launch-batching queue, the per-launch profiler, the split-K / work-queue workspace —
+// Every piece of MUTABLE launcher state — the launch-batching queue, the per-launch profiler, the split-K workspace —
 // lives in a context owned by one handle (Engine / Vocoder / ...), so two handles on two host threads share nothing
-// (include/mtts.h conventions).  The workspace is allocated by the owner's create, never lazily.  One context = one stream
-// (the queue heads alternate between consecutive launches of a context).
+// (include/mtts.h conventions).  The workspace is allocated by the owner's create, never lazily; a context without one (the
+// handle-less kernel entry points) never splits K.  One context = one stream (the split-K slabs / counters of consecutive
+// launches are reused in stream order).
 struct GemmCtx {
     GemmBatch batch;
     GemmProfiler prof;
     GemmWorkspace wsp;
-    int* sk_heads = nullptr;   // two sets of eight queue heads (gemm_sk.h), inside the counter allocation
-    int sk_parity = 0;
     int last_kind = GK_OTHER;  // kernel kind of the last launch (profiler)
+    bool bf16 = false;         // numerics mode of the owner: bf16 operand family (gemm_bf16.h) for every problem it can take
+    const char* error = nullptr;   // sticky: a launch the launcher refused (the C ABI entry points turn it into an error return)
     bool flushing = false;     // gemm_batch_end is issuing the queue
     bool no_glds = false;   // never pick the LDS-DMA kernels (48 KB of LDS per workgroup: a side-stream launch would leave no LDS for the main stream's)
     int alloc_workspace() {
         if (wsp.ws) return 0;
         if (hipMalloc((void**)&wsp.ws, kSplitWsFloats * sizeof(float)) != hipSuccess || hipMalloc((void**)&wsp.ctr, (kSplitCtrs + 16) * sizeof(int)) != hipSuccess ||
             hipMemset(wsp.ctr, 0, (kSplitCtrs + 16) * sizeof(int)) != hipSuccess) { release(); return -1; }
-        sk_heads = wsp.ctr + kSplitCtrs;
         return 0;
     }
     void release() {
         if (wsp.ws) hipFree(wsp.ws);
         if (wsp.ctr) hipFree(wsp.ctr);
-        wsp.ws = nullptr; wsp.ctr = nullptr; sk_heads = nullptr;
+        wsp.ws = nullptr; wsp.ctr = nullptr;
         prof.destroy();
     }
 };
 inline void gemm_batch_begin(GemmCtx& cx) { if (gemm_batch_enabled()) cx.batch.open = true; }
 inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream);
-inline bool gemm_sk_launch(GemmCtx& cx, GemmMulti& mp, const std::vector<GemmPending>& q, hipStream_t stream, bool force);  // gemm_sk.h
-inline int& gemm_sk_enabled();
 
 // LDS-DMA kernel family (gemm_glds.h, device builds only).  MTTS_GLDS=0 keeps the register-staged kernels (A/B runs).
 inline bool& gemm_use_glds() {
@@ -900,6 +893,14 @@ inline void gemm_glds_launch(int form, const GemmArgs& g, dim3 grid, hipStream_t
 inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t stream, bool dual = false);
 #endif
 
+// bf16 operand family (gemm_bf16.h)
+inline bool gemm_bf16_ok(const GemmArgs& g);
+inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipStream_t stream);
+inline void gemm_bf16_multi_launch(const GemmMulti& mp, int T, bool dual, dim3 grid, hipStream_t stream);
+// block tile of a bf16 launch: 128x128 once the launch still fills the chip twice over with it (the MFMA rate is 16x the fp32 kernels':
+// a 64x64 tile moves 1 byte per 16 flop through the L2 -> LDS path), 64x64 for under-filled launches
+inline int gemm_bf16_tile(double rows, int tiles_n128) { return std::ceil(rows / 128.0) * tiles_n128 >= 512.0 ? 128 : 64; }
+
 // Task-per-XCD schedule (XcdSched) of a problem: exactly 8 groups whose sizes the caller knows on the host, whole tiles.  MTTS_XCD_SCHED=0: off.
 inline bool gemm_xcd_sched_for(GemmArgs& g, int max_M, int max_N, int groups, int S, int tile) {
     static const bool on = [] { const char* e = getenv("MTTS_XCD_SCHED"); return e ? atoi(e) != 0 : true; }();
@@ -919,9 +920,8 @@ inline bool gemm_xcd_sched_for(GemmArgs& g, int max_M, int max_N, int groups, in
 inline long gemm_xcd_sched_slots(const XcdSched& s) { return 8L * s.maxlen * (s.on == 1 ? s.tn : 1); }
 
 // Host launcher.  max_M / max_N bound the tile grid over all groups.  tile = 0: automatic — the problem goes through the launch
-// queue (alone if no batch is open): a plain 64x64 grid (LDS-DMA kernels in the latency regime, a multi-problem grid for a batch), or
-// the persistent work-queue kernel when that is switched on (gemm_sk.h).  An explicit tile code picks one kernel: 64 / 128 (+1000 software pipeline,
-// +2000 BK = 32), 4064 LDS-DMA, 5064 / 5032 work-queue kernel with BK = 16 / 32 (kernel tests, micro-benchmarks).
+// queue (alone if no batch is open): a plain 64x64 grid (LDS-DMA kernels in the latency regime, a multi-problem grid for a batch).
+// An explicit tile code picks one kernel: 64 / 128 (+1000 software pipeline, +2000 BK = 32), 4064 LDS-DMA (kernel tests, micro-benchmarks).
 // total_M = sum of the groups' row counts (0: max_M * groups).  alg_flops / alg_bytes: algorithmic (unpadded) work of this launch,
 // profiler only.
 inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, int max_N, int groups, hipStream_t stream,
@@ -934,39 +934,40 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     const int user_tile = tile;
     const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
     auto ntiles = [&](int t) { return (long)((max_M + t - 1) / t) * gemm_tiles_n(g, max_N, t); };
-    if (g.A2 && user_tile != 0 && user_tile != 5064 && user_tile != 5032 && !cx.flushing && !cx.batch.open) {
+    if (g.A2 && user_tile != 0 && !cx.flushing && !cx.batch.open) {
         // dual-source problems exist in the multi-problem kernels only: an explicit tile code picks the family (kernel tests)
         const int code = user_tile % 10000;
         cx.batch.force_family = code == 4064 ? 4064 : (code / 2000 ? 32 : 16);
+        cx.batch.force_tile = code % 1000 == 128 ? 128 : 64;   // (bf16 mode: the block tile of the forced launch)
         cx.batch.q.push_back(GemmPending{form, g, max_M, max_N, groups, alg_flops, rows, alg_bytes});
         gemm_batch_end(cx, stream);
-        cx.batch.force_family = 0;
+        cx.batch.force_family = 0; cx.batch.force_tile = 0;
         return;
     }
-    if (user_tile == 0 || user_tile == 5064 || user_tile == 5032) {
+    if (user_tile == 0) {
         if (!cx.flushing) {
             // through the queue: with the batch's other problems, or alone
             cx.batch.q.push_back(GemmPending{form, g, max_M, max_N, groups, alg_flops, rows, alg_bytes});
-            if (!cx.batch.open || user_tile != 0) {
-                const bool was_open = cx.batch.open;
-                if (user_tile != 0) cx.batch.q.back().g.swizzle = user_tile;   // (flag for gemm_batch_end: forced work-queue kernel)
+            if (!cx.batch.open) {
                 gemm_batch_end(cx, stream);
-                cx.batch.open = was_open;
             } else if ((int)cx.batch.q.size() == kGemmMultiMax) { gemm_batch_end(cx, stream); cx.batch.open = true; }
             return;
         }
         tile = 64;
     }
     if (g.A2) {   // (unreachable from the engine: gemm_batch_end never sends a dual-source problem to the stand-alone kernels)
-        fprintf(stderr, "mtts: dual-source GEMM handed to a stand-alone kernel (explicit tile code inside an open batch)\n");
-        abort();
+        cx.error = "dual-source GEMM handed to a stand-alone kernel (explicit tile code inside an open batch)";   // reported by the C ABI entry
+        return;
     }
     // tile code: 64 / 128 (+1000 software pipeline, +2000 BK=32); plain 64 / 128 take the defaults
     bool pipe = gemm_default_pipe();
     int bk = gemm_default_bk();
     bool glds = false;
+    const bool bf16 = cx.bf16 && gemm_bf16_ok(g) && !g.A2;
+    if (bf16 && user_tile == 0) tile = gemm_bf16_tile(rows, gemm_tiles_n(g, max_N, 128));
 #if !defined(MTTS_EMU)
-    if (tile == 4064) { glds = gemm_glds_ok(g); tile = 64; }            // explicit request (kernel tests, microbenchmarks)
+    if (bf16) { if (tile == 4064) tile = 64; }
+    else if (tile == 4064) { glds = gemm_glds_ok(g); tile = 64; }            // explicit request (kernel tests, microbenchmarks)
     else if (user_tile == 0 && tile == 64) {
         const long wgs = (long)std::ceil(rows / 64.0) * gemm_tiles_n(g, max_N, 64);
         glds = gemm_use_glds() && gemm_glds_ok(g) && wgs <= gemm_glds_max_wgs() && !cx.no_glds;
@@ -979,6 +980,7 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     if (tile >= 1000) { pipe = (tile / 1000) & 1; bk = (tile / 2000) ? 32 : 16; tile %= 1000; }
     if (user_tile == 0 && !g.table && gemm_keff(g) >= 1024 && (form == GEMM_NT || form == GEMM_TN)) bk = 32;  // long K-contiguous panels: full 128-B lines per row
     if (g.taps > 1 && g.tap_k % 32 != 0) bk = 16;  // a K-slice must not straddle two conv taps
+    if (bf16) bk = 32;
     // split-K for under-filled grids (single-task ranks, the phoneme-side GEMMs, small wgrads): enough workgroups for
     // ~4 per CU, each still reducing >= 4 K-chunks
     int S = 1;
@@ -1008,6 +1010,10 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
         else if (pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, true>), grid, block, stream, g); kind = (T == 64 ? GK_F32_64_BK16 : GK_F32_128) + F; }          \
         else { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, false>), grid, block, stream, g); kind = T == 64 ? GK_OTHER : GK_F32_128 + F; }                   \
     }
+    if (bf16) {
+        gemm_bf16_launch(form, g, tile, grid, stream);
+        kind = (tile == 128 ? GK_BF16_128 : GK_BF16_64) + form;
+    } else
 #if !defined(MTTS_EMU)
     if (glds) {
         gemm_glds_launch(form, g, grid, stream);
@@ -1031,7 +1037,7 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     if (prof.enabled) {
         hipEventRecord(e1, stream);
         GemmProfiler::Rec rec{kind, alg_flops, e0, e1};
-        rec.form = form; rec.tile = glds ? 4064 : tile; rec.N = max_N; rec.K = gemm_keff(g); rec.groups = groups; rec.splitk = S;
+        rec.form = form; rec.tile = bf16 ? 16000 + tile : (glds ? 4064 : tile); rec.N = max_N; rec.K = gemm_keff(g); rec.groups = groups; rec.splitk = S;
         rec.rows = rows;
         rec.bytes = alg_bytes;
         prof.recs.push_back(rec);
@@ -1050,33 +1056,6 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     struct Flush { GemmCtx& c; Flush(GemmCtx& x) : c(x) { c.flushing = true; } ~Flush() { c.flushing = false; } } guard(cx);
     std::stable_sort(b.q.begin(), b.q.end(), [](const GemmPending& x, const GemmPending& y) { return gemm_keff(x.g) > gemm_keff(y.g); });
     GemmProfiler& prof = cx.prof;
-    // ---- the persistent work-queue kernel (gemm_sk.h) whenever the launch carries enough work ----
-    int forced = 0;
-    for (GemmPending& p : b.q) if (p.g.swizzle == 5064 || p.g.swizzle == 5032) { forced = p.g.swizzle; p.g.swizzle = 0; }
-    if ((gemm_sk_enabled() || forced) && !b.force_family) {
-        GemmMulti mp;
-        mp.n = (int)b.q.size();
-        double flops = 0.0, rows = 0.0, bytes = 0.0;
-        int maxK = 0;
-        for (int i = 0; i < mp.n; ++i) {
-            const GemmPending& p = b.q[i];
-            mp.form[i] = p.form; mp.groups[i] = p.groups; mp.g[i] = p.g;
-            flops += p.flops; rows += p.rows; bytes += p.bytes; maxK = std::max(maxK, gemm_keff(p.g));
-        }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
-        if (gemm_sk_launch(cx, mp, b.q, stream, forced != 0)) {
-            if (prof.enabled) {
-                hipEventRecord(e1, stream);
-                GemmProfiler::Rec rec{cx.last_kind, flops, e0, e1};
-                rec.form = 3; rec.tile = 5064; rec.N = mp.n; rec.K = maxK; rec.groups = 0; rec.splitk = 1; rec.rows = rows; rec.bytes = bytes;
-                prof.recs.push_back(rec);
-            }
-            b.q.clear();
-            return;
-        }
-        if (prof.enabled) prof.used -= 2;   // (events not used)
-    }
     // MTTS_BATCH_MIN_K=n: pairs with a problem whose K-loop is shorter than n go out back to back instead of batched.  Round 2 measured
     // the K <= 256 pairs (fc, conv2) ~10 % slower batched in the BK = 16 multi-problem kernel (n was 512); with the BK = 32 kernel and the
     // task-per-XCD schedule batching them wins: 8-task step 170.9 -> 166.9 ms, second order 442 -> 436, 4-task rank 97.5 -> 95.2 (round 3) — 0 now.
@@ -1105,20 +1084,27 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     double work = 0.0;
     for (const GemmPending& p : b.q) work += std::ceil(p.rows / 64.0) * gemm_tiles_n(p.g, p.max_N, 64) * std::max(1, (gemm_keff(p.g) + 15) / 16);
     const double per_cu = work / 256.0;
-    double batch_wgs = 0.0;
-    for (const GemmPending& p : b.q) batch_wgs += std::ceil(p.rows / 64.0) * gemm_tiles_n(p.g, p.max_N, 64);
+    double batch_wgs = 0.0, batch_wgs128 = 0.0;
+    for (const GemmPending& p : b.q) {
+        batch_wgs += std::ceil(p.rows / 64.0) * gemm_tiles_n(p.g, p.max_N, 64);
+        batch_wgs128 += std::ceil(p.rows / 128.0) * gemm_tiles_n(p.g, p.max_N, 128);
+    }
     const bool small_batch = batch_wgs <= (double)gemm_glds_max_wgs();  // latency regime: split-K and the LDS-DMA kernels apply
+    // bf16 numerics mode: the whole launch takes the bf16 operand family when every problem qualifies (gemm_bf16_ok); block tile T
+    bool bf16 = cx.bf16;
+    for (const GemmPending& p : b.q) bf16 = bf16 && gemm_bf16_ok(p.g);
+    const int T = !bf16 ? 64 : (b.force_tile ? b.force_tile : (batch_wgs128 >= 512.0 ? 128 : 64));
     GemmWorkspace* wsp = nullptr;
     long long ws_off = 0, ctr_off = 0;
     for (int i = 0; i < mp.n; ++i) {
         const GemmPending& p = b.q[i];
         mp.form[i] = p.form; mp.groups[i] = p.groups; mp.g[i] = p.g;
         mp.g[i].swizzle = 0; mp.g[i].splitk = 1;
-        const int tiles = ((p.max_M + 63) / 64) * gemm_tiles_n(p.g, p.max_N, 64);
+        const int tiles = ((p.max_M + T - 1) / T) * gemm_tiles_n(p.g, p.max_N, T);
         int S = 1;
         const int nch = (gemm_keff(p.g) + 15) / 16;
         static const double ratio = [] { const char* e = getenv("MTTS_SPLIT_RATIO"); return e ? atof(e) : 1.5; }();
-        if (small_batch && !p.g.table && !p.g.colsum && gemm_splitk_target() != 0 && nch > per_cu / ratio) {
+        if (small_batch && T == 64 && !p.g.table && !p.g.colsum && gemm_splitk_target() != 0 && nch > per_cu / ratio) {
             S = (int)std::min<double>(std::min<double>(std::ceil(nch / std::max(per_cu / ratio, 1.0)), nch / 16), 8);
             const long long slots = (long long)tiles * p.groups;
             if (S >= 2 && ((ws_off + slots * S * 4096) > kSplitWsFloats || ctr_off + slots > kSplitCtrs)) S = 1;
@@ -1130,12 +1116,12 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
                 } else S = 1;
             } else S = 1;
         }
-        mp.xcd_group[i] = gemm_xcd_swizzle() ? std::min(gemm_tiles_n(p.g, p.max_N, 64) * S, 64) : 0;
+        mp.xcd_group[i] = gemm_xcd_swizzle() ? std::min(gemm_tiles_n(p.g, p.max_N, T) * S, 64) : 0;
         static const int task_xcd = [] { const char* e = getenv("MTTS_XCD_TASK"); return e ? atoi(e) : 0; }();   // experiment: 1 = NN problems, 2 = all
         if (task_xcd && !p.g.table && p.groups % 8 == 0 && (mp.start[i] & 7) == 0 && (task_xcd >= 2 || p.form == GEMM_NN)) mp.xcd_group[i] = -1;
         mp.tiles_pg[i] = tiles * S;
         long slots = (long)tiles * S * p.groups;
-        if (!task_xcd && gemm_xcd_sched_for(mp.g[i], p.max_M, p.max_N, p.groups, S, 64)) { mp.xcd_group[i] = -2; slots = gemm_xcd_sched_slots(mp.g[i].xs); }
+        if (!task_xcd && gemm_xcd_sched_for(mp.g[i], p.max_M, p.max_N, p.groups, S, T)) { mp.xcd_group[i] = -2; slots = gemm_xcd_sched_slots(mp.g[i].xs); }
         mp.start[i + 1] = mp.start[i] + (int)((slots + 7) & ~7L);   // (every problem starts on a multiple of 8: workgroup slot % 8 = XCD)
         max_groups = std::max(max_groups, p.groups);
         flops += p.flops; rows += p.rows; bytes += p.bytes;
@@ -1158,6 +1144,11 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     if (b.force_family) { glds = b.force_family == 4064; bk32 = bk32 && b.force_family == 32; if (bk32) maxK = std::max(maxK, 1024); }
     for (int i = 0; i < mp.n; ++i) glds = glds && gemm_glds_ok(mp.g[i]);
     int kind = GK_MULTI16;
+    if (bf16) {
+        gemm_bf16_multi_launch(mp, T, any_dual, grid, stream);
+        kind = T == 128 ? (any_dual ? GK_BF16_MULTI128_DUAL : GK_BF16_MULTI128) : (any_dual ? GK_BF16_MULTI64_DUAL : GK_BF16_MULTI64);
+        glds = false;
+    } else
 #if !defined(MTTS_EMU)
     if (glds) { gemm_glds_multi_launch(mp, grid, stream, any_dual); kind = any_dual ? GK_GLDS_MULTI_DUAL : GK_GLDS_MULTI; }
     else
@@ -1171,7 +1162,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     if (prof.enabled) {
         hipEventRecord(e1, stream);
         GemmProfiler::Rec rec{kind, flops, e0, e1};
-        rec.form = 3; rec.tile = glds ? 4064 : 64; rec.N = mp.n; rec.K = maxK; rec.groups = mp.start[mp.n]; rec.splitk = 1; rec.rows = rows; rec.bytes = bytes;  // multi: N = problems, K = longest K, groups = workgroups
+        rec.form = 3; rec.tile = bf16 ? 16000 + T : (glds ? 4064 : 64); rec.N = mp.n; rec.K = maxK; rec.groups = mp.start[mp.n]; rec.splitk = 1; rec.rows = rows; rec.bytes = bytes;  // multi: N = problems, K = longest K, groups = workgroups
         prof.recs.push_back(rec);
     }
     b.q.clear();

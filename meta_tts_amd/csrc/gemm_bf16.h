@@ -1,0 +1,345 @@
+// bf16 operand family of the grouped GEMM (the optional reduced-precision numerics mode, mtts_set_numerics(h, 1); BASELINE.json
+// configs[1] "bf16 on 1xMI355X").  Same problems, operand forms, grouped / multi-problem / dual-source launches, split-K rendezvous
+// and fused epilogue as gemm.h — only the K-loop differs:
+//
+//  * the matrix instruction is v_mfma_f32_32x32x16_bf16 (dense peak ~2.5 PFLOP/s, 16x the fp32-input MFMA): operands rounded to
+//    bf16 (round-to-nearest-even), products exact, fp32 accumulation.  Master weights, optimizer state, LayerNorm / BatchNorm /
+//    softmax statistics, losses and every tensor in HBM stay fp32 — this mode changes the arithmetic of the contractions only;
+//  * operands are read from HBM / L2 as fp32 and rounded ONCE, in the global -> LDS staging pass (one v_cvt_pk_bf16_f32 per two
+//    elements, hidden behind the previous slice's MFMAs); the K-loop itself is ds_read_b128 + MFMA with no VALU work per product
+//    (round 2's "bf16x3" split every operand into three planes inside the K-loop and ran at 1.13x the fp32 step — removed);
+//  * both LDS tiles are K-contiguous [rows][BK + 8] bf16 whatever the source layout: a K-contiguous fp32 operand (NT: A and B, NN: A)
+//    is staged float4 -> 4 bf16 (ds_write_b64); a reduction-major one (NN: B = the [Cout][k][Cin] weight image walked by taps, TN:
+//    both = row-major activations reduced over rows) is staged as 2(k) x 4(cols) register blocks whose column pairs (k, k+1) are
+//    exactly what v_cvt_pk packs — the transpose costs nothing beyond the conversion;
+//  * fragments: lane l feeds row / column l & 31 and the 8 consecutive k of half l >> 5 of a 16-deep MFMA step — ONE ds_read_b128
+//    per 32-row subtile per step for either operand (row stride 2 * (BK + 8) bytes: 80 for BK = 32, conflict-free for the b128
+//    lane groups); A and B use the same k order, so the in-instruction k permutation is immaterial;
+//  * the accumulator tile and its C/D lane mapping are those of the fp32 kernels (dtype-independent on gfx950), so gemm_epilogue,
+//    gemm_finish, slab_combine are shared.
+//
+// Reference ops served: the same as gemm.h (SubLayers.py:39-41,54,86; Modules.py:16,23; modules.py:253-296; Layers.py:33-64;
+// fastspeech2.py:97 and their autograd backward) under torch.autocast(bfloat16)-style operand rounding (BASELINE.md section 2 probe).
+#pragma once
+#include "gemm.h"
+
+namespace mtts {
+
+typedef unsigned short bf16_t;   // storage type of an LDS tile element
+struct alignas(8) u32x2 { unsigned x, y; };   // two packed bf16 pairs: one ds_write_b64
+
+#if defined(MTTS_EMU)
+__device__ __forceinline__ bf16_t f32_to_bf16(float x) {   // round-to-nearest-even (what v_cvt_pk_bf16_f32 does)
+    unsigned u; memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { unsigned u = (unsigned)h << 16; float x; memcpy(&x, &u, 4); return x; }
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
+#else
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {   // -> one v_cvt_pk_bf16_f32
+    f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+#endif
+
+template <int BM, int BN, int BK>
+struct GemmBf16Smem {
+    static constexpr int kLDK = BK + 8;                           // bf16 elements per LDS row
+    static constexpr int TILE_ELEMS = (BM + BN) * kLDK;           // one stage (A rows then B rows)
+    static constexpr int FLOATS = (2 * TILE_ELEMS + 1) / 2;       // two stages, expressed in floats
+};
+
+template <int TM, int TN>
+struct FragsBf16 {
+#if defined(MTTS_EMU)
+    float a[TM][16][16];   // the 16 A rows this lane's accumulators need x the 16 k of a step
+    float b[TN][16];       // the B column this lane's accumulators need
+#else
+    bf16x8 a[TM], b[TN];
+#endif
+};
+
+// K-loop of one output tile over the K-slices [c_lo, c_hi) of BK elements each (same contract as gemm_f32_kloop).
+template <int FORM, int BM, int BN, int BK, int WGM = 2, int WGN = 2>
+__device__ __forceinline__ void gemm_bf16_kloop(const GemmArgs& g, const GemmProb& pr, int z, int m0, int n0, bool cs_tile, int c_lo, int c_hi,
+                                                float* smem_f, f32x16 (&acc)[(BM / WGM) / 32][(BN / WGN) / 32]) {
+    constexpr int NTH = 64 * WGM * WGN;
+    constexpr int kLDK = BK + 8;
+    constexpr int KQ = BK / 4;               // float4 per K-contiguous source row
+    constexpr bool A_KC = (FORM != GEMM_TN);
+    constexpr bool B_KC = (FORM == GEMM_NT);
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    constexpr int STAGE = (BM + BN) * kLDK;  // bf16 elements per stage
+    constexpr int A_LD4 = (BM * KQ) / NTH;   // float4 loads per thread and slice (either source layout)
+    constexpr int B_LD4 = (BN * KQ) / NTH;
+    constexpr int RPP = NTH / KQ;            // K-contiguous rows covered per pass
+    static_assert(A_LD4 >= 2 && B_LD4 >= 2 && A_LD4 % 2 == 0 && B_LD4 % 2 == 0, "tile too small for the 2(k) x 4(col) staging blocks");
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_f);
+    const float* A = pr.A;
+    const float* B = pr.B;
+    const int M = pr.M, N = pr.N, K = pr.K;
+    const int lda = pr.lda;
+    int ldb = pr.ldb;
+
+    const int tid = MTTS_OPAQUE_TID(), lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+    const int M4 = (M + 3) & ~3, N4 = (N + 3) & ~3, K4 = (K + 3) & ~3;
+    int n0b = n0, N4b = N4;   // column window of the B operand
+    if (cs_tile) { B = g.colsum_w + (long long)z * g.colsum_w_gs; ldb = 4; n0b = 0; N4b = 4; }
+
+    float4 areg[A_LD4], breg[B_LD4];
+    int a_tap_i = 0, a_tap_base = 0, b_tap_i = 0, b_tap_base = 0;
+    auto a_tap_of = [&](int k0) { while (k0 - a_tap_base >= g.a_tap_k) { a_tap_base += g.a_tap_k; ++a_tap_i; } return a_tap_i; };
+    auto b_tap_of = [&](int k0) { while (k0 - b_tap_base >= g.tap_k) { b_tap_base += g.tap_k; ++b_tap_i; } return b_tap_i; };
+
+    // per-thread source pointers, hoisted out of the K-loop and advanced by one uniform distance per slice (see gemm_f32_kloop);
+    // rows / columns beyond the operand are clamped to the last valid one (their products only reach accumulator entries the epilogue
+    // never stores).  Reduction-major operands: load 2q + r of a thread is k-row 2 * kk2 + r of its (k-pair kk2, column quad c4) block.
+    const float* a_ptr[A_LD4];
+    const float* b_ptr[B_LD4];
+#pragma unroll
+    for (int i = 0; i < A_LD4; ++i) {
+        if (A_KC) {
+            int gm = m0 + tid / KQ + RPP * i;
+            gm = gm < M ? gm : M - 1;
+            a_ptr[i] = A + (long long)gm * lda + (tid % KQ) * 4;
+        } else {
+            const int u = tid + NTH * (i >> 1), kk = 2 * (u / (BM / 4)) + (i & 1), c4 = u % (BM / 4);
+            int gc = m0 + c4 * 4;
+            gc = gc < M4 ? gc : M4 - 4;
+            a_ptr[i] = A + (long long)kk * lda + gc;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD4; ++i) {
+        if (B_KC) {
+            int gn = n0 + tid / KQ + RPP * i;
+            gn = gn < N ? gn : N - 1;
+            b_ptr[i] = B + (long long)gn * ldb + (tid % KQ) * 4;
+        } else {
+            const int u = tid + NTH * (i >> 1), kk = 2 * (u / (BN / 4)) + (i & 1), c4 = u % (BN / 4);
+            int gc = n0b + c4 * 4;
+            gc = gc < N4b ? gc : N4b - 4;
+            b_ptr[i] = B + (long long)kk * ldb + gc;
+        }
+    }
+    long long a_koff = 0, b_koff = 0;
+    const long long a_tap_stride = (long long)g.a_tap_rows * lda;
+    auto load_a = [&](int k0) {
+        const int atap = A_KC ? a_tap_of(k0) : 0;
+        const long long koff = A_KC ? (long long)atap * a_tap_stride + (k0 - a_tap_base) : (long long)k0 * lda;
+        const long long delta = koff - a_koff;
+        a_koff = koff;
+#pragma unroll
+        for (int i = 0; i < A_LD4; ++i) a_ptr[i] += delta;
+        if (k0 + BK <= K) {
+#pragma unroll
+            for (int i = 0; i < A_LD4; ++i) areg[i] = ld4(a_ptr[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_LD4; ++i) {
+                const bool ok = A_KC ? (k0 + (tid % KQ) * 4 < K4) : (k0 + 2 * ((tid + NTH * (i >> 1)) / (BM / 4)) + (i & 1) < K);
+                areg[i] = ok ? ld4(a_ptr[i]) : zero4();
+            }
+        }
+    };
+    auto load_b = [&](int k0) {
+        const int tap = B_KC ? 0 : b_tap_of(k0);
+        const long long koff = B_KC ? (long long)k0 : (long long)(g.taps - 1 - tap) * g.tap_bstride + (long long)(k0 - b_tap_base) * ldb;
+        const long long delta = koff - b_koff;
+        b_koff = koff;
+#pragma unroll
+        for (int i = 0; i < B_LD4; ++i) b_ptr[i] += delta;
+        if (k0 + BK <= K) {
+#pragma unroll
+            for (int i = 0; i < B_LD4; ++i) breg[i] = ld4(b_ptr[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_LD4; ++i) {
+                const bool ok = B_KC ? (k0 + (tid % KQ) * 4 < K4) : (k0 + 2 * ((tid + NTH * (i >> 1)) / (BN / 4)) + (i & 1) < K);
+                breg[i] = ok ? ld4(b_ptr[i]) : zero4();
+            }
+        }
+    };
+    // fp32 registers -> bf16 LDS image [row][kLDK] (the one rounding of this mode)
+    auto store_ab = [&](int buf) {
+        bf16_t* As = smem + buf * STAGE;
+        bf16_t* Bs = As + BM * kLDK;
+        if (A_KC) {
+#pragma unroll
+            for (int i = 0; i < A_LD4; ++i) {
+                u32x2 v; v.x = pack2_bf16(areg[i].x, areg[i].y); v.y = pack2_bf16(areg[i].z, areg[i].w);
+                *reinterpret_cast<u32x2*>(As + (tid / KQ + RPP * i) * kLDK + (tid % KQ) * 4) = v;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < A_LD4 / 2; ++q) {
+                const int u = tid + NTH * q, kk = 2 * (u / (BM / 4)), c = (u % (BM / 4)) * 4;
+                const float4 r0 = areg[2 * q], r1 = areg[2 * q + 1];
+                *reinterpret_cast<unsigned*>(As + (c + 0) * kLDK + kk) = pack2_bf16(r0.x, r1.x);
+                *reinterpret_cast<unsigned*>(As + (c + 1) * kLDK + kk) = pack2_bf16(r0.y, r1.y);
+                *reinterpret_cast<unsigned*>(As + (c + 2) * kLDK + kk) = pack2_bf16(r0.z, r1.z);
+                *reinterpret_cast<unsigned*>(As + (c + 3) * kLDK + kk) = pack2_bf16(r0.w, r1.w);
+            }
+        }
+        if (B_KC) {
+#pragma unroll
+            for (int i = 0; i < B_LD4; ++i) {
+                u32x2 v; v.x = pack2_bf16(breg[i].x, breg[i].y); v.y = pack2_bf16(breg[i].z, breg[i].w);
+                *reinterpret_cast<u32x2*>(Bs + (tid / KQ + RPP * i) * kLDK + (tid % KQ) * 4) = v;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < B_LD4 / 2; ++q) {
+                const int u = tid + NTH * q, kk = 2 * (u / (BN / 4)), c = (u % (BN / 4)) * 4;
+                const float4 r0 = breg[2 * q], r1 = breg[2 * q + 1];
+                *reinterpret_cast<unsigned*>(Bs + (c + 0) * kLDK + kk) = pack2_bf16(r0.x, r1.x);
+                *reinterpret_cast<unsigned*>(Bs + (c + 1) * kLDK + kk) = pack2_bf16(r0.y, r1.y);
+                *reinterpret_cast<unsigned*>(Bs + (c + 2) * kLDK + kk) = pack2_bf16(r0.z, r1.z);
+                *reinterpret_cast<unsigned*>(Bs + (c + 3) * kLDK + kk) = pack2_bf16(r0.w, r1.w);
+            }
+        }
+    };
+    const int l31 = lane & 31, h = lane >> 5;
+    // the MFMA steps of one staged slice
+    auto compute = [&](int buf) {
+        const bf16_t* As = smem + buf * STAGE;
+        const bf16_t* Bs = As + BM * kLDK;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            FragsBf16<TM, TN> f;
+#if defined(MTTS_EMU)
+            for (int i = 0; i < TM; ++i)
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    for (int k = 0; k < 16; ++k) f.a[i][r][k] = bf16_to_f32(As[row * kLDK + ks * 16 + k]);
+                }
+            for (int j = 0; j < TN; ++j)
+                for (int k = 0; k < 16; ++k) f.b[j][k] = bf16_to_f32(Bs[(wn0 + j * 32 + l31) * kLDK + ks * 16 + k]);
+            for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j)
+                    for (int r = 0; r < 16; ++r) {
+                        float s = acc[i][j][r];
+                        for (int k = 0; k < 16; ++k) s = fmaf(f.a[i][r][k], f.b[j][k], s);
+                        acc[i][j][r] = s;
+                    }
+#else
+#pragma unroll
+            for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const bf16x8*>(As + (wm0 + i * 32 + l31) * kLDK + ks * 16 + 8 * h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn0 + j * 32 + l31) * kLDK + ks * 16 + 8 * h);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+#endif
+        }
+    };
+
+    const int nchunks = c_hi > c_lo ? c_hi - c_lo : 0;
+    if (nchunks == 0) return;
+    const int kb0 = c_lo * BK;
+    load_a(kb0);
+    load_b(kb0);
+    store_ab(0);
+    __syncthreads();
+    // double-buffered: the global loads of slice c+1 are in flight while slice c's MFMAs run; their conversion + LDS store follows
+    // the MFMAs (the loads have landed by then) and one barrier per slice hands the stage over.  Co-resident workgroups (3-6 per CU)
+    // cover each other's barrier intervals.
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) { load_a(kb0 + (c + 1) * BK); load_b(kb0 + (c + 1) * BK); }
+        compute(buf);
+        if (c + 1 < nchunks) store_ab(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// One workgroup's share of one problem (the bf16 twin of gemm_f32_body: same tile / split-K / column-sum / dual-source logic).
+template <int FORM, int BM, int BN, int BK, bool DUAL = false>
+__device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, int z, int bxs, float* smem) {
+    constexpr int WGM = 2, WGN = 2, NTH = 256;
+    constexpr int TM = (BM / WGM) / 32, TN = (BN / WGN) / 32;
+    const GemmProb pr = gemm_resolve(g, z);
+    const bool has_cs = gemm_has_colsum<FORM>(g);
+    const int tiles_nc = (pr.N + BN - 1) / BN, tiles_n = tiles_nc + (has_cs ? 1 : 0), tiles_m = (pr.M + BM - 1) / BM;
+    const int S = g.splitk > 1 ? g.splitk : 1;
+    const int tile_lin = bxs / S, split = bxs - tile_lin * S;
+    if (tile_lin >= tiles_m * tiles_n || pr.K <= 0) return;
+    const int m0 = (tile_lin / tiles_n) * BM, n0 = (tile_lin % tiles_n) * BN;
+    const bool cs_tile = has_cs && n0 == tiles_nc * BN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nch_all = (pr.K + BK - 1) / BK, cps = (nch_all + S - 1) / S;
+    const int c_lo = split * cps, c_hi = (c_lo + cps < nch_all) ? c_lo + cps : nch_all;
+    gemm_bf16_kloop<FORM, BM, BN, BK, WGM, WGN>(g, pr, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
+    if (DUAL) {
+        if (g.A2 != nullptr && !cs_tile) {
+            const GemmProb p2 = gemm_resolve2(g, z, pr);   // (the first K-loop ends on a barrier: its LDS stages are free)
+            gemm_bf16_kloop<FORM, BM, BN, BK, WGM, WGN>(g, p2, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
+        }
+    }
+    if (S > 1 && !splitk_combine<TM, TN, NTH>(g, z, tile_lin, split, S, acc)) return;
+    gemm_finish<TM, TN, WGM, WGN>(g, pr, z, m0, n0, cs_tile, acc);
+}
+
+template <int FORM, int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[GemmBf16Smem<BM, BN, BK>::FLOATS];
+    int z = blockIdx.z;
+    int bxs = blockIdx.x;
+    if (g.xs.on) { if (!xcd_sched_locate(g.xs, bxs, z, bxs)) return; }
+    else if (g.swizzle) bxs = xcd_group_remap(bxs, (int)gridDim.x, xcd_group_size((g.N + BN - 1) / BN, g.splitk));
+    gemm_bf16_body<FORM, BM, BN, BK>(g, z, bxs, smem);
+}
+
+// several independent problems in ONE launch (see gemm_f32_multi_kernel); DUAL: the launch may carry dual-source problems
+template <int BM, int BN, int BK, bool DUAL>
+__global__ __launch_bounds__(256) void gemm_bf16_multi_kernel(GemmMulti mp) {
+    __shared__ __attribute__((aligned(16))) float smem[GemmBf16Smem<BM, BN, BK>::FLOATS];
+    int p, z, bx;
+    if (!gemm_multi_locate(mp, p, z, bx)) return;
+    const int form = mp.form[p];
+    if (form == GEMM_NT) gemm_bf16_body<GEMM_NT, BM, BN, BK, DUAL>(mp.g[p], z, bx, smem);
+    else if (form == GEMM_NN) gemm_bf16_body<GEMM_NN, BM, BN, BK, DUAL>(mp.g[p], z, bx, smem);
+    else gemm_bf16_body<GEMM_TN, BM, BN, BK, DUAL>(mp.g[p], z, bx, smem);
+}
+
+constexpr int kBf16BK = 32;
+// a problem the bf16 K-loop can take: every conv tap must cover whole K-slices (the others — PostNet's 80-channel output layer in
+// dgrad form, the vocoder's dilated taps — keep the fp32 kernels: a few per cent of the step's flops)
+inline bool gemm_bf16_ok(const GemmArgs& g) {
+    if (g.taps > 1 && g.tap_k % kBf16BK != 0) return false;
+    if (g.a_tap_rows != 0) return false;
+    return true;
+}
+// stand-alone launch of one problem; T = 64 / 128
+inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipStream_t stream) {
+    dim3 block(256);
+#define MTTS_BF16_CASE(F, TT) if (form == F && T == TT) { MTTS_LAUNCH((gemm_bf16_kernel<F, TT, TT, kBf16BK>), grid, block, stream, g); return; }
+    MTTS_BF16_CASE(GEMM_NT, 64) MTTS_BF16_CASE(GEMM_NN, 64) MTTS_BF16_CASE(GEMM_TN, 64)
+    MTTS_BF16_CASE(GEMM_NT, 128) MTTS_BF16_CASE(GEMM_NN, 128) MTTS_BF16_CASE(GEMM_TN, 128)
+#undef MTTS_BF16_CASE
+}
+inline void gemm_bf16_multi_launch(const GemmMulti& mp, int T, bool dual, dim3 grid, hipStream_t stream) {
+    dim3 block(256);
+    if (T == 128) {
+        if (dual) MTTS_LAUNCH((gemm_bf16_multi_kernel<128, 128, kBf16BK, true>), grid, block, stream, mp);
+        else MTTS_LAUNCH((gemm_bf16_multi_kernel<128, 128, kBf16BK, false>), grid, block, stream, mp);
+    } else {
+        if (dual) MTTS_LAUNCH((gemm_bf16_multi_kernel<64, 64, kBf16BK, true>), grid, block, stream, mp);
+        else MTTS_LAUNCH((gemm_bf16_multi_kernel<64, 64, kBf16BK, false>), grid, block, stream, mp);
+    }
+}
+
+}  // namespace mtts

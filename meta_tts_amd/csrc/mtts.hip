@@ -27,6 +27,8 @@ static std::string g_create_error;
 // Every compute entry point ends here so such a failure is reported as an error, never as silently stale results.
 static int launched(Engine& e, int rc) {
     if (rc) return rc;
+    for (GemmCtx* cx : {&e.gx, &e.gx_side, &e.gx_side2})
+        if (cx->error) { e.set_error(std::string("GEMM launcher: ") + cx->error); cx->error = nullptr; return -1; }
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) { e.set_error(std::string("kernel launch failed: ") + hipGetErrorString(err)); return -1; }
     return 0;
@@ -89,6 +91,14 @@ int mtts_set_grad_accumulation(mtts_handle* h, int accumulate) {
     h->eng.outer_accumulate = accumulate != 0;
     return 0;
 }
+
+int mtts_set_numerics(mtts_handle* h, int mode) {
+    if (!h) return -1;
+    if (mode != 0 && mode != 1) { h->eng.set_error("numerics mode must be 0 (fp32) or 1 (bf16 operands, fp32 accumulate)"); return -1; }
+    h->eng.gx.bf16 = h->eng.gx_side.bf16 = h->eng.gx_side2.bf16 = (mode == 1);
+    return 0;
+}
+int mtts_get_numerics(mtts_handle* h) { return h && h->eng.gx.bf16 ? 1 : 0; }
 
 int mtts_set_dropout(mtts_handle* h, int enable, unsigned seed) {
     Engine& e = h->eng;
@@ -354,9 +364,10 @@ int mtts_reset_optimizer(mtts_handle* h) {
 
 int mtts_profile_gemm(mtts_handle* h, int enable) {
     if (!h) return -1;
-    GemmProfiler& p = h->eng.gx.prof;
-    p.reset();
-    p.enabled = enable != 0;
+    for (GemmCtx* cx : {&h->eng.gx, &h->eng.gx_side, &h->eng.gx_side2}) {   // the side streams' launches (deferred parameter gradients) count too
+        cx->prof.reset();
+        cx->prof.enabled = enable != 0;
+    }
     return 0;
 }
 
@@ -364,21 +375,31 @@ int mtts_profile_kinds(void) { return GK_COUNT; }
 const char* mtts_profile_kernel_name(int kind) { return gemm_kind_name(kind); }
 int mtts_profile_report(mtts_handle* h, double* out, int kinds) {
     if (!h || !out || kinds < GK_COUNT) return -1;
-    double r[GK_COUNT][4];
-    h->eng.gx.prof.report(r);
-    for (int k = 0; k < GK_COUNT; ++k) for (int j = 0; j < 4; ++j) out[k * 4 + j] = r[k][j];
+    for (int k = 0; k < GK_COUNT * 4; ++k) out[k] = 0.0;
+    for (GemmCtx* cx : {&h->eng.gx, &h->eng.gx_side, &h->eng.gx_side2}) {
+        double r[GK_COUNT][4];
+        cx->prof.report(r);
+        for (int k = 0; k < GK_COUNT; ++k) for (int j = 0; j < 4; ++j) out[k * 4 + j] += r[k][j];
+    }
     return 0;
 }
 
-// launcher state of the handle-less kernel-level entry points: one context per host thread; the work-queue workspace is allocated
-// on the first call of a thread (64 MB, kept for the life of the thread)
+// launcher state of the handle-less kernel-level entry points: one context per host thread, WITHOUT a split-K workspace — nothing is
+// allocated behind the caller's back, nothing is tied to the device that happened to be current on a thread's first call, and two
+// streams driven from one thread share no counters or slabs (the launcher keeps S = 1 when a context has no workspace; split-K is a
+// handle's business: its workspace is allocated by mtts_create on the handle's device and used on the handle's streams only)
 static GemmCtx& kernel_ctx() {
     static thread_local GemmCtx cx;
-    if (!cx.wsp.ws) cx.alloc_workspace();
     return cx;
 }
+// result of a kernel-level GEMM entry: a launch the launcher refused, or a launch error
+static int kernel_launch_rc() {
+    GemmCtx& cx = kernel_ctx();
+    if (cx.error) { cx.error = nullptr; (void)hipGetLastError(); return -1; }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 static bool tile_code_ok(int tile) {
-    return tile == 0 || tile == 4064 || tile == 5064 || tile == 5032 || ((tile % 1000 == 64 || tile % 1000 == 128) && tile % 10000 < 4000);
+    return tile == 0 || tile == 4064 || ((tile % 1000 == 64 || tile % 1000 == 128) && tile % 10000 < 4000);
 }
 
 int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
@@ -389,7 +410,7 @@ int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const 
     g.bias = bias; g.alpha = alpha; g.flags = flags & 0xff;
     if (flags & ~0xff) return -1;
     gemm_launch(kernel_ctx(), form, g, M, N, 1, (hipStream_t)stream, tile);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return kernel_launch_rc();
 }
 
 int mtts_xcd_schedule_check(const int* dims_in, int groups, int cls, int tn, int units_per_group, int* max_load_permille) {
@@ -429,7 +450,20 @@ int mtts_gemm_f32_dual(int form, int M, int N, int K, const float* A, int lda, c
     g.A = A; g.B = B; g.A2 = A2; g.B2 = B2; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.alpha = alpha; g.flags = flags & 0xff;
     gemm_launch(kernel_ctx(), form, g, M, N, 1, (hipStream_t)stream, tile);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return kernel_launch_rc();
+}
+
+int mtts_gemm_bf16(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* A2, const float* B2,
+                   float* C, int ldc, const float* bias, float alpha, int flags, int tile, void* stream) {
+    if (form < 0 || form > 2 || (tile != 0 && tile != 64 && tile != 128) || (flags & ~0xff) || ((A2 == nullptr) != (B2 == nullptr))) return -1;
+    GemmArgs g;
+    g.A = A; g.B = B; g.A2 = A2; g.B2 = B2; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.alpha = alpha; g.flags = flags & 0xff;
+    GemmCtx& cx = kernel_ctx();
+    cx.bf16 = true;
+    gemm_launch(cx, form, g, M, N, 1, (hipStream_t)stream, tile);
+    cx.bf16 = false;
+    return kernel_launch_rc();
 }
 
 int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* a, const float* b, float* out, const float* bias,
@@ -450,7 +484,7 @@ int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* a, c
         g.M = Cout; g.N = k * Cin; g.K = L;
         gemm_launch(kernel_ctx(), GEMM_TN, g, Cout, k * Cin, 1, (hipStream_t)stream, tile);
     }
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return kernel_launch_rc();
 }
 
 #include "kernel_api.inc"

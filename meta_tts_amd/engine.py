@@ -96,6 +96,13 @@ class Engine:
         """Train-mode dropout on/off (off = parity configuration)."""
         self._ck(self.lib.mtts_set_dropout(self.h, int(enable), int(seed) & 0xFFFFFFFF))
 
+    def set_numerics(self, mode: str = "fp32"):
+        """Arithmetic of the contractions: "fp32" (default; the reference's own and the parity mode) or "bf16" (bf16 operands, fp32
+        accumulation: BASELINE.json configs[1]; include/mtts.h: mtts_set_numerics)."""
+        if mode not in ("fp32", "bf16"):
+            raise ValueError("numerics mode must be 'fp32' or 'bf16'")
+        self._ck(self.lib.mtts_set_numerics(self.h, 1 if mode == "bf16" else 0))
+
     def set_grad_accumulation(self, accumulate: bool):
         """meta_grad / plain_grad add to the outer-gradient buffer instead of overwriting it (gradient accumulation, main.py:62)."""
         self._ck(self.lib.mtts_set_grad_accumulation(self.h, int(bool(accumulate))))

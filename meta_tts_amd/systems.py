@@ -389,19 +389,26 @@ class Trainer:
             self.outer = torch.as_tensor(self.system.engine.outer_grad_view(), device=f"cuda:{self.system.engine.device}")
         self.dist.all_reduce(self.outer, op=self.dist.ReduceOp.SUM, group=self.group)
 
-    def _accumulating(self) -> bool:
-        """Arms the engine for this batch; True when the optimizer must NOT step yet."""
-        self.system.engine.set_grad_accumulation(self._acc_i > 0)
+    def _with_accumulation(self, grad_call):
+        """Runs one gradient call of an accumulation window.  The engine's accumulate flag is armed for THIS call only (cleared in a
+        finally: a later direct System.training_step / engine.meta_grad must overwrite the outer buffer, not add to a stale one) and
+        the window advances only when the call succeeded (an exception mid-window leaves the window where it was).  Returns
+        (result, hold): hold = the optimizer must NOT step yet."""
+        eng = self.system.engine
+        eng.set_grad_accumulation(self._acc_i > 0)
+        try:
+            out = grad_call()
+        finally:
+            eng.set_grad_accumulation(False)
         self._acc_i += 1
         if self._acc_i < self.grad_acc:
-            return True
+            return out, True
         self._acc_i = 0
-        return False
+        return out, False
 
     def meta_step(self, local_tasks: Sequence[tuple], total_tasks: int):
         """One batch.  With grad_acc_step = N the optimizer steps on every N-th call (returned lr is None in between)."""
-        hold = self._accumulating()
-        q, s = self.system.meta_learn_tasks(local_tasks, total_tasks=total_tasks * self.grad_acc)
+        (q, s), hold = self._with_accumulation(lambda: self.system.meta_learn_tasks(local_tasks, total_tasks=total_tasks * self.grad_acc))
         if hold:
             return q, s, None
         self._allreduce()
@@ -422,8 +429,7 @@ class Trainer:
             # the LSTM speaker encoder's backward lives in System.training_step (one batch, one rank): stepping the optimizer from here
             # would update it from stale gradients and skew the joint clip norm
             raise NotImplementedError("speaker_emb: encoder / scratch_encoder train through System.training_step (single batch, single rank)")
-        hold = self._accumulating()
-        losses = self.system.engine_plain_grad(local_batches, total_batches * self.grad_acc)
+        losses, hold = self._with_accumulation(lambda: self.system.engine_plain_grad(local_batches, total_batches * self.grad_acc))
         if hold:
             return losses, None
         self._allreduce()

@@ -1,0 +1,178 @@
+"""The bf16 numerics mode (include/mtts.h: mtts_set_numerics; csrc/gemm_bf16.h) — BASELINE.json configs[1] "multi-task baseline bf16".
+
+Kernel level: mtts_gemm_bf16 against a float64 product of the operands ROUNDED TO BF16 (torch's round-to-nearest-even): the only
+differences left are fp32 accumulation order, so the bound is an fp32-roundoff one (the same as the fp32 kernels' tests), for the
+three operand forms, both block tiles, ragged sizes, dual-source problems and the fused epilogue.
+Model level: the whole forward / loss / backward with every contraction in bf16 against the fp32 oracle at a STATED bf16 tolerance
+(BASELINE.md section 2 probe: bf16 autocast moves the reference's mel output by L1 1.4e-3), and the mode must really change the
+arithmetic (results differ from the fp32 mode by more than fp32 noise)."""
+import numpy as np
+import pytest
+import torch
+
+from meta_tts_amd import synth
+from meta_tts_amd.config import ModelDims, default_algorithm_config
+from meta_tts_amd.engine import Engine
+from oracle import fs2_oracle as O
+from tests.test_kernel_entries import Dev
+from tests.oracle_util import tiny_dims
+import __graft_entry__ as ge
+
+# bf16 tolerances of the model-level checks (operands carry 8 significant bits: relative rounding 2^-9 = 2e-3 per operand, amplified by
+# the depth of a random-init network; measured: tiny model mel 1.3e-2 / loss 2e-3 / gradient median 3.5e-2, worst real tensor 0.25)
+BF16_LOSS_RTOL = 2e-2      # the six losses vs the fp32 oracle, relative to the total loss
+BF16_MEL_REL = 4e-2        # mean |mel_post - oracle| / mean |oracle|  (BASELINE.md probe on the reference: L1 1.4e-3 at C1)
+BF16_GRAD_L2 = 0.30        # per sampled parameter-gradient tensor: |g - g_ref|_2 / |g_ref|_2 ...
+BF16_GRAD_L2_MEDIAN = 0.10  # ... and the median over the sampled tensors
+
+
+@pytest.fixture(params=[pytest.param(False, id="emu"), pytest.param(True, id="gpu", marks=pytest.mark.gpu)])
+def dev(request):
+    if request.param:
+        ge.build_device()
+    return Dev(request.param)
+
+
+def _bf(x):
+    return torch.from_numpy(x).bfloat16().double().numpy()
+
+
+@pytest.mark.parametrize("tile", [0, 64, 128])
+@pytest.mark.parametrize("form", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(70, 40, 36), (33, 130, 100), (129, 64, 530), (300, 256, 1024)])
+def test_gemm_bf16_vs_rounded_operands(dev, form, tile, M, N, K):
+    g = np.random.RandomState(M + 3 * N + 7 * K + form)
+    pad4 = lambda x: (x + 3) & ~3
+    if form == 0:
+        A, B = np.zeros((M, pad4(K)), np.float32), np.zeros((N, pad4(K)), np.float32)
+        A[:, :K], B[:, :K] = g.standard_normal((M, K)), g.standard_normal((N, K))
+        ref, lda, ldb = _bf(A[:, :K]) @ _bf(B[:, :K]).T, pad4(K), pad4(K)
+    elif form == 1:
+        A, B = np.zeros((M, pad4(K)), np.float32), g.standard_normal((K, pad4(N))).astype(np.float32)
+        A[:, :K] = g.standard_normal((M, K))
+        ref, lda, ldb = _bf(A[:, :K]) @ _bf(B[:, :N]), pad4(K), pad4(N)
+    else:
+        A, B = g.standard_normal((K, pad4(M))).astype(np.float32), g.standard_normal((K, pad4(N))).astype(np.float32)
+        ref, lda, ldb = _bf(A[:, :M]).T @ _bf(B[:, :N]), pad4(M), pad4(N)
+    bias = g.standard_normal(N).astype(np.float32)
+    dA, dB, dbias = dev.put(A), dev.put(B), dev.put(bias)
+    out = dev.empty((M, pad4(N)), fill=7.0)
+    P = dev.ptr
+    assert dev.lib.mtts_gemm_bf16(form, M, N, K, P(dA), lda, P(dB), ldb, None, None, P(out), pad4(N), P(dbias), 0.5, 0, tile, None) == 0
+    got = dev.get(out)
+    want = 0.5 * ref + bias[None, :].astype(np.float64)
+    err = np.abs(got[:, :N] - want).max()
+    assert err < 3e-6 * np.sqrt(K) * max(1.0, np.abs(want).max()), err      # fp32 accumulation only: NOT a bf16-sized error
+    assert np.all(got[:, N:] == 7.0)
+    # and it is not the fp32 product: the unrounded reference is further away than the rounded one
+    full = A[:, :K].astype(np.float64) @ B[:, :K].astype(np.float64).T if form == 0 else (
+        A[:, :K].astype(np.float64) @ B[:, :N].astype(np.float64) if form == 1 else A[:, :M].astype(np.float64).T @ B[:, :N].astype(np.float64))
+    assert np.abs(got[:, :N] - (0.5 * full + bias[None, :])).max() > 10 * err
+
+
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("form", [0, 1, 2])
+def test_gemm_bf16_dual_source_relu_accumulate(dev, form, tile):
+    """C = relu(C_old + alpha (A B + A2 B2) + bias): one accumulator chain over both operand pairs, the shared fused epilogue."""
+    M, N, K = 152, 72, 200      # (row-major operands are read 4 floats at a time: leading dimensions are multiples of 4)
+    g = np.random.RandomState(form + tile)
+    shp = {0: ((M, K), (N, K)), 1: ((M, K), (K, N)), 2: ((K, M), (K, N))}[form]
+    mk = lambda: (g.standard_normal(shp[0]).astype(np.float32), g.standard_normal(shp[1]).astype(np.float32))
+    A, B = mk(); A2, B2 = mk()
+    prod = (lambda a, b: _bf(a) @ _bf(b).T) if form == 0 else ((lambda a, b: _bf(a) @ _bf(b)) if form == 1 else (lambda a, b: _bf(a).T @ _bf(b)))
+    bias = g.standard_normal(N).astype(np.float32)
+    c0 = g.standard_normal((M, N)).astype(np.float32)
+    out = dev.put(c0.copy())
+    P = dev.ptr
+    d = [dev.put(x) for x in (A, B, A2, B2, bias)]
+    assert dev.lib.mtts_gemm_bf16(form, M, N, K, P(d[0]), A.shape[1], P(d[1]), B.shape[1], P(d[2]), P(d[3]), P(out), N, P(d[4]), 0.25, 3, tile, None) == 0
+    want = np.maximum(c0 + 0.25 * (prod(A, B) + prod(A2, B2)) + bias[None, :], 0.0)
+    assert np.abs(dev.get(out) - want).max() < 1e-4 * max(1.0, np.abs(want).max())
+
+
+def _small_engine(gpu, tasks=1):
+    dims = tiny_dims()
+    mods = default_algorithm_config()["adapt"]["modules"]
+    eng = Engine(dims, adapt_modules=mods, max_tasks=tasks, max_B=3, max_S=16, max_T=96, lib_path=None if gpu else ge.build_emulator())
+    return dims, eng
+
+
+@pytest.mark.parametrize("gpu", [pytest.param(False, id="emu"), pytest.param(True, id="gpu", marks=pytest.mark.gpu)])
+def test_small_model_bf16_mode_tracks_fp32_oracle(gpu):
+    """Tiny architecture, forward + loss + full backward in the bf16 mode vs the fp32 oracle at the bf16 tolerances; the fp32 mode on the
+    same handle is tighter by orders of magnitude (the switch really changes the arithmetic, and switching back restores it)."""
+    dims, eng = _small_engine(gpu)
+    kw = dict(s_range=(5, 13), d_range=(1, 6), first_len=12, vocab=dims.vocab, n_mel=dims.n_mel)
+    batch = synth.make_batch(3, 3, speaker=2, **kw)
+    params = synth.make_params(dims, 0)
+    eng.load_params(params)
+    eng.set_batches(0, [batch])
+    p = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
+    for k in p:
+        if not k.endswith(("position_enc", "pitch_bins", "energy_bins")):
+            p[k].requires_grad_(True)
+    buf = {k: torch.from_numpy(v.copy()) for k, v in synth.make_buffers(dims).items()}
+    tb = O.to_torch_batch(batch)
+    o = O.fs2_forward(p, buf, *tb[2:], n_head=(dims.enc_heads, dims.dec_heads), training=True)
+    lo = O.fs2_loss(tb, o)
+    names = [k for k in p if p[k].requires_grad]
+    gref = dict(zip(names, torch.autograd.grad(lo[0], [p[k] for k in names], allow_unused=True)))
+    res = {}
+    for mode in ("bf16", "fp32"):
+        eng.set_numerics(mode)
+        eng.forward(0, use_fast=False, train=True)
+        mel = eng.outputs(0, 0)["mel_post"]
+        loss = eng.loss(0)[0]
+        eng.backward(0, use_fast=False, scale=1.0, need_encoder=True)
+        rels = []
+        for n in ("mel_linear.weight", "decoder.layer_stack.1.pos_ffn.w_1.weight", "encoder.layer_stack.0.slf_attn.w_qs.weight",
+                  "postnet.convolutions.1.0.conv.weight", "variance_adaptor.duration_predictor.conv_layer.conv1d_1.conv.weight",
+                  "decoder.layer_stack.0.slf_attn.fc.weight", "variance_adaptor.pitch_embedding.weight"):
+            gr = gref[n].numpy()
+            rels.append(float(np.linalg.norm(eng.export(n, 2, 0) - gr) / np.linalg.norm(gr)))
+        ref_mel = o[1].detach().numpy()
+        res[mode] = (float(np.abs(mel - ref_mel).mean() / np.abs(ref_mel).mean()),
+                     float(np.abs(loss - np.array([float(x.detach()) for x in lo])).max() / abs(float(lo[0].detach()))), max(rels), float(np.median(rels)))
+    eng.close()
+    l1_b, dl_b, g_b, gm_b = res["bf16"]
+    l1_f, dl_f, g_f, _ = res["fp32"]
+    assert l1_b < BF16_MEL_REL and dl_b < BF16_LOSS_RTOL and g_b < BF16_GRAD_L2 and gm_b < BF16_GRAD_L2_MEDIAN, res
+    assert l1_f < 1e-4 and dl_f < 1e-4 and g_f < 2e-3, res
+    assert l1_b > 20 * l1_f, res          # the bf16 mode is not the fp32 arithmetic under another name
+
+
+@pytest.mark.gpu
+def test_c2_batch16_bf16_vs_fp32_oracle():
+    """BASELINE config C2 AS STATED: algorithm=baseline, synthetic LibriTTS batch of 16 at full model size, bf16 contractions — the six
+    losses and sampled parameter gradients of the plain step against the fp32 oracle at the stated bf16 tolerances."""
+    ge.build_device()
+    dims = ModelDims()
+    batch = synth.make_batch(0, 16)
+    params = synth.make_params(dims, 0)
+    eng = Engine(dims, adapt_modules=(), max_tasks=1, max_B=16, max_S=80, max_T=int(batch[8]))
+    eng.load_params(params)
+    eng.set_batches(0, [batch])
+    eng.set_numerics("bf16")
+    losses = eng.plain_grad(0, 1.0)[0]
+    p = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
+    for k in p:
+        if not k.endswith(("position_enc", "pitch_bins", "energy_bins")):
+            p[k].requires_grad_(True)
+    buf = {k: torch.from_numpy(v.copy()) for k, v in synth.make_buffers(dims).items()}
+    tb = O.to_torch_batch(batch)
+    lo = O.fs2_loss(tb, O.fs2_forward(p, buf, *tb[2:], n_head=(dims.enc_heads, dims.dec_heads), training=True))
+    ref = np.array([float(x.detach()) for x in lo])
+    assert np.abs(losses - ref).max() < BF16_LOSS_RTOL * abs(ref[0]), (losses, ref)
+    assert np.abs(losses - ref).max() > 1e-6 * abs(ref[0])        # not the fp32 arithmetic
+    names = ["mel_linear.weight", "decoder.layer_stack.5.pos_ffn.w_2.weight", "decoder.layer_stack.0.slf_attn.w_qs.weight",
+             "encoder.layer_stack.3.pos_ffn.w_1.weight", "postnet.convolutions.2.0.conv.weight", "postnet.convolutions.4.0.conv.weight",
+             "variance_adaptor.pitch_predictor.conv_layer.conv1d_2.conv.weight", "encoder.layer_stack.0.slf_attn.fc.bias"]   # (no zero-gradient tensors:
+    # a conv bias in front of a BatchNorm / an attention key bias has an exactly-zero gradient, pure rounding noise in any arithmetic)
+    gr = torch.autograd.grad(lo[0], [p[n] for n in names])
+    rels = {}
+    for n, g in zip(names, gr):
+        got = eng.export(n, 2, 0)
+        rels[n] = float(np.linalg.norm(got - g.numpy()) / np.linalg.norm(g.numpy()))
+    print("C2 bf16 vs fp32 oracle: loss rel", float(np.abs(losses - ref).max() / abs(ref[0])), "grad L2 rel", rels)
+    assert max(rels.values()) < BF16_GRAD_L2 and np.median(list(rels.values())) < BF16_GRAD_L2_MEDIAN, rels
+    eng.close()

@@ -62,11 +62,9 @@ OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "M
 
 
 def _compare(tmp_path, gpu):
-    # emulator arm: whole tiles only (MTTS_SK_SMAX=1) — the work-queue kernel cuts the late tiles of a launch into pieces, and which
-    # tiles are late depends on what shares the launch, i.e. on the very batching the knobs change; without pieces the comparison is exact
     # (MTTS_SO_KEEP_GRAD=0 in both arms: with kept primal gradients the reverse sweep reads the dz of the first sweep's LayerNorm backward
     # instead of the tangent kernel's own — equal up to rounding, compared separately below)
-    common = {"MTTS_SO_KEEP_GRAD": "0"} if gpu else {"MTTS_SK_SMAX": "1", "MTTS_SO_KEEP_GRAD": "0"}
+    common = {"MTTS_SO_KEEP_GRAD": "0"}
     a = _run(tmp_path, "on", dict(common), gpu)
     b = _run(tmp_path, "off", dict(OFF, **common), gpu)
     c = _run(tmp_path, "keepgrad", {k: v for k, v in common.items() if k != "MTTS_SO_KEEP_GRAD"}, gpu)   # the default configuration

@@ -25,7 +25,7 @@ def _rand(g, *shape):
     return torch.from_numpy(g.standard_normal(shape).astype(np.float32)).cuda()
 
 
-@pytest.mark.parametrize("tile", [0, 64, 128, 1064, 1128, 2064, 3064, 3128, 4064, 5064, 5032])
+@pytest.mark.parametrize("tile", [0, 64, 128, 1064, 1128, 2064, 3064, 3128, 4064])
 @pytest.mark.parametrize("form", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 80, 256), (300, 768, 48), (33, 130, 100), (5, 7, 20), (200, 256, 1100), (190, 70, 517)])
 def test_gemm_forms(lib, form, tile, M, N, K):
@@ -60,7 +60,7 @@ def test_gemm_forms(lib, form, tile, M, N, K):
     assert (C2[:, :N].double() - want2).abs().max().item() < 2e-5 * max(1.0, want2.abs().max().item())
 
 
-@pytest.mark.parametrize("tile", [0, 64, 1064, 3064, 4064, 5064, 5032])
+@pytest.mark.parametrize("tile", [0, 64, 1064, 3064, 4064])
 @pytest.mark.parametrize("form", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 80, 256), (33, 130, 100), (200, 256, 1100), (190, 70, 517), (2100, 256, 2304)])
 def test_gemm_dual_source(lib, form, tile, M, N, K):
@@ -97,7 +97,7 @@ def test_gemm_dual_source(lib, form, tile, M, N, K):
     assert (C2[:, :N] - Cm[:, :N]).abs().max().item() < 3e-5 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize("tile", [0, 64, 128, 1064, 1128, 3064, 3128, 4064, 5064, 5032])
+@pytest.mark.parametrize("tile", [0, 64, 128, 1064, 1128, 3064, 3128, 4064])
 @pytest.mark.parametrize("L,Cin,Cout,k", [(97, 32, 48, 3), (300, 256, 1024, 9), (211, 80, 512, 5), (150, 1024, 256, 1), (64, 512, 80, 5)])
 def test_conv1d_fwd_dgrad_wgrad(lib, tile, L, Cin, Cout, k):
     g = np.random.RandomState(L + Cin + Cout + k)
@@ -125,37 +125,3 @@ def test_conv1d_fwd_dgrad_wgrad(lib, tile, L, Cin, Cout, k):
     assert (dx - dxr).abs().max().item() < tol(dxr)
     dwr = wt.grad.permute(0, 2, 1)
     assert (dw - dwr).abs().max().item() < tol(dwr) * 4
-
-
-@pytest.mark.parametrize("tile", [5064, 5032])
-@pytest.mark.parametrize("form", [0, 1, 2])
-@pytest.mark.parametrize("M,N,K", [(20000, 256, 2304), (9000, 1024, 1100), (70000, 64, 600), (2100, 256, 9216), (1300 * 64, 64, 520)])
-def test_work_queue_kernel_split_tail(lib, form, tile, M, N, K):
-    """The persistent work-queue kernel (csrc/gemm_sk.h) on launches of several dispatch rounds whose last round is cut into pieces
-    (partial-tile slabs + last-arriver reduction): same result as a float64 product, bit-identical when repeated (the pieces are
-    summed in piece order, whichever arrives last)."""
-    g = np.random.RandomState(M + N * 3 + K * 5 + form)
-    if form == 2:
-        M, N, K = N, 2304 if K > 2304 else K, M // 8   # wgrad-like: small output, long reduction over rows
-    pad4 = lambda x: (x + 3) & ~3
-    if form == 0:
-        A = _rand(g, M, pad4(K)); B = _rand(g, N, pad4(K)); A[:, K:] = 0; B[:, K:] = 0
-        ref = A[:, :K].double() @ B[:, :K].double().T; lda, ldb = pad4(K), pad4(K)
-    elif form == 1:
-        A = _rand(g, M, pad4(K)); B = _rand(g, K, pad4(N)); A[:, K:] = 0
-        ref = A[:, :K].double() @ B[:, :N].double(); lda, ldb = pad4(K), pad4(N)
-    else:
-        A = _rand(g, K, pad4(M)); B = _rand(g, K, pad4(N))
-        ref = A[:, :M].double().T @ B[:, :N].double(); lda, ldb = pad4(M), pad4(N)
-    bias = _rand(g, N)
-    outs = []
-    for rep in range(2):
-        Cm = torch.full((M, pad4(N)), 7.0, device="cuda")
-        assert lib.mtts_gemm_f32(form, M, N, K, P(A), lda, P(B), ldb, P(Cm), pad4(N), P(bias), 0.5, 0, tile, None) == 0
-        torch.cuda.synchronize()
-        outs.append(Cm)
-    want = 0.5 * ref + bias.double()[None, :]
-    err = (outs[0][:, :N].double() - want).abs().max().item()
-    assert err < 1e-5 * np.sqrt(K) * max(1.0, want.abs().max().item()) / 10, err
-    assert torch.all(outs[0][:, N:] == 7.0)
-    assert torch.equal(outs[0], outs[1])

@@ -123,12 +123,11 @@ def test_second_order_two_of_eight_vs_oracle(tasks):
     eng.close()
 
 
-@pytest.mark.parametrize("knobs", ["MTTS_DEFER_WGRAD=0 MTTS_ENC_AHEAD=0 MTTS_PRED_SIDE=0", "MTTS_SK=1 MTTS_SK_MIN_UNITS=0 MTTS_SK_MIN_TILE=0"])
+@pytest.mark.parametrize("knobs", ["MTTS_DEFER_WGRAD=0 MTTS_ENC_AHEAD=0 MTTS_PRED_SIDE=0"])
 def test_reference_fixtures_on_the_other_launch_paths(knobs):
     """The small-plan tests against the REFERENCE fixtures (small-batch gradients, the contractive lr-1e-3 MAML fixture first and
-    second order, two ragged tasks) once more with (a) the single-stream order — no deferred weight gradients, no encoder run-ahead,
-    no side-stream predictors —, (b) the opt-in persistent work-queue kernel (csrc/gemm_sk.h) forced onto every queued launch.  The
-    switches are read once per process, hence the child."""
+    second order, two ragged tasks) once more with the single-stream order — no deferred weight gradients, no encoder run-ahead,
+    no side-stream predictors.  The switches are read once per process, hence the child."""
     env = dict(os.environ)
     for kv in knobs.split():
         k, v = kv.split("=")

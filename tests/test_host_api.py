@@ -680,6 +680,23 @@ def test_gradient_accumulation_matches_one_step_on_the_joint_batch(cfgs, emu_lib
         a, b = acc.state_dict()[k], ref.state_dict()[k]
         np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-7, err_msg=k)
         assert np.abs(a - (before if k == "model.mel_linear.weight" else a * 0 + 1e9)).max() > 0
+    # the accumulate flag is armed for ONE call: a direct gradient call between two batches of a window overwrites the outer buffer
+    # instead of adding to the window's, and a failing call leaves the window where it was
+    tr2 = Trainer(get_system("meta")(pre, mc, tc2, ac, max_tasks=2, max_batch=3, max_src_len=16, max_mel_len=96, lib_path=emu_lib))
+    tr2.meta_step([t1], total_tasks=1)
+    _, _, lr = tr2.meta_step([t2], total_tasks=1)          # second batch of the window: accumulates, steps
+    assert lr is not None and tr2._acc_i == 0
+    tr2.meta_step([t1], total_tasks=1)                     # a new window is open (outer buffer holds t1's gradient) ...
+    tr2.system.meta_learn_tasks([t2], total_tasks=1)       # ... a direct call must OVERWRITE it
+    direct = tr2.system.engine.export("mel_linear.weight", 1)
+    fresh = get_system("meta")(pre, mc, tc, ac, max_tasks=2, max_batch=3, max_src_len=16, max_mel_len=96, lib_path=emu_lib)
+    fresh.engine.load_params({k[len("model."):]: v for k, v in tr2.system.state_dict().items() if k.startswith("model.") and k[len("model."):] in fresh.engine.params})
+    fresh.meta_learn_tasks([t2], total_tasks=1)
+    np.testing.assert_allclose(direct, fresh.engine.export("mel_linear.weight", 1), rtol=1e-5, atol=1e-8)
+    assert tr2._acc_i == 1
+    with pytest.raises(Exception):
+        tr2.meta_step([(t1[0],)], total_tasks=1)           # malformed task: the gradient call raises ...
+    assert tr2._acc_i == 1                                  # ... and the window has not advanced
     tc0 = copy.deepcopy(tc)
     tc0["optimizer"]["grad_acc_step"] = 0
     with pytest.raises(ValueError):

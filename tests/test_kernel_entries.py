@@ -253,13 +253,13 @@ def test_layernorm_and_softmax_jvp(dev, rows, Cc, full):
     np.testing.assert_allclose(dev.get(dtS)[:, :, :L], ref.numpy(), rtol=2e-4, atol=2e-6)
 
 
-@pytest.mark.parametrize("tile", [0, 64, 5064])
+@pytest.mark.parametrize("tile", [0, 64, 4064])
 @pytest.mark.parametrize("form", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(70, 40, 36), (33, 130, 100), (129, 64, 530)])
 def test_gemm_dual_source(dev, form, tile, M, N, K):
     """mtts_gemm_f32_dual: C = alpha (A B + A2 B2) + bias in ONE accumulator chain (csrc/gemm.h: GemmArgs::A2 — the shape of every tangent
     product of second-order MAML, base_adaptor.py:107) against float64, for the three operand forms, through the launch queue (tile 0),
-    a plain 64x64 grid and the work-queue kernel."""
+    a plain 64x64 grid and the LDS-DMA family."""
     g = np.random.RandomState(M + 3 * N + 7 * K + form)
     pad4 = lambda x: (x + 3) & ~3
 

@@ -81,11 +81,8 @@ def _run(tmp_path, tag, env, gpu, nt=8):
 
 
 def _compare(tmp_path, gpu, nt=8):
-    # (emulator: MTTS_SK=0 — its default, the work-queue kernel, has a schedule of its own and would bypass this one;
-    #  MTTS_XCD_SCHED_MIN_GROUPS=2: the opt-in schedules of 4- and 2-task launches too)
+    # (MTTS_XCD_SCHED_MIN_GROUPS=2: the opt-in schedules of 4- and 2-task launches too)
     common = {"MTTS_XCD_SCHED_DEBUG": "1", "MTTS_XCD_SCHED_MIN_GROUPS": "2"}
-    if not gpu:
-        common["MTTS_SK"] = "0"
     a = _run(tmp_path, "on", dict(common, MTTS_XCD_SCHED="1"), gpu, nt)
     b = _run(tmp_path, "off", dict(common, MTTS_XCD_SCHED="0"), gpu, nt)
     assert set(a) == set(b) and len(a) >= 16

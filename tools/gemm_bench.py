@@ -30,8 +30,8 @@ def bench(form, tile, M, N, K, reps=5):
     return 2.0 * M * N * K / (ms * 1e-3) / 1e12, ms
 
 
-# tile codes (include/mtts.h): 1064 / 3064 register-staged 64x64 BK16 / BK32, 4064 LDS-DMA, 1128 / 3128 128x128, 5064 / 5032 work-queue kernel BK16 / BK32
-TILES = tuple(int(t) for t in os.environ.get('BENCH_TILES', '3064,4064,5064,5032').split(','))
+# tile codes (include/mtts.h): 1064 / 3064 register-staged 64x64 BK16 / BK32, 4064 LDS-DMA, 1128 / 3128 128x128
+TILES = tuple(int(t) for t in os.environ.get('BENCH_TILES', '3064,4064,3128').split(','))
 shapes = [("square4096", 4096, 4096, 4096), ("conv1_fwd 8 tasks", 17047, 1024, 2304), ("conv1_dgrad", 17047, 256, 9216), ("conv2_fwd", 17047, 256, 1024),
           ("qkv", 17047, 768, 256), ("out_proj", 17047, 256, 256), ("postnet_mid", 22132, 512, 2560), ("dec 1 task", 2100, 256, 1024),
           ("1task fc", 1950, 256, 256), ("1task qkv", 1950, 768, 256), ("1task conv1", 1950, 1024, 2304), ("1task dgrad", 1950, 256, 9216), ("1task enc", 424, 256, 768)]
