@@ -566,9 +566,11 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             if outer is None:
-                eng.allreduce_outer()
+                eng.allreduce_outer()          # gradient + exchange tail (loss scalars, BatchNorm buffers) in one ncclAllReduce
             else:
+                eng.sync_pack(1.0 if rank == 0 else 0.0)
                 dist.all_reduce(outer, op=dist.ReduceOp.SUM)
+                eng.sync_unpack()
             if timed_ar:
                 e1.record()
                 ar_events.append((e0, e1))
@@ -729,6 +731,7 @@ def main():
                 "batch_ingest_ms_per_step": round(ingest_ms, 3),
                 "rccl_ranks": n if n > 1 else None, "allreduce_impl": ar_impl, "allreduce_ms_per_step": round(ar_ms, 3) if ar_ms is not None else None,
                 "allreduce_payload_mbytes": round(4e-6 * eng.n_total, 1) if n > 1 else None,
+                "allreduce_carries": "flat outer gradient + 6 loss scalars (sync_dist mean) + PostNet BatchNorm running buffers (rank 0's, as DDP broadcast_buffers)" if n > 1 else None,
                 "query_total_loss_mean": round(float(q_losses[:, 0].mean()), 5) if q_losses is not None else None}
         if so is not None:
             line["second_order"] = so

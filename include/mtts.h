@@ -191,6 +191,19 @@ int mtts_comm_available(mtts_handle* h);   /* 0 when librccl can be loaded in th
 int mtts_comm_unique_id(mtts_handle* h, void* id128);
 int mtts_comm_init(mtts_handle* h, const void* id128, int rank, int world_size);
 int mtts_allreduce_outer(mtts_handle* h);
+/* What DDP moves between ranks BESIDES the gradient rides behind the flat outer gradient in the same buffer and the same collective:
+ * [n_total .. n_total+6) the six losses of the last mtts_meta_grad / mtts_plain_grad call, summed over this rank's tasks and scaled by its
+ * grad_scale — the SUM over ranks is the mean `self.log_dict(..., sync_dist=True)` reports (meta.py:78-79, baseline.py:35); behind them the
+ * PostNet BatchNorm running_mean | running_var of every layer, weighted so that the SUM is rank 0's buffers (mode 0, default: DDP's
+ * broadcast_buffers, main.py:32) or the mean over ranks (mode 1).  mtts_allreduce_outer packs, reduces mtts_outer_sync_floats() floats and
+ * installs the reduced buffers itself; a caller that runs the collective on its own (torch.distributed on mtts_outer_grad_ptr) brackets
+ * it with mtts_sync_pack(h, w) (w = this rank's BatchNorm weight: 1 / 0 for mode 0, 1 / world for mode 1) and mtts_sync_unpack.
+ * mtts_get_synced_losses: the six reduced loss scalars (after the collective; with one rank, after mtts_sync_pack). */
+int64_t mtts_outer_sync_floats(mtts_handle* h);
+int mtts_sync_pack(mtts_handle* h, float bn_weight);
+int mtts_sync_unpack(mtts_handle* h);
+int mtts_get_synced_losses(mtts_handle* h, float* out6_host);
+int mtts_set_bn_sync(mtts_handle* h, int mode);
 /* clip_grad_norm_(max_norm) (main.py:61) + Adam (lightning/optimizer.py:9-15) with the learning rate of
  * lightning/scheduler.py:11-23 supplied by the caller.  grad_dev NULL = the internal outer gradient. */
 int mtts_outer_update(mtts_handle* h, const float* grad_dev, float lr, float beta1, float beta2, float eps,
@@ -225,7 +238,8 @@ int mtts_gemm_f32(int form, int M, int N, int K, const float* A, int lda, const 
 int mtts_gemm_f32_dual(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* A2, const float* B2,
                        float* C, int ldc, const float* bias, float alpha, int flags, int tile, void* hip_stream);
 /* The bf16 operand family on one problem (csrc/gemm_bf16.h): C = alpha * (op(A, B) [+ op(A2, B2)]) + bias with fp32 A / B in memory,
- * rounded to bf16 on the way into LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation.  A2 / B2 both NULL or both set.  tile 0 (auto) / 64 / 128. */
+ * rounded to bf16 on the way into LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation.  A2 / B2 both NULL or both set.  tile 0 (auto) / 64 / 128
+ * (+ 1000 * K-slices kept in flight per workgroup: micro-benchmarks). */
 int mtts_gemm_bf16(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* A2, const float* B2,
                    float* C, int ldc, const float* bias, float alpha, int flags, int tile, void* hip_stream);
 /* Host-only self check of the task-per-XCD workgroup schedule of 8- / 4- / 2-group launches (csrc/gemm.h: XcdSched): builds the schedule

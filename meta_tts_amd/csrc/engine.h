@@ -574,13 +574,16 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         HIP_CHECK(hipMalloc((void**)&theta, n_total * sizeof(float)));
         HIP_CHECK(hipMalloc((void**)&adam_m, n_total * sizeof(float)));
         HIP_CHECK(hipMalloc((void**)&adam_v, n_total * sizeof(float)));
-        HIP_CHECK(hipMalloc((void**)&outer, n_total * sizeof(float)));
+        sync_tail = 8;   // 6 loss scalars (+ 2 pad), then per PostNet layer running mean | running var
+        for (int i = 0; i < cfg.postnet_layers; ++i) sync_tail += 2LL * postP[i].cout;
+        sync_tail = (sync_tail + 3) & ~3LL;
+        HIP_CHECK(hipMalloc((void**)&outer, (n_total + sync_tail) * sizeof(float)));
         HIP_CHECK(hipMalloc((void**)&fast, (size_t)std::max<long long>(n_adapt, 4) * cap_tasks * sizeof(float)));
         HIP_CHECK(hipMalloc((void**)&grad, (size_t)n_total * cap_tasks * sizeof(float)));
         HIP_CHECK(hipMemset(theta, 0, n_total * sizeof(float)));
         HIP_CHECK(hipMemset(adam_m, 0, n_total * sizeof(float)));
         HIP_CHECK(hipMemset(adam_v, 0, n_total * sizeof(float)));
-        HIP_CHECK(hipMemset(outer, 0, n_total * sizeof(float)));
+        HIP_CHECK(hipMemset(outer, 0, (n_total + sync_tail) * sizeof(float)));
         HIP_CHECK(hipMemset(grad, 0, (size_t)n_total * cap_tasks * sizeof(float)));
         fast_cur = fast; grad_dst = grad;
         if (gx.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace)"); return -1; }
@@ -1990,6 +1993,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (backward(pq, grad_scale, true)) return -1;
         MTTS_LAUNCH(sum_tasks_kernel, dim3(blocks_for(n_total / 4)), dim3(256), stream, (const float*)grad, n_total, nt, 1.f, outer,
                     n_total / 4, (int)outer_accumulate);
+        if (!losses_out || losses_out == losses) { sync_nt = nt; sync_scale = grad_scale; }
         return 0;
     }
 
@@ -2025,6 +2029,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (backward(ps, grad_scale, true)) return -1;
         MTTS_LAUNCH(sum_tasks_kernel, dim3(blocks_for(n_total / 4)), dim3(256), stream, (const float*)grad, n_total, p.tasks, 1.f,
                     outer, n_total / 4, (int)outer_accumulate);
+        if (!losses_out || losses_out == losses) { sync_nt = p.tasks; sync_scale = grad_scale; }
         return 0;
     }
 
@@ -2038,6 +2043,39 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         HIP_CHECK(hipMemcpy(out_host, dspk.p + (long long)task * dspk.ts, (size_t)B * cfg.d_model * sizeof(float), hipMemcpyDeviceToHost));
         return 0;
     }
+    // ---- the exchange step's tail: replicated side state that travels with the outer gradient ------------------------------------
+    // outer[n_total ..): [0..5] the six losses of the last gradient call, summed over this rank's tasks and scaled by its grad_scale
+    // (= 1 / total tasks: the SUM over ranks is the mean `log_dict(sync_dist=True)` reports, meta.py:78-79); [8 ..) the PostNet
+    // BatchNorm running buffers weighted by bn_weight — 1 on rank 0 and 0 elsewhere reproduces DDP's broadcast_buffers (every rank
+    // continues with rank 0's buffers, main.py:32), 1 / world their mean.  sync_unpack installs the reduced buffers, so replicas stay
+    // bit-identical INCLUDING buffers.
+    long long sync_tail = 0;
+    int sync_nt = 0;
+    float sync_scale = 1.f;
+    int bn_sync_mode = 0;   // 0: rank 0's buffers (reference semantics), 1: mean over ranks
+    SyncBn sync_bn() {
+        SyncBn b;
+        b.n = std::min(cfg.postnet_layers, 8);
+        int off = 0;
+        for (int i = 0; i < b.n; ++i) { b.rm[i] = bn_rm[i]; b.rv[i] = bn_rv[i]; b.c[i] = postP[i].cout; b.off[i] = off; off += 2 * postP[i].cout; }
+        return b;
+    }
+    int sync_pack(float bn_weight) {
+        if (cfg.postnet_layers > 8) { set_error("more than 8 PostNet layers"); return -1; }
+        MTTS_LAUNCH(sync_pack_kernel, dim3(1 + cfg.postnet_layers), dim3(256), stream, (const float*)losses, sync_nt, sync_scale, outer + n_total,
+                    sync_bn(), bn_weight);
+        return 0;
+    }
+    int sync_unpack() {
+        if (cfg.postnet_layers > 0) MTTS_LAUNCH(sync_unpack_kernel, dim3(cfg.postnet_layers), dim3(256), stream, (const float*)(outer + n_total), sync_bn());
+        return 0;
+    }
+    int get_synced_losses(float* out6) {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipMemcpy(out6, outer + n_total, 6 * sizeof(float), hipMemcpyDeviceToHost));
+        return 0;
+    }
+
     int outer_update(const float* g, float lr, float b1, float b2, float eps, float weight_decay, float max_norm,
                      float* norm_out_host) {
         const int nb = 512;

@@ -756,8 +756,8 @@ enum GemmKind {
     GK_GLDS = 9,          // + form: gemm_glds_kernel<F>
     GK_MULTI16 = 12, GK_MULTI32 = 13, GK_GLDS_MULTI = 14, GK_OTHER = 15,
     GK_MULTI16_DUAL = 16, GK_MULTI32_DUAL = 17, GK_GLDS_MULTI_DUAL = 18,
-    GK_BF16_64 = 19,      // + form: gemm_bf16_kernel<F, 64, 64, 32>
-    GK_BF16_128 = 22,     // + form: gemm_bf16_kernel<F, 128, 128, 32>
+    GK_BF16_64 = 19,      // + form: gemm_bf16_kernel<F, 64, 64, 32, PF>
+    GK_BF16_128 = 22,     // + form: gemm_bf16_kernel<F, 128, 128, 32, PF>
     GK_BF16_MULTI64 = 25, GK_BF16_MULTI128 = 26, GK_BF16_MULTI64_DUAL = 27, GK_BF16_MULTI128_DUAL = 28, GK_COUNT = 29
 };
 inline const char* gemm_kind_name(int k) {
@@ -768,10 +768,10 @@ inline const char* gemm_kind_name(int k) {
         "gemm_glds_kernel<0>", "gemm_glds_kernel<1>", "gemm_glds_kernel<2>",
         "gemm_f32_multi_kernel<64, 64, 16>", "gemm_f32_multi_kernel<64, 64, 32>", "gemm_glds_multi_kernel",
         "gemm_f32_kernel<other>", "gemm_f32_multi_dual_kernel<64, 64, 16>", "gemm_f32_multi_dual_kernel<64, 64, 32>", "gemm_glds_multi_dual_kernel",
-        "gemm_bf16_kernel<0, 64, 64, 32>", "gemm_bf16_kernel<1, 64, 64, 32>", "gemm_bf16_kernel<2, 64, 64, 32>",
-        "gemm_bf16_kernel<0, 128, 128, 32>", "gemm_bf16_kernel<1, 128, 128, 32>", "gemm_bf16_kernel<2, 128, 128, 32>",
-        "gemm_bf16_multi_kernel<64, 64, 32, false>", "gemm_bf16_multi_kernel<128, 128, 32, false>",
-        "gemm_bf16_multi_kernel<64, 64, 32, true>", "gemm_bf16_multi_kernel<128, 128, 32, true>"};
+        "gemm_bf16_kernel<0, 64, 64, 32, 4>", "gemm_bf16_kernel<1, 64, 64, 32, 4>", "gemm_bf16_kernel<2, 64, 64, 32, 4>",
+        "gemm_bf16_kernel<0, 128, 128, 32, 2>", "gemm_bf16_kernel<1, 128, 128, 32, 2>", "gemm_bf16_kernel<2, 128, 128, 32, 2>",
+        "gemm_bf16_multi_kernel<64, 64, 32, 4, false>", "gemm_bf16_multi_kernel<128, 128, 32, 2, false>",
+        "gemm_bf16_multi_kernel<64, 64, 32, 4, true>", "gemm_bf16_multi_kernel<128, 128, 32, 2, true>"};
     return (k >= 0 && k < GK_COUNT) ? names[k] : "?";
 }
 
@@ -895,7 +895,7 @@ inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t s
 
 // bf16 operand family (gemm_bf16.h)
 inline bool gemm_bf16_ok(const GemmArgs& g);
-inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipStream_t stream);
+inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipStream_t stream, int pf);
 inline void gemm_bf16_multi_launch(const GemmMulti& mp, int T, bool dual, dim3 grid, hipStream_t stream);
 // block tile of a bf16 launch: 128x128 once the launch still fills the chip twice over with it (the MFMA rate is 16x the fp32 kernels':
 // a 64x64 tile moves 1 byte per 16 flop through the L2 -> LDS path), 64x64 for under-filled launches
@@ -1011,7 +1011,7 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
         else { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, false>), grid, block, stream, g); kind = T == 64 ? GK_OTHER : GK_F32_128 + F; }                   \
     }
     if (bf16) {
-        gemm_bf16_launch(form, g, tile, grid, stream);
+        gemm_bf16_launch(form, g, tile, grid, stream, (user_tile % 10000) / 1000);   // (bf16 tile codes: T + 1000 * slices in flight, 0 = default)
         kind = (tile == 128 ? GK_BF16_128 : GK_BF16_64) + form;
     } else
 #if !defined(MTTS_EMU)

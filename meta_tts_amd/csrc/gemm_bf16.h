@@ -21,6 +21,8 @@
 // Reference ops served: the same as gemm.h (SubLayers.py:39-41,54,86; Modules.py:16,23; modules.py:253-296; Layers.py:33-64;
 // fastspeech2.py:97 and their autograd backward) under torch.autocast(bfloat16)-style operand rounding (BASELINE.md section 2 probe).
 #pragma once
+#include <type_traits>
+
 #include "gemm.h"
 
 namespace mtts {
@@ -47,6 +49,13 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {   // -> one
 }
 #endif
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N) — register-set indices must be constants BEFORE the optimiser
+// looks at the staging arrays (a run-time set index that only becomes constant after unrolling left them in scratch memory)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
 template <int BM, int BN, int BK>
 struct GemmBf16Smem {
     static constexpr int kLDK = BK + 8;                           // bf16 elements per LDS row
@@ -65,7 +74,10 @@ struct FragsBf16 {
 };
 
 // K-loop of one output tile over the K-slices [c_lo, c_hi) of BK elements each (same contract as gemm_f32_kloop).
-template <int FORM, int BM, int BN, int BK, int WGM = 2, int WGN = 2>
+// PF: K-slices kept IN FLIGHT per workgroup (register sets of the global -> LDS staging).  An under-filled launch (1-2 workgroups per
+// CU: every GEMM of a single-task rank, of C2, of few-shot adaptation) is bound by latency x bytes in flight per CU, not by the matrix
+// pipes: with one slice in flight a workgroup moves 16 KB per ~0.7 us round trip (load -> convert -> LDS -> barrier -> MFMA).
+template <int FORM, int BM, int BN, int BK, int PF, int WGM = 2, int WGN = 2>
 __device__ __forceinline__ void gemm_bf16_kloop(const GemmArgs& g, const GemmProb& pr, int z, int m0, int n0, bool cs_tile, int c_lo, int c_hi,
                                                 float* smem_f, f32x16 (&acc)[(BM / WGM) / 32][(BN / WGN) / 32]) {
     constexpr int NTH = 64 * WGM * WGN;
@@ -92,7 +104,7 @@ __device__ __forceinline__ void gemm_bf16_kloop(const GemmArgs& g, const GemmPro
     int n0b = n0, N4b = N4;   // column window of the B operand
     if (cs_tile) { B = g.colsum_w + (long long)z * g.colsum_w_gs; ldb = 4; n0b = 0; N4b = 4; }
 
-    float4 areg[A_LD4], breg[B_LD4];
+    float4 areg[PF][A_LD4], breg[PF][B_LD4];
     int a_tap_i = 0, a_tap_base = 0, b_tap_i = 0, b_tap_base = 0;
     auto a_tap_of = [&](int k0) { while (k0 - a_tap_base >= g.a_tap_k) { a_tap_base += g.a_tap_k; ++a_tap_i; } return a_tap_i; };
     auto b_tap_of = [&](int k0) { while (k0 - b_tap_base >= g.tap_k) { b_tap_base += g.tap_k; ++b_tap_i; } return b_tap_i; };
@@ -130,7 +142,8 @@ __device__ __forceinline__ void gemm_bf16_kloop(const GemmArgs& g, const GemmPro
     }
     long long a_koff = 0, b_koff = 0;
     const long long a_tap_stride = (long long)g.a_tap_rows * lda;
-    auto load_a = [&](int k0) {
+    auto load_a = [&](int k0, auto set_c) {
+        constexpr int set = decltype(set_c)::value;
         const int atap = A_KC ? a_tap_of(k0) : 0;
         const long long koff = A_KC ? (long long)atap * a_tap_stride + (k0 - a_tap_base) : (long long)k0 * lda;
         const long long delta = koff - a_koff;
@@ -139,16 +152,17 @@ __device__ __forceinline__ void gemm_bf16_kloop(const GemmArgs& g, const GemmPro
         for (int i = 0; i < A_LD4; ++i) a_ptr[i] += delta;
         if (k0 + BK <= K) {
 #pragma unroll
-            for (int i = 0; i < A_LD4; ++i) areg[i] = ld4(a_ptr[i]);
+            for (int i = 0; i < A_LD4; ++i) areg[set][i] = ld4(a_ptr[i]);
         } else {
 #pragma unroll
             for (int i = 0; i < A_LD4; ++i) {
                 const bool ok = A_KC ? (k0 + (tid % KQ) * 4 < K4) : (k0 + 2 * ((tid + NTH * (i >> 1)) / (BM / 4)) + (i & 1) < K);
-                areg[i] = ok ? ld4(a_ptr[i]) : zero4();
+                areg[set][i] = ok ? ld4(a_ptr[i]) : zero4();
             }
         }
     };
-    auto load_b = [&](int k0) {
+    auto load_b = [&](int k0, auto set_c) {
+        constexpr int set = decltype(set_c)::value;
         const int tap = B_KC ? 0 : b_tap_of(k0);
         const long long koff = B_KC ? (long long)k0 : (long long)(g.taps - 1 - tap) * g.tap_bstride + (long long)(k0 - b_tap_base) * ldb;
         const long long delta = koff - b_koff;
@@ -157,30 +171,31 @@ __device__ __forceinline__ void gemm_bf16_kloop(const GemmArgs& g, const GemmPro
         for (int i = 0; i < B_LD4; ++i) b_ptr[i] += delta;
         if (k0 + BK <= K) {
 #pragma unroll
-            for (int i = 0; i < B_LD4; ++i) breg[i] = ld4(b_ptr[i]);
+            for (int i = 0; i < B_LD4; ++i) breg[set][i] = ld4(b_ptr[i]);
         } else {
 #pragma unroll
             for (int i = 0; i < B_LD4; ++i) {
                 const bool ok = B_KC ? (k0 + (tid % KQ) * 4 < K4) : (k0 + 2 * ((tid + NTH * (i >> 1)) / (BN / 4)) + (i & 1) < K);
-                breg[i] = ok ? ld4(b_ptr[i]) : zero4();
+                breg[set][i] = ok ? ld4(b_ptr[i]) : zero4();
             }
         }
     };
     // fp32 registers -> bf16 LDS image [row][kLDK] (the one rounding of this mode)
-    auto store_ab = [&](int buf) {
+    auto store_ab = [&](int buf, auto set_c) {
+        constexpr int set = decltype(set_c)::value;
         bf16_t* As = smem + buf * STAGE;
         bf16_t* Bs = As + BM * kLDK;
         if (A_KC) {
 #pragma unroll
             for (int i = 0; i < A_LD4; ++i) {
-                u32x2 v; v.x = pack2_bf16(areg[i].x, areg[i].y); v.y = pack2_bf16(areg[i].z, areg[i].w);
+                u32x2 v; v.x = pack2_bf16(areg[set][i].x, areg[set][i].y); v.y = pack2_bf16(areg[set][i].z, areg[set][i].w);
                 *reinterpret_cast<u32x2*>(As + (tid / KQ + RPP * i) * kLDK + (tid % KQ) * 4) = v;
             }
         } else {
 #pragma unroll
             for (int q = 0; q < A_LD4 / 2; ++q) {
                 const int u = tid + NTH * q, kk = 2 * (u / (BM / 4)), c = (u % (BM / 4)) * 4;
-                const float4 r0 = areg[2 * q], r1 = areg[2 * q + 1];
+                const float4 r0 = areg[set][2 * q], r1 = areg[set][2 * q + 1];
                 *reinterpret_cast<unsigned*>(As + (c + 0) * kLDK + kk) = pack2_bf16(r0.x, r1.x);
                 *reinterpret_cast<unsigned*>(As + (c + 1) * kLDK + kk) = pack2_bf16(r0.y, r1.y);
                 *reinterpret_cast<unsigned*>(As + (c + 2) * kLDK + kk) = pack2_bf16(r0.z, r1.z);
@@ -190,14 +205,14 @@ __device__ __forceinline__ void gemm_bf16_kloop(const GemmArgs& g, const GemmPro
         if (B_KC) {
 #pragma unroll
             for (int i = 0; i < B_LD4; ++i) {
-                u32x2 v; v.x = pack2_bf16(breg[i].x, breg[i].y); v.y = pack2_bf16(breg[i].z, breg[i].w);
+                u32x2 v; v.x = pack2_bf16(breg[set][i].x, breg[set][i].y); v.y = pack2_bf16(breg[set][i].z, breg[set][i].w);
                 *reinterpret_cast<u32x2*>(Bs + (tid / KQ + RPP * i) * kLDK + (tid % KQ) * 4) = v;
             }
         } else {
 #pragma unroll
             for (int q = 0; q < B_LD4 / 2; ++q) {
                 const int u = tid + NTH * q, kk = 2 * (u / (BN / 4)), c = (u % (BN / 4)) * 4;
-                const float4 r0 = breg[2 * q], r1 = breg[2 * q + 1];
+                const float4 r0 = breg[set][2 * q], r1 = breg[set][2 * q + 1];
                 *reinterpret_cast<unsigned*>(Bs + (c + 0) * kLDK + kk) = pack2_bf16(r0.x, r1.x);
                 *reinterpret_cast<unsigned*>(Bs + (c + 1) * kLDK + kk) = pack2_bf16(r0.y, r1.y);
                 *reinterpret_cast<unsigned*>(Bs + (c + 2) * kLDK + kk) = pack2_bf16(r0.z, r1.z);
@@ -244,24 +259,36 @@ __device__ __forceinline__ void gemm_bf16_kloop(const GemmArgs& g, const GemmPro
     const int nchunks = c_hi > c_lo ? c_hi - c_lo : 0;
     if (nchunks == 0) return;
     const int kb0 = c_lo * BK;
-    load_a(kb0);
-    load_b(kb0);
-    store_ab(0);
+    // slice 0 goes straight to LDS; slices 1 .. PF are put in flight (slice s >= 1 lives in register set (s - 1) % PF)
+    const std::integral_constant<int, 0> set0;
+    load_a(kb0, set0);
+    load_b(kb0, set0);
+    store_ab(0, set0);
+    static_for<0, PF>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        if (1 + d < nchunks) { load_a(kb0 + (1 + d) * BK, dc); load_b(kb0 + (1 + d) * BK, dc); }
+    });
     __syncthreads();
-    // double-buffered: the global loads of slice c+1 are in flight while slice c's MFMAs run; their conversion + LDS store follows
-    // the MFMAs (the loads have landed by then) and one barrier per slice hands the stage over.  Co-resident workgroups (3-6 per CU)
-    // cover each other's barrier intervals.
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) { load_a(kb0 + (c + 1) * BK); load_b(kb0 + (c + 1) * BK); }
-        compute(buf);
-        if (c + 1 < nchunks) store_ab(buf ^ 1);
-        __syncthreads();
+    // steady state, slice cc: its successor (in flight since PF iterations) is converted into the other LDS stage, the register set it
+    // leaves is refilled with slice cc + 1 + PF, then the MFMAs of slice cc run — PF slices' loads stay in flight behind them; one
+    // barrier per slice hands the stage over.
+    for (int c = 0; c < nchunks; c += PF) {
+        static_for<0, PF>([&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            const int cc = c + d;
+            if (cc < nchunks) {
+                const int buf = cc & 1;
+                if (cc + 1 < nchunks) store_ab(buf ^ 1, dc);
+                if (cc + 1 + PF < nchunks) { load_a(kb0 + (cc + 1 + PF) * BK, dc); load_b(kb0 + (cc + 1 + PF) * BK, dc); }
+                compute(buf);
+                __syncthreads();
+            }
+        });
     }
 }
 
 // One workgroup's share of one problem (the bf16 twin of gemm_f32_body: same tile / split-K / column-sum / dual-source logic).
-template <int FORM, int BM, int BN, int BK, bool DUAL = false>
+template <int FORM, int BM, int BN, int BK, int PF, bool DUAL = false>
 __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, int z, int bxs, float* smem) {
     constexpr int WGM = 2, WGN = 2, NTH = 256;
     constexpr int TM = (BM / WGM) / 32, TN = (BN / WGN) / 32;
@@ -282,40 +309,42 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, int z, int bxs
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int nch_all = (pr.K + BK - 1) / BK, cps = (nch_all + S - 1) / S;
     const int c_lo = split * cps, c_hi = (c_lo + cps < nch_all) ? c_lo + cps : nch_all;
-    gemm_bf16_kloop<FORM, BM, BN, BK, WGM, WGN>(g, pr, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
+    gemm_bf16_kloop<FORM, BM, BN, BK, PF, WGM, WGN>(g, pr, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
     if (DUAL) {
         if (g.A2 != nullptr && !cs_tile) {
             const GemmProb p2 = gemm_resolve2(g, z, pr);   // (the first K-loop ends on a barrier: its LDS stages are free)
-            gemm_bf16_kloop<FORM, BM, BN, BK, WGM, WGN>(g, p2, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
+            gemm_bf16_kloop<FORM, BM, BN, BK, PF, WGM, WGN>(g, p2, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
         }
     }
     if (S > 1 && !splitk_combine<TM, TN, NTH>(g, z, tile_lin, split, S, acc)) return;
     gemm_finish<TM, TN, WGM, WGN>(g, pr, z, m0, n0, cs_tile, acc);
 }
 
-template <int FORM, int BM, int BN, int BK>
+template <int FORM, int BM, int BN, int BK, int PF>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[GemmBf16Smem<BM, BN, BK>::FLOATS];
     int z = blockIdx.z;
     int bxs = blockIdx.x;
     if (g.xs.on) { if (!xcd_sched_locate(g.xs, bxs, z, bxs)) return; }
     else if (g.swizzle) bxs = xcd_group_remap(bxs, (int)gridDim.x, xcd_group_size((g.N + BN - 1) / BN, g.splitk));
-    gemm_bf16_body<FORM, BM, BN, BK>(g, z, bxs, smem);
+    gemm_bf16_body<FORM, BM, BN, BK, PF>(g, z, bxs, smem);
 }
 
 // several independent problems in ONE launch (see gemm_f32_multi_kernel); DUAL: the launch may carry dual-source problems
-template <int BM, int BN, int BK, bool DUAL>
+template <int BM, int BN, int BK, int PF, bool DUAL>
 __global__ __launch_bounds__(256) void gemm_bf16_multi_kernel(GemmMulti mp) {
     __shared__ __attribute__((aligned(16))) float smem[GemmBf16Smem<BM, BN, BK>::FLOATS];
     int p, z, bx;
     if (!gemm_multi_locate(mp, p, z, bx)) return;
     const int form = mp.form[p];
-    if (form == GEMM_NT) gemm_bf16_body<GEMM_NT, BM, BN, BK, DUAL>(mp.g[p], z, bx, smem);
-    else if (form == GEMM_NN) gemm_bf16_body<GEMM_NN, BM, BN, BK, DUAL>(mp.g[p], z, bx, smem);
-    else gemm_bf16_body<GEMM_TN, BM, BN, BK, DUAL>(mp.g[p], z, bx, smem);
+    if (form == GEMM_NT) gemm_bf16_body<GEMM_NT, BM, BN, BK, PF, DUAL>(mp.g[p], z, bx, smem);
+    else if (form == GEMM_NN) gemm_bf16_body<GEMM_NN, BM, BN, BK, PF, DUAL>(mp.g[p], z, bx, smem);
+    else gemm_bf16_body<GEMM_TN, BM, BN, BK, PF, DUAL>(mp.g[p], z, bx, smem);
 }
 
+#define MTTS_BF16_PF_SWEEP 1   // explicit slices-in-flight variants for micro-benchmarks (tile code T + 1000 * PF)
 constexpr int kBf16BK = 32;
+constexpr int kBf16PF64 = 4, kBf16PF128 = 2;   // slices in flight per workgroup (64x64 / 128x128 block tile)
 // a problem the bf16 K-loop can take: every conv tap must cover whole K-slices (the others — PostNet's 80-channel output layer in
 // dgrad form, the vocoder's dilated taps — keep the fp32 kernels: a few per cent of the step's flops)
 inline bool gemm_bf16_ok(const GemmArgs& g) {
@@ -323,22 +352,28 @@ inline bool gemm_bf16_ok(const GemmArgs& g) {
     if (g.a_tap_rows != 0) return false;
     return true;
 }
-// stand-alone launch of one problem; T = 64 / 128
-inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipStream_t stream) {
+// stand-alone launch of one problem; T = 64 / 128; pf: 0 = the default depth, else an explicit one (micro-benchmarks: 1 / 2 / 4 for T = 64,
+// 1 / 2 / 3 for T = 128)
+inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipStream_t stream, int pf = 0) {
     dim3 block(256);
-#define MTTS_BF16_CASE(F, TT) if (form == F && T == TT) { MTTS_LAUNCH((gemm_bf16_kernel<F, TT, TT, kBf16BK>), grid, block, stream, g); return; }
-    MTTS_BF16_CASE(GEMM_NT, 64) MTTS_BF16_CASE(GEMM_NN, 64) MTTS_BF16_CASE(GEMM_TN, 64)
-    MTTS_BF16_CASE(GEMM_NT, 128) MTTS_BF16_CASE(GEMM_NN, 128) MTTS_BF16_CASE(GEMM_TN, 128)
+    if (pf == 0) pf = T == 128 ? kBf16PF128 : kBf16PF64;
+#define MTTS_BF16_CASE(F, TT, PP) if (form == F && T == TT && pf == PP) { MTTS_LAUNCH((gemm_bf16_kernel<F, TT, TT, kBf16BK, PP>), grid, block, stream, g); return; }
+#define MTTS_BF16_FORMS(TT, PP) MTTS_BF16_CASE(GEMM_NT, TT, PP) MTTS_BF16_CASE(GEMM_NN, TT, PP) MTTS_BF16_CASE(GEMM_TN, TT, PP)
+    MTTS_BF16_FORMS(64, 4) MTTS_BF16_FORMS(128, 2)
+#if defined(MTTS_BF16_PF_SWEEP)
+    MTTS_BF16_FORMS(64, 1) MTTS_BF16_FORMS(64, 2) MTTS_BF16_FORMS(128, 1) MTTS_BF16_FORMS(128, 3)
+#endif
+#undef MTTS_BF16_FORMS
 #undef MTTS_BF16_CASE
 }
 inline void gemm_bf16_multi_launch(const GemmMulti& mp, int T, bool dual, dim3 grid, hipStream_t stream) {
     dim3 block(256);
     if (T == 128) {
-        if (dual) MTTS_LAUNCH((gemm_bf16_multi_kernel<128, 128, kBf16BK, true>), grid, block, stream, mp);
-        else MTTS_LAUNCH((gemm_bf16_multi_kernel<128, 128, kBf16BK, false>), grid, block, stream, mp);
+        if (dual) MTTS_LAUNCH((gemm_bf16_multi_kernel<128, 128, kBf16BK, kBf16PF128, true>), grid, block, stream, mp);
+        else MTTS_LAUNCH((gemm_bf16_multi_kernel<128, 128, kBf16BK, kBf16PF128, false>), grid, block, stream, mp);
     } else {
-        if (dual) MTTS_LAUNCH((gemm_bf16_multi_kernel<64, 64, kBf16BK, true>), grid, block, stream, mp);
-        else MTTS_LAUNCH((gemm_bf16_multi_kernel<64, 64, kBf16BK, false>), grid, block, stream, mp);
+        if (dual) MTTS_LAUNCH((gemm_bf16_multi_kernel<64, 64, kBf16BK, kBf16PF64, true>), grid, block, stream, mp);
+        else MTTS_LAUNCH((gemm_bf16_multi_kernel<64, 64, kBf16BK, kBf16PF64, false>), grid, block, stream, mp);
     }
 }
 

@@ -341,7 +341,22 @@ int mtts_comm_init(mtts_handle* h, const void* id128, int rank, int world_size) 
 }
 int mtts_allreduce_outer(mtts_handle* h) {
     Engine& e = h->eng;
-    if (h->comm.sum(e.outer, (size_t)e.n_total, e.stream)) { e.set_error(h->comm.err); return -1; }
+    if (!h->comm.comm) { e.set_error("communicator not initialised (mtts_comm_init)"); return -1; }
+    const float w = e.bn_sync_mode == 1 ? 1.f / (float)h->comm.world : (h->comm.rank == 0 ? 1.f : 0.f);
+    if (e.sync_pack(w)) return -1;
+    if (h->comm.sum(e.outer, (size_t)(e.n_total + e.sync_tail), e.stream)) { e.set_error(h->comm.err); return -1; }
+    return launched(e, e.sync_unpack());
+}
+int64_t mtts_outer_sync_floats(mtts_handle* h) { return h->eng.n_total + h->eng.sync_tail; }
+int mtts_sync_pack(mtts_handle* h, float bn_weight) { return launched(h->eng, h->eng.sync_pack(bn_weight)); }
+int mtts_sync_unpack(mtts_handle* h) { return launched(h->eng, h->eng.sync_unpack()); }
+int mtts_get_synced_losses(mtts_handle* h, float* out6) {
+    if (!out6) { h->eng.set_error("null output"); return -1; }
+    return h->eng.get_synced_losses(out6);
+}
+int mtts_set_bn_sync(mtts_handle* h, int mode) {
+    if (mode != 0 && mode != 1) { h->eng.set_error("bn sync mode must be 0 (rank 0's buffers) or 1 (mean over ranks)"); return -1; }
+    h->eng.bn_sync_mode = mode;
     return 0;
 }
 
@@ -455,7 +470,7 @@ int mtts_gemm_f32_dual(int form, int M, int N, int K, const float* A, int lda, c
 
 int mtts_gemm_bf16(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* A2, const float* B2,
                    float* C, int ldc, const float* bias, float alpha, int flags, int tile, void* stream) {
-    if (form < 0 || form > 2 || (tile != 0 && tile != 64 && tile != 128) || (flags & ~0xff) || ((A2 == nullptr) != (B2 == nullptr))) return -1;
+    if (form < 0 || form > 2 || (tile != 0 && ((tile % 1000 != 64 && tile % 1000 != 128) || tile / 1000 > 4)) || (flags & ~0xff) || ((A2 == nullptr) != (B2 == nullptr))) return -1;
     GemmArgs g;
     g.A = A; g.B = B; g.A2 = A2; g.B2 = B2; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.alpha = alpha; g.flags = flags & 0xff;

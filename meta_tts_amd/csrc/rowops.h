@@ -1003,6 +1003,31 @@ __global__ void sum_tasks_kernel(const float* g, long long g_ts, int tasks, floa
     }
 }
 
+// The exchange step's tail (engine.h: sync_pack / sync_unpack): what DDP moves between ranks besides the gradient — the 6 loss scalars
+// of `self.log_dict(..., sync_dist=True)` (meta.py:78-79, baseline.py:35) and the PostNet BatchNorm running buffers (DDP
+// `broadcast_buffers`, main.py:32) — rides behind the flat outer gradient in ONE all-reduce.
+struct SyncBn { float* rm[8]; float* rv[8]; int c[8]; int off[8]; int n; };
+// blockIdx.x == 0: tail[k] = scale * sum_t losses[t][k]; blocks 1 .. n: BatchNorm layer (blockIdx.x - 1): tail_bn = w * (running mean | var)
+__global__ void sync_pack_kernel(const float* losses, int tasks, float scale, float* tail, SyncBn bn, float w) {
+    const int b = blockIdx.x;
+    if (b == 0) {
+        if (threadIdx.x < 8) {
+            float s = 0.f;
+            if (threadIdx.x < 6) for (int t = 0; t < tasks; ++t) s += losses[t * 6 + threadIdx.x];
+            tail[threadIdx.x] = s * scale;
+        }
+        return;
+    }
+    const int l = b - 1;
+    float* dst = tail + 8 + bn.off[l];
+    for (int j = threadIdx.x; j < bn.c[l]; j += blockDim.x) { dst[j] = w * bn.rm[l][j]; dst[bn.c[l] + j] = w * bn.rv[l][j]; }
+}
+__global__ void sync_unpack_kernel(const float* tail, SyncBn bn) {
+    const int l = blockIdx.x;
+    const float* src = tail + 8 + bn.off[l];
+    for (int j = threadIdx.x; j < bn.c[l]; j += blockDim.x) { bn.rm[l][j] = src[j]; bn.rv[l][j] = src[bn.c[l] + j]; }
+}
+
 // global L2 norm, stage 1: per-block partial sums of squares (double accumulation in the
 // second stage keeps it deterministic and accurate)
 __global__ void sumsq_partial_kernel(const float* g, long long n4, float* partial) {

@@ -379,8 +379,30 @@ class Engine:
         return int(self.lib.mtts_outer_grad_ptr(self.h))
 
     def outer_grad_view(self):
-        """Device buffer of the outer gradient as an object torch.as_tensor(..., device='cuda') can alias."""
-        return _DevView(self.outer_grad_ptr(), self.n_total)
+        """Device buffer a host-side collective reduces, as an object torch.as_tensor(..., device='cuda') can alias: the outer gradient
+        followed by the exchange tail (loss scalars + BatchNorm running buffers; bracket the collective with sync_pack / sync_unpack)."""
+        return _DevView(self.outer_grad_ptr(), self.sync_floats)
+
+    @property
+    def sync_floats(self) -> int:
+        return int(self.lib.mtts_outer_sync_floats(self.h))
+
+    def sync_pack(self, bn_weight: float = 1.0):
+        """Fill the exchange tail behind the outer gradient (include/mtts.h): this rank's scaled loss sums and its BatchNorm running
+        buffers x bn_weight (rank 0: 1, others: 0 = DDP's broadcast_buffers; 1 / world = mean)."""
+        self._ck(self.lib.mtts_sync_pack(self.h, float(bn_weight)))
+
+    def sync_unpack(self):
+        self._ck(self.lib.mtts_sync_unpack(self.h))
+
+    def synced_losses(self) -> np.ndarray:
+        """The six loss scalars reduced over the ranks by the last exchange (log_dict(sync_dist=True), meta.py:78-79)."""
+        out = np.empty(6, np.float32)
+        self._ck(self.lib.mtts_get_synced_losses(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_bn_sync(self, mode: str = "rank0"):
+        self._ck(self.lib.mtts_set_bn_sync(self.h, {"rank0": 0, "mean": 1}[mode]))
 
     # ---- RCCL inside the library (include/mtts.h: mtts_comm_*) -------------------
     def comm_available(self) -> bool:

@@ -379,15 +379,26 @@ class Trainer:
                     self.library_comm = bool(flag.item())   # False: torch.distributed's all_reduce on the zero-copy view (_allreduce)
 
     def _allreduce(self):
+        """The exchange step: SUM of the flat outer gradient AND of the tail behind it — the six loss scalars (log_dict(sync_dist=True),
+        meta.py:78-79) and the PostNet BatchNorm running buffers (DDP broadcast_buffers, main.py:32: every rank continues with rank 0's)."""
+        eng = self.system.engine
         if self.dist is None or self.system.world_size == 1:
+            eng.sync_pack(1.0)          # (one rank: the "reduced" losses are its own)
             return
         if self.library_comm:
-            self.system.engine.allreduce_outer()
+            eng.allreduce_outer()       # packs, reduces and unpacks inside the library
             return
         if self.outer is None:
             import torch
-            self.outer = torch.as_tensor(self.system.engine.outer_grad_view(), device=f"cuda:{self.system.engine.device}")
+            self.outer = torch.as_tensor(eng.outer_grad_view(), device=f"cuda:{eng.device}")
+        rank = self.dist.get_rank(self.group)
+        eng.sync_pack(1.0 if rank == 0 else 0.0)
         self.dist.all_reduce(self.outer, op=self.dist.ReduceOp.SUM, group=self.group)
+        eng.sync_unpack()
+
+    def synced_losses(self):
+        """Mean over ALL tasks of the meta-batch of the six losses of the last step (what the reference logs with sync_dist=True)."""
+        return self.system.engine.synced_losses()
 
     def _with_accumulation(self, grad_call):
         """Runs one gradient call of an accumulation window.  The engine's accumulate flag is armed for THIS call only (cleared in a

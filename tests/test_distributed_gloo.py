@@ -21,7 +21,7 @@ def _free_port():
 def _host_view(engine):
     """emulator build: the 'device' outer-gradient buffer is host memory -> alias it as a CPU tensor"""
     import ctypes
-    buf = (ctypes.c_float * engine.n_total).from_address(engine.outer_grad_ptr())
+    buf = (ctypes.c_float * engine.sync_floats).from_address(engine.outer_grad_ptr())   # gradient + exchange tail (losses, BatchNorm buffers)
     return torch.from_numpy(np.ctypeslib.as_array(buf))
 
 
@@ -52,8 +52,10 @@ def _worker(rank, world, port, emu_lib, out_dir):
     tasks = _tasks(dims, world)
     for step in range(2):
         q, s, lr = tr.meta_step([tasks[rank]], total_tasks=world)
+    bn = [np.concatenate(sysm.engine.get_bn_buffers(i)[:2]) for i in range(dims.postnet_layers)]
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), w=sysm.engine.export("mel_linear.weight"),
-             e=sysm.engine.export("encoder.layer_stack.0.slf_attn.fc.weight"), g=sysm.engine.export("mel_linear.weight", 1), q=q)
+             e=sysm.engine.export("encoder.layer_stack.0.slf_attn.fc.weight"), g=sysm.engine.export("mel_linear.weight", 1), q=q,
+             bn=np.concatenate(bn), synced=tr.synced_losses())
     dist.destroy_process_group()
 
 
@@ -65,6 +67,13 @@ def test_two_rank_meta_step_equals_single_process(tmp_path):
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     np.testing.assert_array_equal(r0["w"], r1["w"])  # replicas stay bit-identical
     np.testing.assert_array_equal(r0["g"], r1["g"])
+    # ... INCLUDING the BatchNorm running buffers (DDP broadcast_buffers: every rank continues with rank 0's, main.py:32) — each rank saw
+    # a different task, so without the exchange tail they would differ
+    np.testing.assert_array_equal(r0["bn"], r1["bn"])
+    assert np.abs(r0["bn"]).max() > 0
+    # ... and the logged losses are the mean over BOTH tasks on every rank (log_dict(sync_dist=True), meta.py:78-79)
+    np.testing.assert_array_equal(r0["synced"], r1["synced"])
+    np.testing.assert_allclose(r0["synced"], 0.5 * (r0["q"][0] + r1["q"][0]), rtol=1e-6)
     # single process, both tasks grouped in one launch
     from meta_tts_amd.systems import Trainer
     sysm, dims = _make(emu_lib, 2)

@@ -11,6 +11,15 @@ lib = _lib.load()
 P = lambda t: C.c_void_p(t.data_ptr())
 
 
+BF16 = os.environ.get("BENCH_BF16", "0") == "1"   # the bf16 operand family (tile codes 64 / 128) instead of the fp32 kernels
+
+
+def launch(form, tile, M, N, K, A, lda, B, ldb, Cm):
+    if BF16:
+        return lib.mtts_gemm_bf16(form, M, N, K, P(A), lda, P(B), ldb, None, None, P(Cm), N, None, 1.0, 0, tile, None)
+    return lib.mtts_gemm_f32(form, M, N, K, P(A), lda, P(B), ldb, P(Cm), N, None, 1.0, 0, tile, None)
+
+
 def bench(form, tile, M, N, K, reps=5):
     if form == 0:
         A = torch.randn(M, K, device="cuda"); B = torch.randn(N, K, device="cuda"); lda, ldb = K, K
@@ -19,19 +28,19 @@ def bench(form, tile, M, N, K, reps=5):
     else:
         A = torch.randn(K, M, device="cuda"); B = torch.randn(K, N, device="cuda"); lda, ldb = M, N
     Cm = torch.empty(M, N, device="cuda")
-    lib.mtts_gemm_f32(form, M, N, K, P(A), lda, P(B), ldb, P(Cm), N, None, 1.0, 0, tile, None)
+    assert launch(form, tile, M, N, K, A, lda, B, ldb, Cm) == 0
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        lib.mtts_gemm_f32(form, M, N, K, P(A), lda, P(B), ldb, P(Cm), N, None, 1.0, 0, tile, None)
+        launch(form, tile, M, N, K, A, lda, B, ldb, Cm)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     return 2.0 * M * N * K / (ms * 1e-3) / 1e12, ms
 
 
 # tile codes (include/mtts.h): 1064 / 3064 register-staged 64x64 BK16 / BK32, 4064 LDS-DMA, 1128 / 3128 128x128
-TILES = tuple(int(t) for t in os.environ.get('BENCH_TILES', '3064,4064,3128').split(','))
+TILES = tuple(int(t) for t in os.environ.get('BENCH_TILES', '64,128' if BF16 else '3064,4064,3128').split(','))
 shapes = [("square4096", 4096, 4096, 4096), ("conv1_fwd 8 tasks", 17047, 1024, 2304), ("conv1_dgrad", 17047, 256, 9216), ("conv2_fwd", 17047, 256, 1024),
           ("qkv", 17047, 768, 256), ("out_proj", 17047, 256, 256), ("postnet_mid", 22132, 512, 2560), ("dec 1 task", 2100, 256, 1024),
           ("1task fc", 1950, 256, 256), ("1task qkv", 1950, 768, 256), ("1task conv1", 1950, 1024, 2304), ("1task dgrad", 1950, 256, 9216), ("1task enc", 424, 256, 768)]
