@@ -768,10 +768,10 @@ inline const char* gemm_kind_name(int k) {
         "gemm_glds_kernel<0>", "gemm_glds_kernel<1>", "gemm_glds_kernel<2>",
         "gemm_f32_multi_kernel<64, 64, 16>", "gemm_f32_multi_kernel<64, 64, 32>", "gemm_glds_multi_kernel",
         "gemm_f32_kernel<other>", "gemm_f32_multi_dual_kernel<64, 64, 16>", "gemm_f32_multi_dual_kernel<64, 64, 32>", "gemm_glds_multi_dual_kernel",
-        "gemm_bf16_kernel<0, 64, 64, 32, 4>", "gemm_bf16_kernel<1, 64, 64, 32, 4>", "gemm_bf16_kernel<2, 64, 64, 32, 4>",
-        "gemm_bf16_kernel<0, 128, 128, 32, 2>", "gemm_bf16_kernel<1, 128, 128, 32, 2>", "gemm_bf16_kernel<2, 128, 128, 32, 2>",
-        "gemm_bf16_multi_kernel<64, 64, 32, 4, false>", "gemm_bf16_multi_kernel<128, 128, 32, 2, false>",
-        "gemm_bf16_multi_kernel<64, 64, 32, 4, true>", "gemm_bf16_multi_kernel<128, 128, 32, 2, true>"};
+        "gemm_bf16_kernel<0, 64, 64, 32, 1>", "gemm_bf16_kernel<1, 64, 64, 32, 1>", "gemm_bf16_kernel<2, 64, 64, 32, 1>",
+        "gemm_bf16_kernel<0, 128, 128, 32, 1>", "gemm_bf16_kernel<1, 128, 128, 32, 1>", "gemm_bf16_kernel<2, 128, 128, 32, 1>",
+        "gemm_bf16_multi_kernel<64, 64, 32, 1, false>", "gemm_bf16_multi_kernel<128, 128, 32, 1, false>",
+        "gemm_bf16_multi_kernel<64, 64, 32, 1, true>", "gemm_bf16_multi_kernel<128, 128, 32, 1, true>"};
     return (k >= 0 && k < GK_COUNT) ? names[k] : "?";
 }
 
@@ -792,8 +792,8 @@ struct GemmProfiler {
     // out[kind][4] = launches, total ms, total algorithmic flops, total algorithmic bytes
     void report(double out[GK_COUNT][4]) {
         for (int k = 0; k < GK_COUNT; ++k) out[k][0] = out[k][1] = out[k][2] = out[k][3] = 0.0;
-        FILE* dump = getenv("MTTS_GEMM_DUMP") ? fopen(getenv("MTTS_GEMM_DUMP"), "w") : nullptr;  // per-launch CSV (tools/gemm_sites.py)
-        if (dump) fprintf(dump, "kind,form,tile,N,K,rows,groups,splitk,us,gflop\n");
+        FILE* dump = (getenv("MTTS_GEMM_DUMP") && !recs.empty()) ? fopen(getenv("MTTS_GEMM_DUMP"), "a") : nullptr;  // per-launch CSV (tools/gemm_sites.py); appended: a handle reports its three launch contexts one after the other
+        if (dump && ftell(dump) == 0) fprintf(dump, "kind,form,tile,N,K,rows,groups,splitk,us,gflop\n");
         for (auto& r : recs) {
             hipEventSynchronize(r.e1);
             float ms = 0.f;

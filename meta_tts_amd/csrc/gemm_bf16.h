@@ -342,9 +342,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_multi_kernel(GemmMulti mp) {
     else gemm_bf16_body<GEMM_TN, BM, BN, BK, PF, DUAL>(mp.g[p], z, bx, smem);
 }
 
-#define MTTS_BF16_PF_SWEEP 1   // explicit slices-in-flight variants for micro-benchmarks (tile code T + 1000 * PF)
 constexpr int kBf16BK = 32;
-constexpr int kBf16PF64 = 4, kBf16PF128 = 2;   // slices in flight per workgroup (64x64 / 128x128 block tile)
+// slices in flight per workgroup.  Measured (profiles/r04_bf16_gemm_microbench.md): 1 / 2 / 4 slices in flight make NO difference on
+// under-filled launches (hipcc drains vmcnt(0) in front of every conversion pass, and a CU sustains ~64 outstanding lines whatever is
+// queued behind them) and the extra registers cost the chip-filling launches 10-25 % (occupancy 7 -> 4 workgroups per CU): 1.
+constexpr int kBf16PF64 = 1, kBf16PF128 = 1;
 // a problem the bf16 K-loop can take: every conv tap must cover whole K-slices (the others — PostNet's 80-channel output layer in
 // dgrad form, the vocoder's dilated taps — keep the fp32 kernels: a few per cent of the step's flops)
 inline bool gemm_bf16_ok(const GemmArgs& g) {
@@ -352,16 +354,19 @@ inline bool gemm_bf16_ok(const GemmArgs& g) {
     if (g.a_tap_rows != 0) return false;
     return true;
 }
-// stand-alone launch of one problem; T = 64 / 128; pf: 0 = the default depth, else an explicit one (micro-benchmarks: 1 / 2 / 4 for T = 64,
-// 1 / 2 / 3 for T = 128)
-inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipStream_t stream, int pf = 0) {
+// stand-alone launch of one problem; T = 64 / 128; pf: 0 = the default depth, else an explicit one (MTTS_BF16_PF_SWEEP builds only)
+inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipStream_t stream, int pf_req = 0) {
+    int pf = 0; (void)pf_req;
     dim3 block(256);
-    if (pf == 0) pf = T == 128 ? kBf16PF128 : kBf16PF64;
+    pf = T == 128 ? kBf16PF128 : kBf16PF64;   // (explicit depths exist in MTTS_BF16_PF_SWEEP builds only)
+#if defined(MTTS_BF16_PF_SWEEP)
+    if (pf_req) pf = pf_req;
+#endif
 #define MTTS_BF16_CASE(F, TT, PP) if (form == F && T == TT && pf == PP) { MTTS_LAUNCH((gemm_bf16_kernel<F, TT, TT, kBf16BK, PP>), grid, block, stream, g); return; }
 #define MTTS_BF16_FORMS(TT, PP) MTTS_BF16_CASE(GEMM_NT, TT, PP) MTTS_BF16_CASE(GEMM_NN, TT, PP) MTTS_BF16_CASE(GEMM_TN, TT, PP)
-    MTTS_BF16_FORMS(64, 4) MTTS_BF16_FORMS(128, 2)
-#if defined(MTTS_BF16_PF_SWEEP)
-    MTTS_BF16_FORMS(64, 1) MTTS_BF16_FORMS(64, 2) MTTS_BF16_FORMS(128, 1) MTTS_BF16_FORMS(128, 3)
+    MTTS_BF16_FORMS(64, 1) MTTS_BF16_FORMS(128, 1)
+#if defined(MTTS_BF16_PF_SWEEP)   // explicit slices-in-flight variants for micro-benchmarks (tile code T + 1000 * PF)
+    MTTS_BF16_FORMS(64, 2) MTTS_BF16_FORMS(64, 4) MTTS_BF16_FORMS(128, 2) MTTS_BF16_FORMS(128, 3)
 #endif
 #undef MTTS_BF16_FORMS
 #undef MTTS_BF16_CASE
