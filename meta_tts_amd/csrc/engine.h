@@ -29,6 +29,7 @@
 #include "gemm.h"
 #include "gemm_glds.h"
 #include "gemm_bf16.h"
+#include "attention.h"
 #include "rowops.h"
 #include "plan.h"
 #include "tangent.h"
@@ -1305,13 +1306,39 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         const unsigned char* vm = valid_mask(p, s);
         const unsigned char* im = inrect_mask(p, s);
         conv_fwd(ps, s, xin, d, 1, W(ps, P.wqkv), W(ps, P.bqkv), 3 * d, b.qkv, 0, nullptr);
-        attn_gemm(ps, s, TAB_QK, GEMM_NT, b.qkv.p, 3 * d, b.qkv.p, 3 * d, b.P.p, 0, 1.f / sqrtf((float)dk), heads);
         const int groups = (s == SP_P) ? p.n_enc_groups : p.n_dec_groups;
         const int L = (s == SP_P) ? p.enc_maxL : p.dec_maxL;
         const AttnSeq* seqs = (s == SP_P) ? p.enc_seqs : p.dec_seqs;
-        if (groups > 0 && L > 0)
-            MTTS_LAUNCH(softmax_fwd_kernel, dim3((L + 3) / 4, 1, groups), dim3(256), stream, seqs, b.P.p);
-        attn_gemm(ps, s, TAB_PV, GEMM_NN, b.P.p, 0, b.qkv.p, 3 * d, b.O.p, d, 1.f, heads);
+        // scaled-dot-product attention (Modules.py:14-25): ONE fused launch (attention.h) — the score tile of 32 query rows lives in LDS
+        // between Q K^T, the softmax and P V; the probabilities go to HBM once, for the backward.  MTTS_FUSED_ATTN=0 (A/B runs), the bf16
+        // numerics mode and sequences beyond 1024 keys take the three-launch form: grouped GEMM, softmax kernel, grouped GEMM.
+        static const bool fused_attn = [] { const char* e = getenv("MTTS_FUSED_ATTN"); return e ? atoi(e) != 0 : true; }();
+        if (fused_attn && !gx.bf16 && attn_fused_ok(L, dk) && groups > 0) {
+            AttnFwdArgs fa;
+            fa.seqs = seqs;
+            fa.tab_qk = (s == SP_P) ? p.enc_tab[TAB_QK] : p.dec_tab[TAB_QK];
+            fa.tab_pv = (s == SP_P) ? p.enc_tab[TAB_PV] : p.dec_tab[TAB_PV];
+            fa.Q = fa.K = fa.V = b.qkv.p; fa.ld_q = fa.ld_k = fa.ld_v = 3 * d;
+            fa.P = b.P.p; fa.O = b.O.p; fa.ld_o = d;
+            fa.scale = 1.f / sqrtf((float)dk); fa.dk = dk;
+            GemmProfiler& prof = gx.prof;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
+            attn_fwd_launch(fa, L, groups, stream);
+            if (prof.enabled) {
+                hipEventRecord(e1, stream);
+                const double sumL2 = (s == SP_P) ? p.sum_attn_p : p.sum_attn_f, sumL = (double)((s == SP_P) ? p.sumLp : p.sumLf);
+                GemmProfiler::Rec rec{GK_ATTN_FWD, 2.0 * 2.0 * sumL2 * dk, e0, e1};   // both products
+                rec.form = 4; rec.tile = 32; rec.N = dk; rec.K = L; rec.groups = groups; rec.rows = sumL;
+                rec.bytes = 4.0 * (sumL2 + 4.0 * sumL * dk);                          // Q, K, V read, O and P written once
+                prof.recs.push_back(rec);
+            }
+        } else {
+            attn_gemm(ps, s, TAB_QK, GEMM_NT, b.qkv.p, 3 * d, b.qkv.p, 3 * d, b.P.p, 0, 1.f / sqrtf((float)dk), heads);
+            if (groups > 0 && L > 0)
+                MTTS_LAUNCH(softmax_fwd_kernel, dim3((L + 3) / 4, 1, groups), dim3(256), stream, seqs, b.P.p);
+            attn_gemm(ps, s, TAB_PV, GEMM_NN, b.P.p, 0, b.qkv.p, 3 * d, b.O.p, d, 1.f, heads);
+        }
         conv_fwd(ps, s, b.O, d, 1, W(ps, P.wfc), W(ps, P.bfc), d, b.z1, 0, nullptr);
         // self.dropout(self.fc(output)) + residual -> LayerNorm (SubLayers.py:54-55): the dropout rides in the LayerNorm kernel
         ln_fwd(ps, s, b.z1, xin, P.ln1g, P.ln1b, vm, b.z1, b.y1, b.st1, d, drop_spec(ps, block_dropout(s), site_base));

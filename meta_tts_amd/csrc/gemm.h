@@ -758,7 +758,9 @@ enum GemmKind {
     GK_MULTI16_DUAL = 16, GK_MULTI32_DUAL = 17, GK_GLDS_MULTI_DUAL = 18,
     GK_BF16_64 = 19,      // + form: gemm_bf16_kernel<F, 64, 64, 32, PF>
     GK_BF16_128 = 22,     // + form: gemm_bf16_kernel<F, 128, 128, 32, PF>
-    GK_BF16_MULTI64 = 25, GK_BF16_MULTI128 = 26, GK_BF16_MULTI64_DUAL = 27, GK_BF16_MULTI128_DUAL = 28, GK_COUNT = 29
+    GK_BF16_MULTI64 = 25, GK_BF16_MULTI128 = 26, GK_BF16_MULTI64_DUAL = 27, GK_BF16_MULTI128_DUAL = 28,
+    GK_ATTN_FWD = 29,     // attention.h: the fused QK^T -> softmax -> PV forward (both products' flops)
+    GK_COUNT = 30
 };
 inline const char* gemm_kind_name(int k) {
     static const char* names[GK_COUNT] = {
@@ -771,7 +773,7 @@ inline const char* gemm_kind_name(int k) {
         "gemm_bf16_kernel<0, 64, 64, 32, 1>", "gemm_bf16_kernel<1, 64, 64, 32, 1>", "gemm_bf16_kernel<2, 64, 64, 32, 1>",
         "gemm_bf16_kernel<0, 128, 128, 32, 1>", "gemm_bf16_kernel<1, 128, 128, 32, 1>", "gemm_bf16_kernel<2, 128, 128, 32, 1>",
         "gemm_bf16_multi_kernel<64, 64, 32, 1, false>", "gemm_bf16_multi_kernel<128, 128, 32, 1, false>",
-        "gemm_bf16_multi_kernel<64, 64, 32, 1, true>", "gemm_bf16_multi_kernel<128, 128, 32, 1, true>"};
+        "gemm_bf16_multi_kernel<64, 64, 32, 1, true>", "gemm_bf16_multi_kernel<128, 128, 32, 1, true>", "attn_fwd_kernel"};
     return (k >= 0 && k < GK_COUNT) ? names[k] : "?";
 }
 

@@ -86,8 +86,9 @@ def test_layernorm_fwd_bwd(dev, rows, Cc, with_res, with_mask):
     np.testing.assert_allclose(dev.get(dbt), tb.grad.numpy(), rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("n_mat,L,dk", [(3, 17, 16), (2, 80, 128), (4, 5, 32)])
+@pytest.mark.parametrize("n_mat,L,dk", [(3, 17, 16), (2, 80, 128), (4, 5, 32), (2, 130, 64), (1, 333, 128), (1, 700, 128)])
 def test_sdpa_and_softmax(dev, n_mat, L, dk):
+    # (the fused attention forward, csrc/attention.h: L <= 128 / <= 640 / <= 1024 take the three LDS tile classes)
     g = np.random.RandomState(L * 7 + dk)
     q, k, v = (g.standard_normal((n_mat, L, dk)).astype(np.float32) for _ in range(3))
     ldS = (L + 3) & ~3
