@@ -8,16 +8,17 @@
 // softmax(dim=2), bmm) called from transformer/SubLayers.py:42-52 per head.  Padded keys / query rows are not part of a sequence's rows
 // here (packed frame space, engine.h), so no mask tensor exists: the key loop simply ends at L.
 //
-// Layout per workgroup (256 threads = 4 wavefronts):
-//   LDS  S[32][LCAP + 4]     scores, then probabilities, of the 32 query rows against ALL keys of the sequence (LCAP = 128 / 640 / 1024:
-//                            17 / 82 / 132 KB; row stride = 4 x odd floats: ds_read_b128 fragments conflict-free)
-//        QV[32][dk + 4]      the Q tile (phase A), then one 32-key block of V at a time (phase C)
-//   A    wavefront w computes the 32 x 32 score blocks of key chunks w, w + 4, ...: A fragments (Q) from LDS, B fragments (K rows)
-//        straight from L2 in 16-byte pieces (every K row is read by exactly one wavefront of the workgroup), v_mfma_f32_32x32x2_f32
+// Per workgroup (256 threads = 4 wavefronts, one per SIMD; two workgroups per CU for L <= 608):
+//   LDS  S[32][LCAP + 4]   scores, then probabilities, of the 32 query rows against ALL keys of the sequence — the ONLY LDS object
+//                          (LCAP = 128 / 352 / 608 / 1024: 17 / 46 / 78 / 132 KB; row stride = 4 x odd floats: ds_read_b128 conflict-free)
+//   A    every wavefront holds the whole Q tile as MFMA A fragments in registers (dk / 2 VGPRs, read once from L2) and computes the
+//        32 x 32 score blocks of key chunks w, w + 4, ...: B fragments = K rows straight from L2 in 16-byte pieces, the NEXT chunk's
+//        fragments in flight behind the current chunk's 64 x v_mfma_f32_32x32x2_f32 (every K row is read by exactly one wavefront)
 //   B    wavefront w normalises rows 8w .. 8w + 7: max / sum over the row with the DPP wavefront reductions, exp, one coalesced
 //        store of the row of P to HBM, the probabilities stay in LDS
-//   C    wavefront w owns output columns 32w .. 32w + 31 of O[32][dk]: A fragments (P) from LDS, V staged block-wise through LDS
-// fp32 throughout (exact fp32 MFMA chain), so the result equals the three-launch path up to summation order.
+//   C    wavefront w owns output columns 32w .. 32w + 31 of O[32][dk]: A fragments (P) from LDS, B fragments = its 32 columns of V
+//        straight from L2 (128-byte row segments), the next 32-key block's values in flight behind the current block's MFMAs
+// Three barriers in all (none inside a loop).  fp32 throughout (exact fp32 MFMA chain): equal to the three-launch form up to summation order.
 #pragma once
 #include "gemm.h"
 #include "rowops.h"
@@ -33,17 +34,16 @@ struct AttnFwdArgs {
     float* P;
     float* O; int ld_o;
     float scale;
-    int dk;                          // head width: multiple of 16, <= 128
+    int dk;                          // head width: multiple of 8, <= 128
 };
 
 constexpr int kAttnQ = 32;           // query rows per workgroup
+constexpr int kAttnJ = 16;           // 8-channel steps of the widest head (dk = 128)
 
 template <int LCAP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     constexpr int LD = LCAP + 4;
-    __shared__ __attribute__((aligned(16))) float smem[kAttnQ * LD + kAttnQ * (128 + 4)];
-    float* Ss = smem;
-    float* QVs = smem + kAttnQ * LD;
+    __shared__ __attribute__((aligned(16))) float Ss[kAttnQ * LD];
     const int z = blockIdx.z;
     const AttnSeq sq = a.seqs[z];
     const int L = sq.L, ldS = sq.ldS, dk = a.dk;
@@ -56,45 +56,64 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     float* Og = a.O + dv.c_off;
     float* Pg = a.P + sq.s_off;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-    const int LDQ = dk + 4, dk4 = dk / 4;
+    const int nj = dk / 8;                         // 8-channel steps
     const int nkc = (L + 31) / 32;                 // 32-key chunks
 
-    // ---- Q tile -> LDS (rows beyond the sequence repeat its last row: their results are never stored)
-    for (int idx = tid; idx < kAttnQ * dk4; idx += 256) {
-        const int r = idx / dk4, c4 = idx - r * dk4;
-        const int gr = q0 + r < L ? q0 + r : L - 1;
-        st4(QVs + r * LDQ + c4 * 4, ld4(Qg + (long long)gr * a.ld_q + c4 * 4));
-    }
-    __syncthreads();
-
     // ---- phase A: S = scale * Q K^T
-    for (int c = wave; c < nkc; c += 4) {
-        const int key = c * 32 + l31 < L ? c * 32 + l31 : L - 1;
-        const float* kp = Kg + (long long)key * a.ld_k;
-        f32x16 acc;
+    {
+        // the Q tile as A fragments: lane (row l31, half h) holds channels 8j + 4h .. + 3 of every step j (rows beyond the sequence repeat
+        // its last row: their results are never stored)
+        const float* qp = Qg + (long long)(q0 + l31 < L ? q0 + l31 : L - 1) * a.ld_q + 4 * h;
+        float4 qf[kAttnJ];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int j = 0; j < kAttnJ; ++j) qf[j] = j < nj ? ld4(qp + 8 * j) : zero4();
+        auto kptr = [&](int c) { return Kg + (long long)(c * 32 + l31 < L ? c * 32 + l31 : L - 1) * a.ld_k + 4 * h; };
 #if defined(MTTS_EMU)
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            float s = 0.f;
-            for (int k = 0; k < dk; ++k) s = fmaf(QVs[row * LDQ + k], kp[k], s);
-            acc[r] = s;
+        for (int c = wave; c < nkc; c += 4) {
+            const float* kp = kptr(c) - 4 * h;
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float* qr = Qg + (long long)(q0 + row < L ? q0 + row : L - 1) * a.ld_q;
+                float s = 0.f;
+                for (int k = 0; k < dk; ++k) s = fmaf(qr[k], kp[k], s);
+                Ss[row * LD + c * 32 + l31] = s * a.scale;
+            }
         }
+        (void)qf;
 #else
-#pragma unroll 4
-        for (int j = 0; j < dk / 8; ++j) {
-            const float4 a4 = ld4(QVs + l31 * LDQ + 8 * j + 4 * h);
-            const float4 b4 = ld4(kp + 8 * j + 4 * h);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        float4 kf[2][kAttnJ];
+        if (wave < nkc) {
+            const float* kp = kptr(wave);
+#pragma unroll
+            for (int j = 0; j < kAttnJ; ++j) if (j < nj) kf[0][j] = ld4(kp + 8 * j);
+        }
+        auto chunk = [&](int c, const float4 (&kc)[kAttnJ], float4 (&kn)[kAttnJ]) {
+            if (c + 4 < nkc) {   // the next chunk's fragments go in flight behind this chunk's MFMAs
+                const float* kp = kptr(c + 4);
+#pragma unroll
+                for (int j = 0; j < kAttnJ; ++j) if (j < nj) kn[j] = ld4(kp + 8 * j);
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < kAttnJ; ++j) {
+                if (j < nj) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].x, kc[j].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].y, kc[j].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].z, kc[j].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].w, kc[j].w, acc, 0, 0, 0);
+                }
+            }
+            const int col = c * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ss[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + col] = acc[r] * a.scale;
+        };
+        for (int c = wave; c < nkc; c += 8) {
+            chunk(c, kf[0], kf[1]);
+            if (c + 4 < nkc) chunk(c + 4, kf[1], kf[0]);
         }
 #endif
-        const int col = c * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Ss[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + col] = acc[r] * a.scale;
     }
     __syncthreads();
 
@@ -117,43 +136,51 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
             if (c < ldS) pg[c] = v;
         }
     }
+    __syncthreads();
 
-    // ---- phase C: O = P V, one 32-key block of V through LDS at a time
-    const bool has_cols = 32 * wave < dk;
+    // ---- phase C: O = P V; this wavefront's 32 output columns
+    if (32 * wave >= dk) return;
     const int ocol = 32 * wave + l31 < dk ? 32 * wave + l31 : dk - 1;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int kb = 0; kb < nkc; ++kb) {
-        __syncthreads();   // phase B (kb == 0) / the previous block's fragment reads are done: QV may be overwritten
-        for (int idx = tid; idx < 32 * dk4; idx += 256) {
-            const int r = idx / dk4, c4 = idx - r * dk4;
-            const int key = kb * 32 + r < L ? kb * 32 + r : L - 1;   // (P is zero there)
-            st4(QVs + r * dk + c4 * 4, ld4(Vg + (long long)key * a.ld_v + c4 * 4));
-        }
-        __syncthreads();
-        if (has_cols) {
 #if defined(MTTS_EMU)
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                float s = acc[r];
-                for (int k = 0; k < 32; ++k) s = fmaf(Ss[row * LD + kb * 32 + k], QVs[k * dk + ocol], s);
-                acc[r] = s;
-            }
-#else
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 a4 = ld4(Ss + l31 * LD + kb * 32 + 8 * j + 4 * h);
-                const float* vb = QVs + (8 * j + 4 * h) * dk + ocol;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, vb[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, vb[dk], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, vb[2 * dk], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, vb[3 * dk], acc, 0, 0, 0);
-            }
-#endif
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float s = 0.f;
+        for (int k = 0; k < L; ++k) s = fmaf(Ss[row * LD + k], Vg[(long long)k * a.ld_v + ocol], s);
+        acc[r] = s;
     }
-    if (has_cols && 32 * wave + l31 < dk) {
+#else
+    // B fragments: step (j, e) of a 32-key block needs V[8j + 4h + e][ocol] (keys beyond the sequence: its last row, P is zero there)
+    auto vload = [&](int kb, float (&v)[16]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = kb * 32 + 8 * j + 4 * h + e;
+                v[4 * j + e] = Vg[(long long)(key < L ? key : L - 1) * a.ld_v + ocol];
+            }
+    };
+    float vf[2][16];
+    vload(0, vf[0]);
+    auto block = [&](int kb, const float (&vc)[16], float (&vn)[16]) {
+        if (kb + 1 < nkc) vload(kb + 1, vn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 a4 = ld4(Ss + l31 * LD + kb * 32 + 8 * j + 4 * h);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, vc[4 * j + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, vc[4 * j + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, vc[4 * j + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, vc[4 * j + 3], acc, 0, 0, 0);
+        }
+    };
+    for (int kb = 0; kb < nkc; kb += 2) {
+        block(kb, vf[0], vf[1]);
+        if (kb + 1 < nkc) block(kb + 1, vf[1], vf[0]);
+    }
+#endif
+    if (32 * wave + l31 < dk) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qrow = q0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -164,11 +191,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
 
 // the fused kernel serves sequences of up to 1024 keys and heads of up to 128 channels (everything base.yaml produces in training;
 // eval-mode synthesis beyond max_seq_len and exotic head widths keep the three-launch path)
-inline bool attn_fused_ok(int max_L, int dk) { return max_L >= 1 && max_L <= 1024 && dk >= 16 && dk <= 128 && dk % 8 == 0; }
+inline bool attn_fused_ok(int max_L, int dk) { return max_L >= 1 && max_L <= 1024 && dk >= 8 && dk <= 8 * kAttnJ && dk % 8 == 0; }
 inline void attn_fwd_launch(const AttnFwdArgs& a, int max_L, int groups, hipStream_t stream) {
     dim3 grid((unsigned)((max_L + kAttnQ - 1) / kAttnQ), 1, (unsigned)groups), block(256);
     if (max_L <= 128) MTTS_LAUNCH((attn_fwd_kernel<128>), grid, block, stream, a);
-    else if (max_L <= 640) MTTS_LAUNCH((attn_fwd_kernel<640>), grid, block, stream, a);
+    else if (max_L <= 352) MTTS_LAUNCH((attn_fwd_kernel<352>), grid, block, stream, a);
+    else if (max_L <= 608) MTTS_LAUNCH((attn_fwd_kernel<608>), grid, block, stream, a);
     else MTTS_LAUNCH((attn_fwd_kernel<1024>), grid, block, stream, a);
 }
 

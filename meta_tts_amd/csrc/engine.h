@@ -171,9 +171,9 @@ public:
     // weight-gradient GEMMs consume (dz2 / dh / dz1 / dqkv) are written into per-layer buffers instead of the shared scratch, so the
     // GEMMs no longer have to run before the scratch is reused: they go out as ONE multi-problem launch per layer on a SIDE stream,
     // concurrently with the backward chain of the layers below, and are joined before anything reads the parameter gradients.
-    struct LayerGrad { TS dc, gh, da, gqkv, dy2, dy1; };   // dy2 / dy1: the gradients entering LN2 / LN1 (their gamma / beta reductions are deferred too)
+    struct LayerGrad { TS dc, gh, da, gqkv; float *part2, *part1; };   // part2 / part1: the 8-row gamma / beta partials LN2's / LN1's backward kernel leaves (folded on the side stream)
     std::vector<LayerGrad> encG, decG;
-    struct PredGrad { TS g2a, g2b, dy2, dy1; };   // variance predictor: d(conv2 out), d(conv1 out), the gradients entering its two LayerNorms
+    struct PredGrad { TS g2a, g2b; float *part2, *part1; };   // variance predictor: d(conv2 out), d(conv1 out), the gamma / beta partials of its two LayerNorms
     PredGrad predG[3];
     std::vector<TS> postG;               // per PostNet layer: gradient of the conv output (what its weight-gradient GEMM reads)
     char* arena_defer = nullptr;
@@ -215,6 +215,8 @@ public:
     int* col_ctr = nullptr;                       // arrival counters of the fused column reduction (zero between launches)
     static constexpr int kColCtrPerTask = 8;      // 128-column groups per task (C <= 1024)
     int col_max_chunks = 0;
+    long long col_partial_ts = 0;                 // floats per task of col_partial
+    static int ln_chunks(int rows) { return (rows + kLnRows - 1) / kLnRows; }   // partial chunks of the LayerNorm backward (rowops.h)
     long long S_ts_p = 0, S_ts_f = 0;
 
     char* arena = nullptr;
@@ -531,7 +533,12 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         dspk = flat((long long)cap_B * d);
         for (int i = 0; i < 3; ++i) dpred[i] = rows(capMp, 1);
         col_max_chunks = (std::max(std::max(capMp, capMf), capMr) + kRC - 1) / kRC;
-        col_partial = (float*)take((size_t)cap_tasks * col_max_chunks * 3 * 1024 * sizeof(float));
+        {   // two-stage column reductions: colpart's 32-row chunks x 3 x 1024, or the LayerNorm backward's 8-row chunks x 3 x (its width)
+            const size_t ln_w = (size_t)std::max(cfg.d_model, cfg.vp_filter);
+            const size_t per_task = std::max((size_t)col_max_chunks * 3 * 1024, (size_t)ln_chunks(std::max(std::max(capMp, capMf), capMr)) * 3 * ln_w);
+            col_partial_ts = (long long)per_task;
+            col_partial = (float*)take((size_t)cap_tasks * per_task * sizeof(float));
+        }
         col_ctr = (int*)take((size_t)cap_tasks * kColCtrPerTask * sizeof(int));
         loss_partial = (float*)take((size_t)cap_tasks * kLossBlocks * 5 * sizeof(float));
         losses = (float*)take((size_t)cap_tasks * 6 * sizeof(float));
@@ -705,12 +712,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         defer_tasks = std::min(cap_tasks, max_defer_tasks);
         if (defer_tasks < 1) { defer_tasks = 0; return 0; }
         const int d = cfg.d_model;
-        const long long per_row = 4LL * d + cfg.d_ff + 3LL * d;
+        const long long per_row = 2LL * d + cfg.d_ff + 3LL * d;
         const int post_c = std::max(cfg.postnet_dim, cfg.n_mel);
         const size_t bytes = (size_t)defer_tasks * per_row * sizeof(float) *
                              ((size_t)cfg.enc_layers * (capMp + 2 * G) + (size_t)cfg.dec_layers * (capMf + 2 * G)) +
                              (size_t)defer_tasks * cfg.postnet_layers * (size_t)(capMr + 2 * G) * post_c * sizeof(float) +
-                             (size_t)defer_tasks * 3 * 4 * (size_t)(capMp + 2 * G) * cfg.vp_filter * sizeof(float) +
+                             (size_t)defer_tasks * 3 * 2 * (size_t)(capMp + 2 * G) * cfg.vp_filter * sizeof(float) +
+                             (size_t)defer_tasks * 2 * ((size_t)cfg.enc_layers * ln_chunks(capMp) + (size_t)cfg.dec_layers * ln_chunks(capMf)) * 3 * d * sizeof(float) +
+                             (size_t)defer_tasks * 3 * 2 * (size_t)ln_chunks(capMp) * 3 * cfg.vp_filter * sizeof(float) + 64 * 256 +
                              (size_t)defer_tasks * kAhead * (size_t)(capMp + 2 * G) * d * sizeof(float) + 4096;
         HIP_CHECK(hipMalloc((void**)&arena_defer, bytes));
         HIP_CHECK(hipMemset(arena_defer, 0, bytes));
@@ -721,15 +730,21 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             cur += (size_t)ts * defer_tasks * sizeof(float);
             return TS{p0 + (long long)G * C, ts};
         };
+        auto part_d = [&](int capM, int C) {   // [defer_tasks][ln_chunks(capM)][3][C]: the LayerNorm backward's partial sums of one site
+            cur = (char*)(((uintptr_t)cur + 255) & ~(uintptr_t)255);
+            float* p0 = (float*)cur;
+            cur += (size_t)defer_tasks * ln_chunks(capM) * 3 * C * sizeof(float);
+            return p0;
+        };
         auto mk = [&](std::vector<LayerGrad>& v, int n, int capM) {
             v.resize(n);
             for (int i = 0; i < n; ++i) { v[i].dc = rows_d(capM, d); v[i].gh = rows_d(capM, cfg.d_ff); v[i].da = rows_d(capM, d); v[i].gqkv = rows_d(capM, 3 * d);
-                                          v[i].dy2 = rows_d(capM, d); v[i].dy1 = rows_d(capM, d); }
+                                          v[i].part2 = part_d(capM, d); v[i].part1 = part_d(capM, d); }
         };
         mk(encG, cfg.enc_layers, capMp);
         mk(decG, cfg.dec_layers, capMf);
         for (auto& t : enc_ahead) t = rows_d(capMp, d);
-        for (auto& pg : predG) { pg.g2a = rows_d(capMp, cfg.vp_filter); pg.g2b = rows_d(capMp, cfg.vp_filter); pg.dy2 = rows_d(capMp, cfg.vp_filter); pg.dy1 = rows_d(capMp, cfg.vp_filter); }
+        for (auto& pg : predG) { pg.g2a = rows_d(capMp, cfg.vp_filter); pg.g2b = rows_d(capMp, cfg.vp_filter); pg.part2 = part_d(capMp, cfg.vp_filter); pg.part1 = part_d(capMp, cfg.vp_filter); }
         postG.resize(cfg.postnet_layers);
         for (auto& t : postG) t = rows_d(capMr, post_c);
         {   // non-blocking (a blocking stream would serialise with the legacy default stream on every launch); MTTS_SIDE_PRIO=1: lowest priority
@@ -1211,7 +1226,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             const int chunks_s = (maxM + kRC - 1) / kRC;
             MTTS_LAUNCH(colpart_kernel, dim3((a.C + 127) / 128, chunks_s, p.tasks), dim3(256), side, (const int*)p.meta, a, col_partial_side, col_max_chunks);
             MTTS_LAUNCH(colfinal_kernel, dim3((a.C + 63) / 64, 1, p.tasks), dim3(256), side, (const int*)p.meta, a.mfield, a.mode,
-                        (const float*)col_partial_side, col_max_chunks, a.C, out0, out1, out_ts, 1e-5f, a.accumulate);
+                        (const float*)col_partial_side, col_max_chunks, a.C, out0, out1, out_ts, 1e-5f, a.accumulate, (int)kRC);
             return;
         }
         // single-launch variant A: a workgroup per (32-column stripe, task) walks all rows (rowops.h: colstripe_kernel).  Measured
@@ -1234,7 +1249,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         MTTS_LAUNCH(colpart_kernel, dim3((a.C + 127) / 128, chunks, p.tasks), dim3(256), stream, (const int*)p.meta, a, col_partial,
                     col_max_chunks);
         MTTS_LAUNCH(colfinal_kernel, dim3((a.C + 63) / 64, 1, p.tasks), dim3(256), stream, (const int*)p.meta, a.mfield, a.mode,
-                    (const float*)col_partial, col_max_chunks, a.C, out0, out1, out_ts, 1e-5f, a.accumulate);
+                    (const float*)col_partial, col_max_chunks, a.C, out0, out1, out_ts, 1e-5f, a.accumulate, (int)kRC);
     }
     void colsum(const Pass& ps, Space s, TS x, int C, const unsigned char* mask, TS roww, TS out, bool on_side = false) {
         const Plan& p = *ps.pl;
@@ -1253,29 +1268,33 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     }
     // dz = LayerNorm backward (masked); parameter grads into the per-task grad buffer
     // dz_drop: second output = dropout(dz) with the forward site's mask; copy_always: written even when dropout is off (a plain copy)
+    // din: dropout applied to dy on load (a dropout that sits BEHIND this LayerNorm in the forward, modules.py:222-235)
+    // part: null = the gamma / beta reduction completes here (the kernel's 8-row partials in the shared scratch + one colfinal launch on this
+    //       stream); set = the partials are left in `part` ([tasks][ln_chunks][3][C], a buffer of the site's own) and ln_param_grads_side
+    //       folds them later on the side stream (deferred parameter gradients)
     void ln_bwd(const Pass& ps, Space s, TS dy, TS z, TS st, long long g_off, long long b_off, const unsigned char* mask,
                 TS dz, int C, int relu_on_z, TS dz_drop = TS{nullptr, 0}, DropSpec dd = DropSpec(), bool copy_always = false,
-                TS dy_copy = TS{nullptr, 0}) {   // dy_copy set: dy is kept there and the gamma / beta reduction is left to ln_param_grads_side
+                float* part = nullptr, DropSpec din = DropSpec()) {
         const Plan& p = *ps.pl;
         TS gm = W(ps, g_off);
-        TS gg = Gd(g_off), gb = Gd(b_off);
-        ColArgs a;
-        a.X = dy.p; a.x_ts = dy.ts; a.Z = z.p; a.z_ts = z.ts; a.stats = st.p; a.st_ts = st.ts;
-        a.mask = mask; a.mask_ts = row_ts(s); a.C = C; a.mode = 1; a.mfield = mfield(s);
-        if (!dy_copy.p) colreduce(p, a, gg.p, gb.p, gg.ts, maxM(p, s));
+        const int chunks = ln_chunks(maxM(p, s));
+        float* pbuf = part ? part : col_partial;
         MTTS_LAUNCH_LN(layernorm_bwd_kernel, C, row2_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
                     (const float*)dy.p, dy.ts, (const float*)z.p, z.ts, (const float*)st.p, st.ts, (const float*)gm.p, gm.ts,
                     mask, row_ts(s), dz.p, dz.ts, C, relu_on_z, (dd.thr16 || copy_always) ? dz_drop.p : nullptr, dz_drop.ts, dd,
-                    dy_copy.p, dy_copy.ts);
+                    din, pbuf, chunks);
+        if (!part) ln_fold(p, s, pbuf, chunks, g_off, b_off, C, stream);
     }
-    // the LayerNorm gamma / beta gradients of a deferred layer, from the kept copy of dy, on the side stream
-    void ln_param_grads_side(const Pass& ps, Space s, TS dy_copy, TS z, TS st, long long g_off, long long b_off, const unsigned char* mask, int C) {
-        const Plan& p = *ps.pl;
+    // stage 2 of a LayerNorm's gamma / beta reduction: fold the backward kernel's partial rows
+    void ln_fold(const Plan& p, Space s, const float* part, int chunks, long long g_off, long long b_off, int C, hipStream_t st) {
         TS gg = Gd(g_off), gb = Gd(b_off);
-        ColArgs a;
-        a.X = dy_copy.p; a.x_ts = dy_copy.ts; a.Z = z.p; a.z_ts = z.ts; a.stats = st.p; a.st_ts = st.ts;
-        a.mask = mask; a.mask_ts = row_ts(s); a.C = C; a.mode = 1; a.mfield = mfield(s);
-        colreduce(p, a, gg.p, gb.p, gg.ts, maxM(p, s), true);
+        MTTS_LAUNCH(colfinal_kernel, dim3((C + 63) / 64, 1, p.tasks), dim3(256), st, (const int*)p.meta, mfield(s), 1, part, chunks, C,
+                    gg.p, gb.p, gg.ts, 1e-5f, 0, (int)kLnRows);
+    }
+    // the LayerNorm gamma / beta gradients of a deferred layer, from the partials its backward kernel left, on the side stream
+    void ln_param_grads_side(const Pass& ps, Space s, const float* part, long long g_off, long long b_off, int C) {
+        const Plan& p = *ps.pl;
+        ln_fold(p, s, part, ln_chunks(maxM(p, s)), g_off, b_off, C, side);
     }
     void attn_gemm(const Pass& ps, Space s, int which, int form, const float* A, int lda, const float* B, int ldb,
                    float* C, int ldc, float alpha, int heads, int flags = 0, const float* A2 = nullptr, const float* B2 = nullptr) {
@@ -1364,7 +1383,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         // LN2 (+ row mask) backward -> g1 = dz2
         TS gm = (s == SP_P) ? gPm : gFm;                                   // masked copy feeds the conv branch, g1 the residual
         const DropSpec dd2 = drop_spec(ps, block_dropout(s), site_base + 1);
-        ln_bwd(ps, s, g0_in, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0, df ? lg->dc : gm, dd2, df, df ? lg->dy2 : TS{nullptr, 0});
+        ln_bwd(ps, s, g0_in, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0, df ? lg->dc : gm, dd2, df, df ? lg->part2 : nullptr);
         TS dc = df ? lg->dc : (dd2.thr16 ? gm : g1);
         // conv2
         {   // wgrad and dgrad of a layer are independent: one multi-problem launch (gemm.h: gemm_f32_multi_kernel)
@@ -1380,7 +1399,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         // LN1 backward -> g0 = dz1
         const DropSpec dd1 = drop_spec(ps, block_dropout(s), site_base);
-        ln_bwd(ps, s, g1, b.z1, b.st1, P.ln1g, P.ln1b, vm, g0, d, 0, df ? lg->da : gm, dd1, df, df ? lg->dy1 : TS{nullptr, 0});
+        ln_bwd(ps, s, g1, b.z1, b.st1, P.ln1g, P.ln1b, vm, g0, d, 0, df ? lg->da : gm, dd1, df, df ? lg->part1 : nullptr);
         TS da = df ? lg->da : (dd1.thr16 ? gm : g0);
         // fc
         {
@@ -1422,8 +1441,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                 conv_wgrad(ps, s, gqkv, 3 * d, 1, xin, d, P.wqkv, P.bqkv, vm, 0, &gx_side, side);
                 conv_wgrad(ps, s, da, d, 1, b.O, d, P.wfc, P.bfc, vm, 0, &gx_side, side);
             }
-            ln_param_grads_side(ps, s, lg->dy2, b.z2, b.st2, P.ln2g, P.ln2b, vm, d);
-            ln_param_grads_side(ps, s, lg->dy1, b.z1, b.st1, P.ln1g, P.ln1b, vm, d);
+            ln_param_grads_side(ps, s, lg->part2, P.ln2g, P.ln2b, d);
+            ln_param_grads_side(ps, s, lg->part1, P.ln1g, P.ln1b, d);
             defer_live = true;
         }
     }
@@ -1507,11 +1526,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             TS w = W(ps, P.lw);
             MTTS_LAUNCH(rowdot_bwd_kernel, row_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
                         (const float*)dout.p, dout.ts, (const float*)w.p, w.ts, g1.p, g1.ts, f);
-            drop(ps, s, g1, g1, f, cfg.vp_dropout, site_base + 1);
-            ln_bwd(ps, s, g1, b.r2, b.st2, P.l2g, P.l2b, im, pg->g2a, f, 1, none, DropSpec(), false, pg->dy2);
+            // (the backward of the dropout behind each LayerNorm rides in the LayerNorm backward's load of its incoming gradient)
+            ln_bwd(ps, s, g1, b.r2, b.st2, P.l2g, P.l2b, im, pg->g2a, f, 1, none, DropSpec(), false, pg->part2, drop_spec(ps, cfg.vp_dropout, site_base + 1));
             conv_dgrad(ps, s, pg->g2a, f, k, W(ps, P.c2w), f, g1, 0, im);
-            drop(ps, s, g1, g1, f, cfg.vp_dropout, site_base);
-            ln_bwd(ps, s, g1, b.r1, b.st1, P.l1g, P.l1b, im, pg->g2b, f, 1, none, DropSpec(), false, pg->dy1);
+            ln_bwd(ps, s, g1, b.r1, b.st1, P.l1g, P.l1b, im, pg->g2b, f, 1, none, DropSpec(), false, pg->part1, drop_spec(ps, cfg.vp_dropout, site_base));
             conv_dgrad(ps, s, pg->g2b, f, k, W(ps, P.c1w), d, dx, GEMM_ACCUM, im);
             fork_side();
             {
@@ -1519,8 +1537,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                 conv_wgrad(ps, s, pg->g2a, f, k, b.n1, f, P.c2w, P.c2b, im, 0, &gx_side, side);
                 conv_wgrad(ps, s, pg->g2b, f, k, xin, d, P.c1w, P.c1b, im, 0, &gx_side, side);
             }
-            ln_param_grads_side(ps, s, pg->dy2, b.r2, b.st2, P.l2g, P.l2b, im, f);
-            ln_param_grads_side(ps, s, pg->dy1, b.r1, b.st1, P.l1g, P.l1b, im, f);
+            ln_param_grads_side(ps, s, pg->part2, P.l2g, P.l2b, f);
+            ln_param_grads_side(ps, s, pg->part1, P.l1g, P.l1b, f);
             colsum(ps, s, dout, 1, nullptr, none, Gd(P.lb), true);
             colsum(ps, s, b.n2, f, nullptr, dout, Gd(P.lw), true);
             defer_live = true;
@@ -1531,15 +1549,13 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         TS w = W(ps, P.lw);
         MTTS_LAUNCH(rowdot_bwd_kernel, row_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
                     (const float*)dout.p, dout.ts, (const float*)w.p, w.ts, g1.p, g1.ts, f);
-        drop(ps, s, g1, g1, f, cfg.vp_dropout, site_base + 1);
-        ln_bwd(ps, s, g1, b.r2, b.st2, P.l2g, P.l2b, im, g2, f, 1);       // g2 = d conv2 out
+        ln_bwd(ps, s, g1, b.r2, b.st2, P.l2g, P.l2b, im, g2, f, 1, none, DropSpec(), false, nullptr, drop_spec(ps, cfg.vp_dropout, site_base + 1));       // g2 = d conv2 out
         {
             GemmBatchScope pair(gx, stream);
             conv_wgrad(ps, s, g2, f, k, b.n1, f, P.c2w, P.c2b, im);
             conv_dgrad(ps, s, g2, f, k, W(ps, P.c2w), f, g1, 0, im);     // g1 = d n1
         }
-        drop(ps, s, g1, g1, f, cfg.vp_dropout, site_base);
-        ln_bwd(ps, s, g1, b.r1, b.st1, P.l1g, P.l1b, im, g2, f, 1);       // g2 = d conv1 out
+        ln_bwd(ps, s, g1, b.r1, b.st1, P.l1g, P.l1b, im, g2, f, 1, none, DropSpec(), false, nullptr, drop_spec(ps, cfg.vp_dropout, site_base));       // g2 = d conv1 out
         {
             GemmBatchScope pair(gx, stream);
             conv_wgrad(ps, s, g2, f, k, xin, d, P.c1w, P.c1b, im);
@@ -1570,10 +1586,15 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // Run-ahead (see kAhead): enqueue the encoder forwards of `steps` train-mode passes over plan `pl` on side2; seeds[s] / enc_ahead[s] /
     // ev_enc[s] belong to step s.  Returns false when the regime does not qualify (the caller then runs forward() as usual).
     // per_step_sets: step s writes the encoder's activations into activation set s + 1 (second-order MAML keeps them for its reverse sweep)
-    bool run_encoder_ahead(Plan& pl, int steps, unsigned* seeds, bool per_step_sets = false) {
+    // query (optional): the query pass's encoder forward runs ahead too, after the inner steps' — into the arena's own activation set,
+    // where its backward will find the activations; *query_seed receives its dropout seed, ev_enc[steps] its completion
+    bool run_encoder_ahead(Plan& pl, int steps, unsigned* seeds, bool per_step_sets = false, Plan* query = nullptr, unsigned* query_seed = nullptr) {
         static const int on = [] { const char* e = getenv("MTTS_ENC_AHEAD"); return e ? atoi(e) : 1; }();
-        if (!on || steps < 1 || steps > kAhead || encoder_adapted() || !defer_ok(pl) || side2 == nullptr) return false;
+        if (!on || steps < 1 || steps + (query ? 1 : 0) > kAhead || encoder_adapted() || !defer_ok(pl) || side2 == nullptr) return false;
         for (int s = 0; s < steps; ++s) seeds[s] = next_drop_seed();
+        static const int q_on = [] { const char* e = getenv("MTTS_ENC_AHEAD_QUERY"); return e ? atoi(e) : 1; }();
+        if (query && (!q_on || !defer_ok(*query) || cfg.enc_layers < 1)) query = nullptr;
+        if (query) *query_seed = next_drop_seed();   // (the seed forward() would draw for the query pass: after the inner steps')
         hipEvent_t ev = ev_side[ev_next];
         ev_next = (ev_next + 1) % kSideEvents;
         hipEventRecord(ev, stream);              // the batch image / plan kernels of this plan are on the main stream
@@ -1590,6 +1611,12 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             hipEventRecord(ev_enc[s], stream);
         }
         if (per_step_sets) bind_act(0);
+        if (query) {
+            Pass pe{query, true, true};
+            query->drop_seed = *query_seed;
+            encoder_fwd(pe);                         // (output = encB.back().y2 of activation set 0; nothing overwrites it before the query pass)
+            hipEventRecord(ev_enc[steps], stream);
+        } else if (query_seed) *query_seed = 0;
         std::swap(gx, gx_side2);
         std::swap(stream, side2);
         return true;
@@ -1738,8 +1765,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             TS gm = W(ps, P.g), bt = W(ps, P.beta);
             MTTS_LAUNCH(bn_apply_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (const float*)b.c.p, b.c.ts,
                         (const float*)b.stats.p, b.stats.ts, (const float*)gm.p, (const float*)bt.p, gm.ts,
-                        (const unsigned char*)p.r_inrect, row_ts_r, (int)(i < cfg.postnet_layers - 1), b.a.p, b.a.ts, P.cout);
-            drop(ps, SP_R, b.a, b.a, P.cout, cfg.postnet_dropout, 192 + i);  // F.dropout(..., 0.5, self.training), Layers.py:133-134
+                        (const unsigned char*)p.r_inrect, row_ts_r, (int)(i < cfg.postnet_layers - 1), b.a.p, b.a.ts, P.cout,
+                        drop_spec(ps, cfg.postnet_dropout, 192 + i));  // F.dropout(..., 0.5, self.training), Layers.py:133-134, in passing
             cur = b.a;
         }
         // mel_post = postnet(mel) + mel   (whole [tasks][rows][n_mel] slab incl. guard rows: all zero there)
@@ -1852,10 +1879,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             PostBuf& b = postB[i];
             const int act = (i < cfg.postnet_layers - 1);
             const float ysc = drop_active(ps) ? 1.f - cfg.postnet_dropout : 1.f;
-            cur = drop(ps, SP_R, cur, gR1, P.cout, cfg.postnet_dropout, 192 + i);  // gradient through the mask (gRp itself is kept)
+            const DropSpec pdrop = drop_spec(ps, cfg.postnet_dropout, 192 + i);   // gradient through the mask: applied where dY is read
             TS dgm = Gd(P.g), dbt = Gd(P.beta);
             ColArgs ca;
-            ca.yscale = ysc;
+            ca.yscale = ysc; ca.xdrop = pdrop;
             ca.X = cur.p; ca.x_ts = cur.ts; ca.Y = b.a.p; ca.y_ts = b.a.ts; ca.Z = b.c.p; ca.z_ts = b.c.ts;
             ca.stats = b.stats.p; ca.st_ts = b.stats.ts; ca.mask = p.r_inrect; ca.mask_ts = row_ts_r; ca.C = P.cout;
             ca.mode = 3; ca.do_tanh = act; ca.mfield = META_MR;
@@ -1866,7 +1893,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             MTTS_LAUNCH(bn_bwd_apply_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (const float*)cur.p,
                         cur.ts, (const float*)b.a.p, b.a.ts, (const float*)b.c.p, b.c.ts, (const float*)b.stats.p, b.stats.ts,
                         (const float*)gm.p, gm.ts, (const float*)dgm.p, (const float*)dbt.p, dgm.ts,
-                        (const unsigned char*)p.r_inrect, row_ts_r, act, dc.p, dc.ts, P.cout, ysc);
+                        (const unsigned char*)p.r_inrect, row_ts_r, act, dc.p, dc.ts, P.cout, ysc, pdrop);
             TS xin = (i == 0) ? mel : postB[i - 1].a;
             if (dfp) {   // this layer's weight gradient on the side stream, overlapping the rest of the backward chain
                 fork_side();
@@ -2005,8 +2032,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             MTTS_LAUNCH(broadcast_kernel, dim3(blocks_for(n_adapt / 4), 1, nt), dim3(256), stream,
                         (const float*)(theta + adapt_start), fast, n_adapt / 4, n_adapt);
         Pass ps{&sp, true, true};
-        unsigned seeds[kAhead];
-        const bool ahead = run_encoder_ahead(sp, steps, seeds);
+        unsigned seeds[kAhead], qseed = 0;
+        const bool ahead = run_encoder_ahead(sp, steps, seeds, false, &qp, &qseed);
         for (int s = 0; s < steps; ++s) {
             if (ahead) { hipStreamWaitEvent(stream, ev_enc[s], 0); ps.seed_override = seeds[s]; ps.enc_out = enc_ahead[s]; }
             if (forward(ps)) return -1;
@@ -2015,6 +2042,11 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             inner_update(nt, inner_lr);
         }
         Pass pq{&qp, true, true};
+        if (ahead && qseed) {   // the query pass's encoder ran ahead on the second side stream
+            hipStreamWaitEvent(stream, ev_enc[steps], 0);
+            pq.seed_override = qseed;
+            pq.enc_out = encB[cfg.enc_layers - 1].y2;
+        }
         if (forward(pq)) return -1;
         if (loss(pq, losses_out ? losses_out : losses)) return -1;
         if (backward(pq, grad_scale, true)) return -1;

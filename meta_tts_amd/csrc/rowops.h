@@ -168,24 +168,39 @@ __global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a
 
 // dz = mask ? rstd * (g - mean(g) - xhat * mean(g * xhat)) : 0, g = dy * gamma
 // (relu_on_z additionally multiplies by [z > 0]: z = ReLU(conv) in the variance predictors)
+// The kernel also does STAGE 1 of the gamma / beta gradient reduction (dgamma = sum_rows dy * xhat, dbeta = sum_rows dy over the unmasked
+// rows): every workgroup folds its 8 rows in registers and LDS and writes one partial row pair — partial[task][blockIdx.x][0 | 1][C], the
+// layout colfinal_kernel folds with rows_per_chunk = kLnRows — so the separate colpart launch over the same dy / z is gone.
+// din: dropout applied to the incoming gradient on load (the variance predictors' F.dropout sits behind the LayerNorm, modules.py:222-235:
+// its backward used to be a dropout launch of its own in front of this kernel).
+constexpr int kLnRows = 8;   // rows per workgroup of the LayerNorm kernels = rows per partial chunk
 template <int NV>
-__global__ void layernorm_bwd_kernel(const int* meta, int mfield, const float* dy, long long dy_ts, const float* zin,
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const int* meta, int mfield, const float* dy, long long dy_ts, const float* zin,
                                      long long z_ts, const float* stats, long long st_ts, const float* gamma,
                                      long long par_ts, const unsigned char* mask, long long mask_ts, float* dz,
                                      long long dz_ts, int C, int relu_on_z, float* dz_drop, long long dzd_ts, DropSpec dd,
-                                     float* dy_copy, long long dyc_ts) {
-    // dy_copy (optional): the incoming gradient, kept for a parameter-gradient reduction that runs later (engine.h: deferred path)
+                                     DropSpec din, float* partial, int max_chunks) {
     // dz_drop (optional): dropout(dz) with the mask of the forward site — the gradient entering the dropped branch, while dz
     // itself continues along the residual path
-    ROW2_PROLOGUE(mfield)
+    __shared__ __attribute__((aligned(16))) float red[4][2][256 * NV];
+    const int z = blockIdx.z;
+    const int M_ = meta[z * META_STRIDE + mfield];
+    if ((int)blockIdx.x * kLnRows >= M_) return;                       // (whole workgroup)
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int row0 = blockIdx.x * kLnRows + wave * 2;
+    const bool live0 = row0 < M_, live1 = row0 + 1 < M_;
+    const int rows_[2] = {live0 ? row0 : M_ - 1, live1 ? row0 + 1 : (live0 ? row0 : M_ - 1)};
     const float* g = gamma + (long long)z * par_ts;
-    float4 gv[2][NV], xh[2][NV];
+    float4 gv[2][NV], xh[2][NV], pg[NV], pb[NV];
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rstd[2];
     bool keep[2];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) { pg[n] = zero4(); pb[n] = zero4(); }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int row = rows_[q];
         keep[q] = mask ? (mask[(long long)z * mask_ts + row] != 0) : true;
+        const float wq = (keep[q] && (q == 0 ? live0 : live1)) ? 1.f : 0.f;   // this row counts in the parameter gradients
         const float* pdy = dy + (long long)z * dy_ts + (long long)row * C;
         const float* pz = zin + (long long)z * z_ts + (long long)row * C;
         const float* st = stats + (long long)z * st_ts + (long long)row * 2;
@@ -196,18 +211,28 @@ __global__ void layernorm_bwd_kernel(const int* meta, int mfield, const float* d
             const int c = lane * 4 + 256 * n;
             gv[q][n] = zero4(); xh[q][n] = zero4();
             if (c >= C) continue;
-            const float4 d = ld4(pdy + c), x = ld4(pz + c), g4 = ld4(g + c);
-            if (dy_copy && (q == 0 || live1)) st4(dy_copy + (long long)z * dyc_ts + (long long)row * C + c, d);
+            float4 d = ld4(pdy + c);
+            const float4 x = ld4(pz + c), g4 = ld4(g + c);
+            if (din.thr16) d = drop4(din, z, row, C, c, d);
             gv[q][n] = make_float4(d.x * g4.x, d.y * g4.y, d.z * g4.z, d.w * g4.w);
             xh[q][n] = make_float4((x.x - mean) * rstd[q], (x.y - mean) * rstd[q], (x.z - mean) * rstd[q], (x.w - mean) * rstd[q]);
             s1[q] += (gv[q][n].x + gv[q][n].y) + (gv[q][n].z + gv[q][n].w);
             s2[q] += (gv[q][n].x * xh[q][n].x + gv[q][n].y * xh[q][n].y) + (gv[q][n].z * xh[q][n].z + gv[q][n].w * xh[q][n].w);
+            pg[n].x += wq * d.x * xh[q][n].x; pg[n].y += wq * d.y * xh[q][n].y; pg[n].z += wq * d.z * xh[q][n].z; pg[n].w += wq * d.w * xh[q][n].w;
+            pb[n].x += wq * d.x; pb[n].y += wq * d.y; pb[n].z += wq * d.z; pb[n].w += wq * d.w;
+        }
+    }
+    if (partial) {
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int c = lane * 4 + 256 * n;
+            if (c < C) { st4(&red[wave][0][c], pg[n]); st4(&red[wave][1][c], pb[n]); }
         }
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const float m1 = wave_sum(s1[q]) / (float)C, m2 = wave_sum(s2[q]) / (float)C;
-        if (q == 1 && !live1) break;
+        if (!(q == 0 ? live0 : live1)) continue;
         const int row = rows_[q];
         float* pd = dz + (long long)z * dz_ts + (long long)row * C;
         const float* pz = zin + (long long)z * z_ts + (long long)row * C;
@@ -225,6 +250,13 @@ __global__ void layernorm_bwd_kernel(const int* meta, int mfield, const float* d
             st4(pd + c, o);
             if (dz_drop) st4(dz_drop + (long long)z * dzd_ts + (long long)row * C + c, drop4(dd, z, row, C, c, o));
         }
+    }
+    if (!partial) return;
+    __syncthreads();
+    float* out = partial + ((long long)z * max_chunks + blockIdx.x) * 3 * C;   // (wave order: fixed => run-to-run identical)
+    for (int idx = (int)threadIdx.x; idx < 2 * C; idx += 256) {
+        const int k = idx >= C ? 1 : 0, c = idx - k * C;
+        out[(long long)k * C + c] = (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]);
     }
 }
 
@@ -257,6 +289,7 @@ struct ColArgs {
     const float* Y2 = nullptr; long long y2_ts = 0;
     const float* stats2 = nullptr; long long st2_ts = 0;
     float yscale = 1.f;  // Y holds dropout(tanh(.)): y = Y * yscale with yscale = 1 - p (modes 3, 6)
+    DropSpec xdrop;      // mode 3: dropout applied to X (= dY) on load — the backward of the dropout behind the BatchNorm layer
     int C = 0, mode = 0, do_tanh = 0, mfield = 0, accumulate = 0;
 };
 
@@ -318,6 +351,7 @@ __device__ __forceinline__ void col_body(const int* meta, const ColArgs& a, floa
                     for (int k = 0; k < 4; ++k) { acc0[k] += x[k] * (zz[k] - mean) * rstd; acc1[k] += x[k]; }
                 } else if (a.mode == 3) {
                     float zz[4]; ldv(pz, m, zz);
+                    if (a.xdrop.thr16) { const float4 t = drop4(a.xdrop, z, m, C, c, make_float4(x[0], x[1], x[2], x[3])); x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w; }
                     if (a.do_tanh) { float y[4]; ldv(py, m, y); for (int k = 0; k < 4; ++k) { const float yy = y[k] * a.yscale; x[k] *= (1.f - yy * yy); } }
                     for (int k = 0; k < 4; ++k) { acc0[k] += x[k] * (zz[k] - mu[k]) * rs[k]; acc1[k] += x[k]; }
                 } else if (a.mode == 5) {
@@ -400,14 +434,14 @@ __global__ void colstripe_kernel(const int* meta, ColArgs a, float* out0, float*
 // 64 columns x 4 chunk lanes per workgroup: lane q folds chunks q, q+4, ... of its column, the four lane results are
 // merged in lane order through LDS (fixed order => run-to-run identical).
 __device__ __forceinline__ void colfinal_fold(const int* meta, int mfield, int mode, const float* partial, int max_chunks, int C,
-                                              float* out0, float* out1, long long out_ts, float eps, int accumulate, int c_base) {
+                                              float* out0, float* out1, long long out_ts, float eps, int accumulate, int c_base, int rows_per_chunk = kRC) {
     __shared__ float red[3][4][64];
     __syncthreads();  // the fold may run twice per workgroup (fused tail): red is reused
     const int z = blockIdx.z, cl = (int)threadIdx.x & 63, q = (int)threadIdx.x >> 6;
     const int c = c_base + cl;
     const bool cin = c < C;
     const int M_ = meta[z * META_STRIDE + mfield];
-    const int nch = (M_ + kRC - 1) / kRC;
+    const int nch = (M_ + rows_per_chunk - 1) / rows_per_chunk;
     const float* p = partial + (long long)z * max_chunks * 3 * C + (cin ? c : 0);
     if (mode != 2) {
         float s0 = 0.f, s1 = 0.f;
@@ -453,9 +487,10 @@ __device__ __forceinline__ void colfinal_fold(const int* meta, int mfield, int m
 
 __global__ void colpart_kernel(const int* meta, ColArgs a, float* partial, int max_chunks) { colpart_body(meta, a, partial, max_chunks); }
 
+// rows_per_chunk: kRC for colpart_kernel's partials, kLnRows for the ones layernorm_bwd_kernel writes in passing
 __global__ void colfinal_kernel(const int* meta, int mfield, int mode, const float* partial, int max_chunks, int C,
-                                float* out0, float* out1, long long out_ts, float eps, int accumulate) {
-    colfinal_fold(meta, mfield, mode, partial, max_chunks, C, out0, out1, out_ts, eps, accumulate, blockIdx.x * 64);
+                                float* out0, float* out1, long long out_ts, float eps, int accumulate, int rows_per_chunk) {
+    colfinal_fold(meta, mfield, mode, partial, max_chunks, C, out0, out1, out_ts, eps, accumulate, blockIdx.x * 64, rows_per_chunk);
 }
 
 // Both stages in one launch: every (task, 128-column group) keeps an arrival counter; the last row-chunk workgroup to
@@ -856,10 +891,11 @@ __global__ void bn_eval_stats_kernel(const float* running_mean, const float* run
     }
 }
 
-// y = act((x - mean) * rstd * gamma + beta) on in-rect rows, 0 on guard rows
+// y = dropout(act((x - mean) * rstd * gamma + beta)) on in-rect rows, 0 on guard rows
+// dout: the F.dropout behind every PostNet layer (Layers.py:133-134) applied in passing (it used to be a launch of its own)
 __global__ void bn_apply_kernel(const int* meta, const float* X, long long x_ts, const float* stats, long long st_ts,
                                 const float* gamma, const float* beta, long long par_ts, const unsigned char* inrect,
-                                long long row_ts, int do_tanh, float* Y, long long y_ts, int C) {
+                                long long row_ts, int do_tanh, float* Y, long long y_ts, int C, DropSpec dout) {
     ROW_PROLOGUE(META_MR)
     const bool in = inrect[(long long)z * row_ts + row] != 0;
     const float* px = X + (long long)z * x_ts + (long long)row * C;
@@ -874,6 +910,7 @@ __global__ void bn_apply_kernel(const int* meta, const float* X, long long x_ts,
             o = make_float4((x.x - mu.x) * rs.x * g4.x + b4.x, (x.y - mu.y) * rs.y * g4.y + b4.y,
                             (x.z - mu.z) * rs.z * g4.z + b4.z, (x.w - mu.w) * rs.w * g4.w + b4.w);
             if (do_tanh) o = make_float4(tanhf(o.x), tanhf(o.y), tanhf(o.z), tanhf(o.w));
+            if (dout.thr16) o = drop4(dout, z, row, C, c, o);
         }
         st4(py + c, o);
     }
@@ -884,7 +921,8 @@ __global__ void bn_bwd_apply_kernel(const int* meta, const float* dY, long long 
                                     long long ya_ts, const float* X, long long x_ts, const float* stats,
                                     long long st_ts, const float* gamma, long long par_ts, const float* dgamma,
                                     const float* dbeta, long long dg_ts, const unsigned char* inrect,
-                                    long long row_ts, int do_tanh, float* dX, long long dx_ts, int C, float yscale) {
+                                    long long row_ts, int do_tanh, float* dX, long long dx_ts, int C, float yscale, DropSpec din) {
+    // din: the backward of the dropout behind the layer, applied to dY on load (same mask as the forward's)
     ROW_PROLOGUE(META_MR)
     float* pdx = dX + (long long)z * dx_ts + (long long)row * C;
     if (!inrect[(long long)z * row_ts + row]) { for (int c = lane * 4; c < C; c += 256) st4(pdx + c, zero4()); return; }
@@ -897,7 +935,9 @@ __global__ void bn_bwd_apply_kernel(const int* meta, const float* dY, long long 
     const float* dg = dgamma + (long long)z * dg_ts;
     const float* db = dbeta + (long long)z * dg_ts;
     for (int c = lane * 4; c < C; c += 256) {
-        const float4 d4 = ld4(pdy + c), x4 = ld4(px + c), mu = ld4(st + c), rs = ld4(st + C + c), g4 = ld4(g + c),
+        float4 d4 = ld4(pdy + c);
+        if (din.thr16) d4 = drop4(din, z, row, C, c, d4);
+        const float4 x4 = ld4(px + c), mu = ld4(st + c), rs = ld4(st + C + c), g4 = ld4(g + c),
                      dg4 = ld4(dg + c), db4 = ld4(db + c);
         float dd[4] = {d4.x, d4.y, d4.z, d4.w};
         if (do_tanh) {

@@ -5,7 +5,7 @@ import collections
 import csv
 import sys
 
-FORMS = ["NT", "NN", "TN", "multi"]
+FORMS = ["NT", "NN", "TN", "multi", "attn"]
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for r in csv.DictReader(open(sys.argv[1])):
     key = (FORMS[int(r["form"])] + "/k" + r.get("kind", "?"), int(r["tile"]), int(r["N"]), int(r["K"]), int(float(r["rows"])), int(r["groups"]), int(r["splitk"]))
