@@ -38,15 +38,18 @@ struct AttnFwdArgs {
 };
 
 constexpr int kAttnQ = 32;           // query rows per workgroup
-constexpr int kAttnJ = 16;           // 8-channel steps of the widest head (dk = 128)
 
-template <int LCAP>
+// NJ = dk / 8: a compile-time head width keeps every fragment load unconditional (a load behind a run-time "j < dk / 8" test, or a prefetch
+// behind "is there a next chunk", makes hipcc drain vmcnt(0) in front of the MFMAs that follow: the whole L2 latency exposed per chunk —
+// 61 us instead of the three-launch form's 47 on a single-task rank); the prefetch past the last chunk re-reads the sequence's last row.
+template <int LCAP, int NJ>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     constexpr int LD = LCAP + 4;
     __shared__ __attribute__((aligned(16))) float Ss[kAttnQ * LD];
     const int z = blockIdx.z;
     const AttnSeq sq = a.seqs[z];
-    const int L = sq.L, ldS = sq.ldS, dk = a.dk;
+    const int L = sq.L, ldS = sq.ldS;
+    constexpr int dk = 8 * NJ;
     const int q0 = blockIdx.x * kAttnQ;
     if (q0 >= L) return;
     const GemmGroupDesc dq = a.tab_qk[z], dv = a.tab_pv[z];
@@ -56,7 +59,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     float* Og = a.O + dv.c_off;
     float* Pg = a.P + sq.s_off;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-    const int nj = dk / 8;                         // 8-channel steps
     const int nkc = (L + 31) / 32;                 // 32-key chunks
 
     // ---- phase A: S = scale * Q K^T
@@ -64,9 +66,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
         // the Q tile as A fragments: lane (row l31, half h) holds channels 8j + 4h .. + 3 of every step j (rows beyond the sequence repeat
         // its last row: their results are never stored)
         const float* qp = Qg + (long long)(q0 + l31 < L ? q0 + l31 : L - 1) * a.ld_q + 4 * h;
-        float4 qf[kAttnJ];
+        float4 qf[NJ];
 #pragma unroll
-        for (int j = 0; j < kAttnJ; ++j) qf[j] = j < nj ? ld4(qp + 8 * j) : zero4();
+        for (int j = 0; j < NJ; ++j) qf[j] = ld4(qp + 8 * j);
         auto kptr = [&](int c) { return Kg + (long long)(c * 32 + l31 < L ? c * 32 + l31 : L - 1) * a.ld_k + 4 * h; };
 #if defined(MTTS_EMU)
         for (int c = wave; c < nkc; c += 4) {
@@ -81,29 +83,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
         }
         (void)qf;
 #else
-        float4 kf[2][kAttnJ];
-        if (wave < nkc) {
-            const float* kp = kptr(wave);
+        float4 kf[2][NJ];
+        {
+            const float* kp = kptr(wave);   // (clamped rows when this wavefront has no chunk at all)
 #pragma unroll
-            for (int j = 0; j < kAttnJ; ++j) if (j < nj) kf[0][j] = ld4(kp + 8 * j);
+            for (int j = 0; j < NJ; ++j) kf[0][j] = ld4(kp + 8 * j);
         }
-        auto chunk = [&](int c, const float4 (&kc)[kAttnJ], float4 (&kn)[kAttnJ]) {
-            if (c + 4 < nkc) {   // the next chunk's fragments go in flight behind this chunk's MFMAs
+        auto chunk = [&](int c, const float4 (&kc)[NJ], float4 (&kn)[NJ]) {
+            {   // the next chunk's fragments go in flight behind this chunk's MFMAs (past the end: clamped rows, never used)
                 const float* kp = kptr(c + 4);
 #pragma unroll
-                for (int j = 0; j < kAttnJ; ++j) if (j < nj) kn[j] = ld4(kp + 8 * j);
+                for (int j = 0; j < NJ; ++j) kn[j] = ld4(kp + 8 * j);
             }
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int j = 0; j < kAttnJ; ++j) {
-                if (j < nj) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].x, kc[j].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].y, kc[j].y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].z, kc[j].z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].w, kc[j].w, acc, 0, 0, 0);
-                }
+            for (int j = 0; j < NJ; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].x, kc[j].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].y, kc[j].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].z, kc[j].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].w, kc[j].w, acc, 0, 0, 0);
             }
             const int col = c * 32 + l31;
 #pragma unroll
@@ -117,23 +117,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     }
     __syncthreads();
 
-    // ---- phase B: row softmax over the L valid keys; P -> HBM once, and kept in LDS (columns L .. 32 * nkc zeroed for phase C)
-    for (int rr = 0; rr < kAttnQ / 4; ++rr) {
-        const int row = wave * (kAttnQ / 4) + rr, qrow = q0 + row;
-        if (qrow >= L) break;   // (wave-uniform)
-        float* s = Ss + row * LD;
-        float mx = -3.0e38f;
-        for (int c = lane; c < L; c += 64) mx = fmaxf(mx, s[c]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int c = lane; c < L; c += 64) { const float e = expf(s[c] - mx); s[c] = e; sum += e; }
-        sum = wave_sum(sum);
-        const float inv = 1.f / sum;
-        float* pg = Pg + (long long)qrow * ldS;
+    // ---- phase B: row softmax over the L valid keys; P -> HBM once, and kept in LDS (columns L .. 32 * nkc zeroed for phase C).
+    // A wavefront owns 8 rows and walks them 4 at a time (four independent reduction chains per pass over the LDS row).
+    for (int rg = 0; rg < kAttnQ / 4; rg += 4) {
+        const int row0 = wave * (kAttnQ / 4) + rg;
+        if (q0 + row0 >= L) break;   // (wave-uniform)
+        float* s0 = Ss + row0 * LD;
+        float mx[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        for (int c = lane; c < L; c += 64) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mx[q] = fmaxf(mx[q], s0[q * LD + c]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mx[q] = wave_max(mx[q]);
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = lane; c < L; c += 64) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float e = expf(s0[q * LD + c] - mx[q]); s0[q * LD + c] = e; sum[q] += e; }
+        }
+        float inv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) inv[q] = 1.f / wave_sum(sum[q]);
         for (int c = lane; c < nkc * 32; c += 64) {
-            const float v = c < L ? s[c] * inv : 0.f;
-            s[c] = v;
-            if (c < ldS) pg[c] = v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = c < L ? s0[q * LD + c] * inv[q] : 0.f;
+                s0[q * LD + c] = v;
+                if (c < ldS && q0 + row0 + q < L) Pg[(long long)(q0 + row0 + q) * ldS + c] = v;
+            }
         }
     }
     __syncthreads();
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     float vf[2][16];
     vload(0, vf[0]);
     auto block = [&](int kb, const float (&vc)[16], float (&vn)[16]) {
-        if (kb + 1 < nkc) vload(kb + 1, vn);
+        vload(kb + 1, vn);   // (unconditional: past the last block the keys clamp to the sequence's last row, the values are never used)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 a4 = ld4(Ss + l31 * LD + kb * 32 + 8 * j + 4 * h);
@@ -189,15 +200,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     }
 }
 
-// the fused kernel serves sequences of up to 1024 keys and heads of up to 128 channels (everything base.yaml produces in training;
-// eval-mode synthesis beyond max_seq_len and exotic head widths keep the three-launch path)
-inline bool attn_fused_ok(int max_L, int dk) { return max_L >= 1 && max_L <= 1024 && dk >= 8 && dk <= 8 * kAttnJ && dk % 8 == 0; }
+// the fused kernel serves sequences of up to 1024 keys and heads of 16 / 32 / 64 / 128 channels (everything base.yaml produces in
+// training; eval-mode synthesis beyond max_seq_len and other head widths keep the three-launch path)
+inline bool attn_fused_ok(int max_L, int dk) { return max_L >= 1 && max_L <= 1024 && (dk == 16 || dk == 32 || dk == 64 || dk == 128); }
+template <int NJ>
+inline void attn_fwd_launch_nj(const AttnFwdArgs& a, int max_L, dim3 grid, hipStream_t stream) {
+    dim3 block(256);
+    if (max_L <= 128) MTTS_LAUNCH((attn_fwd_kernel<128, NJ>), grid, block, stream, a);
+    else if (max_L <= 352) MTTS_LAUNCH((attn_fwd_kernel<352, NJ>), grid, block, stream, a);
+    else if (max_L <= 608) MTTS_LAUNCH((attn_fwd_kernel<608, NJ>), grid, block, stream, a);
+    else MTTS_LAUNCH((attn_fwd_kernel<1024, NJ>), grid, block, stream, a);
+}
 inline void attn_fwd_launch(const AttnFwdArgs& a, int max_L, int groups, hipStream_t stream) {
-    dim3 grid((unsigned)((max_L + kAttnQ - 1) / kAttnQ), 1, (unsigned)groups), block(256);
-    if (max_L <= 128) MTTS_LAUNCH((attn_fwd_kernel<128>), grid, block, stream, a);
-    else if (max_L <= 352) MTTS_LAUNCH((attn_fwd_kernel<352>), grid, block, stream, a);
-    else if (max_L <= 608) MTTS_LAUNCH((attn_fwd_kernel<608>), grid, block, stream, a);
-    else MTTS_LAUNCH((attn_fwd_kernel<1024>), grid, block, stream, a);
+    dim3 grid((unsigned)((max_L + kAttnQ - 1) / kAttnQ), 1, (unsigned)groups);
+    if (a.dk == 128) attn_fwd_launch_nj<16>(a, max_L, grid, stream);
+    else if (a.dk == 64) attn_fwd_launch_nj<8>(a, max_L, grid, stream);
+    else if (a.dk == 32) attn_fwd_launch_nj<4>(a, max_L, grid, stream);
+    else attn_fwd_launch_nj<2>(a, max_L, grid, stream);
 }
 
 }  // namespace mtts

@@ -921,6 +921,23 @@ inline bool gemm_xcd_sched_for(GemmArgs& g, int max_M, int max_N, int groups, in
 }
 inline long gemm_xcd_sched_slots(const XcdSched& s) { return 8L * s.maxlen * (s.on == 1 ? s.tn : 1); }
 
+// Long-K problems of an under-filled launch (a single-task rank's conv dgrads: M ~ 2 000 rows, N = 256, K = 9 216): with 64x64 tiles every
+// workgroup streams 512 B per K element through its CU's ~64 outstanding lines — 585 MB through the L2 for 9 GFLOP, 212 us.  A 128x128
+// tile moves half the bytes per flop; cutting its K-loop S ways (the rendezvous of splitk_combine) brings the workgroup count back to
+// the chip's 256 CUs.  Returns S (>= 1) when the rule applies, 0 otherwise.  MTTS_BIGTILE_K=0 switches it off (A/B runs).
+inline int gemm_bigtile_split(const GemmCtx& cx, int form, const GemmArgs& g, double rows, int max_N, int groups) {
+    static const int big_k = [] { const char* e = getenv("MTTS_BIGTILE_K"); return e ? atoi(e) : 2048; }();
+    if (big_k <= 0 || g.table || g.colsum || g.A2 || form == GEMM_TN || !cx.wsp.ws || groups < 1) return 0;
+    if (gemm_keff(g) < big_k || max_N < 128 || (g.taps > 1 && g.tap_k % 32 != 0)) return 0;
+    const double wgs64 = std::ceil(rows / 64.0) * gemm_tiles_n(g, max_N, 64);
+    if (wgs64 > (double)gemm_glds_max_wgs()) return 0;            // chip-filling launches keep the 64x64 grid
+    const double wgs128 = std::ceil(rows / 128.0) * gemm_tiles_n(g, max_N, 128);
+    const int nch = (gemm_keff(g) + 31) / 32;
+    int S = (int)std::min<double>(std::max(1.0, std::floor(320.0 / std::max(wgs128, 1.0))), 8.0);
+    S = std::min(S, std::max(1, nch / 8));
+    return S;
+}
+
 // Host launcher.  max_M / max_N bound the tile grid over all groups.  tile = 0: automatic — the problem goes through the launch
 // queue (alone if no batch is open): a plain 64x64 grid (LDS-DMA kernels in the latency regime, a multi-problem grid for a batch).
 // An explicit tile code picks one kernel: 64 / 128 (+1000 software pipeline, +2000 BK = 32), 4064 LDS-DMA (kernel tests, micro-benchmarks).
@@ -966,11 +983,13 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     int bk = gemm_default_bk();
     bool glds = false;
     const bool bf16 = cx.bf16 && gemm_bf16_ok(g) && !g.A2;
+    const int big_S = user_tile == 0 ? gemm_bigtile_split(cx, form, g, rows, max_N, groups) : 0;
     if (bf16 && user_tile == 0) tile = gemm_bf16_tile(rows, gemm_tiles_n(g, max_N, 128));
+    if (big_S > 0) tile = 128;
 #if !defined(MTTS_EMU)
     if (bf16) { if (tile == 4064) tile = 64; }
     else if (tile == 4064) { glds = gemm_glds_ok(g); tile = 64; }            // explicit request (kernel tests, microbenchmarks)
-    else if (user_tile == 0 && tile == 64) {
+    else if (user_tile == 0 && tile == 64 && big_S == 0) {
         const long wgs = (long)std::ceil(rows / 64.0) * gemm_tiles_n(g, max_N, 64);
         glds = gemm_use_glds() && gemm_glds_ok(g) && wgs <= gemm_glds_max_wgs() && !cx.no_glds;
     }
@@ -982,11 +1001,17 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     if (tile >= 1000) { pipe = (tile / 1000) & 1; bk = (tile / 2000) ? 32 : 16; tile %= 1000; }
     if (user_tile == 0 && !g.table && gemm_keff(g) >= 1024 && (form == GEMM_NT || form == GEMM_TN)) bk = 32;  // long K-contiguous panels: full 128-B lines per row
     if (g.taps > 1 && g.tap_k % 32 != 0) bk = 16;  // a K-slice must not straddle two conv taps
-    if (bf16) bk = 32;
+    if (bf16 || big_S > 0) bk = 32;
+    if (big_S > 0) pipe = true;
     // split-K for under-filled grids (single-task ranks, the phoneme-side GEMMs, small wgrads): enough workgroups for
     // ~4 per CU, each still reducing >= 4 K-chunks
     int S = 1;
-    if (!g.table && gemm_splitk_target() > 0 && !g.colsum) {  // stand-alone launches: opt-in (measured neutral on the model's forward shapes)
+    if (big_S > 1) {   // the long-K rule above: 128x128 tiles, K-loop cut big_S ways
+        const long long slots = (long long)ntiles(128) * groups;
+        if (slots * big_S * 128 * 128 <= kSplitWsFloats && slots <= kSplitCtrs) {
+            S = big_S; g.splitk = S; g.ws = cx.wsp.ws; g.tile_ctr = cx.wsp.ctr; g.tiles_pg = (int)ntiles(128);
+        }
+    } else if (big_S == 0 && !g.table && gemm_splitk_target() > 0 && !g.colsum) {  // stand-alone launches: opt-in (measured neutral on the model's forward shapes)
         const long wgs = (long)std::ceil(rows / tile) * gemm_tiles_n(g, max_N, tile);
         const int nch = (gemm_keff(g) + bk - 1) / bk;
         S = (int)std::min<long>(std::min<long>(gemm_splitk_target() / std::max<long>(wgs, 1), nch / gemm_splitk_minchunks()), 8);
@@ -1066,6 +1091,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     // split-K rule applies (the k=9 dgrad of a single-task rank is 124 tiles x 288 slices: alone it would run at one tile per CU)
     static const int single_multi = [] { const char* e = getenv("MTTS_SINGLE_MULTI"); return e ? atoi(e) : 1; }();
     bool solo = b.q.size() == 1 && (!single_multi || batch_full_regime(b.q));
+    if (b.q.size() == 1 && !b.force_family && gemm_bigtile_split(cx, b.q[0].form, b.q[0].g, b.q[0].rows, b.q[0].max_N, b.q[0].groups) > 0) solo = true;
     for (const GemmPending& p : b.q) if (!p.g.table && gemm_keff(p.g) < min_k && batch_full_regime(b.q)) solo = true;
     bool any_dual = false;   // dual-source problems (GemmArgs::A2) exist in the multi-problem kernels only
     for (const GemmPending& p : b.q) any_dual = any_dual || p.g.A2 != nullptr;
