@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) kn[j] = ld4(kp + 8 * j);
             }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch AHEAD of the MFMAs (hipcc otherwise sinks each load to just before its use)
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     vload(0, vf[0]);
     auto block = [&](int kb, const float (&vc)[16], float (&vn)[16]) {
         vload(kb + 1, vn);   // (unconditional: past the last block the keys clamp to the sequence's last row, the values are never used)
+        __builtin_amdgcn_sched_barrier(0);   // the next block's loads stay in front of this block's MFMAs
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 a4 = ld4(Ss + l31 * LD + kb * 32 + 8 * j + 4 * h);

@@ -212,8 +212,6 @@ public:
     TS gPm, gFm;  // dropout-masked copies of a LayerNorm input gradient
     TS gP0, gP1, gPqkv, gPh, gPf1, gPf2, gF0, gF1, gFqkv, gFh, dSp, dSf, gR0, gR1, gRm, gRp, gMelF, dspk, dpred[3];
     float *loss_partial = nullptr, *losses = nullptr, *col_partial = nullptr;
-    int* col_ctr = nullptr;                       // arrival counters of the fused column reduction (zero between launches)
-    static constexpr int kColCtrPerTask = 8;      // 128-column groups per task (C <= 1024)
     int col_max_chunks = 0;
     long long col_partial_ts = 0;                 // floats per task of col_partial
     static int ln_chunks(int rows) { return (rows + kLnRows - 1) / kLnRows; }   // partial chunks of the LayerNorm backward (rowops.h)
@@ -539,7 +537,6 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             col_partial_ts = (long long)per_task;
             col_partial = (float*)take((size_t)cap_tasks * per_task * sizeof(float));
         }
-        col_ctr = (int*)take((size_t)cap_tasks * kColCtrPerTask * sizeof(int));
         loss_partial = (float*)take((size_t)cap_tasks * kLossBlocks * 5 * sizeof(float));
         losses = (float*)take((size_t)cap_tasks * 6 * sizeof(float));
         // plans
@@ -708,7 +705,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
 
     // buffers, stream and events of the deferred weight-gradient path (see LayerGrad)
     int init_defer() {
-        static const int max_defer_tasks = [] { const char* e = getenv("MTTS_DEFER_TASKS"); return e ? atoi(e) : 2; }();
+        constexpr int max_defer_tasks = 2;
         defer_tasks = std::min(cap_tasks, max_defer_tasks);
         if (defer_tasks < 1) { defer_tasks = 0; return 0; }
         const int d = cfg.d_model;
@@ -747,12 +744,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (auto& pg : predG) { pg.g2a = rows_d(capMp, cfg.vp_filter); pg.g2b = rows_d(capMp, cfg.vp_filter); pg.part2 = part_d(capMp, cfg.vp_filter); pg.part1 = part_d(capMp, cfg.vp_filter); }
         postG.resize(cfg.postnet_layers);
         for (auto& t : postG) t = rows_d(capMr, post_c);
-        {   // non-blocking (a blocking stream would serialise with the legacy default stream on every launch); MTTS_SIDE_PRIO=1: lowest priority
-            static const int prio = [] { const char* e = getenv("MTTS_SIDE_PRIO"); return e ? atoi(e) : 0; }();
-            int lo = 0, hi = 0;
-            if (prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) { HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo)); }
-            else HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-        }
+        HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));   // non-blocking (a blocking stream would serialise with the legacy default stream on every launch)
         for (auto& e : ev_side) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipEventCreate(&ev_join));
         HIP_CHECK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
@@ -761,7 +753,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (gx_side2.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace of the run-ahead stream)"); return -1; }
         const int side_chunks = (std::max(std::max(capMp, capMf), capMr) + kRC - 1) / kRC;   // == col_max_chunks (set by layout(), later)
         HIP_CHECK(hipMalloc((void**)&col_partial_side, (size_t)defer_tasks * side_chunks * 3 * 1024 * sizeof(float)));
-        { const char* e = getenv("MTTS_SIDE_GLDS"); gx_side.no_glds = !(e && atoi(e) != 0); }
+        gx_side.no_glds = true;
         if (gx_side.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace of the side stream)"); return -1; }
         return 0;
     }
@@ -786,6 +778,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (char* a : act_sets) if (a) hipFree(a);
         for (char* a : gs_mem) if (a) hipFree(a);
         if (arena_so) hipFree(arena_so);
+        if (arena_so_defer) hipFree(arena_so_defer);
         if (hv) hipFree(hv);
         if (fast_hist) hipFree(fast_hist);
     }
@@ -1159,14 +1152,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         g.flags = flags;
         g.rowmask = rowmask; g.rowmask_gs = row_ts(s);
         if (relu_ref.p) { g.relu_ref = relu_ref.p; g.relu_ref_gs = relu_ref.ts; g.ld_relu = cout; }
-        // experiment (MTTS_FWD_SINGLE_MULTI=1): under-filled forward GEMMs through the multi-problem path, whose long-chain split-K rule
-        // then applies to them as it does to the single queued dgrads of the deferred backward
-        static const bool fwd_multi = [] { const char* e = getenv("MTTS_FWD_SINGLE_MULTI"); return e ? atoi(e) != 0 : false; }();
-        const bool own_scope = fwd_multi && !gx.batch.open && defer_ok(p);
-        if (own_scope) gemm_batch_begin(gx);
         gemm_launch(gx, GEMM_NT, g, maxM(p, s), cout, p.tasks, stream, 0, nsrc * 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s),
                     4.0 * (alg_rows(p, s) * (nsrc * cin + cout) + nsrc * (double)p.tasks * cout * k * cin));
-        if (own_scope) gemm_batch_end(gx, stream);
     }
     // dX[M,Cin] (+)= sum_taps dY[M +- tap, Cout] * W  (conv dgrad over the same [Cout][k][Cin] image)
     void conv_dgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS w, int cin, TS dx, int flags,
@@ -1207,11 +1194,9 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         g.K = maxM(p, s);  // upper bound of the per-task reduction length (the kernel reads the exact one through dimptr)
         g.flags = flags;
         // the bias gradient rides on the weight-gradient GEMM (GemmArgs::colsum: one extra n-tile against the mask's float image)
-        // instead of two reduction launches per layer.  MTTS_FUSE_COLSUM=0 restores the
-        // separate reduction.
-        static const bool fuse_cs = [] { const char* e = getenv("MTTS_FUSE_COLSUM"); return e ? atoi(e) != 0 : true; }();
+        // instead of two reduction launches per layer
         const float* mw = mask_w(p, bias_mask);
-        const bool fused = b_off >= 0 && fuse_cs && mw != nullptr;
+        const bool fused = b_off >= 0 && mw != nullptr;
         if (fused) {
             TS gb = Gd(b_off);
             g.colsum = gb.p; g.colsum_gs = gb.ts; g.colsum_w = mw; g.colsum_w_gs = 4 * row_ts(s);
@@ -1229,23 +1214,9 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                         (const float*)col_partial_side, col_max_chunks, a.C, out0, out1, out_ts, 1e-5f, a.accumulate, (int)kRC);
             return;
         }
-        // single-launch variant A: a workgroup per (32-column stripe, task) walks all rows (rowops.h: colstripe_kernel).  Measured
-        // SLOWER (8-task step 189.5 -> 208 ms, single-task rank 44 -> 59 ms): 8-256 workgroups streaming ~70 dependent row
-        // iterations each are latency-bound, the two-stage pair keeps ~1000 workgroups in flight.  Opt-in: MTTS_COL_STRIPE=<max rows>
-        static const int stripe_max_rows = [] { const char* e = getenv("MTTS_COL_STRIPE"); return e ? atoi(e) : 0; }();
-        if (maxM <= stripe_max_rows && (a.C & 3) == 0) {
-            MTTS_LAUNCH(colstripe_kernel, dim3((a.C + 31) / 32, 1, p.tasks), dim3(256), stream, (const int*)p.meta, a, out0, out1, out_ts, 1e-5f);
-            return;
-        }
+        // (single-launch variants were built and measured slower in rounds 2-3: a workgroup per 32-column stripe walking all rows is latency-
+        // bound, +10 % on the 8-task step; a last-arriver fold needs an agent-scope release / acquire amid the GEMMs' dirty L2 lines, +10 %)
         const int chunks = (maxM + kRC - 1) / kRC;
-        // single-launch variant B (last-arriving workgroup folds): measured SLOWER (+10 % on the whole meta-step) — its agent-scope
-        // release / acquire writes back and invalidates an L2 that the neighbouring GEMMs keep full of dirty lines; opt-in only
-        static const bool fused = [] { const char* e = getenv("MTTS_COL_FUSED"); return e ? atoi(e) != 0 : false; }();
-        if (fused && col_ctr && (a.C + 127) / 128 <= kColCtrPerTask) {
-            MTTS_LAUNCH(colreduce_kernel, dim3((a.C + 127) / 128, chunks, p.tasks), dim3(256), stream, (const int*)p.meta, a, col_partial,
-                        col_max_chunks, col_ctr, out0, out1, out_ts, 1e-5f);
-            return;
-        }
         MTTS_LAUNCH(colpart_kernel, dim3((a.C + 127) / 128, chunks, p.tasks), dim3(256), stream, (const int*)p.meta, a, col_partial,
                     col_max_chunks);
         MTTS_LAUNCH(colfinal_kernel, dim3((a.C + 63) / 64, 1, p.tasks), dim3(256), stream, (const int*)p.meta, a.mfield, a.mode,
@@ -1450,9 +1421,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // gradient rides on the GEMM — the separate column reduction would run on the main stream)
     bool defer_ok(const Plan& p) const {
         static const int on = [] { const char* e = getenv("MTTS_DEFER_WGRAD"); return e ? atoi(e) : 1; }();
-        static const long long max_rows = [] { const char* e = getenv("MTTS_DEFER_MAX_ROWS"); return e ? atoll(e) : 16000LL; }();
-        static const bool fuse_cs = [] { const char* e = getenv("MTTS_FUSE_COLSUM"); return e ? atoi(e) != 0 : true; }();
-        return on && fuse_cs && defer_tasks > 0 && p.tasks <= defer_tasks && p.sumMf <= max_rows && side != nullptr;
+        constexpr long long max_rows = 16000LL;   // beyond this the launches fill the chip and the wgrad + dgrad pairing wins (measured: 4 / 8 tasks per rank neutral / -1 %)
+        return on && defer_tasks > 0 && p.tasks <= defer_tasks && p.sumMf <= max_rows && side != nullptr;
     }
     // everything enqueued on the main stream so far happens before what is enqueued on the side stream next
     void fork_side() {

@@ -41,7 +41,7 @@
 namespace mtts {
 
 enum GemmForm { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
-enum GemmFlags { GEMM_RELU = 1, GEMM_ACCUM = 2, GEMM_LRELU = 4, GEMM_SLAB_FENCE = 8 };   // SLAB_FENCE: split-K slabs published with plain stores + a release fence (A/B arm)  // LRELU: v < 0 -> act_slope * v (MelGAN generator)
+enum GemmFlags { GEMM_RELU = 1, GEMM_ACCUM = 2, GEMM_LRELU = 4 };   // LRELU: v < 0 -> act_slope * v (MelGAN generator)
 
 struct GemmGroupDesc {
     long long a_off, b_off, c_off;  // element offsets added to A / B / C
@@ -340,7 +340,7 @@ __device__ __forceinline__ void st4_through(float* p, float4 v) {
 // last to arrive (`ctr`) reloads all S partials in split order (its own included, so the sum does not depend on the arrival order)
 // and returns true to run the epilogue; it also re-arms the counter for the next launch.
 template <int TM, int TN, int NTH>
-__device__ __forceinline__ bool slab_combine(float* base, int* ctr, int split, int S, f32x16 (&acc)[TM][TN], bool fence = false) {
+__device__ __forceinline__ bool slab_combine(float* base, int* ctr, int split, int S, f32x16 (&acc)[TM][TN]) {
     constexpr int PART = NTH * 16 * TM * TN;  // floats per partial tile
     const int tid = threadIdx.x;
     const bool act = tid < NTH;   // (workgroups larger than the tile's NTH threads only take part in the barriers)
@@ -354,14 +354,12 @@ __device__ __forceinline__ bool slab_combine(float* base, int* ctr, int split, i
                 if (!act) continue;
                 float4 v;
                 v.x = acc[i][j][4 * r4]; v.y = acc[i][j][4 * r4 + 1]; v.z = acc[i][j][4 * r4 + 2]; v.w = acc[i][j][4 * r4 + 3];
-                if (fence) st4(mine + (((i * TN + j) * 4 + r4) * NTH + tid) * 4, v);
-                else st4_through(mine + (((i * TN + j) * 4 + r4) * NTH + tid) * 4, v);
+                st4_through(mine + (((i * TN + j) * 4 + r4) * NTH + tid) * 4, v);
             }
     __shared__ int s_last;
     MTTS_WAIT_VMEM();      // every storing wave drains its write-through stores
     __syncthreads();
     if (tid == 0) {
-        if (fence) { MTTS_FENCE_RELEASE_AGENT(); MTTS_WAIT_VMEM(); }   // A/B arm (MTTS_SLAB_FENCE=1): plain stores + agent-scope release
         s_last = (MTTS_ATOMIC_INC_AGENT(ctr) == S - 1) ? 1 : 0;
         if (s_last) MTTS_FENCE_ACQUIRE_AGENT();
     }
@@ -388,7 +386,7 @@ __device__ __forceinline__ bool slab_combine(float* base, int* ctr, int split, i
 template <int TM, int TN, int NTH>
 __device__ __forceinline__ bool splitk_combine(const GemmArgs& g, int z, int tile_lin, int split, int S, f32x16 (&acc)[TM][TN]) {
     const long long slot = (long long)z * g.tiles_pg + tile_lin;
-    return slab_combine<TM, TN, NTH>(g.ws + slot * S * (NTH * 16 * TM * TN), g.tile_ctr + slot, split, S, acc, (g.flags & GEMM_SLAB_FENCE) != 0);
+    return slab_combine<TM, TN, NTH>(g.ws + slot * S * (NTH * 16 * TM * TN), g.tile_ctr + slot, split, S, acc);
 }
 
 // WGM x WGN waves per workgroup (64 threads each); the wave tile is (BM/WGM) x (BN/WGN) = TM x TN MFMA tiles.
@@ -691,7 +689,7 @@ struct GemmMulti {
     int start[kGemmMultiMax + 1] = {0};
     int form[kGemmMultiMax] = {0};
     int groups[kGemmMultiMax] = {0};
-    int xcd_group[kGemmMultiMax] = {0};  // > 1: this many consecutive tile slots share an XCD (gemm_multi_locate); -1: task z on XCD z; -2: GemmArgs::xs
+    int xcd_group[kGemmMultiMax] = {0};  // > 1: this many consecutive tile slots share an XCD (gemm_multi_locate); -2: GemmArgs::xs
     int tiles_pg[kGemmMultiMax] = {0};   // tile slots per group (start[p + 1] - start[p] may be padded up to a multiple of 8)
     GemmArgs g[kGemmMultiMax];
 };
@@ -708,14 +706,6 @@ __device__ __forceinline__ bool gemm_multi_locate(const GemmMulti& mp, int& p, i
     const int total = mp.tiles_pg[p] * mp.groups[p];
     if (lin >= total) return false;   // padding up to the next multiple of 8
     const int tiles = mp.tiles_pg[p];
-    if (mp.xcd_group[p] < 0) {
-        // group-per-XCD order (8 | groups): workgroup slot lin belongs to group lin % groups, so the dispatcher's round-robin puts ALL
-        // tiles of a group (a task) on one XCD and the operand every tile of that task streams (the weight image of a dgrad) is fetched
-        // into one L2 instead of eight.  Unbalanced by the raggedness of the tasks.
-        z = lin % mp.groups[p];
-        bx = lin / mp.groups[p];
-        return true;
-    }
     lin = xcd_group_remap(lin, total, mp.xcd_group[p]);
     z = lin / tiles;
     bx = lin - z * tiles;
@@ -806,32 +796,17 @@ struct GemmProfiler {
         if (dump) fclose(dump);
     }
 };
-inline int& gemm_xcd_swizzle() {
-    static int v = [] { const char* e = getenv("MTTS_XCD_GROUP"); return e ? (atoi(e) != 0) : 1; }();
-    return v;
-}
-inline int& gemm_default_bk() {  // MTTS_GEMM_BK=16/32
-    static int v = [] { const char* e = getenv("MTTS_GEMM_BK"); return (e && atoi(e) == 32) ? 32 : 16; }();
-    return v;
-}
-inline bool& gemm_default_pipe() {  // MTTS_GEMM_PIPE=0/1 overrides the built-in default (A/B runs)
-    static bool v = [] { const char* e = getenv("MTTS_GEMM_PIPE"); return e ? atoi(e) != 0 : true; }();
-    return v;
-}
+constexpr int kGemmXcdSwizzle = 1;     // XCD-grouped tile order of the plain grids (xcd_group_remap)
+constexpr int kGemmDefaultBk = 16;     // K-slice of the register-staged kernels (32 for long K-contiguous panels, see gemm_launch)
+constexpr bool kGemmDefaultPipe = true;  // software-pipelined K-loop
+inline int gemm_xcd_swizzle() { return kGemmXcdSwizzle; }
+inline int gemm_default_bk() { return kGemmDefaultBk; }
+inline bool gemm_default_pipe() { return kGemmDefaultPipe; }
 
 // Split-K workspace (partial tiles + tile counters): owned by a GemmCtx, allocated once by its owner's create.
 struct GemmWorkspace { float* ws = nullptr; int* ctr = nullptr; };
 constexpr long long kSplitWsFloats = 16ll << 20;  // 64 MB of partial tiles
 constexpr int kSplitCtrs = 1 << 16;
-inline int& gemm_splitk_target() {  // workgroups a launch should reach before split-K stops adding more; 0 disables (MTTS_SPLITK_TARGET)
-    static int v = [] { const char* e = getenv("MTTS_SPLITK_TARGET"); return e ? atoi(e) : -1; }();  // -1: batched launches only
-    return v;
-}
-
-inline int& gemm_splitk_minchunks() {  // K-chunks every split must keep (MTTS_SPLITK_MINCH)
-    static int v = [] { const char* e = getenv("MTTS_SPLITK_MINCH"); return (e && atoi(e) > 0) ? atoi(e) : 16; }();
-    return v;
-}
 
 // Launch batching: between gemm_batch_begin() and gemm_batch_end() every eligible gemm_launch (automatic tile choice) is queued
 // instead of launched; gemm_batch_end() issues the queue as ONE launch (gemm_f32_multi_kernel / gemm_glds_multi_kernel).
@@ -839,10 +814,6 @@ inline int& gemm_splitk_minchunks() {  // K-chunks every split must keep (MTTS_S
 // reads their outputs (engine: the wgrad / dgrad pair of a layer, dQ / dK / dV of an attention block).
 struct GemmPending { int form; GemmArgs g; int max_M, max_N, groups; double flops, rows, bytes; };
 struct GemmBatch { bool open = false; std::vector<GemmPending> q; int force_family = 0; int force_tile = 0; };   // force_family: 16 / 32 (BK of the register-staged multi-problem kernel) or 4064 (LDS-DMA) for the next flush (explicit tile codes of dual-source problems)
-inline bool& gemm_batch_enabled() {  // MTTS_GEMM_BATCH=0 launches every problem on its own (A/B runs)
-    static bool v = [] { const char* e = getenv("MTTS_GEMM_BATCH"); return e ? atoi(e) != 0 : true; }();
-    return v;
-}
 
 // Every piece of MUTABLE launcher state — the launch-batching queue, the per-launch profiler, the split-K workspace —
 // lives in a context owned by one handle (Engine / Vocoder / ...), so two handles on two host threads share nothing
@@ -871,25 +842,19 @@ struct GemmCtx {
         prof.destroy();
     }
 };
-inline void gemm_batch_begin(GemmCtx& cx) { if (gemm_batch_enabled()) cx.batch.open = true; }
+inline void gemm_batch_begin(GemmCtx& cx) { cx.batch.open = true; }
 inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream);
 
-// LDS-DMA kernel family (gemm_glds.h, device builds only).  MTTS_GLDS=0 keeps the register-staged kernels (A/B runs).
-inline bool& gemm_use_glds() {
-    static bool v = [] { const char* e = getenv("MTTS_GLDS"); return e ? atoi(e) != 0 : true; }();
-    return v;
-}
+// LDS-DMA kernel family (gemm_glds.h, device builds only)
+inline bool gemm_use_glds() { return true; }
 inline bool gemm_glds_ok(const GemmArgs& g) { return !(g.taps > 1 && g.tap_k % 32 != 0); }
 // n-tiles of a problem's grid: the tiles of C plus the column-sum tile (GemmArgs::colsum)
 inline int gemm_tiles_n(const GemmArgs& g, int max_N, int t) { return (max_N + t - 1) / t + (g.colsum ? 1 : 0); }
 // Launches up to this many workgroups take the LDS-DMA kernels (latency regime: few workgroups per CU, where the DMA
 // ring's two slices in flight replace the occupancy the register-staged kernel needs; measured +8 % / +14 % on the
 // single-task first- / second-order step), larger ones the register-staged kernels (5 vs 3 workgroups per CU resident:
-// +3 % on the full 8-task step).  MTTS_GLDS_MAX_WGS overrides.
-inline long& gemm_glds_max_wgs() {
-    static long v = [] { const char* e = getenv("MTTS_GLDS_MAX_WGS"); return e ? atol(e) : 768L; }();
-    return v;
-}
+// +3 % on the full 8-task step).
+inline long gemm_glds_max_wgs() { return 768L; }
 #if !defined(MTTS_EMU)
 inline void gemm_glds_launch(int form, const GemmArgs& g, dim3 grid, hipStream_t stream);
 inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t stream, bool dual = false);
@@ -921,23 +886,6 @@ inline bool gemm_xcd_sched_for(GemmArgs& g, int max_M, int max_N, int groups, in
 }
 inline long gemm_xcd_sched_slots(const XcdSched& s) { return 8L * s.maxlen * (s.on == 1 ? s.tn : 1); }
 
-// Long-K problems of an under-filled launch (a single-task rank's conv dgrads: M ~ 2 000 rows, N = 256, K = 9 216): with 64x64 tiles every
-// workgroup streams 512 B per K element through its CU's ~64 outstanding lines — 585 MB through the L2 for 9 GFLOP, 212 us.  A 128x128
-// tile moves half the bytes per flop; cutting its K-loop S ways (the rendezvous of splitk_combine) brings the workgroup count back to
-// the chip's 256 CUs.  Returns S (>= 1) when the rule applies, 0 otherwise.  MTTS_BIGTILE_K=0 switches it off (A/B runs).
-inline int gemm_bigtile_split(const GemmCtx& cx, int form, const GemmArgs& g, double rows, int max_N, int groups) {
-    static const int big_k = [] { const char* e = getenv("MTTS_BIGTILE_K"); return e ? atoi(e) : 2048; }();
-    if (big_k <= 0 || g.table || g.colsum || g.A2 || form == GEMM_TN || !cx.wsp.ws || groups < 1) return 0;
-    if (gemm_keff(g) < big_k || max_N < 128 || (g.taps > 1 && g.tap_k % 32 != 0)) return 0;
-    const double wgs64 = std::ceil(rows / 64.0) * gemm_tiles_n(g, max_N, 64);
-    if (wgs64 > (double)gemm_glds_max_wgs()) return 0;            // chip-filling launches keep the 64x64 grid
-    const double wgs128 = std::ceil(rows / 128.0) * gemm_tiles_n(g, max_N, 128);
-    const int nch = (gemm_keff(g) + 31) / 32;
-    int S = (int)std::min<double>(std::max(1.0, std::floor(320.0 / std::max(wgs128, 1.0))), 8.0);
-    S = std::min(S, std::max(1, nch / 8));
-    return S;
-}
-
 // Host launcher.  max_M / max_N bound the tile grid over all groups.  tile = 0: automatic — the problem goes through the launch
 // queue (alone if no batch is open): a plain 64x64 grid (LDS-DMA kernels in the latency regime, a multi-problem grid for a batch).
 // An explicit tile code picks one kernel: 64 / 128 (+1000 software pipeline, +2000 BK = 32), 4064 LDS-DMA (kernel tests, micro-benchmarks).
@@ -948,8 +896,6 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     if (max_M <= 0 || max_N <= 0 || groups <= 0) return;
     GemmArgs g = g_in;
     g.swizzle = gemm_xcd_swizzle();
-    static const bool slab_fence = [] { const char* e = getenv("MTTS_SLAB_FENCE"); return e && atoi(e) != 0; }();
-    if (slab_fence) g.flags |= GEMM_SLAB_FENCE;
     const int user_tile = tile;
     const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
     auto ntiles = [&](int t) { return (long)((max_M + t - 1) / t) * gemm_tiles_n(g, max_N, t); };
@@ -983,13 +929,11 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     int bk = gemm_default_bk();
     bool glds = false;
     const bool bf16 = cx.bf16 && gemm_bf16_ok(g) && !g.A2;
-    const int big_S = user_tile == 0 ? gemm_bigtile_split(cx, form, g, rows, max_N, groups) : 0;
     if (bf16 && user_tile == 0) tile = gemm_bf16_tile(rows, gemm_tiles_n(g, max_N, 128));
-    if (big_S > 0) tile = 128;
 #if !defined(MTTS_EMU)
     if (bf16) { if (tile == 4064) tile = 64; }
     else if (tile == 4064) { glds = gemm_glds_ok(g); tile = 64; }            // explicit request (kernel tests, microbenchmarks)
-    else if (user_tile == 0 && tile == 64 && big_S == 0) {
+    else if (user_tile == 0 && tile == 64) {
         const long wgs = (long)std::ceil(rows / 64.0) * gemm_tiles_n(g, max_N, 64);
         glds = gemm_use_glds() && gemm_glds_ok(g) && wgs <= gemm_glds_max_wgs() && !cx.no_glds;
     }
@@ -1001,27 +945,10 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     if (tile >= 1000) { pipe = (tile / 1000) & 1; bk = (tile / 2000) ? 32 : 16; tile %= 1000; }
     if (user_tile == 0 && !g.table && gemm_keff(g) >= 1024 && (form == GEMM_NT || form == GEMM_TN)) bk = 32;  // long K-contiguous panels: full 128-B lines per row
     if (g.taps > 1 && g.tap_k % 32 != 0) bk = 16;  // a K-slice must not straddle two conv taps
-    if (bf16 || big_S > 0) bk = 32;
-    if (big_S > 0) pipe = true;
+    if (bf16) bk = 32;
     // split-K for under-filled grids (single-task ranks, the phoneme-side GEMMs, small wgrads): enough workgroups for
     // ~4 per CU, each still reducing >= 4 K-chunks
-    int S = 1;
-    if (big_S > 1) {   // the long-K rule above: 128x128 tiles, K-loop cut big_S ways
-        const long long slots = (long long)ntiles(128) * groups;
-        if (slots * big_S * 128 * 128 <= kSplitWsFloats && slots <= kSplitCtrs) {
-            S = big_S; g.splitk = S; g.ws = cx.wsp.ws; g.tile_ctr = cx.wsp.ctr; g.tiles_pg = (int)ntiles(128);
-        }
-    } else if (big_S == 0 && !g.table && gemm_splitk_target() > 0 && !g.colsum) {  // stand-alone launches: opt-in (measured neutral on the model's forward shapes)
-        const long wgs = (long)std::ceil(rows / tile) * gemm_tiles_n(g, max_N, tile);
-        const int nch = (gemm_keff(g) + bk - 1) / bk;
-        S = (int)std::min<long>(std::min<long>(gemm_splitk_target() / std::max<long>(wgs, 1), nch / gemm_splitk_minchunks()), 8);
-        const long long slots = (long long)ntiles(tile) * groups;
-        if (S >= 2 && (slots * S * tile * tile > kSplitWsFloats || slots > kSplitCtrs)) S = 1;
-        if (S >= 2) {
-            GemmWorkspace& w = cx.wsp;
-            if (w.ws) { g.splitk = S; g.ws = w.ws; g.tile_ctr = w.ctr; g.tiles_pg = (int)ntiles(tile); } else S = 1;
-        } else S = 1;
-    }
+    const int S = 1;   // (stand-alone launches never split K: the long chains of under-filled batches are cut in gemm_batch_end)
     const int nth = 256;
     const long grid_tiles = ntiles(tile);
     dim3 block(nth), grid((unsigned)(grid_tiles * S), 1, (unsigned)groups);
@@ -1083,16 +1010,10 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     struct Flush { GemmCtx& c; Flush(GemmCtx& x) : c(x) { c.flushing = true; } ~Flush() { c.flushing = false; } } guard(cx);
     std::stable_sort(b.q.begin(), b.q.end(), [](const GemmPending& x, const GemmPending& y) { return gemm_keff(x.g) > gemm_keff(y.g); });
     GemmProfiler& prof = cx.prof;
-    // MTTS_BATCH_MIN_K=n: pairs with a problem whose K-loop is shorter than n go out back to back instead of batched.  Round 2 measured
-    // the K <= 256 pairs (fc, conv2) ~10 % slower batched in the BK = 16 multi-problem kernel (n was 512); with the BK = 32 kernel and the
-    // task-per-XCD schedule batching them wins: 8-task step 170.9 -> 166.9 ms, second order 442 -> 436, 4-task rank 97.5 -> 95.2 (round 3) — 0 now.
-    static const int min_k = [] { const char* e = getenv("MTTS_BATCH_MIN_K"); return e ? atoi(e) : 0; }();
     // a single queued problem normally takes the stand-alone launcher; in the latency regime it stays here, where the long-chain
     // split-K rule applies (the k=9 dgrad of a single-task rank is 124 tiles x 288 slices: alone it would run at one tile per CU)
     static const int single_multi = [] { const char* e = getenv("MTTS_SINGLE_MULTI"); return e ? atoi(e) : 1; }();
     bool solo = b.q.size() == 1 && (!single_multi || batch_full_regime(b.q));
-    if (b.q.size() == 1 && !b.force_family && gemm_bigtile_split(cx, b.q[0].form, b.q[0].g, b.q[0].rows, b.q[0].max_N, b.q[0].groups) > 0) solo = true;
-    for (const GemmPending& p : b.q) if (!p.g.table && gemm_keff(p.g) < min_k && batch_full_regime(b.q)) solo = true;
     bool any_dual = false;   // dual-source problems (GemmArgs::A2) exist in the multi-problem kernels only
     for (const GemmPending& p : b.q) any_dual = any_dual || p.g.A2 != nullptr;
     if (any_dual) solo = false;
@@ -1106,8 +1027,8 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     mp.n = (int)b.q.size();
     int max_groups = 0;
     double flops = 0.0, rows = 0.0, bytes = 0.0;
-    // split-K for the long chains of an under-filled batch: a tile whose K-loop is longer than two thirds (1 / MTTS_SPLIT_RATIO,
-    // swept: 1.25-1.5 best) of the whole batch's per-CU work would finish last on its own (single-task ranks: the k=9 dgrad tile, 576 slices, beside a
+    // split-K for the long chains of an under-filled batch: a tile whose K-loop is longer than two thirds (swept: 1 / 1.25 .. 1 / 1.5)
+    // of the whole batch's per-CU work would finish last on its own (single-task ranks: the k=9 dgrad tile, 576 slices, beside a
     // batch that is worth ~590 slices per CU), so it is cut into S workgroups (rendezvous in splitk_combine)
     double work = 0.0;
     for (const GemmPending& p : b.q) work += std::ceil(p.rows / 64.0) * gemm_tiles_n(p.g, p.max_N, 64) * std::max(1, (gemm_keff(p.g) + 15) / 16);
@@ -1131,8 +1052,8 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
         const int tiles = ((p.max_M + T - 1) / T) * gemm_tiles_n(p.g, p.max_N, T);
         int S = 1;
         const int nch = (gemm_keff(p.g) + 15) / 16;
-        static const double ratio = [] { const char* e = getenv("MTTS_SPLIT_RATIO"); return e ? atof(e) : 1.5; }();
-        if (small_batch && T == 64 && !p.g.table && !p.g.colsum && gemm_splitk_target() != 0 && nch > per_cu / ratio) {
+        constexpr double ratio = 1.5;
+        if (small_batch && T == 64 && !p.g.table && !p.g.colsum && nch > per_cu / ratio) {
             S = (int)std::min<double>(std::min<double>(std::ceil(nch / std::max(per_cu / ratio, 1.0)), nch / 16), 8);
             const long long slots = (long long)tiles * p.groups;
             if (S >= 2 && ((ws_off + slots * S * 4096) > kSplitWsFloats || ctr_off + slots > kSplitCtrs)) S = 1;
@@ -1145,11 +1066,9 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
             } else S = 1;
         }
         mp.xcd_group[i] = gemm_xcd_swizzle() ? std::min(gemm_tiles_n(p.g, p.max_N, T) * S, 64) : 0;
-        static const int task_xcd = [] { const char* e = getenv("MTTS_XCD_TASK"); return e ? atoi(e) : 0; }();   // experiment: 1 = NN problems, 2 = all
-        if (task_xcd && !p.g.table && p.groups % 8 == 0 && (mp.start[i] & 7) == 0 && (task_xcd >= 2 || p.form == GEMM_NN)) mp.xcd_group[i] = -1;
         mp.tiles_pg[i] = tiles * S;
         long slots = (long)tiles * S * p.groups;
-        if (!task_xcd && gemm_xcd_sched_for(mp.g[i], p.max_M, p.max_N, p.groups, S, T)) { mp.xcd_group[i] = -2; slots = gemm_xcd_sched_slots(mp.g[i].xs); }
+        if (gemm_xcd_sched_for(mp.g[i], p.max_M, p.max_N, p.groups, S, T)) { mp.xcd_group[i] = -2; slots = gemm_xcd_sched_slots(mp.g[i].xs); }
         mp.start[i + 1] = mp.start[i] + (int)((slots + 7) & ~7L);   // (every problem starts on a multiple of 8: workgroup slot % 8 = XCD)
         max_groups = std::max(max_groups, p.groups);
         flops += p.flops; rows += p.rows; bytes += p.bytes;
@@ -1160,9 +1079,8 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     // BK = 32 stages K-contiguous operands in full 128-byte lines (half the load instructions, TA transactions and barriers
     // per flop); needs every tapped problem's tap length to be a multiple of 32 and pays off only for long K.  Default since round 3
     // (profiles/r03_sk_queue.md: the multi-problem launches with K >= 1024 run at 0.676 instead of 0.646 of the fp32 matrix peak, the
-    // whole step is unchanged, a single-task rank gains 1.7 %); MTTS_MULTI_BK=16 restores BK = 16 everywhere.
-    static const int multi_bk = [] { const char* e = getenv("MTTS_MULTI_BK"); return e ? atoi(e) : 32; }();
-    bool bk32 = multi_bk == 32;
+    // whole step is unchanged, a single-task rank gains 1.7 %).
+    bool bk32 = true;
     int maxK = 0;
     for (int i = 0; i < mp.n; ++i) {
         if (mp.g[i].taps > 1 && mp.g[i].tap_k % 32 != 0) bk32 = false;

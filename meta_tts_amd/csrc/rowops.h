@@ -425,11 +425,6 @@ __device__ __forceinline__ void col_body(const int* meta, const ColArgs& a, floa
 __device__ __forceinline__ void colpart_body(const int* meta, const ColArgs& a, float* partial, int max_chunks) {
     col_body<32, 8, false>(meta, a, partial, max_chunks, nullptr, nullptr, 0, 0.f);
 }
-// single-launch column reduction over a 32-column stripe of ALL rows of a task (see col_body)
-__global__ void colstripe_kernel(const int* meta, ColArgs a, float* out0, float* out1, long long out_ts, float eps) {
-    col_body<8, 32, true>(meta, a, nullptr, 0, out0, out1, out_ts, eps);
-}
-
 
 // 64 columns x 4 chunk lanes per workgroup: lane q folds chunks q, q+4, ... of its column, the four lane results are
 // merged in lane order through LDS (fixed order => run-to-run identical).
@@ -491,33 +486,6 @@ __global__ void colpart_kernel(const int* meta, ColArgs a, float* partial, int m
 __global__ void colfinal_kernel(const int* meta, int mfield, int mode, const float* partial, int max_chunks, int C,
                                 float* out0, float* out1, long long out_ts, float eps, int accumulate, int rows_per_chunk) {
     colfinal_fold(meta, mfield, mode, partial, max_chunks, C, out0, out1, out_ts, eps, accumulate, blockIdx.x * 64, rows_per_chunk);
-}
-
-// Both stages in one launch: every (task, 128-column group) keeps an arrival counter; the last row-chunk workgroup to
-// publish its partials (one agent-scope release / acquire pair, as in the split-K GEMM) folds the chunks of its 128
-// columns in chunk order.  Same arithmetic and order as colpart + colfinal, one launch fewer per reduction (the row kernels
-// of a single-task rank are launch-latency bound).
-__global__ void colreduce_kernel(const int* meta, ColArgs a, float* partial, int max_chunks, int* ctr, float* out0, float* out1,
-                                 long long out_ts, float eps) {
-    const int z = blockIdx.z;
-    const int M_ = meta[z * META_STRIDE + a.mfield];
-    if ((int)blockIdx.y * kRC >= M_) return;       // dead chunk: not counted
-    colpart_body(meta, a, partial, max_chunks);
-    __shared__ int s_last;
-    MTTS_WAIT_VMEM();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        MTTS_FENCE_RELEASE_AGENT();
-        MTTS_WAIT_VMEM();
-        int* cnt = ctr + z * gridDim.x + blockIdx.x;
-        const int nch = (M_ + kRC - 1) / kRC;
-        s_last = (MTTS_ATOMIC_INC_AGENT(cnt) == nch - 1) ? 1 : 0;
-        if (s_last) { MTTS_FENCE_ACQUIRE_AGENT(); *cnt = 0; }
-    }
-    __syncthreads();
-    if (!s_last) return;
-    colfinal_fold(meta, a.mfield, a.mode, partial, max_chunks, a.C, out0, out1, out_ts, eps, a.accumulate, blockIdx.x * 128);
-    colfinal_fold(meta, a.mfield, a.mode, partial, max_chunks, a.C, out0, out1, out_ts, eps, a.accumulate, blockIdx.x * 128 + 64);
 }
 
 // ------------------------------------------------------------------------------------------

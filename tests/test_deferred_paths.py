@@ -59,6 +59,9 @@ def _run(tmp_path, tag, env, gpu):
 # set per step — the same kernels on the same data either way)
 OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "MTTS_PRED_BATCH": "0", "MTTS_SINGLE_MULTI": "0",
        "MTTS_SO_KEEP_ACT": "0"}
+# kernel-choice knobs: the same mathematics in another summation order (compared at fp32-roundoff tolerance, not bit for bit) — the fused
+# attention forward vs grouped GEMM + softmax kernel + grouped GEMM (csrc/attention.h); and the query pass's encoder run-ahead (re-plumbing)
+KERNEL_ARMS = [{"MTTS_FUSED_ATTN": "0"}, {"MTTS_ENC_AHEAD_QUERY": "0"}]
 
 
 def _compare(tmp_path, gpu):
@@ -85,6 +88,13 @@ def _compare(tmp_path, gpu):
         else:
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     assert np.abs(a["g1_mel_linear.weight"]).max() > 0 and np.abs(a["g2_mel_linear.weight"] - a["g1_mel_linear.weight"]).max() > 0
+    for i, arm in enumerate(KERNEL_ARMS):
+        d = _run(tmp_path, f"kernel{i}", dict(common, **arm), gpu)
+        for k in a:
+            if "MTTS_ENC_AHEAD_QUERY" in arm and not gpu:
+                np.testing.assert_array_equal(a[k], d[k], err_msg=f"{arm} {k}")     # (pure re-plumbing: bit-identical)
+            else:
+                np.testing.assert_allclose(a[k], d[k], rtol=5e-4, atol=2e-6 * max(1.0, float(np.abs(a[k]).max())), err_msg=f"{arm} {k}")
 
 
 def test_side_stream_paths_change_nothing_emulator(tmp_path):
