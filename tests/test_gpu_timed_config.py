@@ -102,16 +102,19 @@ def test_grouped_tasks_equal_the_same_tasks_alone(tasks, order):
         e1.close()
 
 
-def test_second_order_two_of_eight_vs_oracle(tasks):
-    """Second-order MAML (the reference's training mode) on the grouped path against the oracle for two of the eight tasks (the oracle's
-    double backward costs ~20 s per full-size task on host cores)."""
+@pytest.mark.parametrize("which", [pytest.param((1, 6), id="two_of_eight"),
+                                   pytest.param((0, 2, 3, 4, 5, 7), id="other_six", marks=pytest.mark.slow)])
+def test_second_order_grouped_vs_oracle(tasks, which):
+    """Second-order MAML (the reference's training mode, BASELINE config C4's per-GPU work) on the grouped path against the oracle: two of
+    the eight tasks by default, the other six under `-m "gpu and slow"` (the oracle's double backward costs ~20 s per full-size task on
+    host cores) — together every task of the timed meta-batch."""
     eng = _engine(8, tasks)
     _set(eng, tasks)
     q, _ = eng.meta_grad(5, LR, 1.0, second_order=True)
     p = torch_params(DIMS, requires_grad=True, weight_scale=SCALE)
     buf = torch_buffers(DIMS)
     names = SAMPLED + ["encoder.layer_stack.0.slf_attn.w_qs.weight"]   # second order reaches the (non-adapted) encoder through the fast weights
-    for j in (1, 6):
+    for j in which:
         sup, qry = tasks[j]
         ql, _, _, _ = O.maml_task(p, buf, O.to_torch_batch(sup), O.to_torch_batch(qry), steps=5, lr=LR, second_order=True, modules=MODS,
                                   n_head=heads(DIMS))
