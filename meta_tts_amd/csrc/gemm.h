@@ -153,7 +153,8 @@ struct GemmArgs {
     // Conv1d as ONE implicit GEMM (K = taps * C_in) instead of one accumulate pass per tap (vocoder.h).  K-slices must not
     // straddle taps: a_tap_k % 32 == 0.
     int a_tap_k = 0x40000000, a_tap_rows = 0;
-    int swizzle = 0;                                     // XCD-aware tile order (xcd_group_remap; set by the launcher)
+    int swizzle = 0;                                     // XCD-aware tile order (set by the launcher): 1 = xcd_group_remap, 2 = panel order (xcd_panel_locate)
+    int po_tiles_m = 0;                                  // panel order: m-tiles of the tile grid (from the launch's max_M)
     // split-K (set by the launcher for under-filled grids): `splitk` workgroups share one output tile, each reducing a
     // contiguous run of K-chunks; partial tiles go to `ws`, the last workgroup to arrive (tile counter in `tile_ctr`) sums
     // them in split order and runs the fused epilogue, so the result does not depend on the arrival order
@@ -204,6 +205,25 @@ __device__ __forceinline__ int xcd_group_remap(int lin, int total, int G) {
     if ((blk + 1) * run > total) return lin;  // ragged last run: natural order
     const int r = lin - blk * run;
     return blk * run + (r & 7) * G + (r >> 3);
+}
+
+// Panel order (launches of fewer than 8 groups: a single-task rank, C2, few-shot adaptation — where no task-per-XCD schedule applies).
+// With the m-tile-major grouping above an XCD walks a few m-tiles across ALL n-tiles, so it streams the whole B operand — the 9.4 MB
+// weight image of a k = 9 conv against a 4 MB L2 — once per m-tile: every weight line crosses the fabric up to tiles_m times.  Here the
+// tile list is ordered B-panel-major ((n, split) outermost, m innermost) and dealt to the XCDs in contiguous eighths (slot 8 j + x runs
+// on XCD x): an XCD works through one or two (n, split) units, whose B panel (64 columns x its K range: 0.6-2.4 MB) stays in its L2
+// while the m-tiles' A rows stream past — the weight image crosses the fabric once.  Placement only: any order gives the same results.
+// Returns false for padding slots; bxs = (m * tiles_n + n) * S + split as gemm_*_body decodes it.
+__host__ __device__ __forceinline__ int xcd_panel_slots(int tiles_m, int tiles_n, int S) { return 8 * ((tiles_m * tiles_n * S + 7) / 8); }
+__host__ __device__ __forceinline__ bool xcd_panel_locate(int lin, int tiles_m, int tiles_n, int S, int& bxs) {
+    const int total = tiles_m * tiles_n * S, R = (total + 7) / 8;
+    const int x = lin & 7, j = lin >> 3;
+    const int t = x * R + j;
+    if (j >= R || t >= total) return false;
+    const int m = t % tiles_m, u = t / tiles_m;
+    const int sp = u % S, n = u / S;
+    bxs = (m * tiles_n + n) * S + sp;
+    return true;
 }
 
 // Register fragments of one BK=16 slice of the wave tile.  A_KC/B_KC: operand tile is [row][kLDK]
@@ -676,6 +696,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
     int z = blockIdx.z;
     int bxs = blockIdx.x;
     if (g.xs.on) { if (!xcd_sched_locate(g.xs, bxs, z, bxs)) return; }   // 1-D grid, task-per-XCD order
+    else if (g.swizzle == 2) { if (!xcd_panel_locate(bxs, g.po_tiles_m, (g.N + BN - 1) / BN + (gemm_has_colsum<FORM>(g) ? 1 : 0), g.splitk > 1 ? g.splitk : 1, bxs)) return; }
     else if (g.swizzle) bxs = xcd_group_remap(bxs, (int)gridDim.x, xcd_group_size((g.N + BN - 1) / BN, g.splitk));
     gemm_f32_body<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL>(g, z, bxs, smem);
 }
@@ -689,8 +710,9 @@ struct GemmMulti {
     int start[kGemmMultiMax + 1] = {0};
     int form[kGemmMultiMax] = {0};
     int groups[kGemmMultiMax] = {0};
-    int xcd_group[kGemmMultiMax] = {0};  // > 1: this many consecutive tile slots share an XCD (gemm_multi_locate); -2: GemmArgs::xs
+    int xcd_group[kGemmMultiMax] = {0};  // > 1: this many consecutive tile slots share an XCD (gemm_multi_locate); -2: GemmArgs::xs; -3: panel order (xcd_panel_locate)
     int tiles_pg[kGemmMultiMax] = {0};   // tile slots per group (start[p + 1] - start[p] may be padded up to a multiple of 8)
+    short po_tm[kGemmMultiMax] = {0}, po_tn[kGemmMultiMax] = {0}, po_s[kGemmMultiMax] = {0};   // xcd_group == -3 (panel order): m-tiles, n-tiles, split
     GemmArgs g[kGemmMultiMax];
 };
 
@@ -703,6 +725,12 @@ __device__ __forceinline__ bool gemm_multi_locate(const GemmMulti& mp, int& p, i
     while (p + 1 < mp.n && lin >= mp.start[p + 1]) ++p;
     lin -= mp.start[p];
     if (mp.xcd_group[p] == -2) return xcd_sched_locate(mp.g[p].xs, lin, z, bx);   // (starts are multiples of 8 then)
+    if (mp.xcd_group[p] == -3) {   // panel order, group after group (every group's slot run is a multiple of 8)
+        const int per = xcd_panel_slots(mp.po_tm[p], mp.po_tn[p], mp.po_s[p]);
+        z = lin / per;
+        if (z >= mp.groups[p]) return false;
+        return xcd_panel_locate(lin - z * per, mp.po_tm[p], mp.po_tn[p], mp.po_s[p], bx);
+    }
     const int total = mp.tiles_pg[p] * mp.groups[p];
     if (lin >= total) return false;   // padding up to the next multiple of 8
     const int tiles = mp.tiles_pg[p];
@@ -885,6 +913,18 @@ inline bool gemm_xcd_sched_for(GemmArgs& g, int max_M, int max_N, int groups, in
     return g.xs.on != 0;
 }
 inline long gemm_xcd_sched_slots(const XcdSched& s) { return 8L * s.maxlen * (s.on == 1 ? s.tn : 1); }
+// Panel order (xcd_panel_locate) for a problem: TASK mode, fewer than 8 groups (the task-per-XCD schedule covers 8), and a B operand
+// (N x K: the weight image of a forward / input-gradient problem) that is the bigger of the two — otherwise the m-tile-major grouping,
+// which keeps an m-tile's A panel in one L2, is already the right one.  MTTS_PANEL_ORDER=0: off (A/B runs).
+inline bool gemm_panel_order_for(const GemmArgs& g, int form, double rows, int max_M, int max_N, int groups) {
+    static const bool on = [] { const char* e = getenv("MTTS_PANEL_ORDER"); return e ? atoi(e) != 0 : true; }();
+    if (!on || g.table || groups >= 8 || groups < 1) return false;
+    const double K = (double)gemm_keff(g);
+    const double a_bytes = form == GEMM_TN ? rows * max_M : rows / groups * (g.lda > 0 ? g.lda : K);   // unique bytes behind the A operand (per group)
+    const double b_bytes = form == GEMM_TN ? rows * max_N : (double)max_N * K;
+    (void)max_M;
+    return b_bytes > a_bytes;
+}
 
 // Host launcher.  max_M / max_N bound the tile grid over all groups.  tile = 0: automatic — the problem goes through the launch
 // queue (alone if no batch is open): a plain 64x64 grid (LDS-DMA kernels in the latency regime, a multi-problem grid for a batch).
@@ -953,6 +993,10 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     const long grid_tiles = ntiles(tile);
     dim3 block(nth), grid((unsigned)(grid_tiles * S), 1, (unsigned)groups);
     if (gemm_xcd_sched_for(g, max_M, max_N, groups, S, tile)) grid = dim3((unsigned)gemm_xcd_sched_slots(g.xs), 1, 1);   // 1-D, task-per-XCD order
+    else if (gemm_panel_order_for(g, form, rows, max_M, max_N, groups)) {
+        g.swizzle = 2; g.po_tiles_m = (max_M + tile - 1) / tile;
+        grid = dim3((unsigned)xcd_panel_slots(g.po_tiles_m, gemm_tiles_n(g, max_N, tile), S), 1, (unsigned)groups);
+    }
     GemmProfiler& prof = cx.prof;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }
@@ -1069,6 +1113,11 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
         mp.tiles_pg[i] = tiles * S;
         long slots = (long)tiles * S * p.groups;
         if (gemm_xcd_sched_for(mp.g[i], p.max_M, p.max_N, p.groups, S, T)) { mp.xcd_group[i] = -2; slots = gemm_xcd_sched_slots(mp.g[i].xs); }
+        else if (gemm_panel_order_for(p.g, p.form, p.rows, p.max_M, p.max_N, p.groups)) {
+            mp.xcd_group[i] = -3;
+            mp.po_tm[i] = (short)((p.max_M + T - 1) / T); mp.po_tn[i] = (short)gemm_tiles_n(p.g, p.max_N, T); mp.po_s[i] = (short)S;
+            slots = (long)xcd_panel_slots(mp.po_tm[i], mp.po_tn[i], S) * p.groups;
+        }
         mp.start[i + 1] = mp.start[i] + (int)((slots + 7) & ~7L);   // (every problem starts on a multiple of 8: workgroup slot % 8 = XCD)
         max_groups = std::max(max_groups, p.groups);
         flops += p.flops; rows += p.rows; bytes += p.bytes;

@@ -326,6 +326,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     int z = blockIdx.z;
     int bxs = blockIdx.x;
     if (g.xs.on) { if (!xcd_sched_locate(g.xs, bxs, z, bxs)) return; }
+    else if (g.swizzle == 2) { if (!xcd_panel_locate(bxs, g.po_tiles_m, (g.N + BN - 1) / BN + (gemm_has_colsum<FORM>(g) ? 1 : 0), g.splitk > 1 ? g.splitk : 1, bxs)) return; }
     else if (g.swizzle) bxs = xcd_group_remap(bxs, (int)gridDim.x, xcd_group_size((g.N + BN - 1) / BN, g.splitk));
     gemm_bf16_body<FORM, BM, BN, BK, PF>(g, z, bxs, smem);
 }

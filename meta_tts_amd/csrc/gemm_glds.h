@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[kGldsSmemFloats];
     int bx = blockIdx.x, z = blockIdx.z;
     if (g.xs.on) { if (!xcd_sched_locate(g.xs, bx, z, bx)) return; }
+    else if (g.swizzle == 2) { if (!xcd_panel_locate(bx, g.po_tiles_m, (g.N + 63) / 64 + (gemm_has_colsum<FORM>(g) ? 1 : 0), g.splitk > 1 ? g.splitk : 1, bx)) return; }
     else if (g.swizzle) bx = xcd_group_remap(bx, (int)gridDim.x, xcd_group_size((g.N + 63) / 64, g.splitk));
     gemm_glds_body<FORM>(g, z, bx, smem);
 }
