@@ -6,7 +6,10 @@
  *
  * Conventions: every function returns 0 on success, non-zero on error (mtts_last_error() gives the
  * message); nothing throws across the ABI.  A handle owns all device memory it needs (allocated in
- * mtts_create for the stated capacities; no allocation afterwards).  All work is enqueued on the
+ * mtts_create for the stated capacities; no allocation afterwards — with ONE exception: second-order MAML,
+ * mtts_meta_grad(second_order = 1) / mtts_hvp_support, allocates its tangent arena, its per-step activation and gradient
+ * sets and its deferred-gradient buffers on FIRST use, so first-order / baseline / inference users do not pay for them;
+ * mtts_reserve_second_order(h, steps) makes that allocation explicit and up-front).  All work is enqueued on the
  * handle's HIP stream (mtts_set_stream) and is asynchronous w.r.t. the host unless a function
  * copies results to a host pointer, in which case it synchronises that stream.  For small plans the
  * handle additionally uses two private non-blocking streams (parameter gradients, encoder run-ahead);
@@ -156,6 +159,11 @@ int mtts_backward(mtts_handle* h, int slot, int use_fast_weights, float scale, i
  * be NULL (then nothing synchronises). ------------------------------------------------------------ */
 int mtts_meta_grad(mtts_handle* h, int steps, float inner_lr, float grad_scale, int second_order,
                    float* qry_losses_host /* [n_tasks][6] */, float* sup_losses_host /* [steps][n_tasks][6] */);
+/* Pre-allocates everything a second-order mtts_meta_grad of `steps` inner steps would allocate on first use (the tangent arena, one
+ * activation set and one gradient set per step — ~0.95 GB per full-size task and step —, the per-layer tangent-gradient buffers of the
+ * deferred Hessian-vector weight gradients): after it, second-order calls allocate nothing.  Sets that do not fit are skipped (the
+ * engine then recomputes: same results up to rounding, slower); returns 0 unless the mandatory tangent arena itself cannot be allocated. */
+int mtts_reserve_second_order(mtts_handle* h, int steps);
 /* Hessian-vector product of the support loss (slot 0) at the current fast weights in the direction currently held
  * in the per-task gradient buffer (e.g. after mtts_backward): the building block of the second-order sweep,
  * exposed for parity tests against torch.autograd (export with which = 6). */

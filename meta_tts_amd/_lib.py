@@ -64,6 +64,7 @@ EXPORTS = {
     "mtts_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]),
     "mtts_meta_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "mtts_hvp_support": (C.c_int, [C.c_void_p]),
+    "mtts_reserve_second_order": (C.c_int, [C.c_void_p, C.c_int]),
     "mtts_set_inner_prox": (C.c_int, [C.c_void_p, C.c_float]),
     "mtts_imaml_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mtts_imaml_cg_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float]),

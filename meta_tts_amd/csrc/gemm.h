@@ -913,12 +913,14 @@ inline bool gemm_xcd_sched_for(GemmArgs& g, int max_M, int max_N, int groups, in
     return g.xs.on != 0;
 }
 inline long gemm_xcd_sched_slots(const XcdSched& s) { return 8L * s.maxlen * (s.on == 1 ? s.tn : 1); }
-// Panel order (xcd_panel_locate) for a problem: TASK mode, fewer than 8 groups (the task-per-XCD schedule covers 8), and a B operand
-// (N x K: the weight image of a forward / input-gradient problem) that is the bigger of the two — otherwise the m-tile-major grouping,
-// which keeps an m-tile's A panel in one L2, is already the right one.  MTTS_PANEL_ORDER=0: off (A/B runs).
+// Panel order (xcd_panel_locate) for a problem: TASK mode, fewer than 8 groups (the task-per-XCD schedule covers 8), an under-filled
+// launch, and a B operand (N x K: the weight image of a forward / input-gradient problem) that is the bigger of the two — otherwise the
+// m-tile-major grouping, which keeps an m-tile's A panel in one L2, is already the right one.  Measured (profiles/r04_ab_log.md): the
+// k = 9 input gradient of a single-task rank 212 -> 194 us, its step 35.17 -> 34.73 ms.  MTTS_PANEL_ORDER=0: off (A/B runs).
 inline bool gemm_panel_order_for(const GemmArgs& g, int form, double rows, int max_M, int max_N, int groups) {
     static const bool on = [] { const char* e = getenv("MTTS_PANEL_ORDER"); return e ? atoi(e) != 0 : true; }();
     if (!on || g.table || groups >= 8 || groups < 1) return false;
+    if (std::ceil(rows / 64.0) * gemm_tiles_n(g, max_N, 64) > (double)gemm_glds_max_wgs()) return false;   // chip-filling launches: measured slightly worse (C2: +1 %)
     const double K = (double)gemm_keff(g);
     const double a_bytes = form == GEMM_TN ? rows * max_M : rows / groups * (g.lda > 0 ? g.lda : K);   // unique bytes behind the A operand (per group)
     const double b_bytes = form == GEMM_TN ? rows * max_N : (double)max_N * K;

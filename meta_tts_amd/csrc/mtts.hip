@@ -291,6 +291,13 @@ int mtts_meta_grad(mtts_handle* h, int steps, float inner_lr, float grad_scale, 
 }
 
 int mtts_hvp_support(mtts_handle* h) { return launched(h->eng, h->eng.hvp_support()); }
+int mtts_reserve_second_order(mtts_handle* h, int steps) {
+    Engine& e = h->eng;
+    if (steps < 1 || steps > h->sup_losses_cap) { e.set_error("bad step count"); return -1; }
+    if (e.enable_second_order(steps)) return -1;
+    if (e.ensure_act_sets(steps)) (void)e.ensure_grad_sets(steps);   // optional: the engine falls back to recomputation without them
+    return 0;
+}
 
 int mtts_set_inner_prox(mtts_handle* h, float reg_param) {
     if (!(reg_param >= 0.f)) { h->eng.set_error("reg_param must be >= 0"); return -1; }

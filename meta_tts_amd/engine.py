@@ -96,6 +96,10 @@ class Engine:
         """Train-mode dropout on/off (off = parity configuration)."""
         self._ck(self.lib.mtts_set_dropout(self.h, int(enable), int(seed) & 0xFFFFFFFF))
 
+    def reserve_second_order(self, steps: int):
+        """Allocate up front what a second-order meta_grad of `steps` inner steps would allocate on first use (include/mtts.h)."""
+        self._ck(self.lib.mtts_reserve_second_order(self.h, int(steps)))
+
     def set_numerics(self, mode: str = "fp32"):
         """Arithmetic of the contractions: "fp32" (default; the reference's own and the parity mode) or "bf16" (bf16 operands, fp32
         accumulation: BASELINE.json configs[1]; include/mtts.h: mtts_set_numerics)."""

@@ -2,7 +2,7 @@
 # Final evidence of a round: shader clock beside the GEMM kernels, GPU tests, smoke, the default bench line, the single-task emulation,
 # kernel traces (8-task and single-task rank, first + second order) and the PMC passes (HBM bytes + MFMA busy per GEMM kernel, first- and
 # second-order) of the same bench command.   usage: tools/gpu_final.sh [tag]   ->  gpurun_out/<tag>/
-TAG=${1:-r03z}
+TAG=${1:-r04z}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 R=$PWD
