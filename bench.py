@@ -32,7 +32,13 @@ INNER_STEPS = 5
 INNER_LR = 0.001
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PARITY_RTOL = 2e-3  # per-task query losses of the timed configuration (dropout off) vs the oracle; the line is refused above it
-PARITY_GRAD_RTOL = 5e-2  # sampled per-task query-gradient tensors, max-abs error relative to the tensor's max-abs (lr 1e-3 on UNSCALED random weights is an expansive inner loop: rounding differences are amplified through the 5 steps; the contractive fixtures are held to 5e-3 in tests/)
+PARITY_GRAD_RTOL = 1e-2  # sampled per-task query-gradient tensors, max-abs error relative to the tensor's max-abs
+# Random-init weights of the timed meta-step: every Linear / Conv1d weight matrix x 0.5 (synth.make_params), the initialisation on which five
+# inner SGD steps at the reference's lr 1e-3 are contractive (the support loss falls), as in tests/golden/maml_small_lr1e-3_scaled.npz and
+# tests/test_gpu_timed_config.py.  On unscaled random weights the inner loop is expansive: summation-order differences between any two
+# correct fp32 implementations are amplified to several per cent of the query gradient after 5 steps (measured 3.6-5.5 %), which makes a
+# gradient comparison meaningless.  Timing does not depend on the weight values.
+WEIGHT_SCALE = 0.5
 
 
 def noam_lr(step, d_model=256, warm=4000, anneal=(300000, 400000, 500000), rate=0.3):
@@ -97,7 +103,7 @@ GRAD_SAMPLES = ("mel_linear.weight", "decoder.layer_stack.5.pos_ffn.w_2.weight",
 def _oracle_state(dims):
     import torch
     from meta_tts_amd import synth
-    params = {k: torch.from_numpy(v.copy()) for k, v in synth.make_params(dims, 0).items()}
+    params = {k: torch.from_numpy(v.copy()) for k, v in synth.make_params(dims, 0, weight_scale=WEIGHT_SCALE).items()}
     for k, v in params.items():
         if not k.endswith(("position_enc", "pitch_bins", "energy_bins")):
             v.requires_grad_(True)
@@ -218,20 +224,35 @@ def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True):
                      f"best of the swept intra-op thread counts ({cores}); {mean_t:.2f} s/task, clip+Adam excluded (<1%)"}
     conc, conc_err = None, None
     if concurrent:
-        # 8 task processes at once, at 4 / 8 / 16 intra-op threads each (never more than host threads / 8, never more than the swept
-        # optimum): the fastest of them is the concurrent figure (8 x 16 threads measured 2.3x SLOWER than one task at a time on the
-        # 256-thread box: the processes thrash each other's caches / memory channels)
+        # 8 task processes at once; intra-op threads per process searched from 4 downhill (never more than host threads / 8, never more
+        # than the swept optimum): 4, then 2 and 1 while fewer threads keep winning, otherwise 8 and 16 while more do.  Measured on the
+        # 256-thread box: 4 threads 8.3 s per meta-step, 8 threads 12.2 s, 16 threads 22.2 s (the processes thrash each other's caches and
+        # memory channels), one task at a time at 16 threads 10.5 s.  The fastest is the concurrent figure.
         t_conc, sweep_c = time.perf_counter(), {}
-        for thr in sorted({max(1, min(t, cores, host_cores // META_BATCH)) for t in (4, 8, 16)}):
-            if time.perf_counter() - t_conc > 75.0:
-                break
+        cap = max(1, min(cores, host_cores // META_BATCH))
+
+        def leg(thr):
+            nonlocal conc, conc_err
+            thr = max(1, min(thr, cap))
+            if str(thr) in sweep_c or time.perf_counter() - t_conc > 75.0:
+                return sweep_c.get(str(thr))
             try:
                 r = cpu_baseline_concurrent(thr, reps=1)
                 sweep_c[str(r["threads_per_process"])] = r["s_per_meta_step"]
                 if conc is None or r["value"] > conc["value"]:
                     conc = r
+                return r["s_per_meta_step"]
             except Exception as ex:  # noqa: BLE001
                 conc_err = f"{type(ex).__name__}: {ex}"
+                return None
+        t4 = leg(4)
+        t2 = leg(2)
+        if t4 is not None and t2 is not None and t2 < t4:
+            leg(1)
+        else:
+            t8 = leg(8)
+            if t4 is not None and t8 is not None and t8 < t4:
+                leg(16)
         if conc is not None:
             conc["s_per_meta_step_by_threads_per_process"] = sweep_c
     best_leg = "concurrent" if (conc is not None and conc["value"] > seq["value"]) else "sequential"
@@ -525,7 +546,7 @@ def main():
     max_T = max(max(s[8], q[8]) for s, q in tasks)
     eng = Engine(dims, adapt_modules=mods, max_tasks=len(local), max_B=5, max_S=80, max_T=max_T, device=local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng.load_params(synth.make_params(dims, 0))
+    eng.load_params(synth.make_params(dims, 0, weight_scale=WEIGHT_SCALE))
     eng.set_dropout(not args.no_dropout, 1234 + rank)  # train-mode dropout as in the reference's inner/outer loop (per-rank stream)
     sup_b, qry_b = [t[0] for t in tasks], [t[1] for t in tasks]
 
@@ -678,7 +699,7 @@ def main():
     if cpu is not None:
         # same handle, same grouped launches as the timed steps, dropout off (the oracle's configuration); the weights have moved by the
         # timed Adam steps and the oracle ran on the initial ones, so they are loaded again first
-        eng.load_params(synth.make_params(dims, 0))
+        eng.load_params(synth.make_params(dims, 0, weight_scale=WEIGHT_SCALE))
         eng.set_dropout(False, 0)
         ingest()
         q_parity, _ = eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, fetch_losses=True)
@@ -736,6 +757,7 @@ def main():
                 "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": ("C3: Meta-TTS MAML first-order" if args.order == 1 else "C4-style: Meta-TTS MAML second-order") + " (algorithm=meta_emb_vad, inner=5, meta-batch=8 tasks x (5 support + 5 query utts)), "
                                        "FastSpeech2 base.yaml, outer mean + clip(1.0) + Adam/Noam", "meta_batch": META_BATCH,
+                           "weights": "random init, Linear / Conv1d weight matrices x %g (5 inner steps at lr 1e-3 contractive; see WEIGHT_SCALE)" % WEIGHT_SCALE,
                            "tasks_per_gpu": META_BATCH // n, "inner_steps": INNER_STEPS, "order": "first" if args.order == 1 else "second", "parallelism": f"task-dp{n}",
                            "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "dropout": "identity (parity config)" if args.no_dropout else "on (0.2 / 0.5 / 0.5, counter-based masks)",
                            "batch_ingestion": "resident (uploaded once before the timed region)" if args.resident_batches else "inside every timed step (host 12-tuples -> HBM + plans)"},

@@ -210,6 +210,8 @@ public:
     TS d_rounded;
     // backward scratch
     TS gPm, gFm;  // dropout-masked copies of a LayerNorm input gradient
+    TS gPxE, gPxP, gPxD, gPx2;           // input gradients of the energy / pitch / duration predictors (pred_bwd_early); dL/d(x2)
+    hipEvent_t ev_pred = nullptr;
     TS gP0, gP1, gPqkv, gPh, gPf1, gPf2, gF0, gF1, gFqkv, gFh, dSp, dSf, gR0, gR1, gRm, gRp, gMelF, dspk, dpred[3];
     float *loss_partial = nullptr, *losses = nullptr, *col_partial = nullptr;
     int col_max_chunks = 0;
@@ -717,7 +719,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                              (size_t)defer_tasks * 3 * 2 * (size_t)(capMp + 2 * G) * cfg.vp_filter * sizeof(float) +
                              (size_t)defer_tasks * 2 * ((size_t)cfg.enc_layers * ln_chunks(capMp) + (size_t)cfg.dec_layers * ln_chunks(capMf)) * 3 * d * sizeof(float) +
                              (size_t)defer_tasks * 3 * 2 * (size_t)ln_chunks(capMp) * 3 * cfg.vp_filter * sizeof(float) + 64 * 256 +
-                             (size_t)defer_tasks * kAhead * (size_t)(capMp + 2 * G) * d * sizeof(float) + 4096;
+                             (size_t)defer_tasks * (kAhead + 4) * (size_t)(capMp + 2 * G) * d * sizeof(float) + 4096;
         HIP_CHECK(hipMalloc((void**)&arena_defer, bytes));
         HIP_CHECK(hipMemset(arena_defer, 0, bytes));
         char* cur = arena_defer;
@@ -741,18 +743,24 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         mk(encG, cfg.enc_layers, capMp);
         mk(decG, cfg.dec_layers, capMf);
         for (auto& t : enc_ahead) t = rows_d(capMp, d);
+        gPxE = rows_d(capMp, d); gPxP = rows_d(capMp, d); gPxD = rows_d(capMp, d); gPx2 = rows_d(capMp, d);
         for (auto& pg : predG) { pg.g2a = rows_d(capMp, cfg.vp_filter); pg.g2b = rows_d(capMp, cfg.vp_filter); pg.part2 = part_d(capMp, cfg.vp_filter); pg.part1 = part_d(capMp, cfg.vp_filter); }
         postG.resize(cfg.postnet_layers);
         for (auto& t : postG) t = rows_d(capMr, post_c);
         HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));   // non-blocking (a blocking stream would serialise with the legacy default stream on every launch)
         for (auto& e : ev_side) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipEventCreate(&ev_join));
+        HIP_CHECK(hipEventCreate(&ev_pred));
         HIP_CHECK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
         for (auto& e : ev_enc) HIP_CHECK(hipEventCreate(&e));
         gx_side2.no_glds = gx_side.no_glds;
         if (gx_side2.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace of the run-ahead stream)"); return -1; }
         const int side_chunks = (std::max(std::max(capMp, capMf), capMr) + kRC - 1) / kRC;   // == col_max_chunks (set by layout(), later)
-        HIP_CHECK(hipMalloc((void**)&col_partial_side, (size_t)defer_tasks * side_chunks * 3 * 1024 * sizeof(float)));
+        {   // (sized like col_partial: the early predictor backward runs its LayerNorm reductions through it too)
+            const size_t ln_w = (size_t)std::max(cfg.d_model, cfg.vp_filter);
+            const size_t per_task = std::max((size_t)side_chunks * 3 * 1024, (size_t)ln_chunks(std::max(std::max(capMp, capMf), capMr)) * 3 * ln_w);
+            HIP_CHECK(hipMalloc((void**)&col_partial_side, (size_t)defer_tasks * per_task * sizeof(float)));
+        }
         gx_side.no_glds = true;
         if (gx_side.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace of the side stream)"); return -1; }
         return 0;
@@ -761,6 +769,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (side) { hipStreamSynchronize(side); hipStreamDestroy(side); }
         for (auto& e : ev_side) if (e) hipEventDestroy(e);
         if (ev_join) hipEventDestroy(ev_join);
+        if (ev_pred) hipEventDestroy(ev_pred);
         if (side2) { hipStreamSynchronize(side2); hipStreamDestroy(side2); }
         for (auto& e : ev_enc) if (e) hipEventDestroy(e);
         gx_side2.release();
@@ -1486,7 +1495,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // dout: [Mp] gradient of the prediction (0 on masked rows); dx accumulates the input gradient
     // pg != null (phoneme space only): deferred parameter gradients — the two weight-gradient GEMMs, the LayerNorm reductions and the
     // output layer's column sums of this predictor run on the side stream from buffers of its own (see LayerGrad)
-    void pred_bwd(const Pass& ps, const PredP& P, PredBuf& b, TS xin, TS dout, TS dx, Space s = SP_P, PredGrad* pg = nullptr) {
+    void pred_bwd(const Pass& ps, const PredP& P, PredBuf& b, TS xin, TS dout, TS dx, Space s = SP_P, PredGrad* pg = nullptr,
+                  int dx_flags = GEMM_ACCUM) {
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, f = cfg.vp_filter, k = cfg.vp_kernel;
         const unsigned char* im = inrect_mask(p, s);
@@ -1529,8 +1539,28 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         {
             GemmBatchScope pair(gx, stream);
             conv_wgrad(ps, s, g2, f, k, xin, d, P.c1w, P.c1b, im);
-            conv_dgrad(ps, s, g2, f, k, W(ps, P.c1w), d, dx, GEMM_ACCUM, im);
+            conv_dgrad(ps, s, g2, f, k, W(ps, P.c1w), d, dx, dx_flags, im);
         }
+    }
+    // The phoneme-level predictors' backward needs only the loss gradient and the forward's activations, and nothing reads its input
+    // gradients before the length regulator's backward at the far end of the decoder: the whole chain (3 predictors x 11 small launches)
+    // runs on the side stream under the PostNet / decoder backward, each predictor's input gradient into a buffer of its own (gPxE / gPxP / gPxD).
+    bool pred_bwd_early(const Pass& ps) {
+        const Plan& p = *ps.pl;
+        static const int on = [] { const char* e = getenv("MTTS_PRED_EARLY"); return e ? atoi(e) : 1; }();
+        if (!on || !defer_ok(p) || any_frame_level()) return false;
+        fork_side();
+        std::swap(stream, side);
+        std::swap(gx, gx_side);
+        std::swap(col_partial, col_partial_side);
+        site_base = 136; pred_bwd(ps, eneP, eneB, x1, dpred[2], gPxE, SP_P, nullptr, 0);
+        site_base = 132; pred_bwd(ps, pitP, pitB, x0, dpred[1], gPxP, SP_P, nullptr, 0);
+        site_base = 128; pred_bwd(ps, durP, durB, x0, dpred[0], gPxD, SP_P, nullptr, 0);
+        std::swap(col_partial, col_partial_side);
+        std::swap(gx, gx_side);
+        std::swap(stream, side);
+        hipEventRecord(ev_pred, side);
+        return true;
     }
 
     // =================================================================================
@@ -1842,6 +1872,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         // prediction strides in the phoneme space: the [Mp] vectors were allocated as rows(capMp, 1)
         MTTS_LAUNCH(loss_grad_kernel, dim3(kLossBlocks, 1, nt), dim3(256), stream, (const int*)p.meta, a, scale, gRm.p, gRp.p,
                     dpred[1].p, dpred[2].p, dpred[0].p, dpred_r[0].p, dpred_r[1].p);
+        const bool pred_early = pred_bwd_early(ps);
         // ---- PostNet: cur = dL/d(a_i), starts as dL/d(mel_post); dc -> gR0, layer-input grad -> gR1
         TS cur = gRp;
         for (int i = cfg.postnet_layers - 1; i >= 0; --i) {
@@ -1915,6 +1946,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         const TS gF0 = cfg.dec_layers ? K.dec[0].g0 : K.dec_top;   // gradient of the decoder input
         // speaker vector gradient, part 1: every valid frame
+        // (spk_side: parameter-gradient work of a pass whose phoneme-side gradient buffers stay untouched until the next pass — the
+        // segment sums, the speaker table's and the bucket tables' gradients go to the side stream)
+        const bool spk_side = pred_early && !need_encoder;
+        if (!spk_side)
         MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(256), stream, (const int*)p.meta, (const float*)gF0.p,
                     gF0.ts, (const int*)p.f_seg_start, (const int*)p.f_seg_len, (long long)cap_B, dspk.p, dspk.ts, d, 0);
         // ---- frame-level half of the variance adaptor (frame rectangle), then the length regulator -> gP0 = dL/d(va_out) --------
@@ -1936,9 +1971,26 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                         gRx.ts, (const int*)p.f2r, row_ts_f, gFx.p, gFx.ts, d);
             gLR = gFx;
         }
+        const TS gLRo = pred_early ? gPx2 : gP0;
         MTTS_LAUNCH(length_regulate_bwd_kernel, row_grid(p.maxMp, nt), dim3(256), stream, (const int*)p.meta, (const float*)gLR.p,
-                    gLR.ts, (const int*)p.p_first, (const int*)p.p_count, row_ts_p, gP0.p, gP0.ts, d, 0);
+                    gLR.ts, (const int*)p.p_first, (const int*)p.p_count, row_ts_p, gLRo.p, gLRo.ts, d, 0);
         // ---- phoneme-level half of the variance adaptor ---------------------------------------------------------------------
+        if (pred_early) {
+            // the predictors' input gradients are waiting in gPxE / gPxP / gPxD (pred_bwd_early): dL/d(x2) = gPx2 (just written),
+            // dL/d(x1) = gPx2 + gPxE (into gPxE), dL/d(x0) = (dL/d(x1) + gPxP) + gPxD (into gP0) — the order in which three accumulating GEMM
+            // epilogues would have added them; the bucket tables' gradients read gPx2 / gPxE on the side stream
+            const long long n4 = (gP0.ts * nt) / 4, o = (long long)G * d;
+            const dim3 ag((unsigned)std::min<long long>((n4 + 255) / 256, 2048));
+            hipStreamWaitEvent(stream, ev_pred, 0);
+            MTTS_LAUNCH(add2_kernel, ag, dim3(256), stream, (const float*)(gPx2.p - o), (const float*)(gPxE.p - o), gPxE.p - o, n4);
+            MTTS_LAUNCH(add3_kernel, ag, dim3(256), stream, (const float*)(gPxE.p - o), (const float*)(gPxP.p - o), (const float*)(gPxD.p - o),
+                        gP0.p - o, n4);
+            fork_side();
+            MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(256), side, (const int*)p.meta, (int)META_MP,
+                        (const float*)gPx2.p, gPx2.ts, (const int*)eidx, row_ts_p, -1, Gd(energy_emb).p, n_total, d);
+            MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(256), side, (const int*)p.meta, (int)META_MP,
+                        (const float*)gPxE.p, gPxE.ts, (const int*)pidx, row_ts_p, -1, Gd(pitch_emb).p, n_total, d);
+        } else {
         if (!cfg.energy_frame) {
             MTTS_LAUNCH(table_grad_kernel, dim3(cfg.n_bins, 1, nt), dim3(256), stream, (const int*)p.meta, (int)META_MP,
                         (const float*)gP0.p, gP0.ts, (const int*)eidx, row_ts_p, -1, Gd(energy_emb).p, n_total, d);
@@ -1950,11 +2002,16 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             site_base = 132; pred_bwd(ps, pitP, pitB, x0, dpred[1], gP0, SP_P, defer_ok(p) ? &predG[1] : nullptr);
         }
         site_base = 128; pred_bwd(ps, durP, durB, x0, dpred[0], gP0, SP_P, defer_ok(p) ? &predG[0] : nullptr);
+        }
         // speaker vector gradient, part 2: every position of the phoneme rectangle
-        MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(256), stream, (const int*)p.meta, (const float*)gP0.p,
+        const hipStream_t sst = spk_side ? side : stream;
+        if (spk_side)   // (after the fork above: gF0 and gP0 are final)
+        MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(256), sst, (const int*)p.meta, (const float*)gF0.p,
+                    gF0.ts, (const int*)p.f_seg_start, (const int*)p.f_seg_len, (long long)cap_B, dspk.p, dspk.ts, d, 0);
+        MTTS_LAUNCH(segsum_rows_kernel, dim3((d + 63) / 64, p.maxB, nt), dim3(256), sst, (const int*)p.meta, (const float*)gP0.p,
                     gP0.ts, (const int*)p.p_seg_start, (const int*)p.p_seg_len, (long long)cap_B, dspk.p, dspk.ts, d, 1);
         if (!p.ext_spk)
-        MTTS_LAUNCH(speaker_table_grad_kernel, dim3(cfg.n_speaker, 1, nt), dim3(64), stream, (const int*)p.meta,
+        MTTS_LAUNCH(speaker_table_grad_kernel, dim3(cfg.n_speaker, 1, nt), dim3(64), sst, (const int*)p.meta,
                     (const float*)dspk.p, dspk.ts, (const int*)p.spk_ids, (long long)cap_B + 1, cap_B, p.average_spk,
                     Gd(spk_table).p, n_total, d);
         if (!need_encoder) return 0;

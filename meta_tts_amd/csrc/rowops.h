@@ -978,6 +978,14 @@ __global__ void add2_kernel(const float* a, const float* b, float* out, long lon
     }
 }
 
+// out = (a + b) + c, in that order (the order in which three accumulating GEMM epilogues would have added them)
+__global__ void add3_kernel(const float* a, const float* b, const float* c, float* out, long long n4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 x = ld4(a + i * 4), y = ld4(b + i * 4), z = ld4(c + i * 4);
+        st4(out + i * 4, make_float4((x.x + y.x) + z.x, (x.y + y.y) + z.y, (x.z + y.z) + z.z, (x.w + y.w) + z.w));
+    }
+}
+
 // dst[t][i] = src[i]  (clone the adapted parameters into every task's fast weights)
 __global__ void broadcast_kernel(const float* src, float* dst, long long n4, long long dst_ts) {
     float* d = dst + (long long)blockIdx.z * dst_ts;

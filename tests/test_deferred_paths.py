@@ -62,7 +62,8 @@ OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "M
 # kernel-choice knobs: the same mathematics in another summation order (compared at fp32-roundoff tolerance, not bit for bit) — the fused
 # attention forward vs grouped GEMM + softmax kernel + grouped GEMM (csrc/attention.h); and the query pass's encoder run-ahead (re-plumbing)
 # MTTS_PANEL_ORDER=0: the B-panel-major XCD tile order of under-filled launches off (csrc/gemm.h: xcd_panel_locate) — placement only
-KERNEL_ARMS = [{"MTTS_FUSED_ATTN": "0"}, {"MTTS_ENC_AHEAD_QUERY": "0"}, {"MTTS_PANEL_ORDER": "0"}]
+# MTTS_PRED_EARLY=0: the phoneme-level predictors' backward at its textual place on the main stream instead of early on the side stream
+KERNEL_ARMS = [{"MTTS_FUSED_ATTN": "0"}, {"MTTS_ENC_AHEAD_QUERY": "0"}, {"MTTS_PANEL_ORDER": "0"}, {"MTTS_PRED_EARLY": "0"}]
 
 
 def _compare(tmp_path, gpu):
@@ -92,7 +93,7 @@ def _compare(tmp_path, gpu):
     for i, arm in enumerate(KERNEL_ARMS):
         d = _run(tmp_path, f"kernel{i}", dict(common, **arm), gpu)
         for k in a:
-            if ("MTTS_ENC_AHEAD_QUERY" in arm or "MTTS_PANEL_ORDER" in arm) and not gpu:
+            if ("MTTS_ENC_AHEAD_QUERY" in arm or "MTTS_PANEL_ORDER" in arm or "MTTS_PRED_EARLY" in arm) and not gpu:
                 np.testing.assert_array_equal(a[k], d[k], err_msg=f"{arm} {k}")     # (pure re-plumbing: bit-identical)
             else:
                 np.testing.assert_allclose(a[k], d[k], rtol=5e-4, atol=2e-6 * max(1.0, float(np.abs(a[k]).max())), err_msg=f"{arm} {k}")
