@@ -434,16 +434,62 @@ def baseline_c2_leg(dims, device, noam_lr, trn, iters=8):
     return res
 
 
-def gemm_profile(eng, run):
+def gemm_profile(eng, run, sites=False):
     """Run `run()` once with every GEMM launch of this handle timed by HIP events on its stream; rows of
-    (kernel, launches, ms, algorithmic flops, algorithmic bytes)."""
+    (kernel, launches, ms, algorithmic flops, algorithmic bytes).  sites: also the per-launch records (kernel name, longest K-loop,
+    microseconds, algorithmic GFLOP) — the library's MTTS_GEMM_DUMP csv, read back."""
+    import tempfile
     import torch
+    dump = None
+    if sites:
+        fd, dump = tempfile.mkstemp(suffix=".csv", prefix="mtts_gemm_")
+        os.close(fd)
+        os.unlink(dump)
+        os.environ["MTTS_GEMM_DUMP"] = dump
     eng.profile_gemm(True)
     run()
     torch.cuda.synchronize()
     rep = eng.profile_report()   # {kernel name as rocprofv3 prints it: [launches, ms, flops, bytes]}
     eng.profile_gemm(False)
-    return [(name, r[0], r[1], r[2], r[3]) for name, r in rep.items()]
+    rows = [(name, r[0], r[1], r[2], r[3]) for name, r in rep.items()]
+    if not sites:
+        return rows
+    os.environ.pop("MTTS_GEMM_DUMP", None)
+    recs = []
+    try:
+        import csv
+        with open(dump) as f:
+            for r in csv.DictReader(f):
+                recs.append((eng.lib.mtts_profile_kernel_name(int(r["kind"])).decode(), int(r["K"]), float(r["us"]), float(r["gflop"]), int(r.get("site", 0))))
+        os.unlink(dump)
+    except Exception:  # noqa: BLE001
+        recs = []
+    return rows, recs
+
+
+SITE_CLASSES = {0: "other (mel_linear, embeddings)", 1: "encoder FFT blocks", 2: "decoder FFT blocks", 3: "PostNet (k=5 convolutions)", 4: "variance predictors"}
+
+
+def launch_classes(recs, kernel, dims):
+    """The dominant kernel's launches by call-site class (the library tags every launch record with the model part that issued it; inside
+    the FFT blocks the k=9 convolution launches are told apart by their K-loop): launches, ms, achieved TFLOP/s and fraction of the fp32
+    matrix peak per class — a PostNet pair (flops of valid frames, rows of the padded rectangle) and a k=9 FFT-block convolution do not
+    hide behind one average."""
+    k9 = (dims.k1 * dims.d_model, dims.k1 * dims.d_ff)
+    agg = {}
+    for name, K, us, gf, site in recs:
+        if name != kernel:
+            continue
+        label = SITE_CLASSES.get(site, "site %d" % site)
+        if site in (1, 2):
+            label += ": k=%d convolution launches (K = %d / %d)" % (dims.k1, k9[0], k9[1]) if K in k9 else ": other launches"
+        a = agg.setdefault(label, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += us; a[2] += gf
+    out = {}
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        tf = a[2] / a[1] * 1e3 if a[1] > 0 else 0.0   # GFLOP / us = 1e15 flop/s = 1000 TFLOP/s
+        out[k] = {"launches": a[0], "ms": round(a[1] * 1e-3, 2), "achieved": round(tf, 2), "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4)}
+    return out
 
 
 def roofline_of(rows, pmc_key=None):
@@ -655,8 +701,9 @@ def main():
     if rank == 0:
         q_losses, _ = eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, fetch_losses=True)
     if rank == 0 and n == 1 and not args.no_roofline:
-        rows = gemm_profile(eng, lambda: eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=(args.order == 2), fetch_losses=False))
+        rows, recs = gemm_profile(eng, lambda: eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=(args.order == 2), fetch_losses=False), sites=True)
         roof = roofline_of(rows, "kernels")
+        roof["by_site_class"] = launch_classes(recs, roof["kernel"], dims)
         if so is not None:
             rows2 = gemm_profile(eng, lambda: eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=True, fetch_losses=False))
             r2 = roofline_of(rows2, "kernels_second_order")

@@ -177,6 +177,7 @@ public:
     PredGrad predG[3];
     std::vector<TS> postG;               // per PostNet layer: gradient of the conv output (what its weight-gradient GEMM reads)
     char* arena_defer = nullptr;
+    float* arena_pred = nullptr;
     int defer_tasks = 0;                 // task capacity of the deferred buffers (0: not available)
     hipStream_t side = nullptr;
     static constexpr int kSideEvents = 32;   // more than the forks of one backward pass (19 at base.yaml): no event is re-recorded while a wait on it can be pending
@@ -719,7 +720,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                              (size_t)defer_tasks * 3 * 2 * (size_t)(capMp + 2 * G) * cfg.vp_filter * sizeof(float) +
                              (size_t)defer_tasks * 2 * ((size_t)cfg.enc_layers * ln_chunks(capMp) + (size_t)cfg.dec_layers * ln_chunks(capMf)) * 3 * d * sizeof(float) +
                              (size_t)defer_tasks * 3 * 2 * (size_t)ln_chunks(capMp) * 3 * cfg.vp_filter * sizeof(float) + 64 * 256 +
-                             (size_t)defer_tasks * (kAhead + 4) * (size_t)(capMp + 2 * G) * d * sizeof(float) + 4096;
+                             (size_t)defer_tasks * kAhead * (size_t)(capMp + 2 * G) * d * sizeof(float) + 4096;
         HIP_CHECK(hipMalloc((void**)&arena_defer, bytes));
         HIP_CHECK(hipMemset(arena_defer, 0, bytes));
         char* cur = arena_defer;
@@ -743,7 +744,13 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         mk(encG, cfg.enc_layers, capMp);
         mk(decG, cfg.dec_layers, capMf);
         for (auto& t : enc_ahead) t = rows_d(capMp, d);
-        gPxE = rows_d(capMp, d); gPxP = rows_d(capMp, d); gPxD = rows_d(capMp, d); gPx2 = rows_d(capMp, d);
+        {   // the early predictor backward's buffers: every task of a launch (not only the deferred regime's)
+            const long long ts = (long long)(capMp + 2 * G) * d;
+            HIP_CHECK(hipMalloc((void**)&arena_pred, (size_t)4 * cap_tasks * ts * sizeof(float)));
+            HIP_CHECK(hipMemset(arena_pred, 0, (size_t)4 * cap_tasks * ts * sizeof(float)));
+            TS* const bufs[4] = {&gPxE, &gPxP, &gPxD, &gPx2};
+            for (int i = 0; i < 4; ++i) *bufs[i] = TS{arena_pred + (long long)i * cap_tasks * ts + (long long)G * d, ts};
+        }
         for (auto& pg : predG) { pg.g2a = rows_d(capMp, cfg.vp_filter); pg.g2b = rows_d(capMp, cfg.vp_filter); pg.part2 = part_d(capMp, cfg.vp_filter); pg.part1 = part_d(capMp, cfg.vp_filter); }
         postG.resize(cfg.postnet_layers);
         for (auto& t : postG) t = rows_d(capMr, post_c);
@@ -759,7 +766,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         {   // (sized like col_partial: the early predictor backward runs its LayerNorm reductions through it too)
             const size_t ln_w = (size_t)std::max(cfg.d_model, cfg.vp_filter);
             const size_t per_task = std::max((size_t)side_chunks * 3 * 1024, (size_t)ln_chunks(std::max(std::max(capMp, capMf), capMr)) * 3 * ln_w);
-            HIP_CHECK(hipMalloc((void**)&col_partial_side, (size_t)defer_tasks * per_task * sizeof(float)));
+            HIP_CHECK(hipMalloc((void**)&col_partial_side, (size_t)cap_tasks * per_task * sizeof(float)));
         }
         gx_side.no_glds = true;
         if (gx_side.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace of the side stream)"); return -1; }
@@ -775,6 +782,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         gx_side2.release();
         gx_side.release();
         if (arena_defer) hipFree(arena_defer);
+        if (arena_pred) hipFree(arena_pred);
         if (col_partial_side) hipFree(col_partial_side);
         for (float* p : {theta, adam_m, adam_v, outer, fast, grad, norm_partial, norm_out, pos_table, pitch_bins, energy_bins})
             if (p) hipFree(p);
@@ -1219,7 +1227,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (on_side) {   // the deferred path's reductions: side stream, its own partial buffer, plain two-stage form
             const int chunks_s = (maxM + kRC - 1) / kRC;
             MTTS_LAUNCH(colpart_kernel, dim3((a.C + 127) / 128, chunks_s, p.tasks), dim3(256), side, (const int*)p.meta, a, col_partial_side, col_max_chunks);
-            MTTS_LAUNCH(colfinal_kernel, dim3((a.C + 63) / 64, 1, p.tasks), dim3(256), side, (const int*)p.meta, a.mfield, a.mode,
+            MTTS_LAUNCH(colfinal_kernel, dim3(colfinal_blocks(a.C), 1, p.tasks), dim3(256), side, (const int*)p.meta, a.mfield, a.mode,
                         (const float*)col_partial_side, col_max_chunks, a.C, out0, out1, out_ts, 1e-5f, a.accumulate, (int)kRC);
             return;
         }
@@ -1228,7 +1236,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         const int chunks = (maxM + kRC - 1) / kRC;
         MTTS_LAUNCH(colpart_kernel, dim3((a.C + 127) / 128, chunks, p.tasks), dim3(256), stream, (const int*)p.meta, a, col_partial,
                     col_max_chunks);
-        MTTS_LAUNCH(colfinal_kernel, dim3((a.C + 63) / 64, 1, p.tasks), dim3(256), stream, (const int*)p.meta, a.mfield, a.mode,
+        MTTS_LAUNCH(colfinal_kernel, dim3(colfinal_blocks(a.C), 1, p.tasks), dim3(256), stream, (const int*)p.meta, a.mfield, a.mode,
                     (const float*)col_partial, col_max_chunks, a.C, out0, out1, out_ts, 1e-5f, a.accumulate, (int)kRC);
     }
     void colsum(const Pass& ps, Space s, TS x, int C, const unsigned char* mask, TS roww, TS out, bool on_side = false) {
@@ -1268,7 +1276,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // stage 2 of a LayerNorm's gamma / beta reduction: fold the backward kernel's partial rows
     void ln_fold(const Plan& p, Space s, const float* part, int chunks, long long g_off, long long b_off, int C, hipStream_t st) {
         TS gg = Gd(g_off), gb = Gd(b_off);
-        MTTS_LAUNCH(colfinal_kernel, dim3((C + 63) / 64, 1, p.tasks), dim3(256), st, (const int*)p.meta, mfield(s), 1, part, chunks, C,
+        MTTS_LAUNCH(colfinal_kernel, dim3(colfinal_blocks(C), 1, p.tasks), dim3(256), st, (const int*)p.meta, mfield(s), 1, part, chunks, C,
                     gg.p, gb.p, gg.ts, 1e-5f, 0, (int)kLnRows);
     }
     // the LayerNorm gamma / beta gradients of a deferred layer, from the partials its backward kernel left, on the side stream
@@ -1299,6 +1307,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // FFT block (transformer/Layers.py:21-30)
     // =================================================================================
     void fft_fwd(const Pass& ps, Space s, int heads, const FFTP& P, LayerBuf& b, TS xin, TS S_unused) {
+        TagScope tag_scope(*this, s == SP_P ? 1 : 2);
         (void)S_unused;
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, dk = d / heads;
@@ -1330,6 +1339,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                 GemmProfiler::Rec rec{GK_ATTN_FWD, 2.0 * 2.0 * sumL2 * dk, e0, e1};   // both products
                 rec.form = 4; rec.tile = 32; rec.N = dk; rec.K = L; rec.groups = groups; rec.rows = sumL;
                 rec.bytes = 4.0 * (sumL2 + 4.0 * sumL * dk);                          // Q, K, V read, O and P written once
+                rec.tag = prof.tag;
                 prof.recs.push_back(rec);
             }
         } else {
@@ -1353,6 +1363,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // lg's buffers, the GEMMs themselves to the side stream
     void fft_bwd(const Pass& ps, Space s, int heads, const FFTP& P, LayerBuf& b, TS xin, TS g0_in, const LayerKeep& K,
                  TS dS, LayerGrad* lg = nullptr) {
+        TagScope tag_scope(*this, s == SP_P ? 1 : 2);
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, dk = d / heads, ff = cfg.d_ff;
         const unsigned char* vm = valid_mask(p, s);
@@ -1433,6 +1444,19 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         constexpr long long max_rows = 16000LL;   // beyond this the launches fill the chip and the wgrad + dgrad pairing wins (measured: 4 / 8 tasks per rank neutral / -1 %)
         return on && defer_tasks > 0 && p.tasks <= defer_tasks && p.sumMf <= max_rows && side != nullptr;
     }
+    // call-site class of the GEMM launches issued from here on (the profiler's per-launch records carry it: GemmProfiler::tag)
+    void set_tag(int t) { gx.prof.tag = gx_side.prof.tag = gx_side2.prof.tag = t; }
+    struct TagScope {
+        Engine& e; int prev;
+        TagScope(Engine& e_, int t) : e(e_), prev(e_.gx.prof.tag) { e.set_tag(t); }
+        ~TagScope() { e.set_tag(prev); }
+    };
+    // the variance predictors on the side stream (forward: beside the decoder; backward: under the PostNet / decoder backward) — needs no
+    // deferred-gradient buffer, so it also serves launches of more tasks than the deferred regime takes
+    bool side_pred_ok(const Plan& p) const {
+        static const int all = [] { const char* e = getenv("MTTS_SIDE_PRED_ALL"); return e ? atoi(e) : 1; }();
+        return side != nullptr && arena_pred != nullptr && p.tasks <= cap_tasks && (all || defer_ok(p));
+    }
     // everything enqueued on the main stream so far happens before what is enqueued on the side stream next
     void fork_side() {
         hipEvent_t ev = ev_side[ev_next];
@@ -1453,6 +1477,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // variance predictor (lightning/model/modules.py:242-250)
     // =================================================================================
     void pred_fwd(const Pass& ps, const PredP& P, PredBuf& b, TS xin, Space s = SP_P) {
+        TagScope tag_scope(*this, 4);
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, f = cfg.vp_filter, k = cfg.vp_kernel;
         const unsigned char* im = inrect_mask(p, s);   // conv outputs / LayerNorm live on every position of the rectangle
@@ -1470,6 +1495,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // stage so that the three conv1 (then the three conv2) GEMMs — 28 workgroups each on a single-task rank — go out as ONE
     // multi-problem launch each.  Same arithmetic and dropout sites as three pred_fwd calls.
     void pred_fwd3(const Pass& ps, const PredP* const P[3], PredBuf* const b[3], const TS xin[3], const int sites[3]) {
+        TagScope tag_scope(*this, 4);
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, f = cfg.vp_filter, k = cfg.vp_kernel;
         const unsigned char* im = inrect_mask(p, SP_P);
@@ -1497,6 +1523,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // output layer's column sums of this predictor run on the side stream from buffers of its own (see LayerGrad)
     void pred_bwd(const Pass& ps, const PredP& P, PredBuf& b, TS xin, TS dout, TS dx, Space s = SP_P, PredGrad* pg = nullptr,
                   int dx_flags = GEMM_ACCUM) {
+        TagScope tag_scope(*this, 4);
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, f = cfg.vp_filter, k = cfg.vp_kernel;
         const unsigned char* im = inrect_mask(p, s);
@@ -1548,7 +1575,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     bool pred_bwd_early(const Pass& ps) {
         const Plan& p = *ps.pl;
         static const int on = [] { const char* e = getenv("MTTS_PRED_EARLY"); return e ? atoi(e) : 1; }();
-        if (!on || !defer_ok(p) || any_frame_level()) return false;
+        if (!on || !side_pred_ok(p) || any_frame_level()) return false;
         fork_side();
         std::swap(stream, side);
         std::swap(gx, gx_side);
@@ -1662,7 +1689,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             // teacher-forced: nothing downstream in the forward reads the predictions (the decoder input uses the TARGET embeddings); with
             // an idle side stream the predictors overlap the decoder and are joined at the end of forward()
             static const bool pred_side = [] { const char* e = getenv("MTTS_PRED_SIDE"); return e ? atoi(e) != 0 : true; }();
-            if (pred_side && defer_ok(p) && !defer_live) {
+            if (pred_side && side_pred_ok(p) && !defer_live) {
                 fork_side();
                 std::swap(stream, side);
                 std::swap(gx, gx_side);
@@ -1744,6 +1771,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         // PostNet
         TS cur = mel;
+        set_tag(3);
         for (int i = 0; i < cfg.postnet_layers; ++i) {
             const PostP& P = postP[i];
             PostBuf& b = postB[i];
@@ -1753,7 +1781,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                 ca.X = b.c.p; ca.x_ts = b.c.ts; ca.mask = p.r_inrect; ca.mask_ts = row_ts_r; ca.C = P.cout; ca.mode = 2;
                 ca.mfield = META_MR;
                 colreduce(p, ca, b.stats.p, nullptr, b.stats.ts, p.maxMr);
-                if (ps.update_bn) {
+                if (ps.update_bn && cfg.postnet_layers > kBnRunMax) {
                     MTTS_LAUNCH(bn_running_update_kernel, dim3((P.cout + 63) / 64), dim3(64), stream, (const float*)b.stats.p,
                                 b.stats.ts, nt, bn_rm[i], bn_rv[i], P.cout, 0.1f);
                     bn_tracked[i] += nt;
@@ -1768,6 +1796,17 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                         (const unsigned char*)p.r_inrect, row_ts_r, (int)(i < cfg.postnet_layers - 1), b.a.p, b.a.ts, P.cout,
                         drop_spec(ps, cfg.postnet_dropout, 192 + i));  // F.dropout(..., 0.5, self.training), Layers.py:133-134, in passing
             cur = b.a;
+        }
+        set_tag(0);
+        if (ps.train && ps.update_bn && cfg.postnet_layers >= 1 && cfg.postnet_layers <= kBnRunMax) {   // the running buffers of every layer, one launch
+            BnRunArgs ra;
+            int maxC = 0;
+            for (int i = 0; i < cfg.postnet_layers; ++i) {
+                ra.stats[i] = postB[i].stats.p; ra.st_ts[i] = postB[i].stats.ts; ra.rm[i] = bn_rm[i]; ra.rv[i] = bn_rv[i]; ra.C[i] = postP[i].cout;
+                maxC = std::max(maxC, postP[i].cout);
+                bn_tracked[i] += nt;
+            }
+            MTTS_LAUNCH(bn_running_update_multi_kernel, dim3((maxC + 63) / 64, cfg.postnet_layers), dim3(64), stream, ra, nt, 0.1f);
         }
         // mel_post = postnet(mel) + mel   (whole [tasks][rows][n_mel] slab incl. guard rows: all zero there)
         {
@@ -1875,6 +1914,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         const bool pred_early = pred_bwd_early(ps);
         // ---- PostNet: cur = dL/d(a_i), starts as dL/d(mel_post); dc -> gR0, layer-input grad -> gR1
         TS cur = gRp;
+        set_tag(3);
         for (int i = cfg.postnet_layers - 1; i >= 0; --i) {
             const PostP& P = postP[i];
             PostBuf& b = postB[i];
@@ -1917,6 +1957,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             }
         }
         // ---- mel_linear -------------------------------------------------------------------
+        set_tag(0);
         TS none{nullptr, 0};
         const bool dfm = defer_ok(p);   // gRm / gMelF are final from here on: their parameter gradients can run on the side stream
         if (!dfm) colsum(ps, SP_R, gRm, nm, nullptr, none, Gd(mel_b));

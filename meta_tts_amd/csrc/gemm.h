@@ -798,7 +798,8 @@ inline const char* gemm_kind_name(int k) {
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg):
 // one record per launch, aggregated per kernel kind.
 struct GemmProfiler {
-    struct Rec { int kernel; double flops; hipEvent_t e0, e1; int form = 0, tile = 0, N = 0, K = 0, groups = 0, splitk = 1; double rows = 0, bytes = 0; };
+    struct Rec { int kernel; double flops; hipEvent_t e0, e1; int form = 0, tile = 0, N = 0, K = 0, groups = 0, splitk = 1; double rows = 0, bytes = 0; int tag = 0; };
+    int tag = 0;   // call-site class of the launches being recorded (set by the owner: 0 other, 1 encoder blocks, 2 decoder blocks, 3 PostNet, 4 variance predictors)
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
@@ -813,13 +814,13 @@ struct GemmProfiler {
     void report(double out[GK_COUNT][4]) {
         for (int k = 0; k < GK_COUNT; ++k) out[k][0] = out[k][1] = out[k][2] = out[k][3] = 0.0;
         FILE* dump = (getenv("MTTS_GEMM_DUMP") && !recs.empty()) ? fopen(getenv("MTTS_GEMM_DUMP"), "a") : nullptr;  // per-launch CSV (tools/gemm_sites.py); appended: a handle reports its three launch contexts one after the other
-        if (dump && ftell(dump) == 0) fprintf(dump, "kind,form,tile,N,K,rows,groups,splitk,us,gflop\n");
+        if (dump && ftell(dump) == 0) fprintf(dump, "kind,form,tile,N,K,rows,groups,splitk,us,gflop,site\n");
         for (auto& r : recs) {
             hipEventSynchronize(r.e1);
             float ms = 0.f;
             hipEventElapsedTime(&ms, r.e0, r.e1);
             out[r.kernel][0] += 1.0; out[r.kernel][1] += ms; out[r.kernel][2] += r.flops; out[r.kernel][3] += r.bytes;
-            if (dump) fprintf(dump, "%d,%d,%d,%d,%d,%.0f,%d,%d,%.2f,%.4f\n", r.kernel, r.form, r.tile, r.N, r.K, r.rows, r.groups, r.splitk, 1e3 * ms, r.flops * 1e-9);
+            if (dump) fprintf(dump, "%d,%d,%d,%d,%d,%.0f,%d,%d,%.2f,%.4f,%d\n", r.kernel, r.form, r.tile, r.N, r.K, r.rows, r.groups, r.splitk, 1e3 * ms, r.flops * 1e-9, r.tag);
         }
         if (dump) fclose(dump);
     }
@@ -1039,7 +1040,7 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
         GemmProfiler::Rec rec{kind, alg_flops, e0, e1};
         rec.form = form; rec.tile = bf16 ? 16000 + tile : (glds ? 4064 : tile); rec.N = max_N; rec.K = gemm_keff(g); rec.groups = groups; rec.splitk = S;
         rec.rows = rows;
-        rec.bytes = alg_bytes;
+        rec.bytes = alg_bytes; rec.tag = prof.tag;
         prof.recs.push_back(rec);
     }
 }
@@ -1159,7 +1160,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     if (prof.enabled) {
         hipEventRecord(e1, stream);
         GemmProfiler::Rec rec{kind, flops, e0, e1};
-        rec.form = 3; rec.tile = bf16 ? 16000 + T : (glds ? 4064 : 64); rec.N = mp.n; rec.K = maxK; rec.groups = mp.start[mp.n]; rec.splitk = 1; rec.rows = rows; rec.bytes = bytes;  // multi: N = problems, K = longest K, groups = workgroups
+        rec.form = 3; rec.tile = bf16 ? 16000 + T : (glds ? 4064 : 64); rec.N = mp.n; rec.K = maxK; rec.groups = mp.start[mp.n]; rec.splitk = 1; rec.rows = rows; rec.bytes = bytes; rec.tag = prof.tag;  // multi: N = problems, K = longest K, groups = workgroups
         prof.recs.push_back(rec);
     }
     b.q.clear();

@@ -426,54 +426,69 @@ __device__ __forceinline__ void colpart_body(const int* meta, const ColArgs& a, 
     col_body<32, 8, false>(meta, a, partial, max_chunks, nullptr, nullptr, 0, 0.f);
 }
 
-// 64 columns x 4 chunk lanes per workgroup: lane q folds chunks q, q+4, ... of its column, the four lane results are
-// merged in lane order through LDS (fixed order => run-to-run identical).
+// 16 columns x 16 chunk lanes per workgroup (256 threads): lane q folds chunks q, q + 16, ... of its column — four loads in flight per
+// step, added in chunk order — and the sixteen lane results are merged in lane order through LDS (fixed order => run-to-run identical).
+// (The first version ran 64 columns x 4 lanes: a single-task LayerNorm fold is 245 chunks deep, 61 dependent L2 round trips per lane and
+// 4-16 workgroups per launch — 14-18 us a launch, 8 % of a single-task rank's kernel time.)
+constexpr int kCfCols = 16, kCfLanes = 16;
+inline int colfinal_blocks(int C) { return (C + kCfCols - 1) / kCfCols; }
 __device__ __forceinline__ void colfinal_fold(const int* meta, int mfield, int mode, const float* partial, int max_chunks, int C,
                                               float* out0, float* out1, long long out_ts, float eps, int accumulate, int c_base, int rows_per_chunk = kRC) {
-    __shared__ float red[3][4][64];
-    __syncthreads();  // the fold may run twice per workgroup (fused tail): red is reused
-    const int z = blockIdx.z, cl = (int)threadIdx.x & 63, q = (int)threadIdx.x >> 6;
+    __shared__ float red[3][kCfLanes][kCfCols];
+    const int z = blockIdx.z, cl = (int)threadIdx.x % kCfCols, q = (int)threadIdx.x / kCfCols;
     const int c = c_base + cl;
     const bool cin = c < C;
     const int M_ = meta[z * META_STRIDE + mfield];
     const int nch = (M_ + rows_per_chunk - 1) / rows_per_chunk;
     const float* p = partial + (long long)z * max_chunks * 3 * C + (cin ? c : 0);
+    const long long cs = 3LL * C;   // floats per chunk
     if (mode != 2) {
         float s0 = 0.f, s1 = 0.f;
-        if (cin)
-            for (int i = q; i < nch; i += 4) { s0 += p[(long long)i * 3 * C]; s1 += p[(long long)i * 3 * C + C]; }
+        if (cin) {
+            int i = q;
+            for (; i + 3 * kCfLanes < nch; i += 4 * kCfLanes) {
+                const float* r = p + i * cs;
+                const float a0 = r[0], a1 = r[kCfLanes * cs], a2 = r[2 * kCfLanes * cs], a3 = r[3 * kCfLanes * cs];
+                const float b0 = r[C], b1 = r[kCfLanes * cs + C], b2 = r[2 * kCfLanes * cs + C], b3 = r[3 * kCfLanes * cs + C];
+                s0 = (((s0 + a0) + a1) + a2) + a3;
+                s1 = (((s1 + b0) + b1) + b2) + b3;
+            }
+            for (; i < nch; i += kCfLanes) { s0 += p[i * cs]; s1 += p[i * cs + C]; }
+        }
         red[0][q][cl] = s0; red[1][q][cl] = s1;
         __syncthreads();
         if (q != 0 || !cin) return;
-        s0 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-        s1 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+        s0 = red[0][0][cl]; s1 = red[1][0][cl];
+#pragma unroll
+        for (int i = 1; i < kCfLanes; ++i) { s0 += red[0][i][cl]; s1 += red[1][i][cl]; }
         if (accumulate) { s0 += out0[(long long)z * out_ts + c]; if (out1) s1 += out1[(long long)z * out_ts + c]; }
         out0[(long long)z * out_ts + c] = s0;
         if (out1) out1[(long long)z * out_ts + c] = s1;
         return;
     }
     float n = 0.f, mean = 0.f, m2 = 0.f;  // Chan et al. pairwise merge
-    if (cin)
-        for (int i = q; i < nch; i += 4) {
-            const float nb = p[(long long)i * 3 * C], mb = p[(long long)i * 3 * C + C], sb = p[(long long)i * 3 * C + 2 * C];
-            if (nb <= 0.f) continue;
-            const float nn = n + nb, d = mb - mean;
-            mean += d * nb / nn;
-            m2 += sb + d * d * n * nb / nn;
-            n = nn;
-        }
-    red[0][q][cl] = n; red[1][q][cl] = mean; red[2][q][cl] = m2;
-    __syncthreads();
-    if (q != 0 || !cin) return;
-    n = 0.f; mean = 0.f; m2 = 0.f;
-    for (int i = 0; i < 4; ++i) {
-        const float nb = red[0][i][cl], mb = red[1][i][cl], sb = red[2][i][cl];
-        if (nb <= 0.f) continue;
+    auto merge = [&](float nb, float mb, float sb) {
+        if (nb <= 0.f) return;
         const float nn = n + nb, d = mb - mean;
         mean += d * nb / nn;
         m2 += sb + d * d * n * nb / nn;
         n = nn;
+    };
+    if (cin) {
+        int i = q;
+        for (; i + kCfLanes < nch; i += 2 * kCfLanes) {
+            const float* r = p + i * cs;
+            const float n0 = r[0], m0 = r[C], q0 = r[2 * C], n1 = r[kCfLanes * cs], m1 = r[kCfLanes * cs + C], q1 = r[kCfLanes * cs + 2 * C];
+            merge(n0, m0, q0);
+            merge(n1, m1, q1);
+        }
+        for (; i < nch; i += kCfLanes) merge(p[i * cs], p[i * cs + C], p[i * cs + 2 * C]);
     }
+    red[0][q][cl] = n; red[1][q][cl] = mean; red[2][q][cl] = m2;
+    __syncthreads();
+    if (q != 0 || !cin) return;
+    n = 0.f; mean = 0.f; m2 = 0.f;
+    for (int i = 0; i < kCfLanes; ++i) merge(red[0][i][cl], red[1][i][cl], red[2][i][cl]);
     float* so = out0 + (long long)z * out_ts;
     so[c] = mean;
     so[C + c] = rsqrtf(m2 / n + eps);
@@ -485,7 +500,7 @@ __global__ void colpart_kernel(const int* meta, ColArgs a, float* partial, int m
 // rows_per_chunk: kRC for colpart_kernel's partials, kLnRows for the ones layernorm_bwd_kernel writes in passing
 __global__ void colfinal_kernel(const int* meta, int mfield, int mode, const float* partial, int max_chunks, int C,
                                 float* out0, float* out1, long long out_ts, float eps, int accumulate, int rows_per_chunk) {
-    colfinal_fold(meta, mfield, mode, partial, max_chunks, C, out0, out1, out_ts, eps, accumulate, blockIdx.x * 64, rows_per_chunk);
+    colfinal_fold(meta, mfield, mode, partial, max_chunks, C, out0, out1, out_ts, eps, accumulate, blockIdx.x * kCfCols, rows_per_chunk);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -844,6 +859,22 @@ __global__ void bn_running_update_kernel(const float* stats, long long st_ts, in
     }
     running_mean[c] = rm;
     running_var[c] = rv;
+}
+
+// ... every BatchNorm layer of the PostNet in one launch (blockIdx.y = layer)
+constexpr int kBnRunMax = 8;
+struct BnRunArgs { const float* stats[kBnRunMax]; long long st_ts[kBnRunMax]; float* rm[kBnRunMax]; float* rv[kBnRunMax]; int C[kBnRunMax]; };
+__global__ void bn_running_update_multi_kernel(BnRunArgs a, int tasks, float momentum) {
+    const int l = blockIdx.y, C = a.C[l], c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float rm = a.rm[l][c], rv = a.rv[l][c];
+    for (int t = 0; t < tasks; ++t) {
+        const float* s = a.stats[l] + (long long)t * a.st_ts[l];
+        rm = (1.f - momentum) * rm + momentum * s[c];
+        rv = (1.f - momentum) * rv + momentum * s[2 * C + c];
+    }
+    a.rm[l][c] = rm;
+    a.rv[l][c] = rv;
 }
 
 // stats for eval mode from the running buffers: [mean | rstd]

@@ -57,7 +57,7 @@ def _run(tmp_path, tag, env, gpu):
 
 # (MTTS_SO_KEEP_ACT=0: second-order MAML replays the forward of every inner step in its reverse sweep instead of keeping one activation
 # set per step — the same kernels on the same data either way)
-OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "MTTS_PRED_BATCH": "0", "MTTS_SINGLE_MULTI": "0",
+OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "MTTS_PRED_EARLY": "0", "MTTS_PRED_BATCH": "0", "MTTS_SINGLE_MULTI": "0",
        "MTTS_SO_KEEP_ACT": "0"}
 # kernel-choice knobs: the same mathematics in another summation order (compared at fp32-roundoff tolerance, not bit for bit) — the fused
 # attention forward vs grouped GEMM + softmax kernel + grouped GEMM (csrc/attention.h); and the query pass's encoder run-ahead (re-plumbing)

@@ -126,7 +126,7 @@ def test_second_order_grouped_vs_oracle(tasks, which):
     eng.close()
 
 
-@pytest.mark.parametrize("knobs", ["MTTS_DEFER_WGRAD=0 MTTS_ENC_AHEAD=0 MTTS_PRED_SIDE=0"])
+@pytest.mark.parametrize("knobs", ["MTTS_DEFER_WGRAD=0 MTTS_ENC_AHEAD=0 MTTS_PRED_SIDE=0 MTTS_PRED_EARLY=0"])
 def test_reference_fixtures_on_the_other_launch_paths(knobs):
     """The small-plan tests against the REFERENCE fixtures (small-batch gradients, the contractive lr-1e-3 MAML fixture first and
     second order, two ragged tasks) once more with the single-stream order — no deferred weight gradients, no encoder run-ahead,
