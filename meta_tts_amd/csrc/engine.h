@@ -720,7 +720,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                              (size_t)defer_tasks * 3 * 2 * (size_t)(capMp + 2 * G) * cfg.vp_filter * sizeof(float) +
                              (size_t)defer_tasks * 2 * ((size_t)cfg.enc_layers * ln_chunks(capMp) + (size_t)cfg.dec_layers * ln_chunks(capMf)) * 3 * d * sizeof(float) +
                              (size_t)defer_tasks * 3 * 2 * (size_t)ln_chunks(capMp) * 3 * cfg.vp_filter * sizeof(float) + 64 * 256 +
-                             (size_t)defer_tasks * kAhead * (size_t)(capMp + 2 * G) * d * sizeof(float) + 4096;
+                             4096;
         HIP_CHECK(hipMalloc((void**)&arena_defer, bytes));
         HIP_CHECK(hipMemset(arena_defer, 0, bytes));
         char* cur = arena_defer;
@@ -743,13 +743,13 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         };
         mk(encG, cfg.enc_layers, capMp);
         mk(decG, cfg.dec_layers, capMf);
-        for (auto& t : enc_ahead) t = rows_d(capMp, d);
         {   // the early predictor backward's buffers: every task of a launch (not only the deferred regime's)
             const long long ts = (long long)(capMp + 2 * G) * d;
-            HIP_CHECK(hipMalloc((void**)&arena_pred, (size_t)4 * cap_tasks * ts * sizeof(float)));
-            HIP_CHECK(hipMemset(arena_pred, 0, (size_t)4 * cap_tasks * ts * sizeof(float)));
+            HIP_CHECK(hipMalloc((void**)&arena_pred, (size_t)(4 + kAhead) * cap_tasks * ts * sizeof(float)));
+            HIP_CHECK(hipMemset(arena_pred, 0, (size_t)(4 + kAhead) * cap_tasks * ts * sizeof(float)));
             TS* const bufs[4] = {&gPxE, &gPxP, &gPxD, &gPx2};
             for (int i = 0; i < 4; ++i) *bufs[i] = TS{arena_pred + (long long)i * cap_tasks * ts + (long long)G * d, ts};
+            for (int i = 0; i < kAhead; ++i) enc_ahead[i] = TS{arena_pred + (long long)(4 + i) * cap_tasks * ts + (long long)G * d, ts};   // (the encoder run-ahead's outputs)
         }
         for (auto& pg : predG) { pg.g2a = rows_d(capMp, cfg.vp_filter); pg.g2b = rows_d(capMp, cfg.vp_filter); pg.part2 = part_d(capMp, cfg.vp_filter); pg.part1 = part_d(capMp, cfg.vp_filter); }
         postG.resize(cfg.postnet_layers);
@@ -1617,10 +1617,12 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // where its backward will find the activations; *query_seed receives its dropout seed, ev_enc[steps] its completion
     bool run_encoder_ahead(Plan& pl, int steps, unsigned* seeds, bool per_step_sets = false, Plan* query = nullptr, unsigned* query_seed = nullptr) {
         static const int on = [] { const char* e = getenv("MTTS_ENC_AHEAD"); return e ? atoi(e) : 1; }();
-        if (!on || steps < 1 || steps + (query ? 1 : 0) > kAhead || encoder_adapted() || !defer_ok(pl) || side2 == nullptr) return false;
+        static const int all = [] { const char* e = getenv("MTTS_ENC_AHEAD_ALL"); return e ? atoi(e) : 1; }();   // also launches beyond the deferred regime
+        auto ahead_ok = [&](const Plan& q) { return arena_pred != nullptr && q.tasks <= cap_tasks && (all || defer_ok(q)); };
+        if (!on || steps < 1 || steps + (query ? 1 : 0) > kAhead || encoder_adapted() || !ahead_ok(pl) || side2 == nullptr) return false;
         for (int s = 0; s < steps; ++s) seeds[s] = next_drop_seed();
         static const int q_on = [] { const char* e = getenv("MTTS_ENC_AHEAD_QUERY"); return e ? atoi(e) : 1; }();
-        if (query && (!q_on || !defer_ok(*query) || cfg.enc_layers < 1)) query = nullptr;
+        if (query && (!q_on || !ahead_ok(*query) || cfg.enc_layers < 1)) query = nullptr;
         if (query) *query_seed = next_drop_seed();   // (the seed forward() would draw for the query pass: after the inner steps')
         hipEvent_t ev = ev_side[ev_next];
         ev_next = (ev_next + 1) % kSideEvents;
