@@ -88,7 +88,14 @@ int mtts_set_grad_accumulation(mtts_handle* h, int accumulate);
  *    ("multi-task baseline bf16 on 1xMI355X"; what `Trainer(precision="bf16")` / torch.autocast(bfloat16) would make of the Linear /
  *    Conv1d / bmm ops).  Parameters, optimizer state, LayerNorm / BatchNorm / softmax / losses and every tensor in HBM stay fp32.
  *    The few problems whose conv taps do not cover whole 32-element K-slices (the PostNet's 80-channel output layer in its
- *    input-gradient form) keep the fp32 kernels.  May be switched between calls; applies to the handle's three streams. */
+ *    input-gradient form) keep the fp32 kernels — unless planes serve them, see below.  The long NT problems (the FFT blocks' and the
+ *    PostNet's convolutions, forward and input gradient) read their operands from bf16 PLANES: a twin of the activation slab and a
+ *    shadow of the weight (refreshed from the fp32 master once per pass; the input gradient as an NT problem over the transposed
+ *    shadow) — the same rounded values, half the bytes through L2.  Allocated the first time the mode is selected (about half the
+ *    activation arena + 2 bytes per shadowed weight element, twice).
+ * 2: mode 1 without the planes (every operand is read as fp32 and rounded on its way into LDS): the A/B and test arm of mode 1 — the
+ *    forward results are bit-identical to mode 1's.
+ * May be switched between calls; applies to the handle's three streams. */
 int mtts_set_numerics(mtts_handle* h, int mode);
 int mtts_get_numerics(mtts_handle* h);
 
@@ -250,6 +257,14 @@ int mtts_gemm_f32_dual(int form, int M, int N, int K, const float* A, int lda, c
  * (+ 1000 * K-slices kept in flight per workgroup: micro-benchmarks). */
 int mtts_gemm_bf16(int form, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* A2, const float* B2,
                    float* C, int ldc, const float* bias, float alpha, int flags, int tile, void* hip_stream);
+/* bf16 operand planes at kernel level (numerics mode 1's long NT problems): mtts_to_bf16 rounds n (a multiple of 8) floats to bf16
+ * (round to nearest even) — the plane of an activation slab; mtts_gemm_bf16_planes computes C[M][N] = alpha * Ah[M][K] . Bh[N][K]^T
+ * (+ bias, flags as mtts_gemm_f32) from the two planes and, when Ch is set, writes C's own bf16 twin beside it.  K, lda, ldb in whole
+ * groups of 8.  mtts_plane_problems: how many GEMM problems of this handle have run on the plane-staged K-loop so far. */
+int mtts_to_bf16(const float* src, unsigned short* dst, long long n, void* stream);
+int mtts_gemm_bf16_planes(int M, int N, int K, const unsigned short* Ah, int lda, const unsigned short* Bh, int ldb, float* C, unsigned short* Ch,
+                          int ldc, const float* bias, float alpha, int flags, int tile, void* stream);
+long long mtts_plane_problems(mtts_handle* h);
 /* Host-only self check of the task-per-XCD workgroup schedule of 8- / 4- / 2-group launches (csrc/gemm.h: XcdSched): builds the schedule
  * for the `groups` group sizes `dims` (cls 1: M-ragged, units = m-tiles of 64 rows with tn tiles each; cls 2: K-ragged, units_per_group
  * tiles per group whose cost is dims[z]) and walks every workgroup slot.  Returns the number of slots when every (group, tile) is visited

@@ -93,6 +93,10 @@ EXPORTS = {
     "mtts_xcd_schedule_check": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "mtts_gemm_f32_dual": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "mtts_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "mtts_gemm_bf16_planes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "mtts_plane_problems": (C.c_longlong, [C.c_void_p]),
     "mtts_gemm_bf16": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "mtts_conv1d_f32": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

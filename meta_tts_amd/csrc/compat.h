@@ -23,6 +23,18 @@ constexpr int kWave = 64;  // CDNA wavefront width
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// bf16 storage (the operand planes of the bf16 numerics mode: gemm_bf16.h).  Scalar round-to-nearest-even conversion, the rounding
+// v_cvt_pk_bf16_f32 does (the staging passes of gemm_bf16.h use the packed instruction; producers that write one twin value per lane
+// use this one).
+typedef unsigned short bf16_t;
+__device__ __forceinline__ bf16_t f32_to_bf16(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+
 // Wavefront reductions on the DPP cross-lane paths (no LDS traffic): quad_perm xor-1 / xor-2, row_half_mirror and
 // row_mirror leave the sum of each 16-lane row in all of its lanes; four v_readlane + scalar adds combine the rows, so the
 // result is wave-uniform.  (__shfl_xor lowers to six dependent ds_bpermute round trips per reduction, which made the row

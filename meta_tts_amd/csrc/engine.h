@@ -177,7 +177,21 @@ public:
     PredGrad predG[3];
     std::vector<TS> postG;               // per PostNet layer: gradient of the conv output (what its weight-gradient GEMM reads)
     char* arena_defer = nullptr;
+    size_t arena_defer_bytes = 0;
     float* arena_pred = nullptr;
+    // ---- bf16 operand planes (bf16 numerics mode; enable_planes) ----
+    // arena_h / arena_defer_h: a bf16 twin of every float of the two activation arenas at the same element index (a buffer's plane is a
+    // pointer offset away: H()).  sh_*: shadows of the Conv1d weights in the forward layout (_f) and the input-gradient layout (_t), for
+    // the masters (theta) and the per-task fast weights; refreshed by every forward pass (refresh_shadows).
+    bf16_t *arena_h = nullptr, *arena_defer_h = nullptr;
+    bf16_t *sh_theta_f = nullptr, *sh_theta_t = nullptr, *sh_fast_f = nullptr, *sh_fast_t = nullptr;
+    ShadowEnt *d_ents_all = nullptr, *d_ents_theta = nullptr, *d_ents_fast = nullptr;
+    int n_ents_all = 0, n_ents_theta = 0, n_ents_fast = 0, tiles_all = 0, tiles_theta = 0, tiles_fast = 0;
+    std::map<long long, long long> shadow_off;   // weight offset in theta -> offset in the shadow vectors
+    long long n_shadow = 0;
+    const float* shadow_fast_src = nullptr;      // the fast-weight copy the fast shadows were made from
+    bool planes_ready = false;
+    bool planes_wanted = true;                   // numerics mode 1 (planes) vs 2 (bf16 operands rounded in the staging pass only)
     int defer_tasks = 0;                 // task capacity of the deferred buffers (0: not available)
     hipStream_t side = nullptr;
     static constexpr int kSideEvents = 32;   // more than the forks of one backward pass (19 at base.yaml): no event is re-recorded while a wait on it can be pending
@@ -722,6 +736,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                              (size_t)defer_tasks * 3 * 2 * (size_t)ln_chunks(capMp) * 3 * cfg.vp_filter * sizeof(float) + 64 * 256 +
                              4096;
         HIP_CHECK(hipMalloc((void**)&arena_defer, bytes));
+        arena_defer_bytes = bytes;
         HIP_CHECK(hipMemset(arena_defer, 0, bytes));
         char* cur = arena_defer;
         auto rows_d = [&](int capM, int C) {   // [defer_tasks][G + capM + G][C], pointer at row 0 (same shape as rows())
@@ -772,6 +787,107 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (gx_side.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace of the side stream)"); return -1; }
         return 0;
     }
+    // =================================================================================
+    // bf16 operand planes (bf16 numerics mode): allocation, weight shadows, plane lookup
+    // =================================================================================
+    // Called when the bf16 mode is first selected.  Planes serve the long NT problems of the step — the FFT blocks' k = 9 / k = 1
+    // convolutions and the PostNet's, forward and input gradient: the input-gradient conv runs as an NT problem over the transposed
+    // shadow (weight_shadow_kernel) instead of the NN form.
+    int enable_planes() {
+        if (planes_ready) return 0;
+        std::vector<ShadowEnt> all, th, fa;
+        n_shadow = 0;
+        auto add = [&](long long off, int cout, int k, int cin) {
+            if (cin % 8 != 0 || cout % 8 != 0) return;
+            ShadowEnt e{off, n_shadow, cout, k, cin, 0};
+            shadow_off[off] = n_shadow;
+            all.push_back(e);
+            if (n_adapt > 0 && off >= adapt_start && off < adapt_start + n_adapt) { e.off = off - adapt_start; fa.push_back(e); }
+            else th.push_back(e);
+            n_shadow += ((long long)cout * k * cin + 7) & ~7LL;
+        };
+        for (const auto* v : {&encP, &decP})
+            for (const FFTP& P : *v) { add(P.w1, cfg.d_ff, cfg.k1, cfg.d_model); add(P.w2, cfg.d_model, cfg.k2, cfg.d_ff); }
+        for (const PostP& P : postP) add(P.w, P.cout, cfg.postnet_kernel, P.cin);
+        auto finish = [&](std::vector<ShadowEnt>& v, ShadowEnt** dev, int* n, int* tiles) -> int {
+            int t0 = 0;
+            for (ShadowEnt& e : v) { e.tile0 = t0; t0 += e.k * ((e.cout + 31) / 32) * ((e.cin + 31) / 32); }
+            *n = (int)v.size(); *tiles = t0;
+            if (v.empty()) return 0;
+            if (hipMalloc((void**)dev, v.size() * sizeof(ShadowEnt)) != hipSuccess) return -1;
+            return hipMemcpy(*dev, v.data(), v.size() * sizeof(ShadowEnt), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+        };
+        if (finish(all, &d_ents_all, &n_ents_all, &tiles_all) || finish(th, &d_ents_theta, &n_ents_theta, &tiles_theta) ||
+            finish(fa, &d_ents_fast, &n_ents_fast, &tiles_fast)) { set_error("hipMalloc failed (weight shadow tables)"); return -1; }
+        // compact shadow vectors (every shadow starts on a multiple of 8 elements: 16-byte loads), one per task for the fast weights
+        const size_t th_b = (size_t)(n_shadow + 8) * sizeof(bf16_t), fa_b = (size_t)cap_tasks * (size_t)n_shadow * sizeof(bf16_t) + 16;
+        if (hipMalloc((void**)&sh_theta_f, th_b) != hipSuccess || hipMalloc((void**)&sh_theta_t, th_b) != hipSuccess ||
+            (n_adapt > 0 && (hipMalloc((void**)&sh_fast_f, fa_b) != hipSuccess || hipMalloc((void**)&sh_fast_t, fa_b) != hipSuccess)) ||
+            hipMalloc((void**)&arena_h, arena_bytes / 2 + 64) != hipSuccess ||
+            (arena_defer && hipMalloc((void**)&arena_defer_h, arena_defer_bytes / 2 + 64) != hipSuccess)) {
+            set_error("hipMalloc failed (bf16 operand planes)");
+            return -1;
+        }
+        hipMemset(arena_h, 0, arena_bytes / 2 + 64);
+        if (arena_defer_h) hipMemset(arena_defer_h, 0, arena_defer_bytes / 2 + 64);
+        planes_ready = true;
+        return 0;
+    }
+    void destroy_planes() {
+        for (void* q : {(void*)arena_h, (void*)arena_defer_h, (void*)sh_theta_f, (void*)sh_theta_t, (void*)sh_fast_f, (void*)sh_fast_t,
+                        (void*)d_ents_all, (void*)d_ents_theta, (void*)d_ents_fast})
+            if (q) hipFree(q);
+        arena_h = arena_defer_h = sh_theta_f = sh_theta_t = sh_fast_f = sh_fast_t = nullptr;
+        planes_ready = false;
+    }
+    bool planes_on() const {
+        static const int on = [] { const char* e = getenv("MTTS_BF16_PLANES"); return e ? atoi(e) : 1; }();
+        return on && planes_ready && planes_wanted && gx.bf16;
+    }
+    // the weights this pass reads -> their shadows
+    void refresh_shadows(const Pass& ps) {
+        if (!planes_on()) return;
+        auto run = [&](const ShadowEnt* ents, int n, int tiles, const float* src, long long src_ts, bf16_t* f, bf16_t* t, long long dst_ts, int nt) {
+            if (n > 0) MTTS_LAUNCH(weight_shadow_kernel, dim3((unsigned)tiles, 1, (unsigned)nt), dim3(256), stream, ents, n, src, src_ts, f, t, dst_ts);
+        };
+        if (ps.use_fast && n_adapt > 0) {
+            run(d_ents_theta, n_ents_theta, tiles_theta, theta, 0, sh_theta_f, sh_theta_t, 0, 1);
+            run(d_ents_fast, n_ents_fast, tiles_fast, fast_cur, n_adapt, sh_fast_f, sh_fast_t, n_shadow, ps.pl->tasks);
+            shadow_fast_src = fast_cur;
+        } else {
+            run(d_ents_all, n_ents_all, tiles_all, theta, 0, sh_theta_f, sh_theta_t, 0, 1);
+        }
+    }
+    struct HP { const bf16_t* p; long long ts; };
+    // shadow of the weight behind W(ps, off) (tr: the input-gradient layout); null when there is none or it is not current
+    HP Wh(const Pass& ps, TS w, bool tr) const {
+        if (!planes_on()) return HP{nullptr, 0};
+        const bool is_fast = w.ts != 0;
+        const long long off = is_fast ? (w.p - fast_cur) + adapt_start : w.p - theta;
+        if (is_fast ? (fast_cur != shadow_fast_src || off < adapt_start || off >= adapt_start + n_adapt) : (off < 0 || off >= n_total)) return HP{nullptr, 0};
+        // (a theta shadow of an adapted weight is not refreshed by a pass that reads the fast weights)
+        if (!is_fast && ps.use_fast && n_adapt > 0 && off >= adapt_start && off < adapt_start + n_adapt) return HP{nullptr, 0};
+        const auto it = shadow_off.find(off);
+        if (it == shadow_off.end()) return HP{nullptr, 0};
+        if (is_fast) return HP{(tr ? sh_fast_t : sh_fast_f) + it->second, n_shadow};
+        return HP{(tr ? sh_theta_t : sh_theta_f) + it->second, 0};
+    }
+    // the plane of an arena buffer (null outside the two arenas: activation sets of second-order MAML, external buffers)
+    bf16_t* H(const float* q) const {
+        if (!planes_on()) return nullptr;
+        const char* c = (const char*)q;
+        if (c >= arena && c < arena + arena_bytes) return arena_h + (q - (const float*)arena);
+        if (arena_defer && c >= arena_defer && c < arena_defer + arena_defer_bytes) return arena_defer_h + (q - (const float*)arena_defer);
+        return nullptr;
+    }
+    // make the plane of the slab [tasks][G + rows + G][C] behind x (x.p = row 0 of task 0) from its fp32 values; returns it
+    const bf16_t* make_plane(TS x, int C, int nt) {
+        bf16_t* h = H(x.p);
+        if (!h || (x.ts % 8) != 0 || (((long long)G * C) % 8) != 0) return nullptr;
+        const long long n8 = x.ts * nt / 8, o = (long long)G * C;
+        MTTS_LAUNCH(to_bf16_kernel, dim3((unsigned)std::min<long long>((n8 + 255) / 256, 4096)), dim3(256), stream, (const float*)(x.p - o), h - o, n8);
+        return h;
+    }
     void destroy() {
         if (side) { hipStreamSynchronize(side); hipStreamDestroy(side); }
         for (auto& e : ev_side) if (e) hipEventDestroy(e);
@@ -783,6 +899,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         gx_side.release();
         if (arena_defer) hipFree(arena_defer);
         if (arena_pred) hipFree(arena_pred);
+        destroy_planes();
         if (col_partial_side) hipFree(col_partial_side);
         for (float* p : {theta, adam_m, adam_v, outer, fast, grad, norm_partial, norm_out, pos_table, pitch_bins, energy_bins})
             if (p) hipFree(p);
@@ -1169,6 +1286,13 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         g.flags = flags;
         g.rowmask = rowmask; g.rowmask_gs = row_ts(s);
         if (relu_ref.p) { g.relu_ref = relu_ref.p; g.relu_ref_gs = relu_ref.ts; g.ld_relu = cout; }
+        if (!x2.p) {   // bf16 mode: the operands' planes (the weight's shadow + the input slab's twin), where both exist
+            const HP wh = Wh(ps, w, false);
+            if (wh.p) {
+                const bf16_t* xh = make_plane(x, cin, p.tasks);
+                if (xh) { g.Ah = xh - (long long)pad * cin; g.Bh = wh.p; g.bh_gs = wh.ts; }
+            }
+        }
         gemm_launch(gx, GEMM_NT, g, maxM(p, s), cout, p.tasks, stream, 0, nsrc * 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s),
                     4.0 * (alg_rows(p, s) * (nsrc * cin + cout) + nsrc * (double)p.tasks * cout * k * cin));
     }
@@ -1176,8 +1300,28 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     void conv_dgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS w, int cin, TS dx, int flags,
                     const unsigned char* rowmask, TS relu_ref = TS{nullptr, 0}, TS dy2 = TS{nullptr, 0}, TS w2 = TS{nullptr, 0}) {
         const Plan& p = *ps.pl;
-        GemmArgs g = rowgemm(p, s, GEMM_NN);
         const int pad = k / 2;
+        if (!dy2.p) {
+            // bf16 mode with planes: dX = conv(dY; flipped transposed W) as an NT problem over the weight's input-gradient shadow — the
+            // forward conv's kernel path with Cin and Cout exchanged (weight_shadow_kernel)
+            const HP wt = Wh(ps, w, true);
+            const bf16_t* dyh = wt.p ? make_plane(dy, cout, p.tasks) : nullptr;
+            if (dyh) {
+                GemmArgs g = rowgemm(p, s, GEMM_NT);
+                g.A = dy.p - (long long)pad * cout; g.a_gs = dy.ts; g.lda = cout;
+                g.Ah = dyh - (long long)pad * cout;
+                g.B = nullptr; g.b_gs = 0; g.ldb = k * cout; g.Bh = wt.p; g.bh_gs = wt.ts; g.plane_only = true;
+                g.C = dx.p; g.c_gs = dx.ts; g.ldc = cin;
+                g.N = cin; g.K = k * cout;
+                g.flags = flags;
+                g.rowmask = rowmask; g.rowmask_gs = row_ts(s);
+                if (relu_ref.p) { g.relu_ref = relu_ref.p; g.relu_ref_gs = relu_ref.ts; g.ld_relu = cin; }
+                gemm_launch(gx, GEMM_NT, g, maxM(p, s), cin, p.tasks, stream, 0, 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s),
+                            4.0 * (alg_rows(p, s) * (cin + cout) + (double)p.tasks * cout * k * cin));
+                return;
+            }
+        }
+        GemmArgs g = rowgemm(p, s, GEMM_NN);
         const double nsrc = dy2.p ? 2.0 : 1.0;
         g.A = dy.p - (long long)pad * cout; g.a_gs = dy.ts; g.lda = cout;
         g.B = w.p; g.b_gs = w.ts; g.ldb = k * cin;
@@ -1624,6 +1768,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         static const int q_on = [] { const char* e = getenv("MTTS_ENC_AHEAD_QUERY"); return e ? atoi(e) : 1; }();
         if (query && (!q_on || !ahead_ok(*query) || cfg.enc_layers < 1)) query = nullptr;
         if (query) *query_seed = next_drop_seed();   // (the seed forward() would draw for the query pass: after the inner steps')
+        refresh_shadows(Pass{&pl, true, true});   // (bf16 mode: the encoder's weight shadows, before the fork)
         hipEvent_t ev = ev_side[ev_next];
         ev_next = (ev_next + 1) % kSideEvents;
         hipEventRecord(ev, stream);              // the batch image / plan kernels of this plan are on the main stream
@@ -1655,6 +1800,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         const int d = cfg.d_model, nt = p.tasks;
         TS none{nullptr, 0};
         if (ps.train) ps.pl->drop_seed = ps.seed_override ? ps.seed_override : next_drop_seed();
+        refresh_shadows(ps);   // (bf16 mode: the weight shadows this pass and its backward read)
         // encoder
         TS x = ps.enc_out.p ? ps.enc_out : encoder_fwd(ps);
         // speaker vector, added on every position of the phoneme rectangle

@@ -40,7 +40,8 @@
 
 namespace mtts {
 
-enum GemmForm { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
+enum GemmForm { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2,
+                GEMM_NT_H = 3 };   // (bf16 family, kernel-internal: NT staged from the operands' bf16 planes — GemmArgs::Ah / Bh)
 enum GemmFlags { GEMM_RELU = 1, GEMM_ACCUM = 2, GEMM_LRELU = 4 };   // LRELU: v < 0 -> act_slope * v (MelGAN generator)
 
 struct GemmGroupDesc {
@@ -179,6 +180,17 @@ struct GemmArgs {
     const float* A2 = nullptr;
     const float* B2 = nullptr;
     long long a2_gs = 0, b2_gs = 0;
+    // bf16 operand planes (bf16 numerics mode only, gemm_bf16.h).  Ah / Bh: the SAME operands as A / B, element for element (same leading
+    // dimensions, group strides and offsets), already rounded to bf16 by their producer — an NT problem with both set is staged from the
+    // planes (half the bytes through L2, no conversion pass) instead of from A / B.  Ch: bf16 twin of C, written by the epilogue beside
+    // the fp32 value (the next GEMM's plane).
+    // Bh has its own group stride (a weight shadow is packed differently from its fp32 master); plane_only: the problem exists in plane
+    // form alone (an input-gradient conv as NT over the transposed shadow: A / B give offsets and sizes, B is never dereferenced).
+    const bf16_t* Ah = nullptr;
+    const bf16_t* Bh = nullptr;
+    long long bh_gs = 0;
+    bf16_t* Ch = nullptr;
+    bool plane_only = false;
     // task-per-XCD schedule (launches of 8 — opt-in 4 / 2 — groups).  host_dims: HOST array of the groups' dimptr values, read by the
     // launcher to build `xs`; never dereferenced on the device.
     const int* host_dims = nullptr;
@@ -316,6 +328,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int z, f32x16 (
     const unsigned char* rowmask = g.rowmask ? g.rowmask + (long long)z * g.rowmask_gs : nullptr;
     const float* relu_ref = g.relu_ref ? g.relu_ref + (long long)z * g.relu_ref_gs : nullptr;
     const int* rowmap = g.c_rowmap ? g.c_rowmap + (long long)z * g.c_rowmap_gs : nullptr;
+    bf16_t* Ch = g.Ch ? g.Ch + (C - g.C) : nullptr;   // (C carries the group's offset into g.C; the twin has the same layout)
     const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -337,6 +350,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int z, f32x16 (
                 if (relu_ref && !(relu_ref[(long long)m * g.ld_relu + n] > 0.f)) v = 0.f;
                 if (rowmask && !rowmask[m]) v = 0.f;
                 *p = v;
+                if (Ch) Ch[(long long)mo * ldc + n] = f32_to_bf16(v);
             }
         }
 }
@@ -854,6 +868,7 @@ struct GemmCtx {
     GemmProfiler prof;
     GemmWorkspace wsp;
     int last_kind = GK_OTHER;  // kernel kind of the last launch (profiler)
+    long long plane_problems = 0;   // problems launched on the plane-staged K-loop (bf16 mode; a test / diagnostic counter)
     bool bf16 = false;         // numerics mode of the owner: bf16 operand family (gemm_bf16.h) for every problem it can take
     const char* error = nullptr;   // sticky: a launch the launcher refused (the C ABI entry points turn it into an error return)
     bool flushing = false;     // gemm_batch_end is issuing the queue
@@ -891,6 +906,7 @@ inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t s
 
 // bf16 operand family (gemm_bf16.h)
 inline bool gemm_bf16_ok(const GemmArgs& g);
+inline bool gemm_bf16_planes_ok(int form, const GemmArgs& g);
 inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipStream_t stream, int pf);
 inline void gemm_bf16_multi_launch(const GemmMulti& mp, int T, bool dual, dim3 grid, hipStream_t stream);
 // block tile of a bf16 launch: 128x128 once the launch still fills the chip twice over with it (the MFMA rate is 16x the fp32 kernels':
@@ -939,6 +955,12 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     if (max_M <= 0 || max_N <= 0 || groups <= 0) return;
     GemmArgs g = g_in;
     g.swizzle = gemm_xcd_swizzle();
+    // bf16 planes: kept only where the plane-staged K-loop will run (bf16 mode, an NT problem it can take); the twin of C in bf16 mode only
+    if (!(cx.bf16 && gemm_bf16_ok(g) && gemm_bf16_planes_ok(form, g))) {
+        if (g.plane_only) { cx.error = "plane-only GEMM problem outside the bf16 plane path"; return; }
+        g.Ah = g.Bh = nullptr;
+    }
+    if (!cx.bf16) g.Ch = nullptr;
     const int user_tile = tile;
     const double rows = total_M > 0 ? (double)total_M : (double)max_M * groups;
     auto ntiles = [&](int t) { return (long)((max_M + t - 1) / t) * gemm_tiles_n(g, max_N, t); };
@@ -1012,6 +1034,7 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
         else { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, false>), grid, block, stream, g); kind = T == 64 ? GK_OTHER : GK_F32_128 + F; }                   \
     }
     if (bf16) {
+        if (g.Ah) ++cx.plane_problems;
         gemm_bf16_launch(form, g, tile, grid, stream, (user_tile % 10000) / 1000);   // (bf16 tile codes: T + 1000 * slices in flight, 0 = default)
         kind = (tile == 128 ? GK_BF16_128 : GK_BF16_64) + form;
     } else
@@ -1089,6 +1112,9 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     // bf16 numerics mode: the whole launch takes the bf16 operand family when every problem qualifies (gemm_bf16_ok); block tile T
     bool bf16 = cx.bf16;
     for (const GemmPending& p : b.q) bf16 = bf16 && gemm_bf16_ok(p.g);
+    if (!bf16)
+        for (const GemmPending& p : b.q)
+            if (p.g.plane_only) { cx.error = "plane-only GEMM problem queued with one the bf16 kernels cannot take"; b.q.clear(); return; }
     const int T = !bf16 ? 64 : (b.force_tile ? b.force_tile : (batch_wgs128 >= 512.0 ? 128 : 64));
     GemmWorkspace* wsp = nullptr;
     long long ws_off = 0, ctr_off = 0;
@@ -1143,6 +1169,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     for (int i = 0; i < mp.n; ++i) glds = glds && gemm_glds_ok(mp.g[i]);
     int kind = GK_MULTI16;
     if (bf16) {
+        for (int i = 0; i < mp.n; ++i) if (mp.g[i].Ah) ++cx.plane_problems;
         gemm_bf16_multi_launch(mp, T, any_dual, grid, stream);
         kind = T == 128 ? (any_dual ? GK_BF16_MULTI128_DUAL : GK_BF16_MULTI128) : (any_dual ? GK_BF16_MULTI64_DUAL : GK_BF16_MULTI64);
         glds = false;

@@ -27,17 +27,10 @@
 
 namespace mtts {
 
-typedef unsigned short bf16_t;   // storage type of an LDS tile element
 struct alignas(8) u32x2 { unsigned x, y; };   // two packed bf16 pairs: one ds_write_b64
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // eight bf16 of a plane: one 16-byte load / ds_write_b128 (a register value: a struct here ended up in scratch memory behind a pointer select)
 
 #if defined(MTTS_EMU)
-__device__ __forceinline__ bf16_t f32_to_bf16(float x) {   // round-to-nearest-even (what v_cvt_pk_bf16_f32 does)
-    unsigned u; memcpy(&u, &x, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
-__device__ __forceinline__ float bf16_to_f32(bf16_t h) { unsigned u = (unsigned)h << 16; float x; memcpy(&x, &u, 4); return x; }
 __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
 #else
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -77,6 +70,103 @@ struct FragsBf16 {
 // PF: K-slices kept IN FLIGHT per workgroup (register sets of the global -> LDS staging).  An under-filled launch (1-2 workgroups per
 // CU: every GEMM of a single-task rank, of C2, of few-shot adaptation) is bound by latency x bytes in flight per CU, not by the matrix
 // pipes: with one slice in flight a workgroup moves 16 KB per ~0.7 us round trip (load -> convert -> LDS -> barrier -> MFMA).
+// the MFMA steps of one staged slice: LDS stage `buf` ([BM + BN rows][BK + 8] bf16) -> this wave's accumulator tiles
+template <int BM, int BN, int BK, int WGM, int WGN>
+__device__ __forceinline__ void bf16_compute_slice(const bf16_t* smem, int buf, int wm0, int wn0, int lane,
+                                                   f32x16 (&acc)[(BM / WGM) / 32][(BN / WGN) / 32]) {
+    constexpr int kLDK = BK + 8, TM = (BM / WGM) / 32, TN = (BN / WGN) / 32, STAGE = (BM + BN) * kLDK;
+    const int l31 = lane & 31, h = lane >> 5;
+    const bf16_t* As = smem + buf * STAGE;
+    const bf16_t* Bs = As + BM * kLDK;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+        FragsBf16<TM, TN> f;
+#if defined(MTTS_EMU)
+        for (int i = 0; i < TM; ++i)
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                for (int k = 0; k < 16; ++k) f.a[i][r][k] = bf16_to_f32(As[row * kLDK + ks * 16 + k]);
+            }
+        for (int j = 0; j < TN; ++j)
+            for (int k = 0; k < 16; ++k) f.b[j][k] = bf16_to_f32(Bs[(wn0 + j * 32 + l31) * kLDK + ks * 16 + k]);
+        for (int i = 0; i < TM; ++i)
+            for (int j = 0; j < TN; ++j)
+                for (int r = 0; r < 16; ++r) {
+                    float s = acc[i][j][r];
+                    for (int k = 0; k < 16; ++k) s = fmaf(f.a[i][r][k], f.b[j][k], s);
+                    acc[i][j][r] = s;
+                }
+#else
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const bf16x8*>(As + (wm0 + i * 32 + l31) * kLDK + ks * 16 + 8 * h);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn0 + j * 32 + l31) * kLDK + ks * 16 + 8 * h);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+#endif
+    }
+}
+
+// NT problem staged from bf16 planes (GemmArgs::Ah / Bh: the operands as their producers rounded them).  The K-loop above without the
+// conversion pass: one 16-byte load per 8 k-values, written to the LDS tile as it is — half the bytes per workgroup through L2, the bound
+// of the under-filled launches (profiles/r03_gemm_variants.md section 1), and no VALU work at all between the load and the MFMA.
+template <int BM, int BN, int BK, int WGM = 2, int WGN = 2>
+__device__ __forceinline__ void gemm_bf16_kloop_h(const GemmArgs& g, const GemmProb& pr, int z, int m0, int n0, int c_lo, int c_hi,
+                                                  float* smem_f, f32x16 (&acc)[(BM / WGM) / 32][(BN / WGN) / 32]) {
+    constexpr int NTH = 64 * WGM * WGN, kLDK = BK + 8, KQ = BK / 8, RPP = NTH / KQ, STAGE = (BM + BN) * kLDK;
+    constexpr int A_LD = (BM * KQ) / NTH, B_LD = (BN * KQ) / NTH;   // 16-byte loads per thread and slice (64-tile: 1, 128-tile: 2)
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    static_assert(A_LD >= 1 && B_LD >= 1, "tile too small for one 16-byte load per thread");
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_f);
+    const bf16_t* A = g.Ah + (pr.A - g.A);   // (an activation plane shares its fp32 twin's layout: same element offset)
+    const bf16_t* B = g.Bh + (long long)z * g.bh_gs;   // (TASK mode only: gemm_bf16_planes_ok)
+    const int M = pr.M, N = pr.N, K = pr.K, K8 = (K + 7) & ~7;
+    const int tid = MTTS_OPAQUE_TID(), lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+    const int kq = (tid % KQ) * 8;
+    const bf16_t* a_ptr[A_LD];
+    const bf16_t* b_ptr[B_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) { int gm = m0 + tid / KQ + RPP * i; gm = gm < M ? gm : M - 1; a_ptr[i] = A + (long long)gm * pr.lda + kq; }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) { int gn = n0 + tid / KQ + RPP * i; gn = gn < N ? gn : N - 1; b_ptr[i] = B + (long long)gn * pr.ldb + kq; }
+    u32x4 areg[A_LD], breg[B_LD];
+    // the K tail: 8-element groups beyond K are read from the slice's first group (in range) and zeroed on their way into LDS — not
+    // at the load, where the select would wait for the data in front of the MFMAs
+    auto load = [&](int k0) {
+        const int ko = (k0 + kq < K8) ? k0 : k0 - kq;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) areg[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + ko);
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) breg[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + ko);
+    };
+    auto store = [&](int buf, int k0) {
+        const unsigned keep = (k0 + kq < K8) ? 0xffffffffu : 0u;
+        bf16_t* As = smem + buf * STAGE;
+        bf16_t* Bs = As + BM * kLDK;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) *reinterpret_cast<u32x4*>(As + (tid / KQ + RPP * i) * kLDK + kq) = areg[i] & keep;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) *reinterpret_cast<u32x4*>(Bs + (tid / KQ + RPP * i) * kLDK + kq) = breg[i] & keep;
+    };
+    const int nchunks = c_hi > c_lo ? c_hi - c_lo : 0;
+    if (nchunks == 0) return;
+    const int kb0 = c_lo * BK;
+    load(kb0);
+    store(0, kb0);
+    if (nchunks > 1) load(kb0 + BK);
+    __syncthreads();
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const int buf = cc & 1;
+        if (cc + 1 < nchunks) store(buf ^ 1, kb0 + (cc + 1) * BK);
+        if (cc + 2 < nchunks) load(kb0 + (cc + 2) * BK);
+        bf16_compute_slice<BM, BN, BK, WGM, WGN>(smem, buf, wm0, wn0, lane, acc);
+        __syncthreads();
+    }
+}
+
 template <int FORM, int BM, int BN, int BK, int PF, int WGM = 2, int WGN = 2>
 __device__ __forceinline__ void gemm_bf16_kloop(const GemmArgs& g, const GemmProb& pr, int z, int m0, int n0, bool cs_tile, int c_lo, int c_hi,
                                                 float* smem_f, f32x16 (&acc)[(BM / WGM) / 32][(BN / WGN) / 32]) {
@@ -220,41 +310,7 @@ __device__ __forceinline__ void gemm_bf16_kloop(const GemmArgs& g, const GemmPro
             }
         }
     };
-    const int l31 = lane & 31, h = lane >> 5;
-    // the MFMA steps of one staged slice
-    auto compute = [&](int buf) {
-        const bf16_t* As = smem + buf * STAGE;
-        const bf16_t* Bs = As + BM * kLDK;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            FragsBf16<TM, TN> f;
-#if defined(MTTS_EMU)
-            for (int i = 0; i < TM; ++i)
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    for (int k = 0; k < 16; ++k) f.a[i][r][k] = bf16_to_f32(As[row * kLDK + ks * 16 + k]);
-                }
-            for (int j = 0; j < TN; ++j)
-                for (int k = 0; k < 16; ++k) f.b[j][k] = bf16_to_f32(Bs[(wn0 + j * 32 + l31) * kLDK + ks * 16 + k]);
-            for (int i = 0; i < TM; ++i)
-                for (int j = 0; j < TN; ++j)
-                    for (int r = 0; r < 16; ++r) {
-                        float s = acc[i][j][r];
-                        for (int k = 0; k < 16; ++k) s = fmaf(f.a[i][r][k], f.b[j][k], s);
-                        acc[i][j][r] = s;
-                    }
-#else
-#pragma unroll
-            for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const bf16x8*>(As + (wm0 + i * 32 + l31) * kLDK + ks * 16 + 8 * h);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn0 + j * 32 + l31) * kLDK + ks * 16 + 8 * h);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
-#endif
-        }
-    };
+    auto compute = [&](int buf) { bf16_compute_slice<BM, BN, BK, WGM, WGN>(smem, buf, wm0, wn0, lane, acc); };
 
     const int nchunks = c_hi > c_lo ? c_hi - c_lo : 0;
     if (nchunks == 0) return;
@@ -309,8 +365,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, int z, int bxs
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int nch_all = (pr.K + BK - 1) / BK, cps = (nch_all + S - 1) / S;
     const int c_lo = split * cps, c_hi = (c_lo + cps < nch_all) ? c_lo + cps : nch_all;
-    gemm_bf16_kloop<FORM, BM, BN, BK, PF, WGM, WGN>(g, pr, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
-    if (DUAL) {
+    if constexpr (FORM == GEMM_NT_H) gemm_bf16_kloop_h<BM, BN, BK, WGM, WGN>(g, pr, z, m0, n0, c_lo, c_hi, smem, acc);
+    else gemm_bf16_kloop<FORM, BM, BN, BK, PF, WGM, WGN>(g, pr, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
+    if constexpr (DUAL && FORM != GEMM_NT_H) {
         if (g.A2 != nullptr && !cs_tile) {
             const GemmProb p2 = gemm_resolve2(g, z, pr);   // (the first K-loop ends on a barrier: its LDS stages are free)
             gemm_bf16_kloop<FORM, BM, BN, BK, PF, WGM, WGN>(g, p2, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
@@ -338,8 +395,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_multi_kernel(GemmMulti mp) {
     int p, z, bx;
     if (!gemm_multi_locate(mp, p, z, bx)) return;
     const int form = mp.form[p];
-    if (form == GEMM_NT) gemm_bf16_body<GEMM_NT, BM, BN, BK, PF, DUAL>(mp.g[p], z, bx, smem);
-    else if (form == GEMM_NN) gemm_bf16_body<GEMM_NN, BM, BN, BK, PF, DUAL>(mp.g[p], z, bx, smem);
+    if (form == GEMM_NT) {
+        if (mp.g[p].Ah != nullptr) gemm_bf16_body<GEMM_NT_H, BM, BN, BK, PF, DUAL>(mp.g[p], z, bx, smem);   // (set by the launcher only when both planes exist)
+        else gemm_bf16_body<GEMM_NT, BM, BN, BK, PF, DUAL>(mp.g[p], z, bx, smem);
+    } else if (form == GEMM_NN) gemm_bf16_body<GEMM_NN, BM, BN, BK, PF, DUAL>(mp.g[p], z, bx, smem);
     else gemm_bf16_body<GEMM_TN, BM, BN, BK, PF, DUAL>(mp.g[p], z, bx, smem);
 }
 
@@ -355,6 +414,12 @@ inline bool gemm_bf16_ok(const GemmArgs& g) {
     if (g.a_tap_rows != 0) return false;
     return true;
 }
+// an NT problem whose operand planes the plane-staged K-loop can take: 16-byte loads (leading dimensions and K in whole groups of 8), plain
+// K-contiguous operands (an implicit conv over overlapping rows is one), single source.  The launcher clears Ah / Bh otherwise.
+inline bool gemm_bf16_planes_ok(int form, const GemmArgs& g) {
+    return form == GEMM_NT && g.Ah != nullptr && g.Bh != nullptr && g.A2 == nullptr && g.table == nullptr && g.a_tap_rows == 0 &&
+           g.K % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0;
+}
 // stand-alone launch of one problem; T = 64 / 128; pf: 0 = the default depth, else an explicit one (MTTS_BF16_PF_SWEEP builds only)
 inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipStream_t stream, int pf_req = 0) {
     int pf = 0; (void)pf_req;
@@ -363,6 +428,11 @@ inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipS
 #if defined(MTTS_BF16_PF_SWEEP)
     if (pf_req) pf = pf_req;
 #endif
+    if (form == GEMM_NT && g.Ah != nullptr) {   // both planes exist (gemm_bf16_planes_ok): the plane-staged K-loop
+        if (T == 128) MTTS_LAUNCH((gemm_bf16_kernel<GEMM_NT_H, 128, 128, kBf16BK, 1>), grid, block, stream, g);
+        else MTTS_LAUNCH((gemm_bf16_kernel<GEMM_NT_H, 64, 64, kBf16BK, 1>), grid, block, stream, g);
+        return;
+    }
 #define MTTS_BF16_CASE(F, TT, PP) if (form == F && T == TT && pf == PP) { MTTS_LAUNCH((gemm_bf16_kernel<F, TT, TT, kBf16BK, PP>), grid, block, stream, g); return; }
 #define MTTS_BF16_FORMS(TT, PP) MTTS_BF16_CASE(GEMM_NT, TT, PP) MTTS_BF16_CASE(GEMM_NN, TT, PP) MTTS_BF16_CASE(GEMM_TN, TT, PP)
     MTTS_BF16_FORMS(64, 1) MTTS_BF16_FORMS(128, 1)

@@ -94,11 +94,13 @@ int mtts_set_grad_accumulation(mtts_handle* h, int accumulate) {
 
 int mtts_set_numerics(mtts_handle* h, int mode) {
     if (!h) return -1;
-    if (mode != 0 && mode != 1) { h->eng.set_error("numerics mode must be 0 (fp32) or 1 (bf16 operands, fp32 accumulate)"); return -1; }
-    h->eng.gx.bf16 = h->eng.gx_side.bf16 = h->eng.gx_side2.bf16 = (mode == 1);
+    if (mode < 0 || mode > 2) { h->eng.set_error("numerics mode must be 0 (fp32), 1 (bf16 operands, fp32 accumulate) or 2 (1 without operand planes)"); return -1; }
+    if (mode == 1 && h->eng.enable_planes()) return -1;   // (operand planes + weight shadows: allocated the first time the mode is selected)
+    h->eng.planes_wanted = (mode == 1);
+    h->eng.gx.bf16 = h->eng.gx_side.bf16 = h->eng.gx_side2.bf16 = (mode != 0);
     return 0;
 }
-int mtts_get_numerics(mtts_handle* h) { return h && h->eng.gx.bf16 ? 1 : 0; }
+int mtts_get_numerics(mtts_handle* h) { return !h || !h->eng.gx.bf16 ? 0 : (h->eng.planes_wanted ? 1 : 2); }
 
 int mtts_set_dropout(mtts_handle* h, int enable, unsigned seed) {
     Engine& e = h->eng;
@@ -486,6 +488,32 @@ int mtts_gemm_bf16(int form, int M, int N, int K, const float* A, int lda, const
     gemm_launch(cx, form, g, M, N, 1, (hipStream_t)stream, tile);
     cx.bf16 = false;
     return kernel_launch_rc();
+}
+
+int mtts_to_bf16(const float* src, unsigned short* dst, long long n, void* stream) {
+    if (!src || !dst || n < 0 || n % 8 != 0) return -1;
+    if (n == 0) return 0;
+    MTTS_LAUNCH(to_bf16_kernel, dim3((unsigned)std::min<long long>((n / 8 + 255) / 256, 4096)), dim3(256), (hipStream_t)stream, src, (bf16_t*)dst, n / 8);
+    return 0;
+}
+
+int mtts_gemm_bf16_planes(int M, int N, int K, const unsigned short* Ah, int lda, const unsigned short* Bh, int ldb, float* C, unsigned short* Ch,
+                          int ldc, const float* bias, float alpha, int flags, int tile, void* stream) {
+    if (!Ah || !Bh || !C || (tile != 0 && tile != 64 && tile != 128) || (flags & ~0xff) || K % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0) return -1;
+    GemmArgs g;
+    static const float anchor = 0.f;   // (plane-only problem: A / B carry no data, the planes are addressed relative to them)
+    g.A = &anchor; g.B = nullptr; g.Ah = (const bf16_t*)Ah; g.Bh = (const bf16_t*)Bh; g.plane_only = true;
+    g.C = C; g.Ch = (bf16_t*)Ch; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.alpha = alpha; g.flags = flags & 0xff;
+    GemmCtx& cx = kernel_ctx();
+    cx.bf16 = true;
+    gemm_launch(cx, GEMM_NT, g, M, N, 1, (hipStream_t)stream, tile);
+    cx.bf16 = false;
+    return kernel_launch_rc();
+}
+
+long long mtts_plane_problems(mtts_handle* h) {
+    return h ? h->eng.gx.plane_problems + h->eng.gx_side.plane_problems + h->eng.gx_side2.plane_problems : -1;
 }
 
 int mtts_conv1d_f32(int mode, int L, int Cin, int Cout, int k, const float* a, const float* b, float* out, const float* bias,

@@ -1017,6 +1017,55 @@ __global__ void add3_kernel(const float* a, const float* b, const float* c, floa
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 operand planes (bf16 numerics mode, gemm_bf16.h: GemmArgs::Ah / Bh)
+// ------------------------------------------------------------------------------------------
+// dst[i] = bf16(src[i]) over a flat range (n8 groups of 8): the plane of an activation slab whose producer does not write one in passing
+__global__ void to_bf16_kernel(const float* src, bf16_t* dst, long long n8) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const float4 a = ld4(src + i * 8), b = ld4(src + i * 8 + 4);
+        struct alignas(16) { bf16_t v[8]; } o;
+        o.v[0] = f32_to_bf16(a.x); o.v[1] = f32_to_bf16(a.y); o.v[2] = f32_to_bf16(a.z); o.v[3] = f32_to_bf16(a.w);
+        o.v[4] = f32_to_bf16(b.x); o.v[5] = f32_to_bf16(b.y); o.v[6] = f32_to_bf16(b.z); o.v[7] = f32_to_bf16(b.w);
+        *reinterpret_cast<decltype(o)*>(dst + i * 8) = o;
+    }
+}
+
+// The bf16 shadows of the Conv1d / Linear weights, refreshed once per pass from the fp32 masters: `fwd` keeps the [Cout][k][Cin] layout
+// (the forward conv's B operand), `tr` is the image the input-gradient conv reads as ITS K-contiguous B operand —
+// tr[ci][(k - 1 - t) * Cout + co] = w[co][t * Cin + ci] (dX = conv(dY, flipped transposed W): an NT problem like the forward).
+// One workgroup = one 32 x 32 (co, ci) tile of one tap, transposed through LDS; blockIdx.z = task (per-task fast weights).
+struct ShadowEnt { long long off, dst; int cout, k, cin, tile0; };   // off / dst: element offset of the weight in the source vector / of its shadow in the shadow vectors (a multiple of 8); tile0: first tile
+__global__ void weight_shadow_kernel(const ShadowEnt* ents, int n_ents, const float* src, long long src_ts, bf16_t* fwd, bf16_t* tr, long long dst_ts) {
+    __shared__ float tile[32][33];
+    int e = 0;
+    while (e + 1 < n_ents && (int)blockIdx.x >= ents[e + 1].tile0) ++e;
+    const ShadowEnt en = ents[e];
+    const int tci = (en.cin + 31) / 32, tco = (en.cout + 31) / 32;
+    int t = (int)blockIdx.x - en.tile0;
+    const int tap = t / (tci * tco); t -= tap * tci * tco;
+    const int co0 = (t / tci) * 32, ci0 = (t % tci) * 32;
+    const float* w = src + (long long)blockIdx.z * src_ts + en.off;
+    bf16_t* f = fwd + (long long)blockIdx.z * dst_ts + en.dst;
+    bf16_t* r = tr + (long long)blockIdx.z * dst_ts + en.dst;
+    const int tx = (int)threadIdx.x & 31, ty = (int)threadIdx.x >> 5;   // 256 threads: 32 x 8
+    const long long ldw = (long long)en.k * en.cin, ldt = (long long)en.k * en.cout;
+    for (int j = ty; j < 32; j += 8) {
+        const int co = co0 + j, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < en.cout && ci < en.cin) {
+            v = w[co * ldw + (long long)tap * en.cin + ci];
+            f[co * ldw + (long long)tap * en.cin + ci] = f32_to_bf16(v);
+        }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int ci = ci0 + j, co = co0 + tx;
+        if (co < en.cout && ci < en.cin) r[ci * ldt + (long long)(en.k - 1 - tap) * en.cout + co] = f32_to_bf16(tile[tx][j]);
+    }
+}
+
 // dst[t][i] = src[i]  (clone the adapted parameters into every task's fast weights)
 __global__ void broadcast_kernel(const float* src, float* dst, long long n4, long long dst_ts) {
     float* d = dst + (long long)blockIdx.z * dst_ts;

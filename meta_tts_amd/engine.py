@@ -102,10 +102,12 @@ class Engine:
 
     def set_numerics(self, mode: str = "fp32"):
         """Arithmetic of the contractions: "fp32" (default; the reference's own and the parity mode) or "bf16" (bf16 operands, fp32
-        accumulation: BASELINE.json configs[1]; include/mtts.h: mtts_set_numerics)."""
-        if mode not in ("fp32", "bf16"):
-            raise ValueError("numerics mode must be 'fp32' or 'bf16'")
-        self._ck(self.lib.mtts_set_numerics(self.h, 1 if mode == "bf16" else 0))
+        accumulation, the long convolutions fed from bf16 operand planes: BASELINE.json configs[1]) or "bf16-staged" (the same without
+        the planes; include/mtts.h: mtts_set_numerics)."""
+        modes = {"fp32": 0, "bf16": 1, "bf16-staged": 2}
+        if mode not in modes:
+            raise ValueError("numerics mode must be one of %s" % sorted(modes))
+        self._ck(self.lib.mtts_set_numerics(self.h, modes[mode]))
 
     def set_grad_accumulation(self, accumulate: bool):
         """meta_grad / plain_grad add to the outer-gradient buffer instead of overwriting it (gradient accumulation, main.py:62)."""

@@ -90,6 +90,37 @@ def test_gemm_bf16_dual_source_relu_accumulate(dev, form, tile):
     assert np.abs(dev.get(out) - want).max() < 1e-4 * max(1.0, np.abs(want).max())
 
 
+def _bf16_bits(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).bfloat16().view(torch.int16).numpy()
+
+
+@pytest.mark.parametrize("tile", [0, 64, 128])
+@pytest.mark.parametrize("M,N,K", [(70, 40, 40), (33, 130, 104), (129, 64, 536), (300, 256, 2304)])
+def test_plane_gemm_equals_staged_rounding(dev, tile, M, N, K):
+    """The plane-staged NT K-loop (numerics mode 1's long problems): planes made by mtts_to_bf16 are torch's round-to-nearest-even bit
+    for bit; the product from the planes is BIT-IDENTICAL to mtts_gemm_bf16 on the fp32 operands (same rounded values, same order of
+    accumulation) and within fp32 round-off of the float64 product of the rounded operands; the epilogue's twin of C is bf16(C)."""
+    g = np.random.RandomState(M + 3 * N + 7 * K)
+    A, B = g.standard_normal((M, K)).astype(np.float32), g.standard_normal((N, K)).astype(np.float32)
+    bias = g.standard_normal(N).astype(np.float32)
+    P = dev.ptr
+    dA, dB, dbias = dev.put(A), dev.put(B), dev.put(bias)
+    hA, hB = dev.empty((M, K), np.int16), dev.empty((N, K), np.int16)
+    assert dev.lib.mtts_to_bf16(P(dA), P(hA), M * K, None) == 0 and dev.lib.mtts_to_bf16(P(dB), P(hB), N * K, None) == 0
+    assert np.array_equal(dev.get(hA), _bf16_bits(A)) and np.array_equal(dev.get(hB), _bf16_bits(B))
+    ldc = (N + 7) & ~7
+    out, twin, ref_out = dev.empty((M, ldc), fill=7.0), dev.empty((M, ldc), np.int16, fill=5), dev.empty((M, ldc), fill=7.0)
+    assert dev.lib.mtts_gemm_bf16_planes(M, N, K, P(hA), K, P(hB), K, P(out), P(twin), ldc, P(dbias), 0.5, 1, tile, None) == 0   # flags 1: ReLU
+    assert dev.lib.mtts_gemm_bf16(0, M, N, K, P(dA), K, P(dB), K, None, None, P(ref_out), ldc, P(dbias), 0.5, 1, tile, None) == 0
+    got, staged = dev.get(out), dev.get(ref_out)
+    assert np.array_equal(got, staged)
+    want = np.maximum(0.5 * (_bf(A) @ _bf(B).T) + bias[None, :].astype(np.float64), 0.0)
+    assert np.abs(got[:, :N] - want).max() < 3e-6 * np.sqrt(K) * max(1.0, np.abs(want).max())
+    assert np.all(got[:, N:] == 7.0)
+    tw = dev.get(twin)
+    assert np.array_equal(tw[:, :N], _bf16_bits(got[:, :N])) and np.all(tw[:, N:] == 5)
+
+
 def _small_engine(gpu, tasks=1):
     dims = tiny_dims()
     mods = default_algorithm_config()["adapt"]["modules"]
@@ -117,11 +148,13 @@ def test_small_model_bf16_mode_tracks_fp32_oracle(gpu):
     lo = O.fs2_loss(tb, o)
     names = [k for k in p if p[k].requires_grad]
     gref = dict(zip(names, torch.autograd.grad(lo[0], [p[k] for k in names], allow_unused=True)))
-    res = {}
-    for mode in ("bf16", "fp32"):
+    res, mels, grads, planes = {}, {}, {}, {}
+    for mode in ("bf16", "bf16-staged", "fp32"):
         eng.set_numerics(mode)
+        n0 = int(eng.lib.mtts_plane_problems(eng.h))
         eng.forward(0, use_fast=False, train=True)
         mel = eng.outputs(0, 0)["mel_post"]
+        mels[mode] = mel.copy()
         loss = eng.loss(0)[0]
         eng.backward(0, use_fast=False, scale=1.0, need_encoder=True)
         rels = []
@@ -129,7 +162,9 @@ def test_small_model_bf16_mode_tracks_fp32_oracle(gpu):
                   "postnet.convolutions.1.0.conv.weight", "variance_adaptor.duration_predictor.conv_layer.conv1d_1.conv.weight",
                   "decoder.layer_stack.0.slf_attn.fc.weight", "variance_adaptor.pitch_embedding.weight"):
             gr = gref[n].numpy()
-            rels.append(float(np.linalg.norm(eng.export(n, 2, 0) - gr) / np.linalg.norm(gr)))
+            grads.setdefault(mode, {})[n] = eng.export(n, 2, 0)
+            rels.append(float(np.linalg.norm(grads[mode][n] - gr) / np.linalg.norm(gr)))
+        planes[mode] = int(eng.lib.mtts_plane_problems(eng.h)) - n0
         ref_mel = o[1].detach().numpy()
         res[mode] = (float(np.abs(mel - ref_mel).mean() / np.abs(ref_mel).mean()),
                      float(np.abs(loss - np.array([float(x.detach()) for x in lo])).max() / abs(float(lo[0].detach()))), max(rels), float(np.median(rels)))
@@ -139,6 +174,15 @@ def test_small_model_bf16_mode_tracks_fp32_oracle(gpu):
     assert l1_b < BF16_MEL_REL and dl_b < BF16_LOSS_RTOL and g_b < BF16_GRAD_L2 and gm_b < BF16_GRAD_L2_MEDIAN, res
     assert l1_f < 1e-4 and dl_f < 1e-4 and g_f < 2e-3, res
     assert l1_b > 20 * l1_f, res          # the bf16 mode is not the fp32 arithmetic under another name
+    # operand planes (mode "bf16") vs rounding in the staging pass only ("bf16-staged"): the FFT blocks' and the PostNet's convolutions
+    # ran from planes (forward + input gradient), the forward is bit-identical; the input gradients are accumulated in another order (NT over
+    # the transposed shadow vs the NN form), and a last-bit difference that crosses a bf16 rounding boundary at the next contraction's
+    # operand becomes a 2^-8 one there: the gradients agree to a few 1e-3, far inside the mode's own distance from fp32
+    assert planes["bf16"] >= 2 * (2 * 3 + 5) - 1 and planes["bf16-staged"] == 0 and planes["fp32"] == 0, planes
+    assert np.array_equal(mels["bf16"], mels["bf16-staged"])
+    for n in grads["bf16"]:
+        a, b = grads["bf16"][n], grads["bf16-staged"][n]
+        assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b), n
 
 
 @pytest.mark.gpu

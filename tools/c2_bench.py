@@ -6,4 +6,5 @@ import torch
 import bench
 from meta_tts_amd.config import ModelDims, default_train_config
 torch.cuda.set_device(0)
-print(json.dumps(bench.baseline_c2_leg(ModelDims(), 0, bench.noam_lr, default_train_config()["optimizer"], iters=int(os.environ.get("C2_ITERS", "10")))))
+print(json.dumps(bench.baseline_c2_leg(ModelDims(), 0, bench.noam_lr, default_train_config()["optimizer"], iters=int(os.environ.get("C2_ITERS", "10")),
+                                   modes=tuple(os.environ.get("C2_MODES", "fp32,bf16").split(",")))))
