@@ -191,6 +191,8 @@ public:
     long long n_shadow = 0;
     const float* shadow_fast_src = nullptr;      // the fast-weight copy the fast shadows were made from
     bool planes_ready = false;
+    hipEvent_t ev_shadow = nullptr;
+    bool shadow_wait = false;                    // an asynchronous refresh is in flight: the next shadow reader waits for ev_shadow
     bool planes_wanted = true;                   // numerics mode 1 (planes) vs 2 (bf16 operands rounded in the staging pass only)
     int defer_tasks = 0;                 // task capacity of the deferred buffers (0: not available)
     hipStream_t side = nullptr;
@@ -830,6 +832,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         hipMemset(arena_h, 0, arena_bytes / 2 + 64);
         if (arena_defer_h) hipMemset(arena_defer_h, 0, arena_defer_bytes / 2 + 64);
+        if (hipEventCreate(&ev_shadow) != hipSuccess) ev_shadow = nullptr;
         planes_ready = true;
         return 0;
     }
@@ -837,6 +840,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (void* q : {(void*)arena_h, (void*)arena_defer_h, (void*)sh_theta_f, (void*)sh_theta_t, (void*)sh_fast_f, (void*)sh_fast_t,
                         (void*)d_ents_all, (void*)d_ents_theta, (void*)d_ents_fast})
             if (q) hipFree(q);
+        if (ev_shadow) hipEventDestroy(ev_shadow);
+        ev_shadow = nullptr;
         arena_h = arena_defer_h = sh_theta_f = sh_theta_t = sh_fast_f = sh_fast_t = nullptr;
         planes_ready = false;
     }
@@ -845,10 +850,21 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         return on && planes_ready && planes_wanted && gx.bf16;
     }
     // the weights this pass reads -> their shadows
-    void refresh_shadows(const Pass& ps) {
+    // async: on the second side stream (idle outside an encoder run-ahead), beside the pass's first kernels; the first conv that reads a
+    // shadow waits for it (shadow_wait)
+    void refresh_shadows(const Pass& ps, bool async = false) {
         if (!planes_on()) return;
+        hipStream_t st = stream;
+        async = async && side2 != nullptr && ev_shadow != nullptr;
+        if (async) {
+            hipEvent_t ev = ev_side[ev_next];
+            ev_next = (ev_next + 1) % kSideEvents;
+            hipEventRecord(ev, stream);          // (after whatever last wrote the weights on this stream: the optimizer, the inner update)
+            hipStreamWaitEvent(side2, ev, 0);
+            st = side2;
+        }
         auto run = [&](const ShadowEnt* ents, int n, int tiles, const float* src, long long src_ts, bf16_t* f, bf16_t* t, long long dst_ts, int nt) {
-            if (n > 0) MTTS_LAUNCH(weight_shadow_kernel, dim3((unsigned)tiles, 1, (unsigned)nt), dim3(256), stream, ents, n, src, src_ts, f, t, dst_ts);
+            if (n > 0) MTTS_LAUNCH(weight_shadow_kernel, dim3((unsigned)tiles, 1, (unsigned)nt), dim3(256), st, ents, n, src, src_ts, f, t, dst_ts);
         };
         if (ps.use_fast && n_adapt > 0) {
             run(d_ents_theta, n_ents_theta, tiles_theta, theta, 0, sh_theta_f, sh_theta_t, 0, 1);
@@ -857,7 +873,9 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         } else {
             run(d_ents_all, n_ents_all, tiles_all, theta, 0, sh_theta_f, sh_theta_t, 0, 1);
         }
+        if (async) { hipEventRecord(ev_shadow, side2); shadow_wait = true; }
     }
+    void await_shadows() { if (shadow_wait) { hipStreamWaitEvent(stream, ev_shadow, 0); shadow_wait = false; } }
     struct HP { const bf16_t* p; long long ts; };
     // shadow of the weight behind W(ps, off) (tr: the input-gradient layout); null when there is none or it is not current
     HP Wh(const Pass& ps, TS w, bool tr) const {
@@ -1271,8 +1289,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
 
     // Y[M,N] = conv_k(X)[M, k*Cin] * W[N][k*Cin]^T + b   (k = 1: Linear)
     // (x2, w2): second source of a dual-source launch, y = conv(x; w) + conv(x2; w2) (GemmArgs::A2 — the tangent pairs of engine_so.inc)
+    // x_plane: x's operand plane is current (its producer wrote it); y_twin: write y's plane in the epilogue (bf16 mode, see H())
     void conv_fwd(const Pass& ps, Space s, TS x, int cin, int k, TS w, TS b, int cout, TS y, int flags,
-                  const unsigned char* rowmask, TS relu_ref = TS{nullptr, 0}, TS x2 = TS{nullptr, 0}, TS w2 = TS{nullptr, 0}) {
+                  const unsigned char* rowmask, TS relu_ref = TS{nullptr, 0}, TS x2 = TS{nullptr, 0}, TS w2 = TS{nullptr, 0},
+                  bool x_plane = false, bool y_twin = false) {
         const Plan& p = *ps.pl;
         GemmArgs g = rowgemm(p, s, GEMM_NT);
         const int pad = k / 2;
@@ -1289,29 +1309,33 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (!x2.p) {   // bf16 mode: the operands' planes (the weight's shadow + the input slab's twin), where both exist
             const HP wh = Wh(ps, w, false);
             if (wh.p) {
-                const bf16_t* xh = make_plane(x, cin, p.tasks);
-                if (xh) { g.Ah = xh - (long long)pad * cin; g.Bh = wh.p; g.bh_gs = wh.ts; }
+                const bf16_t* xh = x_plane ? H(x.p) : make_plane(x, cin, p.tasks);
+                if (xh) { g.Ah = xh - (long long)pad * cin; g.Bh = wh.p; g.bh_gs = wh.ts; await_shadows(); }
             }
         }
+        if (y_twin) g.Ch = H(y.p);
         gemm_launch(gx, GEMM_NT, g, maxM(p, s), cout, p.tasks, stream, 0, nsrc * 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s),
                     4.0 * (alg_rows(p, s) * (nsrc * cin + cout) + nsrc * (double)p.tasks * cout * k * cin));
     }
     // dX[M,Cin] (+)= sum_taps dY[M +- tap, Cout] * W  (conv dgrad over the same [Cout][k][Cin] image)
     void conv_dgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS w, int cin, TS dx, int flags,
-                    const unsigned char* rowmask, TS relu_ref = TS{nullptr, 0}, TS dy2 = TS{nullptr, 0}, TS w2 = TS{nullptr, 0}) {
+                    const unsigned char* rowmask, TS relu_ref = TS{nullptr, 0}, TS dy2 = TS{nullptr, 0}, TS w2 = TS{nullptr, 0},
+                    bool dy_plane = false, bool dx_twin = false) {
         const Plan& p = *ps.pl;
         const int pad = k / 2;
         if (!dy2.p) {
             // bf16 mode with planes: dX = conv(dY; flipped transposed W) as an NT problem over the weight's input-gradient shadow — the
             // forward conv's kernel path with Cin and Cout exchanged (weight_shadow_kernel)
             const HP wt = Wh(ps, w, true);
-            const bf16_t* dyh = wt.p ? make_plane(dy, cout, p.tasks) : nullptr;
+            const bf16_t* dyh = !wt.p ? nullptr : (dy_plane ? H(dy.p) : make_plane(dy, cout, p.tasks));
             if (dyh) {
+                await_shadows();
                 GemmArgs g = rowgemm(p, s, GEMM_NT);
                 g.A = dy.p - (long long)pad * cout; g.a_gs = dy.ts; g.lda = cout;
                 g.Ah = dyh - (long long)pad * cout;
                 g.B = nullptr; g.b_gs = 0; g.ldb = k * cout; g.Bh = wt.p; g.bh_gs = wt.ts; g.plane_only = true;
                 g.C = dx.p; g.c_gs = dx.ts; g.ldc = cin;
+                if (dx_twin) g.Ch = H(dx.p);
                 g.N = cin; g.K = k * cout;
                 g.flags = flags;
                 g.rowmask = rowmask; g.rowmask_gs = row_ts(s);
@@ -1327,6 +1351,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         g.B = w.p; g.b_gs = w.ts; g.ldb = k * cin;
         if (dy2.p) { g.A2 = dy2.p - (long long)pad * cout; g.a2_gs = dy2.ts; g.B2 = w2.p; g.b2_gs = w2.ts; }
         g.C = dx.p; g.c_gs = dx.ts; g.ldc = cin;
+        if (dx_twin) g.Ch = H(dx.p);
         g.N = cin; g.K = k * cout;
         g.taps = k; g.tap_k = cout; g.tap_bstride = cin;
         g.flags = flags;
@@ -1391,12 +1416,13 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         colreduce(p, a, out.p, nullptr, out.ts, maxM(p, s), on_side);
     }
     void ln_fwd(const Pass& ps, Space s, TS a, TS res, long long g_off, long long b_off, const unsigned char* mask,
-                TS zout, TS y, TS st, int C, DropSpec din = DropSpec(), DropSpec dout = DropSpec()) {
+                TS zout, TS y, TS st, int C, DropSpec din = DropSpec(), DropSpec dout = DropSpec(), bool y_twin = false) {
+        // y_twin: bf16 mode — also write y's operand plane (H(y)): the next conv reads it instead of a conversion pass
         const Plan& p = *ps.pl;
         TS gm = W(ps, g_off), bt = W(ps, b_off);
         MTTS_LAUNCH_LN(layernorm_fwd_kernel, C, row2_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
                     (const float*)a.p, a.ts, (const float*)res.p, res.ts, (const float*)gm.p, (const float*)bt.p, gm.ts, mask,
-                    row_ts(s), zout.p, zout.ts, y.p, y.ts, st.p, st.ts, C, 1e-5f, din, dout);
+                    row_ts(s), zout.p, zout.ts, y.p, y.ts, st.p, st.ts, C, 1e-5f, din, dout, y_twin ? H(y.p) : (bf16_t*)nullptr);
     }
     // dz = LayerNorm backward (masked); parameter grads into the per-task grad buffer
     // dz_drop: second output = dropout(dz) with the forward site's mask; copy_always: written even when dropout is off (a plain copy)
@@ -1406,15 +1432,18 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     //       folds them later on the side stream (deferred parameter gradients)
     void ln_bwd(const Pass& ps, Space s, TS dy, TS z, TS st, long long g_off, long long b_off, const unsigned char* mask,
                 TS dz, int C, int relu_on_z, TS dz_drop = TS{nullptr, 0}, DropSpec dd = DropSpec(), bool copy_always = false,
-                float* part = nullptr, DropSpec din = DropSpec()) {
+                float* part = nullptr, DropSpec din = DropSpec(), int twin_sel = 0) {
+        // twin_sel: bf16 mode — also write the operand plane of dz (1) or of dz_drop (2)
         const Plan& p = *ps.pl;
         TS gm = W(ps, g_off);
         const int chunks = ln_chunks(maxM(p, s));
         float* pbuf = part ? part : col_partial;
+        bf16_t* twin = twin_sel == 1 ? H(dz.p) : (twin_sel == 2 ? H(dz_drop.p) : nullptr);
+        if (!twin) twin_sel = 0;
         MTTS_LAUNCH_LN(layernorm_bwd_kernel, C, row2_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
                     (const float*)dy.p, dy.ts, (const float*)z.p, z.ts, (const float*)st.p, st.ts, (const float*)gm.p, gm.ts,
                     mask, row_ts(s), dz.p, dz.ts, C, relu_on_z, (dd.thr16 || copy_always) ? dz_drop.p : nullptr, dz_drop.ts, dd,
-                    din, pbuf, chunks);
+                    din, pbuf, chunks, twin, twin_sel);
         if (!part) ln_fold(p, s, pbuf, chunks, g_off, b_off, C, stream);
     }
     // stage 2 of a LayerNorm's gamma / beta reduction: fold the backward kernel's partial rows
@@ -1463,7 +1492,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         const AttnSeq* seqs = (s == SP_P) ? p.enc_seqs : p.dec_seqs;
         // scaled-dot-product attention (Modules.py:14-25): ONE fused launch (attention.h) — the score tile of 32 query rows lives in LDS
         // between Q K^T, the softmax and P V; the probabilities go to HBM once, for the backward.  MTTS_FUSED_ATTN=0 (A/B runs), the bf16
-        // numerics mode and sequences beyond 1024 keys take the three-launch form: grouped GEMM, softmax kernel, grouped GEMM.
+        // numerics mode (measured on C2: 7.28 ms with this fp32 kernel, 7.15 ms with bf16 grouped GEMMs around the softmax kernel) and
+        // sequences beyond 1024 keys take the three-launch form: grouped GEMM, softmax kernel, grouped GEMM.
         static const bool fused_attn = [] { const char* e = getenv("MTTS_FUSED_ATTN"); return e ? atoi(e) != 0 : true; }();
         if (fused_attn && !gx.bf16 && attn_fused_ok(L, dk) && groups > 0) {
             AttnFwdArgs fa;
@@ -1494,9 +1524,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         conv_fwd(ps, s, b.O, d, 1, W(ps, P.wfc), W(ps, P.bfc), d, b.z1, 0, nullptr);
         // self.dropout(self.fc(output)) + residual -> LayerNorm (SubLayers.py:54-55): the dropout rides in the LayerNorm kernel
-        ln_fwd(ps, s, b.z1, xin, P.ln1g, P.ln1b, vm, b.z1, b.y1, b.st1, d, drop_spec(ps, block_dropout(s), site_base));
-        conv_fwd(ps, s, b.y1, d, cfg.k1, W(ps, P.w1), W(ps, P.b1), cfg.d_ff, b.h, GEMM_RELU, im);
-        conv_fwd(ps, s, b.h, cfg.d_ff, cfg.k2, W(ps, P.w2), W(ps, P.b2), d, b.z2, 0, nullptr);
+        // (bf16 mode: y1's and h's operand planes are written by their producers — the LayerNorm kernel, conv1's epilogue)
+        ln_fwd(ps, s, b.z1, xin, P.ln1g, P.ln1b, vm, b.z1, b.y1, b.st1, d, drop_spec(ps, block_dropout(s), site_base), DropSpec(), true);
+        conv_fwd(ps, s, b.y1, d, cfg.k1, W(ps, P.w1), W(ps, P.b1), cfg.d_ff, b.h, GEMM_RELU, im, TS{nullptr, 0}, TS{nullptr, 0}, TS{nullptr, 0}, true, true);
+        conv_fwd(ps, s, b.h, cfg.d_ff, cfg.k2, W(ps, P.w2), W(ps, P.b2), d, b.z2, 0, nullptr, TS{nullptr, 0}, TS{nullptr, 0}, TS{nullptr, 0}, true, false);
         // self.dropout(output) + residual -> LayerNorm (SubLayers.py:90-91)
         ln_fwd(ps, s, b.z2, b.y1, P.ln2g, P.ln2b, vm, b.z2, b.y2, b.st2, d, drop_spec(ps, block_dropout(s), site_base + 1));
     }
@@ -1518,19 +1549,21 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         // LN2 (+ row mask) backward -> g1 = dz2
         TS gm = (s == SP_P) ? gPm : gFm;                                   // masked copy feeds the conv branch, g1 the residual
         const DropSpec dd2 = drop_spec(ps, block_dropout(s), site_base + 1);
-        ln_bwd(ps, s, g0_in, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0, df ? lg->dc : gm, dd2, df, df ? lg->part2 : nullptr);
+        // (bf16 mode: the plane of dc — whichever of the kernel's two outputs that is — and, below, gh's by conv2's epilogue)
+        ln_bwd(ps, s, g0_in, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0, df ? lg->dc : gm, dd2, df, df ? lg->part2 : nullptr, DropSpec(),
+               (df || dd2.thr16) ? 2 : 1);
         TS dc = df ? lg->dc : (dd2.thr16 ? gm : g1);
         // conv2
         {   // wgrad and dgrad of a layer are independent: one multi-problem launch (gemm.h: gemm_f32_multi_kernel)
             GemmBatchScope pair(gx, stream);
             if (!df) conv_wgrad(ps, s, dc, d, cfg.k2, b.h, ff, P.w2, P.b2, vm);
-            conv_dgrad(ps, s, dc, d, cfg.k2, W(ps, P.w2), ff, gh, 0, im, b.h);
+            conv_dgrad(ps, s, dc, d, cfg.k2, W(ps, P.w2), ff, gh, 0, im, b.h, TS{nullptr, 0}, TS{nullptr, 0}, true, true);
         }
         // conv1: g1 += dgrad -> dy1
         {
             GemmBatchScope pair(gx, stream);
             if (!df) conv_wgrad(ps, s, gh, ff, cfg.k1, b.y1, d, P.w1, P.b1, im);
-            conv_dgrad(ps, s, gh, ff, cfg.k1, W(ps, P.w1), d, g1, GEMM_ACCUM, im);
+            conv_dgrad(ps, s, gh, ff, cfg.k1, W(ps, P.w1), d, g1, GEMM_ACCUM, im, TS{nullptr, 0}, TS{nullptr, 0}, TS{nullptr, 0}, true, false);
         }
         // LN1 backward -> g0 = dz1
         const DropSpec dd1 = drop_spec(ps, block_dropout(s), site_base);
@@ -1800,7 +1833,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         const int d = cfg.d_model, nt = p.tasks;
         TS none{nullptr, 0};
         if (ps.train) ps.pl->drop_seed = ps.seed_override ? ps.seed_override : next_drop_seed();
-        refresh_shadows(ps);   // (bf16 mode: the weight shadows this pass and its backward read)
+        refresh_shadows(ps, !ps.enc_out.p);   // (bf16 mode: the weight shadows this pass and its backward read)
         // encoder
         TS x = ps.enc_out.p ? ps.enc_out : encoder_fwd(ps);
         // speaker vector, added on every position of the phoneme rectangle
@@ -1923,7 +1956,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (int i = 0; i < cfg.postnet_layers; ++i) {
             const PostP& P = postP[i];
             PostBuf& b = postB[i];
-            conv_fwd(ps, SP_R, cur, P.cin, cfg.postnet_kernel, W(ps, P.w), W(ps, P.b), P.cout, b.c, 0, p.r_inrect);
+            conv_fwd(ps, SP_R, cur, P.cin, cfg.postnet_kernel, W(ps, P.w), W(ps, P.b), P.cout, b.c, 0, p.r_inrect, TS{nullptr, 0}, TS{nullptr, 0},
+                     TS{nullptr, 0}, i > 0, false);   // (bf16 mode: the previous layer's bn_apply wrote its output's operand plane)
             if (ps.train) {
                 ColArgs ca;
                 ca.X = b.c.p; ca.x_ts = b.c.ts; ca.mask = p.r_inrect; ca.mask_ts = row_ts_r; ca.C = P.cout; ca.mode = 2;
@@ -1942,7 +1976,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             MTTS_LAUNCH(bn_apply_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (const float*)b.c.p, b.c.ts,
                         (const float*)b.stats.p, b.stats.ts, (const float*)gm.p, (const float*)bt.p, gm.ts,
                         (const unsigned char*)p.r_inrect, row_ts_r, (int)(i < cfg.postnet_layers - 1), b.a.p, b.a.ts, P.cout,
-                        drop_spec(ps, cfg.postnet_dropout, 192 + i));  // F.dropout(..., 0.5, self.training), Layers.py:133-134, in passing
+                        drop_spec(ps, cfg.postnet_dropout, 192 + i),   // F.dropout(..., 0.5, self.training), Layers.py:133-134, in passing
+                        i + 1 < cfg.postnet_layers ? H(b.a.p) : (bf16_t*)nullptr);
             cur = b.a;
         }
         set_tag(0);
@@ -2082,7 +2117,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             MTTS_LAUNCH(bn_bwd_apply_kernel, row_grid(p.maxMr, nt), dim3(256), stream, (const int*)p.meta, (const float*)cur.p,
                         cur.ts, (const float*)b.a.p, b.a.ts, (const float*)b.c.p, b.c.ts, (const float*)b.stats.p, b.stats.ts,
                         (const float*)gm.p, gm.ts, (const float*)dgm.p, (const float*)dbt.p, dgm.ts,
-                        (const unsigned char*)p.r_inrect, row_ts_r, act, dc.p, dc.ts, P.cout, ysc, pdrop);
+                        (const unsigned char*)p.r_inrect, row_ts_r, act, dc.p, dc.ts, P.cout, ysc, pdrop, H(dc.p));
             TS xin = (i == 0) ? mel : postB[i - 1].a;
             if (dfp) {   // this layer's weight gradient on the side stream, overlapping the rest of the backward chain
                 fork_side();
@@ -2093,7 +2128,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             GemmBatchScope pair(gx, stream);
             if (!dfp) conv_wgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, xin, P.cin, P.w, P.b, p.r_inrect);
             if (i > 0) {
-                conv_dgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, W(ps, P.w), P.cin, K.post_cur[i - 1], 0, p.r_inrect);
+                conv_dgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, W(ps, P.w), P.cin, K.post_cur[i - 1], 0, p.r_inrect, TS{nullptr, 0}, TS{nullptr, 0},
+                           TS{nullptr, 0}, true, false);
                 cur = K.post_cur[i - 1];
             } else {
                 // dL/d(mel) total = direct L1 term + residual path + PostNet input gradient
@@ -2101,7 +2137,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                 MTTS_LAUNCH(add2_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), stream,
                             (const float*)(gRm.p - (long long)G * nm), (const float*)(gRp.p - (long long)G * nm),
                             gRm.p - (long long)G * nm, n4);
-                conv_dgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, W(ps, P.w), P.cin, gRm, GEMM_ACCUM, p.r_inrect);
+                conv_dgrad(ps, SP_R, dc, P.cout, cfg.postnet_kernel, W(ps, P.w), P.cin, gRm, GEMM_ACCUM, p.r_inrect, TS{nullptr, 0}, TS{nullptr, 0},
+                           TS{nullptr, 0}, true, false);
             }
         }
         // ---- mel_linear -------------------------------------------------------------------

@@ -792,7 +792,9 @@ enum GemmKind {
     GK_BF16_128 = 22,     // + form: gemm_bf16_kernel<F, 128, 128, 32, PF>
     GK_BF16_MULTI64 = 25, GK_BF16_MULTI128 = 26, GK_BF16_MULTI64_DUAL = 27, GK_BF16_MULTI128_DUAL = 28,
     GK_ATTN_FWD = 29,     // attention.h: the fused QK^T -> softmax -> PV forward (both products' flops)
-    GK_COUNT = 30
+    GK_BF16_64_H64 = 30, GK_BF16_64_H32 = 31, GK_BF16_128_H = 32,   // gemm_bf16_kernel<GEMM_NT_H, ...>: NT staged from bf16 operand planes
+    GK_BF16_MULTI64_PLANES = 33,                                      // gemm_bf16_multi_planes_kernel: a multi-problem launch that carries plane problems
+    GK_COUNT = 34
 };
 inline const char* gemm_kind_name(int k) {
     static const char* names[GK_COUNT] = {
@@ -805,7 +807,9 @@ inline const char* gemm_kind_name(int k) {
         "gemm_bf16_kernel<0, 64, 64, 32, 1>", "gemm_bf16_kernel<1, 64, 64, 32, 1>", "gemm_bf16_kernel<2, 64, 64, 32, 1>",
         "gemm_bf16_kernel<0, 128, 128, 32, 1>", "gemm_bf16_kernel<1, 128, 128, 32, 1>", "gemm_bf16_kernel<2, 128, 128, 32, 1>",
         "gemm_bf16_multi_kernel<64, 64, 32, 1, false>", "gemm_bf16_multi_kernel<128, 128, 32, 1, false>",
-        "gemm_bf16_multi_kernel<64, 64, 32, 1, true>", "gemm_bf16_multi_kernel<128, 128, 32, 1, true>", "attn_fwd_kernel"};
+        "gemm_bf16_multi_kernel<64, 64, 32, 1, true>", "gemm_bf16_multi_kernel<128, 128, 32, 1, true>", "attn_fwd_kernel",
+        "gemm_bf16_kernel<3, 64, 64, 64, 1>", "gemm_bf16_kernel<3, 64, 64, 32, 1>", "gemm_bf16_kernel<3, 128, 128, 32, 1>",
+        "gemm_bf16_multi_planes_kernel<64, 64, 32, 64, 1>"};
     return (k >= 0 && k < GK_COUNT) ? names[k] : "?";
 }
 
@@ -907,8 +911,8 @@ inline void gemm_glds_multi_launch(const GemmMulti& mp, dim3 grid, hipStream_t s
 // bf16 operand family (gemm_bf16.h)
 inline bool gemm_bf16_ok(const GemmArgs& g);
 inline bool gemm_bf16_planes_ok(int form, const GemmArgs& g);
-inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipStream_t stream, int pf);
-inline void gemm_bf16_multi_launch(const GemmMulti& mp, int T, bool dual, dim3 grid, hipStream_t stream);
+inline int gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipStream_t stream, int pf);      // returns the GemmKind launched
+inline int gemm_bf16_multi_launch(const GemmMulti& mp, int T, bool dual, dim3 grid, hipStream_t stream);
 // block tile of a bf16 launch: 128x128 once the launch still fills the chip twice over with it (the MFMA rate is 16x the fp32 kernels':
 // a 64x64 tile moves 1 byte per 16 flop through the L2 -> LDS path), 64x64 for under-filled launches
 inline int gemm_bf16_tile(double rows, int tiles_n128) { return std::ceil(rows / 128.0) * tiles_n128 >= 512.0 ? 128 : 64; }
@@ -1035,8 +1039,7 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     }
     if (bf16) {
         if (g.Ah) ++cx.plane_problems;
-        gemm_bf16_launch(form, g, tile, grid, stream, (user_tile % 10000) / 1000);   // (bf16 tile codes: T + 1000 * slices in flight, 0 = default)
-        kind = (tile == 128 ? GK_BF16_128 : GK_BF16_64) + form;
+        kind = gemm_bf16_launch(form, g, tile, grid, stream, (user_tile % 10000) / 1000);   // (bf16 tile codes: T + 1000 * slices in flight, 0 = default)
     } else
 #if !defined(MTTS_EMU)
     if (glds) {
@@ -1170,8 +1173,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     int kind = GK_MULTI16;
     if (bf16) {
         for (int i = 0; i < mp.n; ++i) if (mp.g[i].Ah) ++cx.plane_problems;
-        gemm_bf16_multi_launch(mp, T, any_dual, grid, stream);
-        kind = T == 128 ? (any_dual ? GK_BF16_MULTI128_DUAL : GK_BF16_MULTI128) : (any_dual ? GK_BF16_MULTI64_DUAL : GK_BF16_MULTI64);
+        kind = gemm_bf16_multi_launch(mp, T, any_dual, grid, stream);
         glds = false;
     } else
 #if !defined(MTTS_EMU)

@@ -402,6 +402,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_multi_kernel(GemmMulti mp) {
     else gemm_bf16_body<GEMM_TN, BM, BN, BK, PF, DUAL>(mp.g[p], z, bx, smem);
 }
 
+// a multi-problem launch that carries plane problems (non-dual, 64x64): the plane K-loop runs at HBK (64: whole 128-byte lines per row and
+// slice) in an LDS allocation sized for it; the launch's other problems keep BK.  A kernel of its own: launches without planes keep the
+// smaller allocation (7 instead of 4 workgroups per CU).
+template <int BM, int BN, int BK, int HBK, int PF>
+__global__ __launch_bounds__(256) void gemm_bf16_multi_planes_kernel(GemmMulti mp) {
+    constexpr int F0 = GemmBf16Smem<BM, BN, BK>::FLOATS, F1 = GemmBf16Smem<BM, BN, HBK>::FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[F0 > F1 ? F0 : F1];
+    int p, z, bx;
+    if (!gemm_multi_locate(mp, p, z, bx)) return;
+    const int form = mp.form[p];
+    if (form == GEMM_NT) {
+        if (mp.g[p].Ah != nullptr) gemm_bf16_body<GEMM_NT_H, BM, BN, HBK, PF, false>(mp.g[p], z, bx, smem);
+        else gemm_bf16_body<GEMM_NT, BM, BN, BK, PF, false>(mp.g[p], z, bx, smem);
+    } else if (form == GEMM_NN) gemm_bf16_body<GEMM_NN, BM, BN, BK, PF, false>(mp.g[p], z, bx, smem);
+    else gemm_bf16_body<GEMM_TN, BM, BN, BK, PF, false>(mp.g[p], z, bx, smem);
+}
+
 constexpr int kBf16BK = 32;
 // slices in flight per workgroup.  Measured (profiles/r04_bf16_gemm_microbench.md): 1 / 2 / 4 slices in flight make NO difference on
 // under-filled launches (hipcc drains vmcnt(0) in front of every conversion pass, and a CU sustains ~64 outstanding lines whatever is
@@ -421,7 +438,7 @@ inline bool gemm_bf16_planes_ok(int form, const GemmArgs& g) {
            g.K % 8 == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0;
 }
 // stand-alone launch of one problem; T = 64 / 128; pf: 0 = the default depth, else an explicit one (MTTS_BF16_PF_SWEEP builds only)
-inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipStream_t stream, int pf_req = 0) {
+inline int gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipStream_t stream, int pf_req = 0) {
     int pf = 0; (void)pf_req;
     dim3 block(256);
     pf = T == 128 ? kBf16PF128 : kBf16PF64;   // (explicit depths exist in MTTS_BF16_PF_SWEEP builds only)
@@ -429,11 +446,13 @@ inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipS
     if (pf_req) pf = pf_req;
 #endif
     if (form == GEMM_NT && g.Ah != nullptr) {   // both planes exist (gemm_bf16_planes_ok): the plane-staged K-loop
-        if (T == 128) MTTS_LAUNCH((gemm_bf16_kernel<GEMM_NT_H, 128, 128, kBf16BK, 1>), grid, block, stream, g);
-        else MTTS_LAUNCH((gemm_bf16_kernel<GEMM_NT_H, 64, 64, kBf16BK, 1>), grid, block, stream, g);
-        return;
+        static const int plane_bk = [] { const char* e = getenv("MTTS_PLANE_BK"); return e ? atoi(e) : 64; }();
+        if (T == 128) { MTTS_LAUNCH((gemm_bf16_kernel<GEMM_NT_H, 128, 128, kBf16BK, 1>), grid, block, stream, g); return GK_BF16_128_H; }
+        if (plane_bk == 64 && g.K >= 512) { MTTS_LAUNCH((gemm_bf16_kernel<GEMM_NT_H, 64, 64, 64, 1>), grid, block, stream, g); return GK_BF16_64_H64; }   // whole 128-byte lines per row and slice
+        MTTS_LAUNCH((gemm_bf16_kernel<GEMM_NT_H, 64, 64, kBf16BK, 1>), grid, block, stream, g);
+        return GK_BF16_64_H32;
     }
-#define MTTS_BF16_CASE(F, TT, PP) if (form == F && T == TT && pf == PP) { MTTS_LAUNCH((gemm_bf16_kernel<F, TT, TT, kBf16BK, PP>), grid, block, stream, g); return; }
+#define MTTS_BF16_CASE(F, TT, PP) if (form == F && T == TT && pf == PP) { MTTS_LAUNCH((gemm_bf16_kernel<F, TT, TT, kBf16BK, PP>), grid, block, stream, g); return (TT == 128 ? GK_BF16_128 : GK_BF16_64) + F; }
 #define MTTS_BF16_FORMS(TT, PP) MTTS_BF16_CASE(GEMM_NT, TT, PP) MTTS_BF16_CASE(GEMM_NN, TT, PP) MTTS_BF16_CASE(GEMM_TN, TT, PP)
     MTTS_BF16_FORMS(64, 1) MTTS_BF16_FORMS(128, 1)
 #if defined(MTTS_BF16_PF_SWEEP)   // explicit slices-in-flight variants for micro-benchmarks (tile code T + 1000 * PF)
@@ -441,16 +460,25 @@ inline void gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipS
 #endif
 #undef MTTS_BF16_FORMS
 #undef MTTS_BF16_CASE
+    return GK_OTHER;
 }
-inline void gemm_bf16_multi_launch(const GemmMulti& mp, int T, bool dual, dim3 grid, hipStream_t stream) {
+inline int gemm_bf16_multi_launch(const GemmMulti& mp, int T, bool dual, dim3 grid, hipStream_t stream) {
     dim3 block(256);
     if (T == 128) {
         if (dual) MTTS_LAUNCH((gemm_bf16_multi_kernel<128, 128, kBf16BK, kBf16PF128, true>), grid, block, stream, mp);
         else MTTS_LAUNCH((gemm_bf16_multi_kernel<128, 128, kBf16BK, kBf16PF128, false>), grid, block, stream, mp);
-    } else {
-        if (dual) MTTS_LAUNCH((gemm_bf16_multi_kernel<64, 64, kBf16BK, kBf16PF64, true>), grid, block, stream, mp);
-        else MTTS_LAUNCH((gemm_bf16_multi_kernel<64, 64, kBf16BK, kBf16PF64, false>), grid, block, stream, mp);
+        return dual ? GK_BF16_MULTI128_DUAL : GK_BF16_MULTI128;
     }
+    bool planes = false;
+    for (int i = 0; i < mp.n; ++i) planes = planes || mp.g[i].Ah != nullptr;
+    static const int plane_bk = [] { const char* e = getenv("MTTS_PLANE_BK"); return e ? atoi(e) : 64; }();
+    if (planes && !dual && plane_bk == 64) {
+        MTTS_LAUNCH((gemm_bf16_multi_planes_kernel<64, 64, kBf16BK, 64, kBf16PF64>), grid, block, stream, mp);
+        return GK_BF16_MULTI64_PLANES;
+    }
+    if (dual) MTTS_LAUNCH((gemm_bf16_multi_kernel<64, 64, kBf16BK, kBf16PF64, true>), grid, block, stream, mp);
+    else MTTS_LAUNCH((gemm_bf16_multi_kernel<64, 64, kBf16BK, kBf16PF64, false>), grid, block, stream, mp);
+    return dual ? GK_BF16_MULTI64_DUAL : GK_BF16_MULTI64;
 }
 
 }  // namespace mtts

@@ -87,6 +87,12 @@ __device__ __forceinline__ float4 drop4(const DropSpec& d, int z, int row, int C
         else { MTTS_LAUNCH((kernel<4>), grid, block, stream, __VA_ARGS__); }                           \
     } while (0)
 
+// four values of a row and their bf16 twin (the operand plane a GEMM of the bf16 numerics mode reads instead: gemm_bf16.h)
+__device__ __forceinline__ void st4_bf16(bf16_t* p, float4 v) {
+    const unsigned lo = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16), hi = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<unsigned long long*>(p) = (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
+
 inline dim3 row2_grid(int max_rows, int tasks) { return dim3((unsigned)((max_rows + 7) / 8), 1, (unsigned)tasks); }
 
 // NV = float4 a lane holds per row (1: C <= 256, 4: C <= 1024): a compile-time bound keeps the row in VGPRs (with a runtime
@@ -96,7 +102,8 @@ __global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a
                                      long long res_ts, const float* gamma, const float* beta, long long par_ts,
                                      const unsigned char* mask, long long mask_ts, float* z_out, long long z_ts,
                                      float* y, long long y_ts, float* stats, long long st_ts, int C, float eps,
-                                     DropSpec din, DropSpec dout) {
+                                     DropSpec din, DropSpec dout, bf16_t* yh) {
+    // yh (optional): bf16 twin of y, same layout
     // din: dropout applied to `a` before the residual add (self.dropout(sublayer(x)) + residual, SubLayers.py:54-55,90-91);
     // dout: dropout applied to the normalised output (LayerNorm -> Dropout of the variance predictors, modules.py:222-235)
     ROW2_PROLOGUE(mfield)
@@ -157,6 +164,7 @@ __global__ void layernorm_fwd_kernel(const int* meta, int mfield, const float* a
                 if (dout.thr16) o = drop4(dout, z, row, C, c, o);
             }
             st4(py + c, o);
+            if (yh) st4_bf16(yh + (long long)z * y_ts + (long long)row * C + c, o);
         }
         if (lane == 0) {
             float* st = stats + (long long)z * st_ts + (long long)row * 2;
@@ -179,7 +187,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const int* meta, int
                                      long long z_ts, const float* stats, long long st_ts, const float* gamma,
                                      long long par_ts, const unsigned char* mask, long long mask_ts, float* dz,
                                      long long dz_ts, int C, int relu_on_z, float* dz_drop, long long dzd_ts, DropSpec dd,
-                                     DropSpec din, float* partial, int max_chunks) {
+                                     DropSpec din, float* partial, int max_chunks, bf16_t* twin, int twin_sel) {
+    // twin / twin_sel: bf16 twin of dz (1) or of dz_drop (2), same layout as its fp32 buffer; 0: none
     // dz_drop (optional): dropout(dz) with the mask of the forward site — the gradient entering the dropped branch, while dz
     // itself continues along the residual path
     __shared__ __attribute__((aligned(16))) float red[4][2][256 * NV];
@@ -248,7 +257,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const int* meta, int
             }
             if (!keep[q]) o = zero4();
             st4(pd + c, o);
-            if (dz_drop) st4(dz_drop + (long long)z * dzd_ts + (long long)row * C + c, drop4(dd, z, row, C, c, o));
+            if (twin_sel == 1) st4_bf16(twin + (long long)z * dz_ts + (long long)row * C + c, o);
+            if (dz_drop) {
+                const float4 od = drop4(dd, z, row, C, c, o);
+                st4(dz_drop + (long long)z * dzd_ts + (long long)row * C + c, od);
+                if (twin_sel == 2) st4_bf16(twin + (long long)z * dzd_ts + (long long)row * C + c, od);
+            }
         }
     }
     if (!partial) return;
@@ -894,7 +908,7 @@ __global__ void bn_eval_stats_kernel(const float* running_mean, const float* run
 // dout: the F.dropout behind every PostNet layer (Layers.py:133-134) applied in passing (it used to be a launch of its own)
 __global__ void bn_apply_kernel(const int* meta, const float* X, long long x_ts, const float* stats, long long st_ts,
                                 const float* gamma, const float* beta, long long par_ts, const unsigned char* inrect,
-                                long long row_ts, int do_tanh, float* Y, long long y_ts, int C, DropSpec dout) {
+                                long long row_ts, int do_tanh, float* Y, long long y_ts, int C, DropSpec dout, bf16_t* Yh) {
     ROW_PROLOGUE(META_MR)
     const bool in = inrect[(long long)z * row_ts + row] != 0;
     const float* px = X + (long long)z * x_ts + (long long)row * C;
@@ -912,6 +926,7 @@ __global__ void bn_apply_kernel(const int* meta, const float* X, long long x_ts,
             if (dout.thr16) o = drop4(dout, z, row, C, c, o);
         }
         st4(py + c, o);
+        if (Yh) st4_bf16(Yh + (long long)z * y_ts + (long long)row * C + c, o);
     }
 }
 
@@ -920,11 +935,15 @@ __global__ void bn_bwd_apply_kernel(const int* meta, const float* dY, long long 
                                     long long ya_ts, const float* X, long long x_ts, const float* stats,
                                     long long st_ts, const float* gamma, long long par_ts, const float* dgamma,
                                     const float* dbeta, long long dg_ts, const unsigned char* inrect,
-                                    long long row_ts, int do_tanh, float* dX, long long dx_ts, int C, float yscale, DropSpec din) {
-    // din: the backward of the dropout behind the layer, applied to dY on load (same mask as the forward's)
+                                    long long row_ts, int do_tanh, float* dX, long long dx_ts, int C, float yscale, DropSpec din, bf16_t* dXh) {
+    // din: the backward of the dropout behind the layer, applied to dY on load (same mask as the forward's); dXh: bf16 twin of dX
     ROW_PROLOGUE(META_MR)
     float* pdx = dX + (long long)z * dx_ts + (long long)row * C;
-    if (!inrect[(long long)z * row_ts + row]) { for (int c = lane * 4; c < C; c += 256) st4(pdx + c, zero4()); return; }
+    bf16_t* pdh = dXh ? dXh + (long long)z * dx_ts + (long long)row * C : nullptr;
+    if (!inrect[(long long)z * row_ts + row]) {
+        for (int c = lane * 4; c < C; c += 256) { st4(pdx + c, zero4()); if (pdh) st4_bf16(pdh + c, zero4()); }
+        return;
+    }
     const float inv_n = 1.f / (float)(meta[z * META_STRIDE + META_B] * meta[z * META_STRIDE + META_TCAP]);
     const float* pdy = dY + (long long)z * dy_ts + (long long)row * C;
     const float* pya = Yact + (long long)z * ya_ts + (long long)row * C;
@@ -953,6 +972,7 @@ __global__ void bn_bwd_apply_kernel(const int* meta, const float* dY, long long 
             o[i] = gs[i] * rr[i] * (dd[i] - dbs[i] * inv_n - xh * dgs[i] * inv_n);
         }
         st4(pdx + c, make_float4(o[0], o[1], o[2], o[3]));
+        if (pdh) st4_bf16(pdh + c, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
