@@ -508,8 +508,11 @@ __device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb
     // tap of the K-slice starting at k0 WITHOUT a runtime integer division per slice (k0 only ever grows inside a workgroup, so
     // a running (tap, tap * tap_k) pair is advanced instead; the division cost ~25 scalar/vector instructions per operand per slice)
     int a_tap_i = 0, a_tap_base = 0, b_tap_i = 0, b_tap_base = 0;
-    auto a_tap_of = [&](int k0) { while (k0 - a_tap_base >= g.a_tap_k) { a_tap_base += g.a_tap_k; ++a_tap_i; } return a_tap_i; };
-    auto b_tap_of = [&](int k0) { while (k0 - b_tap_base >= g.tap_k) { b_tap_base += g.tap_k; ++b_tap_i; } return b_tap_i; };
+    // (the tap geometry in registers: read through `g` inside the K-loop it is re-loaded from the kernel-argument segment every slice, and
+    // the s_waitcnt lgkmcnt(0) behind each scalar load also drains the LDS fragment reads in flight)
+    const int g_a_tap_k = g.a_tap_k, g_tap_k = g.tap_k, g_taps = g.taps, g_tap_bstride = g.tap_bstride, g_a_tap_rows = g.a_tap_rows;
+    auto a_tap_of = [&](int k0) { while (k0 - a_tap_base >= g_a_tap_k) { a_tap_base += g_a_tap_k; ++a_tap_i; } return a_tap_i; };
+    auto b_tap_of = [&](int k0) { while (k0 - b_tap_base >= g_tap_k) { b_tap_base += g_tap_k; ++b_tap_i; } return b_tap_i; };
 
     // Per-thread operand offsets are hoisted out of the K-loop; a slice then costs one uniform 64-bit base per operand
     // (the per-slice 64-bit row * lda multiplies and the exec-mask branches of predicated loads cost ~60 instructions
@@ -548,7 +551,7 @@ __device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb
         }
     }
     long long a_koff = 0, b_koff = 0;   // uniform element offset of the slice the pointers currently address
-    const long long a_tap_stride = (long long)g.a_tap_rows * lda;
+    const long long a_tap_stride = (long long)g_a_tap_rows * lda;
     auto load_a = [&](int k0) {
         const int atap = A_KC ? a_tap_of(k0) : 0;   // 0 unless the operand has dilated taps
         const long long koff = A_KC ? (long long)atap * a_tap_stride + (k0 - a_tap_base) : (long long)k0 * lda;
@@ -569,7 +572,7 @@ __device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb
     };
     auto load_b = [&](int k0) {
         const int tap = B_KC ? 0 : b_tap_of(k0);
-        const long long koff = B_KC ? (long long)k0 : (long long)(g.taps - 1 - tap) * g.tap_bstride + (long long)(k0 - b_tap_base) * ldb;
+        const long long koff = B_KC ? (long long)k0 : (long long)(g_taps - 1 - tap) * g_tap_bstride + (long long)(k0 - b_tap_base) * ldb;
         const long long delta = koff - b_koff;
         b_koff = koff;
 #pragma unroll

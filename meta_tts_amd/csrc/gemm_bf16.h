@@ -196,8 +196,11 @@ __device__ __forceinline__ void gemm_bf16_kloop(const GemmArgs& g, const GemmPro
 
     float4 areg[PF][A_LD4], breg[PF][B_LD4];
     int a_tap_i = 0, a_tap_base = 0, b_tap_i = 0, b_tap_base = 0;
-    auto a_tap_of = [&](int k0) { while (k0 - a_tap_base >= g.a_tap_k) { a_tap_base += g.a_tap_k; ++a_tap_i; } return a_tap_i; };
-    auto b_tap_of = [&](int k0) { while (k0 - b_tap_base >= g.tap_k) { b_tap_base += g.tap_k; ++b_tap_i; } return b_tap_i; };
+    // (the tap geometry in registers: read through `g` inside the K-loop it is re-loaded from the kernel-argument segment every slice, and
+    // the s_waitcnt lgkmcnt(0) behind each scalar load also drains the LDS fragment reads in flight)
+    const int g_a_tap_k = g.a_tap_k, g_tap_k = g.tap_k, g_taps = g.taps, g_tap_bstride = g.tap_bstride, g_a_tap_rows = g.a_tap_rows;
+    auto a_tap_of = [&](int k0) { while (k0 - a_tap_base >= g_a_tap_k) { a_tap_base += g_a_tap_k; ++a_tap_i; } return a_tap_i; };
+    auto b_tap_of = [&](int k0) { while (k0 - b_tap_base >= g_tap_k) { b_tap_base += g_tap_k; ++b_tap_i; } return b_tap_i; };
 
     // per-thread source pointers, hoisted out of the K-loop and advanced by one uniform distance per slice (see gemm_f32_kloop);
     // rows / columns beyond the operand are clamped to the last valid one (their products only reach accumulator entries the epilogue
@@ -231,7 +234,7 @@ __device__ __forceinline__ void gemm_bf16_kloop(const GemmArgs& g, const GemmPro
         }
     }
     long long a_koff = 0, b_koff = 0;
-    const long long a_tap_stride = (long long)g.a_tap_rows * lda;
+    const long long a_tap_stride = (long long)g_a_tap_rows * lda;
     auto load_a = [&](int k0, auto set_c) {
         constexpr int set = decltype(set_c)::value;
         const int atap = A_KC ? a_tap_of(k0) : 0;
@@ -254,7 +257,7 @@ __device__ __forceinline__ void gemm_bf16_kloop(const GemmArgs& g, const GemmPro
     auto load_b = [&](int k0, auto set_c) {
         constexpr int set = decltype(set_c)::value;
         const int tap = B_KC ? 0 : b_tap_of(k0);
-        const long long koff = B_KC ? (long long)k0 : (long long)(g.taps - 1 - tap) * g.tap_bstride + (long long)(k0 - b_tap_base) * ldb;
+        const long long koff = B_KC ? (long long)k0 : (long long)(g_taps - 1 - tap) * g_tap_bstride + (long long)(k0 - b_tap_base) * ldb;
         const long long delta = koff - b_koff;
         b_koff = koff;
 #pragma unroll

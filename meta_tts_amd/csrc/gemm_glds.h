@@ -94,8 +94,11 @@ __device__ __forceinline__ void gemm_glds_kloop(const GemmArgs& g, const GemmPro
     auto is_full = [&](int c) { return kb0 + (c + 1) * BK <= K; };
     // running tap state instead of a runtime integer division per slice (gemm.h: a_tap_of / b_tap_of)
     int a_tap_i = 0, a_tap_base = 0, b_tap_i = 0, b_tap_base = 0;
-    auto a_tap_of = [&](int k0) { while (k0 - a_tap_base >= g.a_tap_k) { a_tap_base += g.a_tap_k; ++a_tap_i; } return a_tap_i; };
-    auto b_tap_of = [&](int k0) { while (k0 - b_tap_base >= g.tap_k) { b_tap_base += g.tap_k; ++b_tap_i; } return b_tap_i; };
+    // (the tap geometry in registers: read through `g` inside the K-loop it is re-loaded from the kernel-argument segment every slice, and
+    // the s_waitcnt lgkmcnt(0) behind each scalar load also drains the LDS fragment reads in flight)
+    const int g_a_tap_k = g.a_tap_k, g_tap_k = g.tap_k, g_taps = g.taps, g_tap_bstride = g.tap_bstride, g_a_tap_rows = g.a_tap_rows;
+    auto a_tap_of = [&](int k0) { while (k0 - a_tap_base >= g_a_tap_k) { a_tap_base += g_a_tap_k; ++a_tap_i; } return a_tap_i; };
+    auto b_tap_of = [&](int k0) { while (k0 - b_tap_base >= g_tap_k) { b_tap_base += g_tap_k; ++b_tap_i; } return b_tap_i; };
     // stage slice c into ring slot st: 4 DMA instructions per wave, or (partial last slice) zero-filled register staging
     auto stage = [&](int c, int st) {
         const int k0 = kb0 + c * BK;
@@ -104,12 +107,12 @@ __device__ __forceinline__ void gemm_glds_kloop(const GemmArgs& g, const GemmPro
         if (is_full(c)) {
             const unsigned sa = lds_base + (unsigned)(st * kGldsStage) * 4u, sb = sa + (unsigned)kGldsTile * 4u;
             const int atap = A_KC ? a_tap_of(k0) : 0;   // dilated taps of a K-contiguous A operand (gemm.h)
-            const float* Ab = A_KC ? A + (long long)atap * g.a_tap_rows * lda + (k0 - a_tap_base) : A + (long long)k0 * lda;
+            const float* Ab = A_KC ? A + (long long)atap * g_a_tap_rows * lda + (k0 - a_tap_base) : A + (long long)k0 * lda;
             const float* Bb;
             if (B_KC) Bb = B + k0;
             else {
                 const int tap = b_tap_of(k0), kin = k0 - b_tap_base;
-                Bb = B + (long long)(g.taps - 1 - tap) * g.tap_bstride + (long long)kin * ldb;
+                Bb = B + (long long)(g_taps - 1 - tap) * g_tap_bstride + (long long)kin * ldb;
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -127,7 +130,7 @@ __device__ __forceinline__ void gemm_glds_kloop(const GemmArgs& g, const GemmPro
                         const int r = idx >> 3, pos = idx & 7, kq = pos ^ ((r >> 1) & 7), gk = k0 + 4 * kq;
                         if (m0 + r < M) {
                             const int atap = a_tap_of(k0);
-                            const float* p = A + ((long long)(m0 + r) + (long long)atap * g.a_tap_rows) * lda + (gk - a_tap_base);
+                            const float* p = A + ((long long)(m0 + r) + (long long)atap * g_a_tap_rows) * lda + (gk - a_tap_base);
                             if (gk + 3 < K) v = ld4(p);
                             else { if (gk < K) v.x = p[0]; if (gk + 1 < K) v.y = p[1]; if (gk + 2 < K) v.z = p[2]; }
                         }
@@ -151,7 +154,7 @@ __device__ __forceinline__ void gemm_glds_kloop(const GemmArgs& g, const GemmPro
                     } else {
                         const int kk = idx >> 4, c4 = (idx & 15) * 4;
                         const int tap = b_tap_of(k0), kin = k0 - b_tap_base;
-                        const float* Bc = B + (long long)(g.taps - 1 - tap) * g.tap_bstride;
+                        const float* Bc = B + (long long)(g_taps - 1 - tap) * g_tap_bstride;
                         if (k0 + kk < K && n0b + c4 < N4b) v = ld4(Bc + (long long)(kin + kk) * ldb + n0b + c4);
                         st4(Bs + kk * 64 + c4, v);
                     }
