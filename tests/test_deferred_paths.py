@@ -22,11 +22,12 @@ lib = None if gpu else ge.build_emulator()
 dims = tiny_dims()
 kw = dict(n_mel=dims.n_mel, vocab=dims.vocab, s_range=(5, 13), d_range=(1, 6), first_len=12)
 mods = ["speaker_emb", "variance_adaptor", "decoder", "mel_linear", "postnet"]
-eng = Engine(dims, adapt_modules=mods, max_tasks=2, max_B=3, max_S=16, max_T=96, lib_path=lib)
+tasks = {tasks}
+eng = Engine(dims, adapt_modules=mods, max_tasks=tasks, max_B=3, max_S=16, max_T=96, lib_path=lib)
 eng.load_params(synth.make_params(dims, 0))
 eng.set_dropout(True, 77)
-sup = [synth.make_batch(3, 3, speaker=2, **kw), synth.make_batch(4, 2, speaker=5, **kw)]
-qry = [synth.make_batch(5, 2, speaker=2, **kw), synth.make_batch(6, 3, speaker=5, **kw)]
+sup = [synth.make_batch(3, 3, speaker=2, **kw), synth.make_batch(4, 2, speaker=5, **kw), synth.make_batch(8, 3, speaker=7, **kw)][:tasks]
+qry = [synth.make_batch(5, 2, speaker=2, **kw), synth.make_batch(6, 3, speaker=5, **kw), synth.make_batch(9, 2, speaker=7, **kw)][:tasks]
 out = {{}}
 for order in (1, 2):
     eng.set_batches(0, sup)
@@ -40,14 +41,14 @@ for order in (1, 2):
         out[f"g{{order}}_" + n] = eng.export(n, 1)
 eng.set_batches(0, sup)
 eng.adapt(2, 0.02, reset=True, fetch_losses=False)
-out["fast"] = eng.export("mel_linear.weight", 3, 1)
+out["fast"] = eng.export("mel_linear.weight", 3, tasks - 1)
 np.savez({path!r}, **out)
 """
 
 
-def _run(tmp_path, tag, env, gpu):
+def _run(tmp_path, tag, env, gpu, tasks=2):
     path = str(tmp_path / f"{tag}.npz")
-    code = WORKER.format(root=ROOT, tests=os.path.join(ROOT, "tests"), gpu=gpu, path=path)
+    code = WORKER.format(root=ROOT, tests=os.path.join(ROOT, "tests"), gpu=gpu, path=path, tasks=tasks)
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
@@ -101,6 +102,29 @@ def _compare(tmp_path, gpu):
 
 def test_side_stream_paths_change_nothing_emulator(tmp_path):
     _compare(tmp_path, False)
+
+
+def _compare_beyond_deferred_regime(tmp_path, gpu):
+    """Three tasks in the launches — more than the deferred-gradient buffers take: the side-stream predictors (forward and early
+    backward) and the encoder run-ahead still apply (MTTS_SIDE_PRED_ALL / MTTS_ENC_AHEAD_ALL) and still change nothing."""
+    a = _run(tmp_path, "all_on", {}, gpu, tasks=3)
+    b = _run(tmp_path, "all_off", {"MTTS_SIDE_PRED_ALL": "0", "MTTS_ENC_AHEAD_ALL": "0"}, gpu, tasks=3)
+    assert set(a) == set(b) and len(a) >= 15
+    for k in a:
+        assert np.isfinite(a[k]).all(), k
+        if gpu:
+            np.testing.assert_allclose(a[k], b[k], rtol=2e-4, atol=1e-6 * max(1.0, float(np.abs(b[k]).max())), err_msg=k)
+        else:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_side_stream_paths_beyond_the_deferred_regime_emulator(tmp_path):
+    _compare_beyond_deferred_regime(tmp_path, False)
+
+
+@pytest.mark.gpu
+def test_side_stream_paths_beyond_the_deferred_regime_gpu(tmp_path):
+    _compare_beyond_deferred_regime(tmp_path, True)
 
 
 @pytest.mark.gpu
