@@ -820,14 +820,15 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             return hipMemcpy(*dev, v.data(), v.size() * sizeof(ShadowEnt), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
         };
         if (finish(all, &d_ents_all, &n_ents_all, &tiles_all) || finish(th, &d_ents_theta, &n_ents_theta, &tiles_theta) ||
-            finish(fa, &d_ents_fast, &n_ents_fast, &tiles_fast)) { set_error("hipMalloc failed (weight shadow tables)"); return -1; }
+            finish(fa, &d_ents_fast, &n_ents_fast, &tiles_fast)) { destroy_planes(); set_error("hipMalloc failed (weight shadow tables)"); return -1; }
         // compact shadow vectors (every shadow starts on a multiple of 8 elements: 16-byte loads), one per task for the fast weights
         const size_t th_b = (size_t)(n_shadow + 8) * sizeof(bf16_t), fa_b = (size_t)cap_tasks * (size_t)n_shadow * sizeof(bf16_t) + 16;
         if (hipMalloc((void**)&sh_theta_f, th_b) != hipSuccess || hipMalloc((void**)&sh_theta_t, th_b) != hipSuccess ||
             (n_adapt > 0 && (hipMalloc((void**)&sh_fast_f, fa_b) != hipSuccess || hipMalloc((void**)&sh_fast_t, fa_b) != hipSuccess)) ||
             hipMalloc((void**)&arena_h, arena_bytes / 2 + 64) != hipSuccess ||
             (arena_defer && hipMalloc((void**)&arena_defer_h, arena_defer_bytes / 2 + 64) != hipSuccess)) {
-            set_error("hipMalloc failed (bf16 operand planes)");
+            destroy_planes();
+            set_error("hipMalloc failed (bf16 operand planes: half the activation arena again + the weight shadows)");
             return -1;
         }
         hipMemset(arena_h, 0, arena_bytes / 2 + 64);
@@ -843,6 +844,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (ev_shadow) hipEventDestroy(ev_shadow);
         ev_shadow = nullptr;
         arena_h = arena_defer_h = sh_theta_f = sh_theta_t = sh_fast_f = sh_fast_t = nullptr;
+        d_ents_all = d_ents_theta = d_ents_fast = nullptr;
+        shadow_off.clear();
         planes_ready = false;
     }
     bool planes_on() const {

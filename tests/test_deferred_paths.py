@@ -122,10 +122,6 @@ def test_side_stream_paths_beyond_the_deferred_regime_emulator(tmp_path):
     _compare_beyond_deferred_regime(tmp_path, False)
 
 
-@pytest.mark.gpu
-def test_side_stream_paths_beyond_the_deferred_regime_gpu(tmp_path):
-    _compare_beyond_deferred_regime(tmp_path, True)
-
 
 @pytest.mark.gpu
 def test_side_stream_paths_change_nothing_gpu(tmp_path):
