@@ -185,6 +185,63 @@ def test_small_model_bf16_mode_tracks_fp32_oracle(gpu):
         assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b), n
 
 
+def test_meta_grad_with_fast_weight_shadows_emulator():
+    """MAML in the bf16 mode: the adapted modules read per-task fast weights, so their shadows are per task too (refreshed from the fast
+    weights at every forward).  (1) One pass through the fast-weight path with fast == theta (an inner step at lr 0) must give what the
+    theta path gives, in either bf16 mode.  (2) Two tasks, three inner steps, first and second order: operand planes ("bf16") against
+    rounding in the staging pass ("bf16-staged") and fp32.  A perturbation of the fast weights in the last bits re-draws the bf16
+    roundings downstream, so the two bf16 modes differ from each other by about as much as each differs from fp32 (measured: 0.6-1.3x)
+    — a wrong shadow (task stride, offset, transposed layout, a stale copy after the inner update) would be a different model."""
+    dims, eng = _small_engine(False, tasks=2)
+    kw = dict(s_range=(5, 13), d_range=(1, 6), first_len=12, vocab=dims.vocab, n_mel=dims.n_mel)
+    sup = [synth.make_batch(3, 3, speaker=2, **kw), synth.make_batch(4, 2, speaker=5, **kw)]
+    qry = [synth.make_batch(5, 2, speaker=2, **kw), synth.make_batch(6, 3, speaker=5, **kw)]
+    eng.load_params(synth.make_params(dims, 0))
+    names = ("mel_linear.weight", "decoder.layer_stack.1.pos_ffn.w_1.weight", "decoder.layer_stack.0.pos_ffn.w_2.weight",
+             "postnet.convolutions.1.0.conv.weight", "encoder.layer_stack.0.pos_ffn.w_1.weight")
+    rel = lambda x, y: float(np.linalg.norm(x - y) / max(float(np.linalg.norm(y)), 1e-30))
+    res = {}
+    for mode in ("fp32", "bf16", "bf16-staged"):
+        eng.set_numerics(mode)
+        # (1) fast == theta
+        per = {}
+        for uf in (False, True):
+            eng.set_batches(0, sup)
+            if uf:
+                eng.adapt(1, 0.0, reset=True, fetch_losses=False)
+            eng.forward(0, use_fast=uf, train=True)
+            loss = np.array(eng.loss(0))
+            eng.backward(0, use_fast=uf, scale=1.0, need_encoder=True)
+            per[uf] = (loss, {n: np.stack([eng.export(n, 2, t) for t in range(2)]) for n in names})
+        np.testing.assert_array_equal(per[True][0], per[False][0])
+        for n in names:
+            np.testing.assert_array_equal(per[True][1][n], per[False][1][n], err_msg=f"{mode} {n}")
+        # (2) the meta-gradient
+        n0 = int(eng.lib.mtts_plane_problems(eng.h))
+        out = {}
+        for order in (1, 2):
+            eng.set_batches(0, sup)
+            eng.set_batches(1, qry, spk_from=sup, average_spk=True)
+            q, _ = eng.meta_grad(3, 0.02, 0.5, second_order=(order == 2))
+            out[f"q{order}"] = np.array(q)
+            for n in names:
+                out[f"g{order}_{n}"] = eng.export(n, 1)
+        out["planes"] = int(eng.lib.mtts_plane_problems(eng.h)) - n0
+        res[mode] = out
+    eng.close()
+    f, a, b = res["fp32"], res["bf16"], res["bf16-staged"]
+    assert a["planes"] > 100 and b["planes"] == 0 and f["planes"] == 0, (a["planes"], b["planes"], f["planes"])
+    for k in f:
+        if k == "planes":
+            continue
+        assert np.isfinite(a[k]).all(), k
+        d_ab, d_af, d_bf = rel(a[k], b[k]), rel(a[k], f[k]), rel(b[k], f[k])
+        if k[0] == "q":
+            assert d_ab < 2e-3 and d_af < BF16_LOSS_RTOL * 2, (k, d_ab, d_af)
+        else:
+            assert d_af < 0.35 and d_af <= 2.0 * d_bf + 1e-3 and d_ab <= 2.0 * max(d_af, d_bf) + 1e-3, (k, d_ab, d_af, d_bf)
+
+
 @pytest.mark.gpu
 def test_c2_batch16_bf16_vs_fp32_oracle():
     """BASELINE config C2 AS STATED: algorithm=baseline, synthetic LibriTTS batch of 16 at full model size, bf16 contractions — the six
