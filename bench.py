@@ -443,7 +443,7 @@ def gemm_profile(eng, run, sites=False):
     microseconds, algorithmic GFLOP) — the library's MTTS_GEMM_DUMP csv, read back."""
     import tempfile
     import torch
-    dump = None
+    dump, user_dump = None, os.environ.get("MTTS_GEMM_DUMP")
     if sites:
         fd, dump = tempfile.mkstemp(suffix=".csv", prefix="mtts_gemm_")
         os.close(fd)
@@ -458,6 +458,8 @@ def gemm_profile(eng, run, sites=False):
     if not sites:
         return rows
     os.environ.pop("MTTS_GEMM_DUMP", None)
+    if user_dump is not None:   # (a caller's own dump request: restored for the legs that follow; this leg's records go to the temp file)
+        os.environ["MTTS_GEMM_DUMP"] = user_dump
     recs = []
     try:
         import csv
