@@ -185,17 +185,18 @@ def test_small_model_bf16_mode_tracks_fp32_oracle(gpu):
         assert np.linalg.norm(a - b) <= 1e-2 * np.linalg.norm(b), n
 
 
-def test_meta_grad_with_fast_weight_shadows_emulator():
+@pytest.mark.parametrize("tasks", [2, 3])   # 2: the deferred regime (weight gradients on the side stream); 3: wgrad + dgrad pairs in one launch
+def test_meta_grad_with_fast_weight_shadows_emulator(tasks):
     """MAML in the bf16 mode: the adapted modules read per-task fast weights, so their shadows are per task too (refreshed from the fast
     weights at every forward).  (1) One pass through the fast-weight path with fast == theta (an inner step at lr 0) must give what the
     theta path gives, in either bf16 mode.  (2) Two tasks, three inner steps, first and second order: operand planes ("bf16") against
     rounding in the staging pass ("bf16-staged") and fp32.  A perturbation of the fast weights in the last bits re-draws the bf16
     roundings downstream, so the two bf16 modes differ from each other by about as much as each differs from fp32 (measured: 0.6-1.3x)
     — a wrong shadow (task stride, offset, transposed layout, a stale copy after the inner update) would be a different model."""
-    dims, eng = _small_engine(False, tasks=2)
+    dims, eng = _small_engine(False, tasks=tasks)
     kw = dict(s_range=(5, 13), d_range=(1, 6), first_len=12, vocab=dims.vocab, n_mel=dims.n_mel)
-    sup = [synth.make_batch(3, 3, speaker=2, **kw), synth.make_batch(4, 2, speaker=5, **kw)]
-    qry = [synth.make_batch(5, 2, speaker=2, **kw), synth.make_batch(6, 3, speaker=5, **kw)]
+    sup = [synth.make_batch(3, 3, speaker=2, **kw), synth.make_batch(4, 2, speaker=5, **kw), synth.make_batch(8, 3, speaker=7, **kw)][:tasks]
+    qry = [synth.make_batch(5, 2, speaker=2, **kw), synth.make_batch(6, 3, speaker=5, **kw), synth.make_batch(9, 2, speaker=7, **kw)][:tasks]
     eng.load_params(synth.make_params(dims, 0))
     names = ("mel_linear.weight", "decoder.layer_stack.1.pos_ffn.w_1.weight", "decoder.layer_stack.0.pos_ffn.w_2.weight",
              "postnet.convolutions.1.0.conv.weight", "encoder.layer_stack.0.pos_ffn.w_1.weight")
@@ -212,7 +213,7 @@ def test_meta_grad_with_fast_weight_shadows_emulator():
             eng.forward(0, use_fast=uf, train=True)
             loss = np.array(eng.loss(0))
             eng.backward(0, use_fast=uf, scale=1.0, need_encoder=True)
-            per[uf] = (loss, {n: np.stack([eng.export(n, 2, t) for t in range(2)]) for n in names})
+            per[uf] = (loss, {n: np.stack([eng.export(n, 2, t) for t in range(tasks)]) for n in names})
         np.testing.assert_array_equal(per[True][0], per[False][0])
         for n in names:
             np.testing.assert_array_equal(per[True][1][n], per[False][1][n], err_msg=f"{mode} {n}")
