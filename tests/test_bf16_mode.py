@@ -3,6 +3,10 @@
 Kernel level: mtts_gemm_bf16 against a float64 product of the operands ROUNDED TO BF16 (torch's round-to-nearest-even): the only
 differences left are fp32 accumulation order, so the bound is an fp32-roundoff one (the same as the fp32 kernels' tests), for the
 three operand forms, both block tiles, ragged sizes, dual-source problems and the fused epilogue.
+Operand planes (numerics mode 1's long convolutions): a plane made by mtts_to_bf16 is torch's rounding bit for bit; the plane-staged NT
+product is bit-identical to mtts_gemm_bf16 on the fp32 operands; the epilogue's twin of C is bf16(C); at model level mode 1 (planes) and
+mode 2 (rounding in the staging pass only) give a bit-identical forward, the planes path really runs (mtts_plane_problems), and MAML
+with per-task fast-weight shadows stays inside the mode's own distance from fp32.
 Model level: the whole forward / loss / backward with every contraction in bf16 against the fp32 oracle at a STATED bf16 tolerance
 (BASELINE.md section 2 probe: bf16 autocast moves the reference's mel output by L1 1.4e-3), and the mode must really change the
 arithmetic (results differ from the fp32 mode by more than fp32 noise)."""
