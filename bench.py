@@ -100,6 +100,23 @@ GRAD_SAMPLES = ("mel_linear.weight", "decoder.layer_stack.5.pos_ffn.w_2.weight",
                 "variance_adaptor.pitch_embedding.weight", "speaker_emb.model.weight")
 
 
+DROPOUT_SEED = 1234      # mtts_set_dropout(h, 1, DROPOUT_SEED + rank) for the timed steps AND for the parity run
+
+
+def _oracle_masks(dims, sup, qry, task, seed=DROPOUT_SEED):
+    """The engine's dropout masks of one task's 5 inner steps + query pass (plan seeds in draw order), generated BEFORE any clock
+    starts: the timed oracle then pays one multiply per dropout site, as the reference does."""
+    from oracle.dropout_masks import DropoutMasks, plan_seed
+    probs = dict(enc=dims.enc_dropout, dec=dims.dec_dropout, vp=dims.vp_dropout, postnet=0.5)
+    out = []
+    for k in range(INNER_STEPS + 1):
+        b = sup if k < INNER_STEPS else qry
+        out.append(DropoutMasks(plan_seed(seed, k + 1), task, probs).precompute(
+            len(b[4]), int(b[5]), [int(x) for x in b[7]], int(b[8]), enc_layers=dims.enc_layers, dec_layers=dims.dec_layers, d_model=dims.d_model,
+            vp_filter=dims.vp_filter, postnet_dim=dims.postnet_dim, postnet_layers=dims.postnet_layers, n_mel=dims.n_mel, max_seq_len=dims.max_seq_len))
+    return out
+
+
 def _oracle_state(dims):
     import torch
     from meta_tts_amd import synth
@@ -112,7 +129,7 @@ def _oracle_state(dims):
     return params, buffers, names
 
 
-def _cpu_task_worker(j, threads, reps, barrier, out_q):
+def _cpu_task_worker(j, threads, reps, barrier, out_q, dropout=True):
     """One task process of the concurrent CPU baseline: task j of the meta-batch (5 inner steps + query forward / backward, first
     order, the oracle), `threads` intra-op threads; all processes leave the barrier together, the parent clocks the slowest."""
     import torch
@@ -125,6 +142,7 @@ def _cpu_task_worker(j, threads, reps, barrier, out_q):
     params, buffers, names = _oracle_state(dims)
     sup, qry = synth.make_task(j)
     tb_s, tb_q = O.to_torch_batch(sup), O.to_torch_batch(qry)
+    masks = _oracle_masks(dims, sup, qry, j) if dropout else None
     # warm-up: one inner step's worth (allocator, thread pool)
     lo = O.fs2_loss(tb_s, O.fs2_forward(params, buffers, *tb_s[2:], n_head=(dims.enc_heads, dims.dec_heads), training=True))
     torch.autograd.grad(lo[0], [params[n] for n in names], allow_unused=True)
@@ -133,14 +151,14 @@ def _cpu_task_worker(j, threads, reps, barrier, out_q):
         barrier.wait()
         t0 = time.perf_counter()
         ql, _, _, _ = O.maml_task(params, buffers, tb_s, tb_q, steps=INNER_STEPS, lr=INNER_LR, second_order=False, modules=mods,
-                                  n_head=(dims.enc_heads, dims.dec_heads))
+                                  n_head=(dims.enc_heads, dims.dec_heads), dropout=masks)
         torch.autograd.grad(ql[0], [params[n] for n in names], allow_unused=True)
         times.append(time.perf_counter() - t0)
         barrier.wait()
     out_q.put((j, times))
 
 
-def cpu_baseline_concurrent(threads_cap, reps=2, timeout_s=240.0):
+def cpu_baseline_concurrent(threads_cap, reps=2, timeout_s=240.0, dropout=True):
     """BASELINE.md section 3 "all host cores": the 8 tasks of a meta-batch as 8 processes started together, each with
     min(host threads / 8, the swept optimum) intra-op threads; one meta-step = the wall time from the common start to the LAST
     process finishing its task (mean + clip + Adam excluded: < 1 %)."""
@@ -150,7 +168,7 @@ def cpu_baseline_concurrent(threads_cap, reps=2, timeout_s=240.0):
     ctx = mp.get_context("spawn")
     barrier = ctx.Barrier(META_BATCH + 1)
     q = ctx.Queue()
-    procs = [ctx.Process(target=_cpu_task_worker, args=(j, threads, reps, barrier, q), daemon=True) for j in range(META_BATCH)]
+    procs = [ctx.Process(target=_cpu_task_worker, args=(j, threads, reps, barrier, q, dropout), daemon=True) for j in range(META_BATCH)]
     for pr in procs:
         pr.start()
     walls = []
@@ -175,7 +193,7 @@ def cpu_baseline_concurrent(threads_cap, reps=2, timeout_s=240.0):
                       f"slowest = one meta-step; best of {reps}"}
 
 
-def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True):
+def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True, dropout=True):
     """Oracle (oracle/fs2_oracle.py) on the host cores.  Sequential leg: whole first-order tasks of the same workload, one after the
     other at the best swept intra-op thread count, until ~budget_s of CPU time is spent; meta-steps/s = 1 / (8 * mean task time).
     Concurrent leg (cpu_baseline_concurrent): the 8 tasks as 8 processes at once — the harder same-box baseline; `value` is the
@@ -209,9 +227,11 @@ def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True):
     j = 0
     while j < META_BATCH and (time.perf_counter() - t_all) < budget_s:
         sup, qry = synth.make_task(j)
+        masks = _oracle_masks(dims, sup, qry, j) if dropout else None   # (untimed: the engine's counter-based masks, so that the oracle runs the TIMED configuration)
         t0 = time.perf_counter()
         ql, _, _, _ = O.maml_task(params, buffers, O.to_torch_batch(sup), O.to_torch_batch(qry), steps=INNER_STEPS, lr=INNER_LR,
-                                  second_order=False, modules=mods, n_head=(dims.enc_heads, dims.dec_heads))
+                                  second_order=False, modules=mods, n_head=(dims.enc_heads, dims.dec_heads), dropout=masks)
+        del masks
         gr = torch.autograd.grad(ql[0], [params[n] for n in names], allow_unused=True)
         times.append(time.perf_counter() - t0)
         q_ref.append([float(x) for x in ql])
@@ -220,7 +240,7 @@ def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True):
         j += 1
     mean_t = float(np.mean(times))
     seq = {"value": 1.0 / (META_BATCH * mean_t), "unit": "meta-steps/s", "cores": int(cores),
-           "sample": f"{len(times)} of {META_BATCH} tasks (5 inner steps + query fwd/bwd each, first-order, fp32 torch-CPU oracle) one after the other at the "
+           "sample": f"{len(times)} of {META_BATCH} tasks (5 inner steps + query fwd/bwd each, first-order, dropout {'on' if dropout else 'off'}, fp32 torch-CPU oracle) one after the other at the "
                      f"best of the swept intra-op thread counts ({cores}); {mean_t:.2f} s/task, clip+Adam excluded (<1%)"}
     conc, conc_err = None, None
     if concurrent:
@@ -237,7 +257,7 @@ def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True):
             if str(thr) in sweep_c or time.perf_counter() - t_conc > 75.0:
                 return sweep_c.get(str(thr))
             try:
-                r = cpu_baseline_concurrent(thr, reps=1)
+                r = cpu_baseline_concurrent(thr, reps=1, dropout=dropout)
                 sweep_c[str(r["threads_per_process"])] = r["s_per_meta_step"]
                 if conc is None or r["value"] > conc["value"]:
                     conc = r
@@ -598,7 +618,7 @@ def main():
     eng = Engine(dims, adapt_modules=mods, max_tasks=len(local), max_B=5, max_S=80, max_T=max_T, device=local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.load_params(synth.make_params(dims, 0, weight_scale=WEIGHT_SCALE))
-    eng.set_dropout(not args.no_dropout, 1234 + rank)  # train-mode dropout as in the reference's inner/outer loop (per-rank stream)
+    eng.set_dropout(not args.no_dropout, DROPOUT_SEED + rank)  # train-mode dropout as in the reference's inner/outer loop (per-rank stream)
     sup_b, qry_b = [t[0] for t in tasks], [t[1] for t in tasks]
 
     def ingest():
@@ -742,17 +762,18 @@ def main():
     cpu_error = None
     if rank == 0 and n == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(dims, mods, concurrent=not args.no_cpu_concurrent)
+            cpu = cpu_baseline(dims, mods, concurrent=not args.no_cpu_concurrent, dropout=not args.no_dropout)
         except Exception as ex:  # noqa: BLE001
             cpu_error = f"{type(ex).__name__}: {ex}"
     # parity of the TIMED configuration (this rank's grouped tasks, the kernels and launch paths the clock just ran) against the
     # oracle's per-task query losses: the line is refused when they disagree
     parity = None
     if cpu is not None:
-        # same handle, same grouped launches as the timed steps, dropout off (the oracle's configuration); the weights have moved by the
-        # timed Adam steps and the oracle ran on the initial ones, so they are loaded again first
+        # same handle, same grouped launches, same dropout configuration AND seed as the timed steps (re-seeding restarts the pass
+        # counter, so the plan seeds are those of the first timed meta-step; the oracle ran with exactly those masks, _oracle_masks);
+        # the weights have moved by the timed Adam steps and the oracle ran on the initial ones, so they are loaded again first
         eng.load_params(synth.make_params(dims, 0, weight_scale=WEIGHT_SCALE))
-        eng.set_dropout(False, 0)
+        eng.set_dropout(not args.no_dropout, DROPOUT_SEED)
         ingest()
         q_parity, _ = eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, fetch_losses=True)
         # oracle row j = task j = local[j] on rank 0; an emulated rank holds fewer tasks than the oracle may have run (and the oracle's
@@ -773,7 +794,8 @@ def main():
                 if r > g_rel:
                     g_rel, g_worst = r, f"task {jt}: {name}"
         parity = {"tasks_checked": int(m), "tasks_grouped_in_the_launches": len(local), "max_rel": float(rel.max()), "rtol": PARITY_RTOL,
-                  "what": "per-task query (total, mel, postnet mel, pitch, energy, duration) losses after 5 inner steps, dropout off, vs oracle/fs2_oracle.py",
+                  "what": "per-task query (total, mel, postnet mel, pitch, energy, duration) losses after 5 inner steps, " + ("dropout off" if args.no_dropout else
+                          "dropout on (the timed configuration and seed; the oracle applies the engine's counter-based masks, oracle/dropout_masks.py)") + ", vs oracle/fs2_oracle.py",
                   "grad_max_rel": g_rel, "grad_rtol": PARITY_GRAD_RTOL, "grad_worst": g_worst, "grad_tensors": list(GRAD_SAMPLES),
                   "grad_what": "max |got - ref| / max |ref| over the sampled per-task query-gradient tensors (first-order outer gradient before the mean), same run"}
         if not (rel.max() <= PARITY_RTOL) or not (g_rel <= PARITY_GRAD_RTOL):

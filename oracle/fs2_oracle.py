@@ -15,7 +15,9 @@ its published definition (theta' = theta - lr * grad, create_graph = second orde
 "parity unpinned" against learn2learn itself; the model arithmetic underneath it is pinned.
 
 Parameters are a dict {reference state_dict name (without the ``model.`` prefix): tensor}.
-Dropout is the identity here (parity runs patch it out).
+Dropout: the identity by default (the fixture configuration).  With ``dropout=`` a
+``oracle.dropout_masks.DropoutMasks`` the reference's five dropout sites (SubLayers.py:54,90, modules.py:223,235,
+Layers.py:133-134) multiply by keep / (1 - p) with the HIP engine's own counter-based masks — the configuration bench.py times.
 """
 from __future__ import annotations
 
@@ -60,9 +62,14 @@ def scaled_dot_product_attention(q, k, v, mask, temperature):
     return torch.bmm(attn, v), attn
 
 
-def multi_head_attention(x, p: Params, pre: str, slf_attn_mask, n_head: int):
+def _drop(x, dropout, site: int, space: str, which: str):
+    """One of the reference's nn.Dropout / F.dropout sites; identity without a mask source."""
+    return x if dropout is None else dropout.apply(x, site, space, dropout.probs[which])
+
+
+def multi_head_attention(x, p: Params, pre: str, slf_attn_mask, n_head: int, dropout=None, site: int = 0, space: str = "P"):
     """transformer/SubLayers.py:29-57 — head-major split (permute(2,0,1,3)), mask repeated per
-    head, fc, (dropout = identity), post-LayerNorm over (out + residual), eps 1e-5."""
+    head, fc, dropout (:54), post-LayerNorm over (out + residual), eps 1e-5."""
     B, L, d = x.shape
     d_k = d // n_head
     q = F.linear(x, p[f"{pre}.w_qs.weight"], p[f"{pre}.w_qs.bias"]).view(B, L, n_head, d_k)
@@ -75,25 +82,26 @@ def multi_head_attention(x, p: Params, pre: str, slf_attn_mask, n_head: int):
     out, attn = scaled_dot_product_attention(q, k, v, mask, math.sqrt(d_k))
     out = out.view(n_head, B, L, d_k).permute(1, 2, 0, 3).contiguous().view(B, L, -1)
     out = F.linear(out, p[f"{pre}.fc.weight"], p[f"{pre}.fc.bias"])
+    out = _drop(out, dropout, site, space, "enc" if space == "P" else "dec")
     out = F.layer_norm(out + x, (d,), p[f"{pre}.layer_norm.weight"], p[f"{pre}.layer_norm.bias"], 1e-5)
     return out, attn
 
 
-def positionwise_ffn(x, p: Params, pre: str):
-    """transformer/SubLayers.py:85-93 — LN(W2 * relu(W1 * x) + x) with Conv1d W1 (k=9,pad=4), W2 (k=1)."""
+def positionwise_ffn(x, p: Params, pre: str, dropout=None, site: int = 0, space: str = "P"):
+    """transformer/SubLayers.py:85-93 — LN(dropout(W2 * relu(W1 * x)) + x) with Conv1d W1 (k=9,pad=4), W2 (k=1)."""
     w1, w2 = p[f"{pre}.w_1.weight"], p[f"{pre}.w_2.weight"]
     h = F.conv1d(x.transpose(1, 2), w1, p[f"{pre}.w_1.bias"], padding=(w1.shape[2] - 1) // 2)
     h = F.conv1d(F.relu(h), w2, p[f"{pre}.w_2.bias"], padding=(w2.shape[2] - 1) // 2)
-    h = h.transpose(1, 2)
+    h = _drop(h.transpose(1, 2), dropout, site, space, "enc" if space == "P" else "dec")
     d = x.shape[-1]
     return F.layer_norm(h + x, (d,), p[f"{pre}.layer_norm.weight"], p[f"{pre}.layer_norm.bias"], 1e-5)
 
 
-def fft_block(x, p: Params, pre: str, mask, slf_attn_mask, n_head: int):
-    """transformer/Layers.py:21-30 — MHA, zero padded rows, FFN, zero padded rows."""
-    x, attn = multi_head_attention(x, p, f"{pre}.slf_attn", slf_attn_mask, n_head)
+def fft_block(x, p: Params, pre: str, mask, slf_attn_mask, n_head: int, dropout=None, site: int = 0, space: str = "P"):
+    """transformer/Layers.py:21-30 — MHA, zero padded rows, FFN, zero padded rows.  Mask-stream sites: `site` (attention), `site + 1` (FFN)."""
+    x, attn = multi_head_attention(x, p, f"{pre}.slf_attn", slf_attn_mask, n_head, dropout, site, space)
     x = x.masked_fill(mask.unsqueeze(-1), 0)
-    x = positionwise_ffn(x, p, f"{pre}.pos_ffn")
+    x = positionwise_ffn(x, p, f"{pre}.pos_ffn", dropout, site + 1, space)
     x = x.masked_fill(mask.unsqueeze(-1), 0)
     return x, attn
 
@@ -105,7 +113,7 @@ def _n_layers(p: Params, prefix: str) -> int:
     return n
 
 
-def encoder(texts, mask, p: Params, n_head: int, training: bool, max_seq_len: int):
+def encoder(texts, mask, p: Params, n_head: int, training: bool, max_seq_len: int, dropout=None):
     """transformer/Models.py:73-100 — word embedding (pad row 0) + sinusoid positions, 4 FFT blocks."""
     B, L = texts.shape
     slf_attn_mask = mask.unsqueeze(1).expand(-1, L, -1)
@@ -117,11 +125,11 @@ def encoder(texts, mask, p: Params, n_head: int, training: bool, max_seq_len: in
         pos = p["encoder.position_enc"][:, :L, :]
     x = emb + pos.expand(B, -1, -1)
     for i in range(_n_layers(p, "encoder")):
-        x, _ = fft_block(x, p, f"encoder.layer_stack.{i}", mask, slf_attn_mask, n_head)
+        x, _ = fft_block(x, p, f"encoder.layer_stack.{i}", mask, slf_attn_mask, n_head, dropout, 2 * i, "P")
     return x
 
 
-def decoder(x, mask, p: Params, n_head: int, training: bool, max_seq_len: int):
+def decoder(x, mask, p: Params, n_head: int, training: bool, max_seq_len: int, dropout=None):
     """transformer/Models.py:139-171 — training truncates to max_seq_len, eval extends the table."""
     B, L, d = x.shape
     if (not training) and L > max_seq_len:
@@ -134,16 +142,16 @@ def decoder(x, mask, p: Params, n_head: int, training: bool, max_seq_len: int):
         mask = mask[:, :L]
         slf_attn_mask = slf_attn_mask[:, :, :L]
     for i in range(_n_layers(p, "decoder")):
-        x, _ = fft_block(x, p, f"decoder.layer_stack.{i}", mask, slf_attn_mask, n_head)
+        x, _ = fft_block(x, p, f"decoder.layer_stack.{i}", mask, slf_attn_mask, n_head, dropout, 64 + 2 * i, "F")
     return x, mask
 
 
 # --------------------------------------------------------------------------------------
 # variance adaptor
 # --------------------------------------------------------------------------------------
-def variance_predictor(x, mask, p: Params, pre: str):
-    """lightning/model/modules.py:242-250 (+ Conv :253-296) — [Conv1d k=3 -> ReLU -> LN]x2 -> Linear(->1)
-    -> masked_fill(mask, 0); dropout = identity."""
+def variance_predictor(x, mask, p: Params, pre: str, dropout=None, site: int = 128, space: str = "P"):
+    """lightning/model/modules.py:242-250 (+ Conv :253-296) — [Conv1d k=3 -> ReLU -> LN -> Dropout]x2 -> Linear(->1)
+    -> masked_fill(mask, 0)."""
     for i in (1, 2):
         w = p[f"{pre}.conv_layer.conv1d_{i}.conv.weight"]
         pad = (w.shape[2] - 1) // 2 if i == 1 else 1
@@ -151,6 +159,7 @@ def variance_predictor(x, mask, p: Params, pre: str):
         x = F.relu(x)
         x = F.layer_norm(x, (x.shape[-1],), p[f"{pre}.conv_layer.layer_norm_{i}.weight"],
                          p[f"{pre}.conv_layer.layer_norm_{i}.bias"], 1e-5)
+        x = _drop(x, dropout, site + i - 1, space, "vp")
     out = F.linear(x, p[f"{pre}.linear_layer.weight"], p[f"{pre}.linear_layer.bias"]).squeeze(-1)
     if mask is not None:
         out = out.masked_fill(mask, 0.0)
@@ -173,15 +182,15 @@ def length_regulate(x, durations, max_len: Optional[int]):
 
 
 def variance_adaptor(x, src_mask, mel_mask, max_len, p_t, e_t, d_t, p: Params,
-                     p_control=1.0, e_control=1.0, d_control=1.0, pitch_level="phoneme_level", energy_level="phoneme_level"):
+                     p_control=1.0, e_control=1.0, d_control=1.0, pitch_level="phoneme_level", energy_level="phoneme_level", dropout=None):
     """lightning/model/modules.py:102-158: duration predictor on x; phoneme-level features (:118-127): pitch predictor on x,
     x += pitch_emb[bucketize(target or pred*ctl, bins)]; energy predictor on the updated x, x += energy_emb[...]; length
     regulation with the targets or clamp(round(exp(logd) - 1) * ctl, 0); frame-level features (:139-148): the same two steps
     AFTER the length regulator, on the zero-padded frame rectangle with the mel mask."""
     va = "variance_adaptor"
 
-    def embed(x, target, mask, control, name):               # get_pitch_embedding / get_energy_embedding, modules.py:80-100
-        pred = variance_predictor(x, mask, p, f"{va}.{name}_predictor")
+    def embed(x, target, mask, control, name, space):        # get_pitch_embedding / get_energy_embedding, modules.py:80-100
+        pred = variance_predictor(x, mask, p, f"{va}.{name}_predictor", dropout, 132 if name == "pitch" else 136, space)
         if target is not None:
             idx = torch.bucketize(target, p[f"{va}.{name}_bins"])
         else:
@@ -189,13 +198,13 @@ def variance_adaptor(x, src_mask, mel_mask, max_len, p_t, e_t, d_t, p: Params,
             idx = torch.bucketize(pred, p[f"{va}.{name}_bins"])
         return pred, F.embedding(idx, p[f"{va}.{name}_embedding.weight"])
 
-    logd = variance_predictor(x, src_mask, p, f"{va}.duration_predictor")
+    logd = variance_predictor(x, src_mask, p, f"{va}.duration_predictor", dropout, 128, "P")
     pp = ep = None
     if pitch_level == "phoneme_level":
-        pp, emb = embed(x, p_t, src_mask, p_control, "pitch")
+        pp, emb = embed(x, p_t, src_mask, p_control, "pitch", "P")
         x = x + emb
     if energy_level == "phoneme_level":
-        ep, emb = embed(x, e_t, src_mask, e_control, "energy")
+        ep, emb = embed(x, e_t, src_mask, e_control, "energy", "P")
         x = x + emb
     if d_t is not None:
         x, mel_len = length_regulate(x, d_t, max_len)
@@ -205,10 +214,10 @@ def variance_adaptor(x, src_mask, mel_mask, max_len, p_t, e_t, d_t, p: Params,
         x, mel_len = length_regulate(x, d_rounded, max_len)
         mel_mask = mask_from_lengths(mel_len)
     if pitch_level == "frame_level":
-        pp, emb = embed(x, p_t, mel_mask, p_control, "pitch")
+        pp, emb = embed(x, p_t, mel_mask, p_control, "pitch", "R")
         x = x + emb
     if energy_level == "frame_level":
-        ep, emb = embed(x, e_t, mel_mask, e_control, "energy")
+        ep, emb = embed(x, e_t, mel_mask, e_control, "energy", "R")
         x = x + emb
     return x, pp, ep, logd, d_rounded, mel_len, mel_mask
 
@@ -216,9 +225,9 @@ def variance_adaptor(x, src_mask, mel_mask, max_len, p_t, e_t, d_t, p: Params,
 # --------------------------------------------------------------------------------------
 # PostNet
 # --------------------------------------------------------------------------------------
-def postnet(x, p: Params, buffers: Optional[Dict[str, torch.Tensor]], training: bool):
-    """transformer/Layers.py:129-137 — NCL: 4x[Conv1d k=5 -> BatchNorm1d -> tanh] + [Conv -> BN];
-    dropout = identity.  BatchNorm in training mode uses batch statistics over all B*T_max
+def postnet(x, p: Params, buffers: Optional[Dict[str, torch.Tensor]], training: bool, dropout=None):
+    """transformer/Layers.py:129-137 — NCL: 4x[Conv1d k=5 -> BatchNorm1d -> tanh -> F.dropout 0.5] + [Conv -> BN -> F.dropout 0.5]
+    (:133-134).  BatchNorm in training mode uses batch statistics over all B*T_max
     positions (padding included) and updates running stats with momentum 0.1 (unbiased var)."""
     h = x.transpose(1, 2)
     n = 0
@@ -239,6 +248,8 @@ def postnet(x, p: Params, buffers: Optional[Dict[str, torch.Tensor]], training: 
             h = F.batch_norm(h, rm, rv, p[f"{pre}.1.weight"], p[f"{pre}.1.bias"], False, 0.1, 1e-5)
         if i < n - 1:
             h = torch.tanh(h)
+        if dropout is not None:
+            h = _drop(h.transpose(1, 2), dropout, 192 + i, "R", "postnet").transpose(1, 2)
     return h.transpose(1, 2)
 
 
@@ -248,23 +259,27 @@ def postnet(x, p: Params, buffers: Optional[Dict[str, torch.Tensor]], training: 
 def fs2_forward(p: Params, buffers, speakers, texts, src_lens, max_src_len, mels=None, mel_lens=None,
                 max_mel_len=None, p_targets=None, e_targets=None, d_targets=None,
                 p_control=1.0, e_control=1.0, d_control=1.0, *, n_head=(2, 2), max_seq_len=1000,
-                training=False, average_spk_emb=False, pitch_level="phoneme_level", energy_level="phoneme_level"):
+                training=False, average_spk_emb=False, pitch_level="phoneme_level", energy_level="phoneme_level", dropout=None):
     """lightning/model/fastspeech2.py:40-112 and, with ``average_spk_emb``, the learner variant
-    lightning/systems/base_adaptor.py:41-95 (mean of the support speakers' rows, expanded)."""
+    lightning/systems/base_adaptor.py:41-95 (mean of the support speakers' rows, expanded).
+    ``dropout``: a DropoutMasks (train-mode, teacher-forced passes only) or None = identity."""
     src_masks = mask_from_lengths(src_lens, max_src_len)
     mel_masks = mask_from_lengths(mel_lens, max_mel_len) if mel_lens is not None else None
-    out = encoder(texts, src_masks, p, n_head[0], training, max_seq_len)
+    if dropout is not None:
+        assert training and mel_lens is not None, "dropout masks: train-mode teacher-forced passes"
+        dropout.bind(max_src_len, mel_lens.tolist(), min(int(max_mel_len), max_seq_len))
+    out = encoder(texts, src_masks, p, n_head[0], training, max_seq_len, dropout)
     spk = F.embedding(speakers, p["speaker_emb.model.weight"])
     if average_spk_emb:
         spk = spk.mean(dim=0, keepdim=True).expand(out.shape[0], -1)
     out = out + spk.unsqueeze(1).expand(-1, max_src_len, -1)
     out, pp, ep, logd, d_rounded, mel_lens, mel_masks = variance_adaptor(
         out, src_masks, mel_masks, max_mel_len, p_targets, e_targets, d_targets, p,
-        p_control, e_control, d_control, pitch_level, energy_level)
+        p_control, e_control, d_control, pitch_level, energy_level, dropout)
     out = out + spk.unsqueeze(1).expand(-1, out.shape[1], -1)
-    out, mel_masks = decoder(out, mel_masks, p, n_head[1], training, max_seq_len)
+    out, mel_masks = decoder(out, mel_masks, p, n_head[1], training, max_seq_len, dropout)
     mel = F.linear(out, p["mel_linear.weight"], p["mel_linear.bias"])
-    mel_post = postnet(mel, p, buffers, training) + mel
+    mel_post = postnet(mel, p, buffers, training, dropout) + mel
     return (mel, mel_post, pp, ep, logd, d_rounded, src_masks, mel_masks, src_lens, mel_lens)
 
 
@@ -311,8 +326,11 @@ def adapted_names(p: Params, modules: Sequence[str]) -> List[str]:
 
 
 def maml_task(p: Params, buffers, sup, qry, *, steps: int, lr: float, second_order: bool,
-              modules: Sequence[str], n_head=(2, 2), max_seq_len=1000, training=True):
-    """One task of a meta-step: ``steps`` inner SGD updates on the support batch
+              modules: Sequence[str], n_head=(2, 2), max_seq_len=1000, training=True, dropout=None):
+    """``dropout``: None, or a list of steps + 1 DropoutMasks (one per inner step, then the query pass — the order in which the
+    engine draws its plan seeds, engine.h: meta_grad / run_encoder_ahead).
+
+    One task of a meta-step: ``steps`` inner SGD updates on the support batch
     (base_adaptor.py:100-112, ``first_order = not train``), then the query pass with the support
     speaker ids and ``average_spk_emb=True`` (base_adaptor.py:114-124).  ``p`` tensors that should
     receive outer gradients must have requires_grad=True.  Returns
@@ -320,10 +338,11 @@ def maml_task(p: Params, buffers, sup, qry, *, steps: int, lr: float, second_ord
     names = adapted_names(p, modules)
     fast = {k: p[k] for k in names}
     sup_losses = []
-    for _ in range(steps):
+    for s_ in range(steps):
         cur = dict(p)
         cur.update(fast)
-        preds = fs2_forward(cur, buffers, *sup[2:], n_head=n_head, max_seq_len=max_seq_len, training=training)
+        preds = fs2_forward(cur, buffers, *sup[2:], n_head=n_head, max_seq_len=max_seq_len, training=training,
+                            dropout=dropout[s_] if dropout else None)
         loss = fs2_loss(sup, preds)
         sup_losses.append(loss)
         grads = torch.autograd.grad(loss[0], [fast[k] for k in names], create_graph=second_order,
@@ -336,7 +355,7 @@ def maml_task(p: Params, buffers, sup, qry, *, steps: int, lr: float, second_ord
     cur = dict(p)
     cur.update(fast)
     preds = fs2_forward(cur, buffers, sup[2], *qry[3:], n_head=n_head, max_seq_len=max_seq_len,
-                        training=training, average_spk_emb=True)
+                        training=training, average_spk_emb=True, dropout=dropout[steps] if dropout else None)
     qloss = fs2_loss(qry, preds)
     return qloss, sup_losses, fast, preds
 
