@@ -190,6 +190,8 @@ public:
     std::map<long long, long long> shadow_off;   // weight offset in theta -> offset in the shadow vectors
     long long n_shadow = 0;
     const float* shadow_fast_src = nullptr;      // the fast-weight copy the fast shadows were made from
+    bool shadows_current = false;                // the shadows hold the weights as a forward of the CURRENT numerics mode last saw them: cleared by
+                                                 // whatever writes theta or switches the mode (a mode switch takes effect at the next forward)
     bool planes_ready = false;
     hipEvent_t ev_shadow = nullptr;
     bool shadow_wait = false;                    // an asynchronous refresh is in flight: the next shadow reader waits for ev_shadow
@@ -876,13 +878,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         } else {
             run(d_ents_all, n_ents_all, tiles_all, theta, 0, sh_theta_f, sh_theta_t, 0, 1);
         }
+        shadows_current = true;
         if (async) { hipEventRecord(ev_shadow, side2); shadow_wait = true; }
     }
     void await_shadows() { if (shadow_wait) { hipStreamWaitEvent(stream, ev_shadow, 0); shadow_wait = false; } }
     struct HP { const bf16_t* p; long long ts; };
     // shadow of the weight behind W(ps, off) (tr: the input-gradient layout); null when there is none or it is not current
     HP Wh(const Pass& ps, TS w, bool tr) const {
-        if (!planes_on()) return HP{nullptr, 0};
+        if (!planes_on() || !shadows_current) return HP{nullptr, 0};
         const bool is_fast = w.ts != 0;
         const long long off = is_fast ? (w.p - fast_cur) + adapt_start : w.p - theta;
         if (is_fast ? (fast_cur != shadow_fast_src || off < adapt_start || off >= adapt_start + n_adapt) : (off < 0 || off >= n_total)) return HP{nullptr, 0};
@@ -1799,7 +1802,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         static const int on = [] { const char* e = getenv("MTTS_ENC_AHEAD"); return e ? atoi(e) : 1; }();
         static const int all = [] { const char* e = getenv("MTTS_ENC_AHEAD_ALL"); return e ? atoi(e) : 1; }();   // also launches beyond the deferred regime
         auto ahead_ok = [&](const Plan& q) { return arena_pred != nullptr && q.tasks <= cap_tasks && (all || defer_ok(q)); };
-        if (!on || steps < 1 || steps + (query ? 1 : 0) > kAhead || encoder_adapted() || !ahead_ok(pl) || side2 == nullptr) return false;
+        if (query && steps + 1 > kAhead) { query = nullptr; if (query_seed) *query_seed = 0; }   // no slot left for the query pass: the inner steps still run ahead
+        if (!on || steps < 1 || steps > kAhead || encoder_adapted() || !ahead_ok(pl) || side2 == nullptr) return false;
         for (int s = 0; s < steps; ++s) seeds[s] = next_drop_seed();
         static const int q_on = [] { const char* e = getenv("MTTS_ENC_AHEAD_QUERY"); return e ? atoi(e) : 1; }();
         if (query && (!q_on || !ahead_ok(*query) || cfg.enc_layers < 1)) query = nullptr;
@@ -2394,6 +2398,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     int outer_update(const float* g, float lr, float b1, float b2, float eps, float weight_decay, float max_norm,
                      float* norm_out_host) {
         const int nb = 512;
+        shadows_current = false;   // theta is about to move
         MTTS_LAUNCH(sumsq_partial_kernel, dim3(nb), dim3(256), stream, g, n_total / 4, norm_partial);
         MTTS_LAUNCH(sumsq_final_kernel, dim3(1), dim3(64), stream, (const float*)norm_partial, nb, norm_out, extra_sumsq);
         ++adam_step_count;

@@ -1118,9 +1118,25 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     // bf16 numerics mode: the whole launch takes the bf16 operand family when every problem qualifies (gemm_bf16_ok); block tile T
     bool bf16 = cx.bf16;
     for (const GemmPending& p : b.q) bf16 = bf16 && gemm_bf16_ok(p.g);
-    if (!bf16)
-        for (const GemmPending& p : b.q)
-            if (p.g.plane_only) { cx.error = "plane-only GEMM problem queued with one the bf16 kernels cannot take"; b.q.clear(); return; }
+    if (!bf16) {
+        // A batch that mixes plane-only problems (bf16 mode: the input-gradient conv over the weight's transposed shadow has no fp32 B operand)
+        // with problems the bf16 kernels cannot take (a dual-source tangent product whose tap length is not a multiple of 32: the
+        // Hessian-vector pass through the PostNet's output layer) goes out as two launches: the plane-only problems on the bf16 family, the
+        // rest on the fp32 family.  The problems of a batch are independent, so the split changes nothing but the launch count.
+        std::vector<GemmPending> planes, rest;
+        for (const GemmPending& p : b.q) (p.g.plane_only ? planes : rest).push_back(p);
+        if (!planes.empty()) {
+            bool ok = cx.bf16 && !rest.empty();
+            for (const GemmPending& p : planes) ok = ok && gemm_bf16_ok(p.g);
+            if (!ok) { cx.error = "plane-only GEMM problem queued outside the bf16 plane path"; b.q.clear(); return; }
+            const int ff = b.force_family, ft = b.force_tile;
+            b.q = planes; b.force_family = 0;
+            gemm_batch_end(cx, stream);
+            b.q = rest; b.force_family = ff; b.force_tile = ft;
+            gemm_batch_end(cx, stream);
+            return;
+        }
+    }
     const int T = !bf16 ? 64 : (b.force_tile ? b.force_tile : (batch_wgs128 >= 512.0 ? 128 : 64));
     GemmWorkspace* wsp = nullptr;
     long long ws_off = 0, ctr_off = 0;

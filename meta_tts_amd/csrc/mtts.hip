@@ -97,6 +97,7 @@ int mtts_set_numerics(mtts_handle* h, int mode) {
     if (mode < 0 || mode > 2) { h->eng.set_error("numerics mode must be 0 (fp32), 1 (bf16 operands, fp32 accumulate) or 2 (1 without operand planes)"); return -1; }
     if (mode == 1 && h->eng.enable_planes()) return -1;   // (operand planes + weight shadows: allocated the first time the mode is selected)
     h->eng.planes_wanted = (mode == 1);
+    h->eng.shadows_current = false;   // a forward in another mode did not refresh the weight shadows: planes again from the next forward on
     h->eng.gx.bf16 = h->eng.gx_side.bf16 = h->eng.gx_side2.bf16 = (mode != 0);
     return 0;
 }
@@ -126,8 +127,9 @@ int mtts_param_info(mtts_handle* h, int i, const char** name, int* ndim, int sha
 }
 int64_t mtts_param_total(mtts_handle* h) { return h->eng.n_total; }
 int64_t mtts_adapt_start(mtts_handle* h) { return h->eng.adapt_start; }
-int mtts_load_param(mtts_handle* h, const char* name, const float* host, int64_t numel) { return h->eng.load_param(name, host, numel); }
+int mtts_load_param(mtts_handle* h, const char* name, const float* host, int64_t numel) { h->eng.shadows_current = false; return h->eng.load_param(name, host, numel); }
 int mtts_import_state(mtts_handle* h, const char* name, int which, const float* host, int64_t numel) {
+    h->eng.shadows_current = false;
     return h->eng.load_param(name, host, numel, which);
 }
 int mtts_set_optimizer_step(mtts_handle* h, int64_t step) { h->eng.adam_step_count = step; return 0; }
@@ -494,7 +496,7 @@ int mtts_to_bf16(const float* src, unsigned short* dst, long long n, void* strea
     if (!src || !dst || n < 0 || n % 8 != 0) return -1;
     if (n == 0) return 0;
     MTTS_LAUNCH(to_bf16_kernel, dim3((unsigned)std::min<long long>((n / 8 + 255) / 256, 4096)), dim3(256), (hipStream_t)stream, src, (bf16_t*)dst, n / 8);
-    return 0;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int mtts_gemm_bf16_planes(int M, int N, int K, const unsigned short* Ah, int lda, const unsigned short* Bh, int ldb, float* C, unsigned short* Ch,

@@ -409,6 +409,15 @@ class Engine:
 
     def set_bn_sync(self, mode: str = "rank0"):
         self._ck(self.lib.mtts_set_bn_sync(self.h, {"rank0": 0, "mean": 1}[mode]))
+        self.bn_sync = mode
+
+    def bn_pack_weight(self, rank: int, world: int) -> float:
+        """Weight of this rank's BatchNorm running buffers in the exchange tail when the collective is issued OUTSIDE the library
+        (sync_pack / all_reduce / sync_unpack): the same rule mtts_allreduce_outer applies — "rank0": rank 0's buffers (DDP
+        broadcast_buffers, main.py:32), "mean": 1 / world."""
+        if getattr(self, "bn_sync", "rank0") == "mean":
+            return 1.0 / float(world)
+        return 1.0 if rank == 0 else 0.0
 
     # ---- RCCL inside the library (include/mtts.h: mtts_comm_*) -------------------
     def comm_available(self) -> bool:

@@ -334,6 +334,11 @@ class Trainer:
         self.group = process_group
         self.system.world_size = self.dist.get_world_size(self.group) if self.dist else 1
         self.outer = outer_grad_tensor  # torch view of engine.outer_grad_ptr() (zero copy on GPU)
+        if outer_grad_tensor is not None and int(outer_grad_tensor.numel()) != int(system.engine.sync_floats):
+            # the collective covers the gradient AND the exchange tail behind it (loss scalars + BatchNorm buffers): a view of the
+            # gradient alone would leave every non-zero rank unpacking its own zeroed tail into its BatchNorm running buffers
+            raise ValueError(f"outer_grad_tensor has {int(outer_grad_tensor.numel())} elements; the exchange buffer is engine.sync_floats = "
+                             f"{int(system.engine.sync_floats)} (outer gradient + exchange tail): build it from engine.outer_grad_view()")
         self.library_comm = False
         # accumulate_grad_batches (main.py:62; config/train/base.yaml: optimizer.grad_acc_step): gradients of N consecutive batches are
         # summed (each scaled by 1/N, as PL divides the loss), the ranks reduce and the optimizer steps on the N-th — DDP's no_sync
@@ -392,7 +397,7 @@ class Trainer:
             import torch
             self.outer = torch.as_tensor(eng.outer_grad_view(), device=f"cuda:{eng.device}")
         rank = self.dist.get_rank(self.group)
-        eng.sync_pack(1.0 if rank == 0 else 0.0)
+        eng.sync_pack(eng.bn_pack_weight(rank, self.system.world_size))   # (the engine's BatchNorm sync mode, as the library path)
         self.dist.all_reduce(self.outer, op=self.dist.ReduceOp.SUM, group=self.group)
         eng.sync_unpack()
 

@@ -29,6 +29,20 @@ import torch.nn.functional as F
 
 Params = Dict[str, torch.Tensor]
 
+# ReLU kinks.  The loss is piecewise smooth: at a ReLU whose pre-activation is within fp32 noise of zero two correct fp32
+# implementations may land on different sides, and their GRADIENTS then differ by that unit's whole contribution (a few rows of a
+# few tensors) although every forward value agrees to 1e-7.  A caller that compares gradients can ask which passes had such units:
+# with KINK_LOG a list, every ReLU of the model appends (min |pre-activation|, number of units with |pre-activation| < KINK_EPS).
+KINK_LOG: Optional[list] = None
+KINK_EPS = 1e-6
+
+
+def _relu(x):
+    if KINK_LOG is not None:
+        a = x.detach().abs()
+        KINK_LOG.append((float(a.min()), int((a < KINK_EPS).sum())))
+    return F.relu(x)
+
 
 # --------------------------------------------------------------------------------------
 # masks / tables
@@ -91,7 +105,7 @@ def positionwise_ffn(x, p: Params, pre: str, dropout=None, site: int = 0, space:
     """transformer/SubLayers.py:85-93 — LN(dropout(W2 * relu(W1 * x)) + x) with Conv1d W1 (k=9,pad=4), W2 (k=1)."""
     w1, w2 = p[f"{pre}.w_1.weight"], p[f"{pre}.w_2.weight"]
     h = F.conv1d(x.transpose(1, 2), w1, p[f"{pre}.w_1.bias"], padding=(w1.shape[2] - 1) // 2)
-    h = F.conv1d(F.relu(h), w2, p[f"{pre}.w_2.bias"], padding=(w2.shape[2] - 1) // 2)
+    h = F.conv1d(_relu(h), w2, p[f"{pre}.w_2.bias"], padding=(w2.shape[2] - 1) // 2)
     h = _drop(h.transpose(1, 2), dropout, site, space, "enc" if space == "P" else "dec")
     d = x.shape[-1]
     return F.layer_norm(h + x, (d,), p[f"{pre}.layer_norm.weight"], p[f"{pre}.layer_norm.bias"], 1e-5)
@@ -156,7 +170,7 @@ def variance_predictor(x, mask, p: Params, pre: str, dropout=None, site: int = 1
         w = p[f"{pre}.conv_layer.conv1d_{i}.conv.weight"]
         pad = (w.shape[2] - 1) // 2 if i == 1 else 1
         x = F.conv1d(x.transpose(1, 2), w, p[f"{pre}.conv_layer.conv1d_{i}.conv.bias"], padding=pad).transpose(1, 2)
-        x = F.relu(x)
+        x = _relu(x)
         x = F.layer_norm(x, (x.shape[-1],), p[f"{pre}.conv_layer.layer_norm_{i}.weight"],
                          p[f"{pre}.conv_layer.layer_norm_{i}.bias"], 1e-5)
         x = _drop(x, dropout, site + i - 1, space, "vp")
@@ -326,9 +340,10 @@ def adapted_names(p: Params, modules: Sequence[str]) -> List[str]:
 
 
 def maml_task(p: Params, buffers, sup, qry, *, steps: int, lr: float, second_order: bool,
-              modules: Sequence[str], n_head=(2, 2), max_seq_len=1000, training=True, dropout=None):
+              modules: Sequence[str], n_head=(2, 2), max_seq_len=1000, training=True, dropout=None, kink_log: Optional[list] = None):
     """``dropout``: None, or a list of steps + 1 DropoutMasks (one per inner step, then the query pass — the order in which the
-    engine draws its plan seeds, engine.h: meta_grad / run_encoder_ahead).
+    engine draws its plan seeds, engine.h: meta_grad / run_encoder_ahead).  ``kink_log``: a list that receives one
+    (min |pre-activation|, units below KINK_EPS) pair per ReLU of the QUERY pass.
 
     One task of a meta-step: ``steps`` inner SGD updates on the support batch
     (base_adaptor.py:100-112, ``first_order = not train``), then the query pass with the support
@@ -354,8 +369,13 @@ def maml_task(p: Params, buffers, sup, qry, *, steps: int, lr: float, second_ord
             pass
     cur = dict(p)
     cur.update(fast)
-    preds = fs2_forward(cur, buffers, sup[2], *qry[3:], n_head=n_head, max_seq_len=max_seq_len,
-                        training=training, average_spk_emb=True, dropout=dropout[steps] if dropout else None)
+    global KINK_LOG
+    KINK_LOG = kink_log          # (the query pass only: its ReLU kinks are the ones a first-order outer gradient can see)
+    try:
+        preds = fs2_forward(cur, buffers, sup[2], *qry[3:], n_head=n_head, max_seq_len=max_seq_len,
+                            training=training, average_spk_emb=True, dropout=dropout[steps] if dropout else None)
+    finally:
+        KINK_LOG = None
     qloss = fs2_loss(qry, preds)
     return qloss, sup_losses, fast, preds
 

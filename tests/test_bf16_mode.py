@@ -247,6 +247,49 @@ def test_meta_grad_with_fast_weight_shadows_emulator(tasks):
             assert d_af < 0.35 and d_af <= 2.0 * d_bf + 1e-3 and d_ab <= 2.0 * max(d_af, d_bf) + 1e-3, (k, d_ab, d_af, d_bf)
 
 
+def test_hvp_support_and_mode_switch_in_plane_mode_emulator():
+    """(1) mtts_hvp_support (every iMAML CG step) under numerics mode 1: conv_bwd_t opens one batch that holds a plane-only
+    input-gradient problem AND a dual-source tangent problem the bf16 kernels cannot take (PostNet output layer, tap length 48 here / 80 at
+    full size) — the launcher now splits such a batch instead of refusing it; the product must track the fp32 and the staged-bf16 HVP.
+    (2) A forward in fp32, then set_numerics("bf16"), then backward: the weight shadows were not refreshed by that forward, so the
+    backward must not read them (it takes the staged path) — gradients stay at bf16 distance from fp32 instead of garbage."""
+    dims, eng = _small_engine(False, tasks=2)
+    kw = dict(s_range=(5, 13), d_range=(1, 6), first_len=12, vocab=dims.vocab, n_mel=dims.n_mel)
+    sup = [synth.make_batch(3, 3, speaker=2, **kw), synth.make_batch(4, 2, speaker=5, **kw)]
+    eng.load_params(synth.make_params(dims, 0))
+    names = ("mel_linear.weight", "decoder.layer_stack.1.pos_ffn.w_1.weight", "postnet.convolutions.4.0.conv.weight",
+             "postnet.convolutions.1.0.conv.weight", "variance_adaptor.pitch_predictor.conv_layer.conv1d_1.conv.weight")
+    rel = lambda x, y: float(np.linalg.norm(x - y) / max(float(np.linalg.norm(y)), 1e-30))
+    hv = {}
+    for mode in ("fp32", "bf16", "bf16-staged"):
+        eng.set_numerics(mode)
+        eng.set_batches(0, sup)
+        eng.adapt(0, 0.0, reset=True)
+        eng.forward(0, use_fast=True, train=True)
+        eng.backward(0, use_fast=True, scale=1.0, need_encoder=True)
+        eng.hvp_support()                                   # (raised "plane-only GEMM problem queued with one the bf16 kernels cannot take")
+        hv[mode] = {n: np.stack([eng.export(n, 2, t) for t in range(2)]) for n in names}
+    for n in names:
+        assert np.isfinite(hv["bf16"][n]).all(), n
+        d_af, d_bf, d_ab = rel(hv["bf16"][n], hv["fp32"][n]), rel(hv["bf16-staged"][n], hv["fp32"][n]), rel(hv["bf16"][n], hv["bf16-staged"][n])
+        assert d_af < 0.35 and d_af <= 2.5 * d_bf + 1e-3 and d_ab <= 2.5 * max(d_af, d_bf) + 1e-3, (n, d_af, d_bf, d_ab)
+    # (2) mode switch between forward and backward
+    eng.set_numerics("fp32")
+    eng.set_batches(0, sup)
+    w = "decoder.layer_stack.1.pos_ffn.w_1.weight"
+    eng.load_params({w: -2.0 * synth.make_params(dims, 0)[w]}, strict=False)   # (a shadowed weight moves: the shadows of the bf16 passes above are stale now)
+    eng.forward(0, use_fast=False, train=True)
+    eng.backward(0, use_fast=False, scale=1.0, need_encoder=True)
+    g32 = {n: eng.export(n, 2, 0) for n in names}
+    eng.forward(0, use_fast=False, train=True)              # fp32 forward: no shadow refresh
+    eng.set_numerics("bf16")
+    eng.backward(0, use_fast=False, scale=1.0, need_encoder=True)
+    for n in names:
+        g = eng.export(n, 2, 0)
+        assert np.isfinite(g).all() and rel(g, g32[n]) < 0.2, (n, rel(g, g32[n]))
+    eng.close()
+
+
 @pytest.mark.gpu
 def test_c2_batch16_bf16_vs_fp32_oracle():
     """BASELINE config C2 AS STATED: algorithm=baseline, synthetic LibriTTS batch of 16 at full model size, bf16 contractions — the six
