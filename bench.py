@@ -129,11 +129,48 @@ def _oracle_state(dims):
     return params, buffers, names
 
 
-def _cpu_task_worker(j, threads, reps, barrier, out_q, dropout=True):
+def _cpu_partition(nproc):
+    """Host hardware threads this process may use, grouped by physical core (sysfs topology) and dealt to `nproc` task processes in
+    contiguous runs of whole cores of one package.  Each entry: the cpu ids of the group ordered one-hardware-thread-per-core first,
+    then the SMT siblings — so that the first t ids are the right affinity set for t <= cores threads."""
+    allowed = sorted(os.sched_getaffinity(0))
+    cores = {}
+    for c in allowed:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as fh:
+                sib = fh.read().strip()
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id") as fh:
+                pkg = int(fh.read().strip())
+            first = int(sib.replace("-", ",").split(",")[0])
+        except (OSError, ValueError):
+            pkg, first = 0, c
+        cores.setdefault((pkg, first), []).append(c)
+    phys = [sorted(v) for _, v in sorted(cores.items())]
+    per = max(1, len(phys) // nproc)
+    groups = []
+    for k in range(nproc):
+        mine = phys[k * per:(k + 1) * per] or [phys[k % len(phys)]]
+        depth = max(len(c) for c in mine)
+        groups.append([c[d] for d in range(depth) for c in mine if d < len(c)])
+    return groups, len(phys)
+
+
+def _cpu_task_worker(j, cpus, thread_legs, barrier, out_q, dropout=True):
     """One task process of the concurrent CPU baseline: task j of the meta-batch (5 inner steps + query forward / backward, first
-    order, the oracle), `threads` intra-op threads; all processes leave the barrier together, the parent clocks the slowest."""
+    order, the oracle, dropout as timed), pinned to its own run of physical cores (`cpus`, _cpu_partition) BEFORE torch / OpenMP start
+    (OMP_PLACES=cores, OMP_PROC_BIND=close: intra-op thread i sits on core i of the run).  One leg per entry of `thread_legs` (intra-op
+    threads); all processes leave the barrier together, the parent clocks the slowest."""
+    pinned = False
+    if cpus:
+        try:
+            os.sched_setaffinity(0, set(cpus))
+            os.environ["OMP_PLACES"] = "cores"
+            os.environ["OMP_PROC_BIND"] = "close"
+            pinned = True
+        except OSError:
+            pass
     import torch
-    torch.set_num_threads(threads)
+    torch.set_num_threads(max(thread_legs))
     from meta_tts_amd import synth
     from meta_tts_amd.config import ModelDims, default_algorithm_config
     from oracle import fs2_oracle as O
@@ -147,7 +184,8 @@ def _cpu_task_worker(j, threads, reps, barrier, out_q, dropout=True):
     lo = O.fs2_loss(tb_s, O.fs2_forward(params, buffers, *tb_s[2:], n_head=(dims.enc_heads, dims.dec_heads), training=True))
     torch.autograd.grad(lo[0], [params[n] for n in names], allow_unused=True)
     times = []
-    for _ in range(reps):
+    for thr in thread_legs:
+        torch.set_num_threads(thr)
         barrier.wait()
         t0 = time.perf_counter()
         ql, _, _, _ = O.maml_task(params, buffers, tb_s, tb_q, steps=INNER_STEPS, lr=INNER_LR, second_order=False, modules=mods,
@@ -155,42 +193,49 @@ def _cpu_task_worker(j, threads, reps, barrier, out_q, dropout=True):
         torch.autograd.grad(ql[0], [params[n] for n in names], allow_unused=True)
         times.append(time.perf_counter() - t0)
         barrier.wait()
-    out_q.put((j, times))
+    out_q.put((j, times, pinned))
 
 
-def cpu_baseline_concurrent(threads_cap, reps=2, timeout_s=240.0, dropout=True):
-    """BASELINE.md section 3 "all host cores": the 8 tasks of a meta-batch as 8 processes started together, each with
-    min(host threads / 8, the swept optimum) intra-op threads; one meta-step = the wall time from the common start to the LAST
-    process finishing its task (mean + clip + Adam excluded: < 1 %)."""
+def cpu_baseline_concurrent(thread_legs, pin=True, timeout_s=240.0, dropout=True):
+    """BASELINE.md section 3 "all host cores": the 8 tasks of a meta-batch as 8 processes started together, each pinned to 1/8 of the
+    box's physical cores (pin=True) and run once per entry of `thread_legs` intra-op threads; one meta-step = the wall time from the
+    common start to the LAST process finishing its task (mean + clip + Adam excluded: < 1 %).  Returns one record per leg."""
     import multiprocessing as mp
     host = os.cpu_count() or 8
-    threads = max(1, min(host // META_BATCH, threads_cap)) if host >= META_BATCH else 1
+    groups, n_phys = _cpu_partition(META_BATCH)
+    if not pin:
+        groups = [None] * META_BATCH
     ctx = mp.get_context("spawn")
     barrier = ctx.Barrier(META_BATCH + 1)
     q = ctx.Queue()
-    procs = [ctx.Process(target=_cpu_task_worker, args=(j, threads, reps, barrier, q, dropout), daemon=True) for j in range(META_BATCH)]
+    procs = [ctx.Process(target=_cpu_task_worker, args=(j, groups[j], list(thread_legs), barrier, q, dropout), daemon=True) for j in range(META_BATCH)]
     for pr in procs:
         pr.start()
     walls = []
     try:
-        for _ in range(reps):
+        for _ in thread_legs:
             barrier.wait(timeout_s)          # every worker has built its task and warmed up
             t0 = time.perf_counter()
             barrier.wait(timeout_s)          # ... and finished it
             walls.append(time.perf_counter() - t0)
-        per_task = dict(q.get(timeout=timeout_s) for _ in procs)
+        got = [q.get(timeout=timeout_s) for _ in procs]
     finally:
         for pr in procs:
             pr.join(5.0)
             if pr.is_alive():
                 pr.terminate()
-    wall = float(min(walls))
-    return {"value": 1.0 / wall, "unit": "meta-steps/s", "processes": META_BATCH, "threads_per_process": int(threads),
-            "cores": int(threads * META_BATCH), "host_cores": int(host), "s_per_meta_step": round(wall, 3),
-            "s_per_meta_step_all_reps": [round(w, 3) for w in walls],
-            "slowest_task_s": round(max(min(t) for t in per_task.values()), 3), "fastest_task_s": round(min(min(t) for t in per_task.values()), 3),
-            "sample": f"{reps} whole 8-task meta-steps, 8 task processes x {threads} intra-op threads started together (barrier), wall time of the "
-                      f"slowest = one meta-step; best of {reps}"}
+    per_task = {j: t for j, t, _ in got}
+    pinned = all(p for _, _, p in got)
+    out = []
+    for i, thr in enumerate(thread_legs):
+        hw = min(thr, len(groups[0])) if groups[0] else thr
+        out.append({"value": 1.0 / walls[i], "unit": "meta-steps/s", "processes": META_BATCH, "threads_per_process": int(thr), "pinned": bool(pin and pinned),
+                    "cores": int(min(host, hw * META_BATCH)), "host_cores": int(host), "physical_cores": int(n_phys), "s_per_meta_step": round(walls[i], 3),
+                    "slowest_task_s": round(max(t[i] for t in per_task.values()), 3), "fastest_task_s": round(min(t[i] for t in per_task.values()), 3),
+                    "sample": f"one whole 8-task meta-step (dropout {'on' if dropout else 'off'}), 8 task processes x {thr} intra-op threads started together (barrier), "
+                              + (f"each pinned to its own {len(groups[0])} hardware threads = {max(1, n_phys // META_BATCH)} physical cores (sched_setaffinity, OMP_PLACES=cores, "
+                                 f"OMP_PROC_BIND=close), " if (pin and pinned and groups[0]) else "unpinned, ") + "wall time of the slowest = one meta-step"})
+    return out
 
 
 def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True, dropout=True):
@@ -244,39 +289,31 @@ def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True, dropout=True):
     seq = {"value": 1.0 / (META_BATCH * mean_t), "unit": "meta-steps/s", "cores": int(cores),
            "sample": f"{len(times)} of {META_BATCH} tasks (5 inner steps + query fwd/bwd each, first-order, dropout {'on' if dropout else 'off'}, fp32 torch-CPU oracle) one after the other at the "
                      f"best of the swept intra-op thread counts ({cores}); {mean_t:.2f} s/task, clip+Adam excluded (<1%)"}
-    conc, conc_err = None, None
+    conc, conc_err, sweep_c = None, None, {}
     if concurrent:
-        # 8 task processes at once; intra-op threads per process searched from 4 downhill (never more than host threads / 8, never more
-        # than the swept optimum): 4, then 2 and 1 while fewer threads keep winning, otherwise 8 and 16 while more do.  Measured on the
-        # 256-thread box: 4 threads 8.3 s per meta-step, 8 threads 12.2 s, 16 threads 22.2 s (the processes thrash each other's caches and
-        # memory channels), one task at a time at 16 threads 10.5 s.  The fastest is the concurrent figure.
-        t_conc, sweep_c = time.perf_counter(), {}
-        cap = max(1, min(cores, host_cores // META_BATCH))
-
-        def leg(thr):
-            nonlocal conc, conc_err
-            thr = max(1, min(thr, cap))
-            if str(thr) in sweep_c or time.perf_counter() - t_conc > 75.0:
-                return sweep_c.get(str(thr))
-            try:
-                r = cpu_baseline_concurrent(thr, reps=1, dropout=dropout)
-                sweep_c[str(r["threads_per_process"])] = r["s_per_meta_step"]
+        # 8 task processes at once, each pinned to its own eighth of the box's physical cores (unpinned, 8 x 16 threads
+        # measured SLOWER than one process at 16 — thread-pool / affinity thrash of the harness, not a property of the CPU).  One spawn, one
+        # leg per intra-op thread count: one thread per physical core of the share, both SMT threads of every core, half the cores; then the
+        # round-4 harness (unpinned, 2 threads per process) once more for continuity.  The fastest leg is the concurrent figure.
+        groups, n_phys = _cpu_partition(META_BATCH)
+        share = max(1, n_phys // META_BATCH)             # physical cores per task process
+        legs = sorted({share, min(len(groups[0]), 2 * share), max(1, share // 2)}, key=lambda t: (t != share, t))
+        try:
+            for r in cpu_baseline_concurrent(legs, pin=True, dropout=dropout):
+                sweep_c[f"pinned x{r['threads_per_process']}"] = r["s_per_meta_step"]
                 if conc is None or r["value"] > conc["value"]:
                     conc = r
-                return r["s_per_meta_step"]
-            except Exception as ex:  # noqa: BLE001
-                conc_err = f"{type(ex).__name__}: {ex}"
-                return None
-        t4 = leg(4)
-        t2 = leg(2)
-        if t4 is not None and t2 is not None and t2 < t4:
-            leg(1)
-        else:
-            t8 = leg(8)
-            if t4 is not None and t8 is not None and t8 < t4:
-                leg(16)
+        except Exception as ex:  # noqa: BLE001
+            conc_err = f"{type(ex).__name__}: {ex}"
+        try:
+            for r in cpu_baseline_concurrent([2], pin=False, dropout=dropout):
+                sweep_c[f"unpinned x{r['threads_per_process']}"] = r["s_per_meta_step"]
+                if conc is None or r["value"] > conc["value"]:
+                    conc = r
+        except Exception as ex:  # noqa: BLE001
+            conc_err = conc_err or f"{type(ex).__name__}: {ex}"
         if conc is not None:
-            conc["s_per_meta_step_by_threads_per_process"] = sweep_c
+            conc["s_per_meta_step_by_leg"] = sweep_c
     best_leg = "concurrent" if (conc is not None and conc["value"] > seq["value"]) else "sequential"
     top = conc if best_leg == "concurrent" else seq
     return {"value": top["value"], "unit": "meta-steps/s", "cores": int(top["cores"]), "kind": "port", "sample": top["sample"], "leg": best_leg,
@@ -330,10 +367,29 @@ def inference_leg(dims, mods, device, iters=5):
             frames += int(mel_lens.sum())
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        last_lens = [int(x) for x in mel_lens]
         res[name] = {"mels_per_sec": round(frames / dt, 1), "ms_per_iter": round(1e3 * dt / iters, 2), "frames_per_iter": frames // iters,
                      "rtf": round(dt / (frames * 256 / 22050.0), 5)}
     eng.close()
     voc.close()
+    # roofline of the two inference stages (blk(L) = 2,883,584 L + 512 L^2 MAC per FFT block,
+    # F(S, T) = 4 blk(S) + 3 * 393,472 S + 6 blk(T) + 20,480 T + 4,341,760 T MAC per utterance; MelGAN generator 45.15 MMAC per mel frame),
+    # algorithmic flops of VALID phonemes / produced frames over the leg's wall time (which also holds the batch upload and the read-backs)
+    blk = lambda L: 2883584.0 * L + 512.0 * L * L
+    F = lambda S, T: 4 * blk(S) + 3 * 393472.0 * S + 6 * blk(T) + 20480.0 * T + 4341760.0 * T
+    syn_flop = 2.0 * sum(F(int(sl), tl) for sl, tl in zip(qry[4], last_lens))
+    voc_flop = 2.0 * 45.15e6 * sum(last_lens)
+    t_syn = 1e-3 * res["synthesis_only"]["ms_per_iter"]
+    t_voc = max(1e-9, 1e-3 * (res["synthesis_plus_vocoder"]["ms_per_iter"] - res["synthesis_only"]["ms_per_iter"]))
+    res["roofline"] = {
+        "bound": "mfma", "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "synthesis_only": {"alg_gflop_per_iter": round(1e-9 * syn_flop, 2), "achieved": round(1e-12 * syn_flop / t_syn, 2),
+                           "frac": round(1e-12 * syn_flop / t_syn / FP32_MATRIX_PEAK_TFLOPS, 4)},
+        "vocoder": {"alg_gflop_per_iter": round(1e-9 * voc_flop, 2), "achieved": round(1e-12 * voc_flop / t_voc, 2),
+                    "frac": round(1e-12 * voc_flop / t_voc / FP32_MATRIX_PEAK_TFLOPS, 4),
+                    "time": "synthesis_plus_vocoder - synthesis_only (generator launches + the waveform's int16 conversion and download)"},
+        "note": "whole-leg rates (5 utterances per iteration: launch-bound, see DESIGN.md section 8); the vocoder's early layers (<= 64 channels at 128-256x the "
+                "mel rate) are HBM-bound, not MFMA-bound"}
     res["note"] = ("5 query utterances per iteration; host->device batch upload, the duration read-back and (vocoder legs) the mel download, "
                    "waveform int16 conversion and download are inside the timed loop (the mel itself stays in HBM); MelGAN generator with synthetic weights "
                    "(~90 MFLOP per mel frame)")
@@ -448,7 +504,7 @@ def baseline_c2_leg(dims, device, noam_lr, trn, iters=8, modes=("fp32", "bf16"))
                                   "frac": round(dom[3] / (dom[2] * 1e-3) / 1e12 / peak, 4) if dom[2] > 0 else 0.0,
                                   "all_gemm_ms": round(tot_ms, 3), "all_gemm_achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else 0.0,
                                   "all_gemm_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4) if tot_ms > 0 else 0.0,
-                                  "non_gemm_ms": round(1e3 * dt - tot_ms, 3),
+                                  "all_gemm_ms_note": "sum over ALL streams (weight-gradient and predictor GEMMs run on side streams beside the critical one), so it may exceed ms_per_step",
                                   "per_kernel": {r[0]: {"launches": int(r[1]), "ms": round(r[2], 3), "tflop": round(r[3] / 1e12, 4)} for r in rows if r[1] > 0}}}
     eng.set_numerics("fp32")
     if "fp32" in res and "bf16" in res:
