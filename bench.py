@@ -621,6 +621,7 @@ def main():
     ap.add_argument("--order", type=int, default=1, choices=(1, 2),
                     help="MAML order of the timed meta-step: 1 = BASELINE config C3 (first-order), 2 = the reference's training mode / config C4")
     ap.add_argument("--no-second-order", action="store_true", help="skip the extra second-order measurement")
+    ap.add_argument("--no-ar-overlap", action="store_true", help="one blocking all-reduce after the backward instead of the bucketed, overlapped exchange")
     ap.add_argument("--no-dropout", action="store_true", help="parity configuration (dropout = identity) instead of train-mode dropout")
     ap.add_argument("--resident-batches", action="store_true",
                     help="upload the batches once before the timed region instead of every step (round-1 behaviour; the default re-ingests the "
@@ -718,17 +719,21 @@ def main():
 
     step_no = [0]
     ar_events = []
+    ar_overlapped = [False]
 
     def meta_step(order=None, timed_ar=False):
         if not args.resident_batches:
             ingest()  # host 12-tuples -> HBM + row-space plans, every step (what PL's batch transfer + collate hand-off cost)
+        if n > 1 and outer is None and not args.no_ar_overlap:
+            ar_overlapped[0] = eng.arm_allreduce_overlap()   # the buckets leave on the comm stream as the backward completes them
         eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=((order or args.order) == 2), fetch_losses=False)
         if n > 1:
             if timed_ar:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             if outer is None:
-                eng.allreduce_outer()          # gradient + exchange tail (loss scalars, BatchNorm buffers) in one ncclAllReduce
+                eng.allreduce_outer()          # overlapped: joins the bucket collectives already in flight (what is timed here is the EXPOSED part);
+                                               # otherwise gradient + exchange tail (loss scalars, BatchNorm buffers) in one ncclAllReduce
             else:
                 eng.sync_pack(eng.bn_pack_weight(rank, n))
                 dist.all_reduce(outer, op=dist.ReduceOp.SUM)
@@ -762,6 +767,7 @@ def main():
         meta_step()
     dt = timed(args.steps, timed_ar=True)
     ar_ms = None
+    ar_launches = eng.allreduce_launches if (n > 1 and ar_overlapped[0]) else (1 if n > 1 else None)
     if ar_events:
         ar_ms = float(np.mean([a.elapsed_time(b) for a, b in ar_events]))  # events on the stream RCCL was enqueued on (torch's current stream)
     # cost of the per-step ingestion alone (host -> HBM + plans), for the record
@@ -912,6 +918,10 @@ def main():
                 "batch_ingest_ms_per_step": round(ingest_ms, 3),
                 "rccl_ranks": n if n > 1 else None, "allreduce_impl": ar_impl, "allreduce_ms_per_step": round(ar_ms, 3) if ar_ms is not None else None,
                 "allreduce_payload_mbytes": round(4e-6 * eng.n_total, 1) if n > 1 else None,
+                "allreduce_overlap": ({"on": bool(ar_overlapped[0]), "collectives_per_step": ar_launches,
+                                       "what": "one ncclAllReduce per module bucket in backward-completion order (PostNet, decoder 5 + mel_linear .. decoder 0, variance adaptor, speaker table, "
+                                               "encoder 3 .. 0 + word embedding) + the exchange tail, on a communication stream behind events of the main / weight-gradient streams; "
+                                               "allreduce_ms_per_step = what mtts_allreduce_outer still waits for (exposed)"} if n > 1 else None),
                 "allreduce_carries": "flat outer gradient + 6 loss scalars (sync_dist mean) + PostNet BatchNorm running buffers (rank 0's, as DDP broadcast_buffers)" if n > 1 else None,
                 "query_total_loss_mean": round(float(q_losses[:, 0].mean()), 5) if q_losses is not None else None}
         if so is not None:

@@ -206,6 +206,19 @@ int mtts_comm_available(mtts_handle* h);   /* 0 when librccl can be loaded in th
 int mtts_comm_unique_id(mtts_handle* h, void* id128);
 int mtts_comm_init(mtts_handle* h, const void* id128, int rank, int world_size);
 int mtts_allreduce_outer(mtts_handle* h);
+/* Overlapped, bucketed exchange (DDP's bucketed gradient all-reduce overlapping the backward, main.py:30-38): call BEFORE the gradient call
+ * that fills the outer gradient (mtts_meta_grad first or second order, mtts_plain_grad; with gradient accumulation: the window's LAST
+ * call).  That call then cuts the flat buffer at module boundaries in backward-completion order (PostNet, decoder L-1 + mel_linear ...
+ * decoder 0, variance adaptor, speaker table, encoder L-1 ... encoder 0 + word embedding) and issues one ncclAllReduce per bucket on a
+ * communication stream of the handle the moment the backward has completed the module — behind events of the main and the
+ * weight-gradient side stream — while the main stream continues; the exchange tail goes out first.  The following mtts_allreduce_outer
+ * only makes the handle's stream wait for those collectives (its time is the EXPOSED part of the exchange).  One-shot: disarmed by
+ * the gradient call.  Returns 0 when armed, 1 when the overlapped path is not available (no communicator, MTTS_AR_OVERLAP=0, an
+ * architecture whose modules are not contiguous runs of the flat buffer) — mtts_allreduce_outer then reduces the whole buffer as before.
+ * Results equal the one-shot exchange's (the same floats, the same collective, in pieces).  mtts_allreduce_launches: collectives the
+ * last overlapped exchange issued (buckets + tail). */
+int mtts_arm_allreduce_overlap(mtts_handle* h);
+int mtts_allreduce_launches(mtts_handle* h);
 /* What DDP moves between ranks BESIDES the gradient rides behind the flat outer gradient in the same buffer and the same collective:
  * [n_total .. n_total+6) the six losses of the last mtts_meta_grad / mtts_plain_grad call, summed over this rank's tasks and scaled by its
  * grad_scale — the SUM over ranks is the mean `self.log_dict(..., sync_dist=True)` reports (meta.py:78-79, baseline.py:35); behind them the

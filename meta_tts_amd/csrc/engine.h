@@ -913,6 +913,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         return h;
     }
     void destroy() {
+        ar_destroy();
         if (side) { hipStreamSynchronize(side); hipStreamDestroy(side); }
         for (auto& e : ev_side) if (e) hipEventDestroy(e);
         if (ev_join) hipEventDestroy(ev_join);
@@ -1640,6 +1641,134 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         static const int all = [] { const char* e = getenv("MTTS_SIDE_PRED_ALL"); return e ? atoi(e) : 1; }();
         return side != nullptr && arena_pred != nullptr && p.tasks <= cap_tasks && (all || defer_ok(p));
     }
+    // ---- bucketed exchange, overlapped with the backward that produces the outer gradient (main.py:30-38: DDP's bucketed gradient
+    // all-reduce) ------------------------------------------------------------------------------------------------
+    // The flat buffer is cut at module boundaries into buckets in backward-COMPLETION order — PostNet, decoder L-1 (+ mel_linear) ... decoder 0,
+    // variance adaptor, speaker table, encoder L-1 ... encoder 0 (+ word embedding) — and the moment a module's parameter gradients are
+    // complete (ar_ready, called from backward_impl / backward_t) its bucket is summed over the rank's tasks and all-reduced on `comm_stream`
+    // behind events of the main and the weight-gradient side stream, while the main stream carries on with the next module's backward.
+    // The exchange tail (loss scalars, BatchNorm buffers) is final before the backward starts and goes first.  mtts_allreduce_outer then only
+    // joins the comm stream.  Armed per gradient call by the host (mtts_arm_allreduce_overlap); results are those of the one-shot exchange
+    // (the same floats are summed by the same collective, in pieces).
+    struct ArHook { void* ctx = nullptr; int (*sum)(void*, float*, size_t, hipStream_t) = nullptr; int rank = 0, world = 1; };
+    ArHook ar;
+    hipStream_t comm_stream = nullptr;
+    static constexpr int kArEvents = 8;
+    hipEvent_t ev_ar[kArEvents] = {};
+    hipEvent_t ev_ar_done = nullptr;
+    int ev_ar_next = 0;
+    std::vector<std::pair<long long, long long>> ar_buckets;   // [lo, hi) float ranges of outer[], completion order
+    bool ar_armed = false, ar_active = false, ar_issued = false, ar_failed = false;
+    int ar_next = 0, ar_nt = 0;
+    float ar_axpy = 0.f;            // second order: grad[range] += ar_axpy * hv[range] in front of the task sum (the last reverse step's update)
+    int ar_launches = 0;            // collectives issued by the last overlapped exchange (tests, bench line)
+    int ar_idx_postnet() const { return 0; }
+    int ar_idx_dec(int l) const { return 1 + (cfg.dec_layers - 1 - l); }
+    int ar_idx_va() const { return 1 + cfg.dec_layers; }
+    int ar_idx_spk() const { return 2 + cfg.dec_layers; }
+    int ar_idx_enc(int l) const { return 3 + cfg.dec_layers + (cfg.enc_layers - 1 - l); }
+    int ar_idx_last() const { return 2 + cfg.dec_layers + cfg.enc_layers; }
+    // streams / events and the bucket table; 0 when the overlapped exchange is available
+    int ar_setup() {
+        if (!comm_stream) {
+            HIP_CHECK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+            for (auto& e : ev_ar) HIP_CHECK(hipEventCreate(&e));
+            HIP_CHECK(hipEventCreate(&ev_ar_done));
+        }
+        ar_buckets.clear();
+        if (cfg.enc_layers < 1) return 1;
+        std::vector<const ParamEntry*> order;
+        for (const ParamEntry& e : entries) order.push_back(&e);
+        std::sort(order.begin(), order.end(), [](const ParamEntry* a, const ParamEntry* b) { return a->off < b->off; });
+        auto layer_of = [](const std::string& n, const char* pre) { return atoi(n.c_str() + strlen(pre)); };
+        auto bucket_of = [&](const std::string& n) -> int {
+            if (n.rfind("postnet.", 0) == 0) return ar_idx_postnet();
+            if (n.rfind("mel_linear.", 0) == 0) return cfg.dec_layers > 0 ? ar_idx_dec(cfg.dec_layers - 1) : ar_idx_postnet();
+            if (n.rfind("decoder.layer_stack.", 0) == 0) return ar_idx_dec(layer_of(n, "decoder.layer_stack."));
+            if (n.rfind("variance_adaptor.", 0) == 0) return ar_idx_va();
+            if (n.rfind("speaker_emb.", 0) == 0) return ar_idx_spk();
+            if (n.rfind("encoder.layer_stack.", 0) == 0) return ar_idx_enc(layer_of(n, "encoder.layer_stack."));
+            if (n.rfind("encoder.", 0) == 0) return ar_idx_last();
+            return -1;
+        };
+        const int nb = ar_idx_last() + 1;
+        std::vector<std::pair<long long, long long>> rng((size_t)nb, {-1, -1});
+        int prev = -2;
+        for (size_t i = 0; i < order.size(); ++i) {
+            const int b = bucket_of(order[i]->name);
+            if (b < 0 || b >= nb) return 1;
+            if (b != prev) {
+                if (rng[(size_t)b].first >= 0) return 1;          // a module's tensors are not one contiguous run of the flat buffer
+                rng[(size_t)b].first = order[i]->off;
+                if (prev >= 0) rng[(size_t)prev].second = order[i]->off;
+                prev = b;
+            }
+        }
+        if (prev >= 0) rng[(size_t)prev].second = n_total;
+        for (auto& r : rng) if (r.first >= 0 && r.second > r.first && ((r.second - r.first) % 4) == 0 && (r.first % 4) == 0) ar_buckets.push_back(r); else if (r.first >= 0) { ar_buckets.clear(); return 1; }
+        // (a module without parameters has no bucket: the completion-order indices above then no longer match, so require them all)
+        if ((int)ar_buckets.size() != nb) { ar_buckets.clear(); return 1; }
+        return 0;
+    }
+    void ar_destroy() {
+        if (comm_stream) { hipStreamSynchronize(comm_stream); hipStreamDestroy(comm_stream); comm_stream = nullptr; }
+        for (auto& e : ev_ar) if (e) { hipEventDestroy(e); e = nullptr; }
+        if (ev_ar_done) { hipEventDestroy(ev_ar_done); ev_ar_done = nullptr; }
+    }
+    // start of an overlapped exchange (the gradient call that fills outer[]): true when armed and possible
+    bool ar_begin(int nt, float axpy = 0.f) {
+        const bool go = ar_armed && ar.sum != nullptr && comm_stream != nullptr && !ar_buckets.empty();
+        ar_armed = false;
+        if (!go) return false;
+        ar_active = true; ar_failed = false; ar_next = 0; ar_nt = nt; ar_axpy = axpy; ar_launches = 0;
+        return true;
+    }
+    void ar_wait_for(hipStream_t producer) {
+        hipEvent_t ev = ev_ar[ev_ar_next];
+        ev_ar_next = (ev_ar_next + 1) % kArEvents;
+        hipEventRecord(ev, producer);
+        hipStreamWaitEvent(comm_stream, ev, 0);
+    }
+    // the exchange tail (final once the loss of the pass is known): packed on the main stream, reduced on the comm stream
+    void ar_tail() {
+        const float w = bn_sync_mode == 1 ? 1.f / (float)ar.world : (ar.rank == 0 ? 1.f : 0.f);
+        if (sync_pack(w)) { ar_failed = true; return; }
+        ar_wait_for(stream);
+        if (ar.sum(ar.ctx, outer + n_total, (size_t)sync_tail, comm_stream)) ar_failed = true;
+        ++ar_launches;
+    }
+    // buckets 0 .. upto are complete (everything that writes them has been enqueued on the main / side stream): reduce those not yet sent
+    void ar_ready(int upto) {
+        if (!ar_active) return;
+        if (upto >= (int)ar_buckets.size()) upto = (int)ar_buckets.size() - 1;
+        if (ar_next > upto) return;
+        ar_wait_for(stream);
+        if (defer_live && side) ar_wait_for(side);
+        for (; ar_next <= upto; ++ar_next) {
+            const long long lo = ar_buckets[(size_t)ar_next].first, n = ar_buckets[(size_t)ar_next].second - lo;
+            if (ar_axpy != 0.f)
+                MTTS_LAUNCH(axpy_kernel, dim3(blocks_for(n / 4), 1, ar_nt), dim3(256), comm_stream, grad + lo, n_total, (const float*)(hv + lo), n_total, ar_axpy, n / 4);
+            MTTS_LAUNCH(sum_tasks_kernel, dim3(blocks_for(n / 4)), dim3(256), comm_stream, (const float*)(grad + lo), n_total, ar_nt, 1.f, outer + lo, n / 4,
+                        (int)outer_accumulate);
+            if (ar.sum(ar.ctx, outer + lo, (size_t)n, comm_stream)) ar_failed = true;
+            ++ar_launches;
+        }
+    }
+    // end of the gradient call: whatever is left goes out, the exchange is "issued" (mtts_allreduce_outer joins it)
+    int ar_end() {
+        ar_ready((int)ar_buckets.size() - 1);
+        ar_active = false; ar_axpy = 0.f;
+        ar_issued = true;
+        if (ar_failed) { set_error("overlapped all-reduce: a collective could not be issued"); return -1; }
+        return 0;
+    }
+    // the main stream waits for the comm stream's collectives (before the clip + Adam reads outer[])
+    void ar_join() {
+        hipEventRecord(ev_ar_done, comm_stream);
+        hipStreamWaitEvent(stream, ev_ar_done, 0);
+        ar_issued = false;
+    }
+
     // everything enqueued on the main stream so far happens before what is enqueued on the side stream next
     void fork_side() {
         hipEvent_t ev = ev_side[ev_next];
@@ -2151,6 +2280,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         // ---- mel_linear -------------------------------------------------------------------
         set_tag(0);
         TS none{nullptr, 0};
+        ar_ready(ar_idx_postnet());
         const bool dfm = defer_ok(p);   // gRm / gMelF are final from here on: their parameter gradients can run on the side stream
         if (!dfm) colsum(ps, SP_R, gRm, nm, nullptr, none, Gd(mel_b));
         MTTS_LAUNCH(gather_rows_kernel, row_grid(p.maxMf, nt), dim3(256), stream, (const int*)p.meta, (int)META_MF,
@@ -2176,6 +2306,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             site_base = 64 + 2 * l;
             fft_bwd(ps, SP_F, cfg.dec_heads, decP[l], decB[l], xin, l == cfg.dec_layers - 1 ? K.dec_top : K.dec[l + 1].g0, K.dec[l], dSf,
                     defer_ok(p) ? &decG[l] : nullptr);
+            ar_ready(ar_idx_dec(l));   // (overlapped exchange: PostNet, mel_linear and the decoder layers down to l are complete)
         }
         const TS gF0 = cfg.dec_layers ? K.dec[0].g0 : K.dec_top;   // gradient of the decoder input
         // speaker vector gradient, part 1: every valid frame
@@ -2247,12 +2378,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         MTTS_LAUNCH(speaker_table_grad_kernel, dim3(cfg.n_speaker, 1, nt), dim3(64), sst, (const int*)p.meta,
                     (const float*)dspk.p, dspk.ts, (const int*)p.spk_ids, (long long)cap_B + 1, cap_B, p.average_spk,
                     Gd(spk_table).p, n_total, d);
+        ar_ready(ar_idx_spk());        // variance adaptor + speaker table
         if (!need_encoder) return 0;
         // ---- encoder ------------------------------------------------------------------------
         for (int l = cfg.enc_layers - 1; l >= 0; --l) {
             TS xin = l == 0 ? emb_out : encB[l - 1].y2;
             site_base = 2 * l;
             fft_bwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], xin, gP0, LayerKeep{gP0, gPh, gP1, gP1, gPqkv}, dSp, defer_ok(p) ? &encG[l] : nullptr);
+            if (l > 0) ar_ready(ar_idx_enc(l));   // (layer 0's bucket also holds the word embedding, below)
         }
         // word embedding (padding row 0 keeps a zero gradient); p_tok is 0 on invalid rows, and
         // gP0 is only meaningful on valid rows -> scan with the token ids masked by validity
@@ -2309,10 +2442,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         if (forward(pq)) return -1;
         if (loss(pq, losses_out ? losses_out : losses)) return -1;
-        if (backward(pq, grad_scale, true)) return -1;
+        if (!losses_out || losses_out == losses) { sync_nt = nt; sync_scale = grad_scale; }
+        const bool overlap = ar_begin(nt);   // (mtts_arm_allreduce_overlap: the buckets leave as the query backward completes them)
+        if (overlap) ar_tail();
+        const int rc = backward(pq, grad_scale, true);
+        if (overlap) { if (ar_end() || rc) return -1; return 0; }
+        if (rc) return -1;
         MTTS_LAUNCH(sum_tasks_kernel, dim3(blocks_for(n_total / 4)), dim3(256), stream, (const float*)grad, n_total, nt, 1.f, outer,
                     n_total / 4, (int)outer_accumulate);
-        if (!losses_out || losses_out == losses) { sync_nt = nt; sync_scale = grad_scale; }
         return 0;
     }
 
@@ -2345,10 +2482,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         Pass ps{&p, false, true};
         if (forward(ps)) return -1;
         if (loss(ps, losses_out ? losses_out : losses)) return -1;
-        if (backward(ps, grad_scale, true)) return -1;
+        if (!losses_out || losses_out == losses) { sync_nt = p.tasks; sync_scale = grad_scale; }
+        const bool overlap = ar_begin(p.tasks);
+        if (overlap) ar_tail();
+        const int rc = backward(ps, grad_scale, true);
+        if (overlap) { if (ar_end() || rc) return -1; return 0; }
+        if (rc) return -1;
         MTTS_LAUNCH(sum_tasks_kernel, dim3(blocks_for(n_total / 4)), dim3(256), stream, (const float*)grad, n_total, p.tasks, 1.f,
                     outer, n_total / 4, (int)outer_accumulate);
-        if (!losses_out || losses_out == losses) { sync_nt = p.tasks; sync_scale = grad_scale; }
         return 0;
     }
 

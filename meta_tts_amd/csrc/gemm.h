@@ -319,6 +319,58 @@ __device__ __forceinline__ void mma_half(const Frags<TM, TN, BK>& f, int hf, f32
 #endif
 }
 
+// ---- register-lean K-loop (KL >= 1, BK = 32, device builds) ----------------------------------------------------------------------
+// Half fragments: the operands of ONE half (16 k-values) of a slice.  The rotating loop of gemm_f32_kloop keeps two of them (32 VGPRs for a
+// 32x32 wave tile) instead of two whole-slice fragment sets (64): the dominant kernels drop from 124 + 16 to under 112 + 16 registers,
+// i.e. from 3 to 4 resident waves per SIMD (the unified VGPR file holds 512 per lane).
+template <int TM, int TN>
+struct HalfFrags { float a[2][TM][4], b[2][TN][4]; };
+template <int V> struct KlTag { static constexpr int value = V; };   // 3: store + load (steady state), 2: store only, 1: last slice, 0: generic (tested per slice)
+
+#if !defined(MTTS_EMU)
+template <int TM, int TN, bool A_KC, bool B_KC, int LDA, int LDB>
+__device__ __forceinline__ void read_half(const float* As, const float* Bs, int wm0, int wn0, int lane, int hf, HalfFrags<TM, TN>& f) {
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int kb = 8 * (2 * hf + q) + 4 * h;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (A_KC) {
+                const float4 v = ld4(As + (wm0 + i * 32 + l31) * LDA + kb);
+                f.a[q][i][0] = v.x; f.a[q][i][1] = v.y; f.a[q][i][2] = v.z; f.a[q][i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f.a[q][i][e] = As[(kb + e) * LDA + wm0 + i * 32 + l31];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (B_KC) {
+                const float4 v = ld4(Bs + (wn0 + j * 32 + l31) * LDB + kb);
+                f.b[q][j][0] = v.x; f.b[q][j][1] = v.y; f.b[q][j][2] = v.z; f.b[q][j][3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f.b[q][j][e] = Bs[(kb + e) * LDB + wn0 + j * 32 + l31];
+            }
+        }
+    }
+}
+// the 8 x TM x TN MFMAs of a half, in the k order of mma_half (results are bit-identical to the KL = 0 loop)
+template <int TM, int TN>
+__device__ __forceinline__ void mma_hfrags(const HalfFrags<TM, TN>& f, f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][i][e], f.b[q][j][e], acc[i][j], 0, 0, 0);
+}
+#endif
+
 // Fused epilogue shared by the fp32 and the split-bf16 kernels: alpha, bias, accumulate, ReLU, ReLU-mask of a
 // saved activation, row mask, output row remap.  (mb, nb) = origin of this wave's tile.
 template <int TM, int TN>
@@ -472,11 +524,19 @@ __device__ __forceinline__ GemmProb gemm_resolve2(const GemmArgs& g, int z, cons
 template <int FORM>
 __device__ __forceinline__ bool gemm_has_colsum(const GemmArgs& g) { return (FORM == GEMM_TN) && g.colsum != nullptr && !g.table; }
 
+#if defined(MTTS_EMU)
+#define MTTS_KL_PRIO(p) ((void)0)
+#else
+#define MTTS_KL_PRIO(p) do { if (KL == 3) __builtin_amdgcn_s_setprio(p); } while (0)
+#endif
 // K-loop of one output tile (origin m0, n0) of a resolved problem over the K-chunks [c_lo, c_hi): the products are added into acc.
 // cs_tile: the tile is the column-sum tile (its B operand is GemmArgs::colsum_w).
 // ABL (diagnostic builds only, results are wrong): bit 0 drops the in-loop global loads, bit 1 the LDS stores, bit 2 the
 // in-loop fragment reads, bit 3 the barrier — timing the kernel with one stage removed shows what that stage costs.
-template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0>
+// KL (K-loop variant, BK = 32 pipelined kernels; profiles/r05_kloop_ab.md): 0 = two whole-slice fragment sets, clustered phases (rounds 2-4);
+// 1 = rotating half fragments + loop-invariant pointer steps; 2 = 1 with s_setprio around the MFMA clusters; 3 = 0 with s_setprio;
+// 4 = 1 with the slice's LDS / global instructions interleaved into the MFMA chain (sched_group_barrier).
+template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0, int KL = 0>
 __device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb& pr, int z, int m0, int n0, bool cs_tile, int c_lo, int c_hi,
                                                float* smem, f32x16 (&acc)[(BM / WGM) / 32][(BN / WGN) / 32]) {
     constexpr int NTH = 64 * WGM * WGN;
@@ -610,6 +670,112 @@ __device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb
     load_b(kb0);
     store_ab(0);
     __syncthreads();
+#if !defined(MTTS_EMU)
+    if constexpr (PIPE && BK == 32 && (KL == 1 || KL == 2 || KL == 4)) {
+        // Rotating half fragments.  Per slice c:  [read half 1 of c | store c+1 to LDS | issue the loads of c+2]  MFMA(half 0)  barrier
+        // [read half 0 of c+1]  MFMA(half 1) — every LDS read is issued one MFMA cluster (8 x 64 cycles) before its first use.
+        // Pointer steps: the K-slices of a workgroup are consecutive, so an operand's pointer advances by one of two loop-invariant
+        // distances (inside a conv tap / across a tap boundary: taps are multiples of 32) chosen by one scalar compare — the generic
+        // load_a / load_b above re-derive the tap from k0 every slice (~40 scalar instructions and two loops per slice).
+        int a_in = 0, b_in = 0;   // offset of the NEXT slice inside its tap
+        {
+            const int k1 = kb0;   // (position after the prologue's load of slice kb0)
+            a_in = A_KC ? k1 - a_tap_base : 0;
+            b_in = B_KC ? 0 : k1 - b_tap_base;
+        }
+        const long long a_s1 = A_KC ? (long long)BK : (long long)BK * lda;
+        const long long a_s2 = A_KC ? a_tap_stride - (long long)(g_a_tap_k - BK) : a_s1;
+        const long long b_s1 = B_KC ? (long long)BK : (long long)BK * ldb;
+        const long long b_s2 = B_KC ? b_s1 : -(long long)g_tap_bstride - (long long)(g_tap_k - BK) * ldb;
+        int k_next = kb0;
+        // fast: the slice is known to be a full one (no zero-filled tail) — straight-line code, which is what lets the scheduler interleave
+        auto load_next = [&](auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value == 3;
+            k_next += BK;
+            a_in += BK; b_in += BK;
+            const bool a_x = A_KC && a_in >= g_a_tap_k, b_x = !B_KC && b_in >= g_tap_k;
+            const long long da = a_x ? a_s2 : a_s1, db = b_x ? b_s2 : b_s1;
+            if (a_x) a_in = 0;
+            if (b_x) b_in = 0;
+#pragma unroll
+            for (int i = 0; i < A_LD4; ++i) a_ptr[i] += da;
+#pragma unroll
+            for (int i = 0; i < B_LD4; ++i) b_ptr[i] += db;
+            if (FAST || k_next + BK <= K) {
+#pragma unroll
+                for (int i = 0; i < A_LD4; ++i) areg[i] = ld4(a_ptr[i]);
+#pragma unroll
+                for (int i = 0; i < B_LD4; ++i) breg[i] = ld4(b_ptr[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < A_LD4; ++i) {
+                    const bool ok = A_KC ? (k_next + (tid % KQ) * 4 < K4) : (k_next + (tid + NTH * i) / (BM / 4) < K);
+                    areg[i] = ok ? ld4(a_ptr[i]) : zero4();
+                }
+#pragma unroll
+                for (int i = 0; i < B_LD4; ++i) {
+                    const bool ok = B_KC ? (k_next + (tid % KQ) * 4 < K4) : (k_next + (tid + NTH * i) / (BN / 4) < K);
+                    breg[i] = ok ? ld4(b_ptr[i]) : zero4();
+                }
+            }
+        };
+        HalfFrags<TM, TN> h0, h1;
+        constexpr int NDR = ((A_KC ? 2 : 8) * TM + (B_KC ? 2 : 8) * TN);   // LDS read instructions of a half (ds_read_b128 / ds_read_b32)
+        auto body = [&](int c, auto mode_tag) {
+            // MODE 3: slices c + 1 and c + 2 exist and c + 2 is a whole one (steady state); 2: c + 1 exists, nothing left to load; 1: the last
+            // slice; 0: decided per slice (the iteration that loads a zero-filled tail).  Modes 1-3 are straight-line code — which is what
+            // lets the scheduler interleave (KL = 4).
+            constexpr int MODE = decltype(mode_tag)::value;
+            const int nb = (c & 1) ^ 1;
+            const float* Ac = smem + (c & 1) * (A_TILE + B_TILE);
+            read_half<TM, TN, A_KC, B_KC, LDA_S, LDB_S>(Ac, Ac + A_TILE, wm0, wn0, lane, 1, h1);
+            if (MODE >= 2 || (MODE == 0 && c + 1 < nchunks)) store_ab(nb);
+            if (MODE == 3) load_next(mode_tag);
+            else if (MODE == 0 && c + 2 < nchunks) load_next(mode_tag);
+            if (KL != 4) __builtin_amdgcn_sched_barrier(0);
+            if (KL == 2) __builtin_amdgcn_s_setprio(2);
+            mma_hfrags<TM, TN>(h0, acc);
+            if (KL == 2) __builtin_amdgcn_s_setprio(0);
+            if (KL == 4 && MODE != 0) {
+                // one group of memory instructions behind each MFMA of the cluster: the chain is dependent (an MFMA issues when its
+                // predecessor retires, 64 cycles later), so the LDS reads / writes and the global loads ride in its shadow instead of in front of it
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                                                    // MFMA
+                    if (q < 4) __builtin_amdgcn_sched_group_barrier(0x100, (NDR + 3) / 4, 0);                                   // DS read (half 1 of this slice)
+                    else if (q < 6) { if (MODE >= 2) __builtin_amdgcn_sched_group_barrier(0x200, (A_LD4 + B_LD4 + 1) / 2, 0); }  // DS write (slice c + 1)
+                    else if (MODE == 3) __builtin_amdgcn_sched_group_barrier(0x020, (A_LD4 + B_LD4 + 1) / 2, 0);                // global loads (slice c + 2)
+                }
+            }
+            __syncthreads();
+            if (MODE >= 2 || (MODE == 0 && c + 1 < nchunks)) {
+                const float* An = smem + nb * (A_TILE + B_TILE);
+                read_half<TM, TN, A_KC, B_KC, LDA_S, LDB_S>(An, An + A_TILE, wm0, wn0, lane, 0, h0);
+            }
+            if (KL != 4) __builtin_amdgcn_sched_barrier(0);
+            if (KL == 2) __builtin_amdgcn_s_setprio(2);
+            mma_hfrags<TM, TN>(h1, acc);
+            if (KL == 2) __builtin_amdgcn_s_setprio(0);
+            if (KL == 4 && MODE >= 2) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                    if (q < 4) __builtin_amdgcn_sched_group_barrier(0x100, (NDR + 3) / 4, 0);   // half 0 of slice c + 1
+                }
+            }
+        };
+        if (nchunks > 1) load_next(KlTag<0>{});
+        read_half<TM, TN, A_KC, B_KC, LDA_S, LDB_S>(smem, smem + A_TILE, wm0, wn0, lane, 0, h0);
+        const int full = (K - kb0) / BK;                                        // whole slices from kb0 on
+        const int n_fast = nchunks - 2 < full - 2 ? nchunks - 2 : full - 2;     // iterations whose slice c + 2 exists and is whole
+        int c = 0;
+        for (; c < n_fast; ++c) body(c, KlTag<3>{});
+        for (; c < nchunks - 2; ++c) body(c, KlTag<0>{});                       // (at most one: it loads the zero-filled tail slice)
+        if (c == nchunks - 2) { body(c, KlTag<2>{}); ++c; }
+        body(c, KlTag<1>{});
+        return;
+    }
+#endif
     if (!PIPE) {
         // simple double buffer: fragments read and consumed inside one barrier interval
         Frags<TM, TN, BK> f;
@@ -634,13 +800,17 @@ __device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb
             const int nb = (c & 1) ^ 1;
             if (!(ABL & 2) && c + 1 < nchunks) store_ab(nb);
             if (!(ABL & 1) && c + 2 < nchunks) { load_a(kb0 + (c + 2) * BK); load_b(kb0 + (c + 2) * BK); }
+            MTTS_KL_PRIO(2);
             mma_half<TM, TN, BK>(fc, 0, acc);
+            MTTS_KL_PRIO(0);
             if (!(ABL & 8)) __syncthreads();
             if (!(ABL & 4) && c + 1 < nchunks) {
                 const float* As = smem + nb * (A_TILE + B_TILE);
                 read_frags<TM, TN, BK, A_KC, B_KC, LDA_S, LDB_S>(As, As + A_TILE, wm0, wn0, lane, fn);
             }
+            MTTS_KL_PRIO(2);
             mma_half<TM, TN, BK>(fc, 1, acc);
+            MTTS_KL_PRIO(0);
         };
         for (int c = 0; c < nchunks; c += 2) {
             step(c, f0, f1);
@@ -674,7 +844,7 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& g, const GemmProb& p
 // DUAL: the kernel also runs the second source of dual-source problems (GemmArgs::A2) — a second, separately inlined K-loop into the
 // same accumulators.  (A runtime loop over the sources around ONE inlined K-loop costs every kernel ~10 VGPRs of spilled SGPR state
 // — the multi-problem BK = 32 kernel drops from 4 to 3 workgroups per CU — so only the kernels that may be handed such problems pay for it.)
-template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0, bool DUAL = false>
+template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0, bool DUAL = false, int KL = 0>
 __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs, float* smem) {
     constexpr int NTH = 64 * WGM * WGN;
     constexpr int TM = (BM / WGM) / 32, TN = (BN / WGN) / 32;
@@ -695,19 +865,19 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int nch_all = (pr.K + BK - 1) / BK, cps = (nch_all + S - 1) / S;
     const int c_lo = split * cps, c_hi = (c_lo + cps < nch_all) ? c_lo + cps : nch_all;   // (all chunks when S == 1)
-    gemm_f32_kloop<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL>(g, pr, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
+    gemm_f32_kloop<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL, KL>(g, pr, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
     if (DUAL) {
         if (g.A2 != nullptr && !cs_tile) {
             __syncthreads();   // every wave is done with the first source's LDS tiles
             const GemmProb p2 = gemm_resolve2(g, z, pr);
-            gemm_f32_kloop<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL>(g, p2, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
+            gemm_f32_kloop<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL, KL>(g, p2, z, m0, n0, cs_tile, c_lo, c_hi, smem, acc);
         }
     }
     if (S > 1 && !splitk_combine<TM, TN, NTH>(g, z, tile_lin, split, S, acc)) return;
     gemm_finish<TM, TN, WGM, WGN>(g, pr, z, m0, n0, cs_tile, acc);
 }
 
-template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0>
+template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0, int KL = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[GemmSmem<FORM, BM, BN, BK>::FLOATS];
     int z = blockIdx.z;
@@ -715,7 +885,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
     if (g.xs.on) { if (!xcd_sched_locate(g.xs, bxs, z, bxs)) return; }   // 1-D grid, task-per-XCD order
     else if (g.swizzle == 2) { if (!xcd_panel_locate(bxs, g.po_tiles_m, (g.N + BN - 1) / BN + (gemm_has_colsum<FORM>(g) ? 1 : 0), g.splitk > 1 ? g.splitk : 1, bxs)) return; }
     else if (g.swizzle) bxs = xcd_group_remap(bxs, (int)gridDim.x, xcd_group_size((g.N + BN - 1) / BN, g.splitk));
-    gemm_f32_body<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL>(g, z, bxs, smem);
+    gemm_f32_body<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL, false, KL>(g, z, bxs, smem);
 }
 
 // Several independent problems (any mix of forms, e.g. the dgrad and the wgrad of one layer) in ONE launch: workgroups
@@ -756,7 +926,7 @@ __device__ __forceinline__ bool gemm_multi_locate(const GemmMulti& mp, int& p, i
     bx = lin - z * tiles;
     return true;
 }
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int KL = 0>
 __global__ __launch_bounds__(256) void gemm_f32_multi_kernel(GemmMulti mp) {
     constexpr int F0 = GemmSmem<GEMM_NT, BM, BN, BK>::FLOATS, F1 = GemmSmem<GEMM_NN, BM, BN, BK>::FLOATS, F2 = GemmSmem<GEMM_TN, BM, BN, BK>::FLOATS;
     constexpr int FL = F0 > F1 ? (F0 > F2 ? F0 : F2) : (F1 > F2 ? F1 : F2);
@@ -764,13 +934,13 @@ __global__ __launch_bounds__(256) void gemm_f32_multi_kernel(GemmMulti mp) {
     int p, z, bx;
     if (!gemm_multi_locate(mp, p, z, bx)) return;
     const int form = mp.form[p];
-    if (form == GEMM_NT) gemm_f32_body<GEMM_NT, BM, BN, BK, true>(mp.g[p], z, bx, smem);
-    else if (form == GEMM_NN) gemm_f32_body<GEMM_NN, BM, BN, BK, true>(mp.g[p], z, bx, smem);
-    else gemm_f32_body<GEMM_TN, BM, BN, BK, true>(mp.g[p], z, bx, smem);
+    if (form == GEMM_NT) gemm_f32_body<GEMM_NT, BM, BN, BK, true, 2, 2, 0, false, KL>(mp.g[p], z, bx, smem);
+    else if (form == GEMM_NN) gemm_f32_body<GEMM_NN, BM, BN, BK, true, 2, 2, 0, false, KL>(mp.g[p], z, bx, smem);
+    else gemm_f32_body<GEMM_TN, BM, BN, BK, true, 2, 2, 0, false, KL>(mp.g[p], z, bx, smem);
 }
 
 // the same grid for launches that carry dual-source problems (GemmArgs::A2)
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int KL = 0>
 __global__ __launch_bounds__(256) void gemm_f32_multi_dual_kernel(GemmMulti mp) {
     constexpr int F0 = GemmSmem<GEMM_NT, BM, BN, BK>::FLOATS, F1 = GemmSmem<GEMM_NN, BM, BN, BK>::FLOATS, F2 = GemmSmem<GEMM_TN, BM, BN, BK>::FLOATS;
     constexpr int FL = F0 > F1 ? (F0 > F2 ? F0 : F2) : (F1 > F2 ? F1 : F2);
@@ -778,9 +948,9 @@ __global__ __launch_bounds__(256) void gemm_f32_multi_dual_kernel(GemmMulti mp) 
     int p, z, bx;
     if (!gemm_multi_locate(mp, p, z, bx)) return;
     const int form = mp.form[p];
-    if (form == GEMM_NT) gemm_f32_body<GEMM_NT, BM, BN, BK, true, 2, 2, 0, true>(mp.g[p], z, bx, smem);
-    else if (form == GEMM_NN) gemm_f32_body<GEMM_NN, BM, BN, BK, true, 2, 2, 0, true>(mp.g[p], z, bx, smem);
-    else gemm_f32_body<GEMM_TN, BM, BN, BK, true, 2, 2, 0, true>(mp.g[p], z, bx, smem);
+    if (form == GEMM_NT) gemm_f32_body<GEMM_NT, BM, BN, BK, true, 2, 2, 0, true, KL>(mp.g[p], z, bx, smem);
+    else if (form == GEMM_NN) gemm_f32_body<GEMM_NN, BM, BN, BK, true, 2, 2, 0, true, KL>(mp.g[p], z, bx, smem);
+    else gemm_f32_body<GEMM_TN, BM, BN, BK, true, 2, 2, 0, true, KL>(mp.g[p], z, bx, smem);
 }
 
 // Kernel kinds of the launcher: one per real kernel symbol, so that a profiler line can be matched to a rocprofv3 kernel-trace row.
@@ -849,6 +1019,13 @@ struct GemmProfiler {
 constexpr int kGemmXcdSwizzle = 1;     // XCD-grouped tile order of the plain grids (xcd_group_remap)
 constexpr int kGemmDefaultBk = 16;     // K-slice of the register-staged kernels (32 for long K-contiguous panels, see gemm_launch)
 constexpr bool kGemmDefaultPipe = true;  // software-pipelined K-loop
+// K-loop variant of the 64x64 BK = 32 pipelined kernels (gemm_f32_kloop: KL).  MTTS_KLOOP=0..4 picks another one for A/B runs
+// (profiles/r05_kloop_ab.md); results are bit-identical across variants (same k order in every accumulator chain).
+constexpr int kGemmDefaultKloop = 4;
+inline int gemm_kloop_variant() {
+    static const int v = [] { const char* e = getenv("MTTS_KLOOP"); const int x = e ? atoi(e) : kGemmDefaultKloop; return (x >= 0 && x <= 4) ? x : kGemmDefaultKloop; }();
+    return v;
+}
 inline int gemm_xcd_swizzle() { return kGemmXcdSwizzle; }
 inline int gemm_default_bk() { return kGemmDefaultBk; }
 inline bool gemm_default_pipe() { return kGemmDefaultPipe; }
@@ -897,7 +1074,10 @@ inline void gemm_batch_begin(GemmCtx& cx) { cx.batch.open = true; }
 inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream);
 
 // LDS-DMA kernel family (gemm_glds.h, device builds only)
-inline bool gemm_use_glds() { return true; }
+inline bool gemm_use_glds() {   // MTTS_GLDS=0: the register-staged kernels also in the latency regime (A/B runs)
+    static const bool on = [] { const char* e = getenv("MTTS_GLDS"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
 inline bool gemm_glds_ok(const GemmArgs& g) { return !(g.taps > 1 && g.tap_k % 32 != 0); }
 // n-tiles of a problem's grid: the tiles of C plus the column-sum tile (GemmArgs::colsum)
 inline int gemm_tiles_n(const GemmArgs& g, int max_N, int t) { return (max_N + t - 1) / t + (g.colsum ? 1 : 0); }
@@ -1035,7 +1215,17 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     int kind = GK_OTHER;
 #define MTTS_GEMM_CASE(F, T)                                                                              \
     if (form == F && tile == T) {                                                                         \
-        if (bk == 32 && pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 32, true>), grid, block, stream, g); kind = (T == 64 ? GK_F32_64_BK32 : GK_F32_128) + F; }   \
+        if (bk == 32 && pipe && T == 64) {                                                                \
+            switch (gemm_kloop_variant()) {                                                               \
+                case 1: MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 1>), grid, block, stream, g); break;   \
+                case 2: MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 2>), grid, block, stream, g); break;   \
+                case 3: MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 3>), grid, block, stream, g); break;   \
+                case 4: MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 4>), grid, block, stream, g); break;   \
+                default: MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 0>), grid, block, stream, g);         \
+            }                                                                                             \
+            kind = GK_F32_64_BK32 + F;                                                                    \
+        }                                                                                                 \
+        else if (bk == 32 && pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 32, true>), grid, block, stream, g); kind = (T == 64 ? GK_F32_64_BK32 : GK_F32_128) + F; }   \
         else if (bk == 32) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 32, false>), grid, block, stream, g); kind = T == 64 ? GK_OTHER : GK_F32_128 + F; }     \
         else if (pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, true>), grid, block, stream, g); kind = (T == 64 ? GK_F32_64_BK16 : GK_F32_128) + F; }          \
         else { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 16, false>), grid, block, stream, g); kind = T == 64 ? GK_OTHER : GK_F32_128 + F; }                   \
@@ -1200,8 +1390,26 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     else
 #endif
     if (bk32 && maxK >= 1024) {
-        if (any_dual) { MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32>), grid, block, stream, mp); kind = GK_MULTI32_DUAL; }
-        else { MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32>), grid, block, stream, mp); kind = GK_MULTI32; }
+        const int kl = gemm_kloop_variant();
+        if (any_dual) {
+            switch (kl) {
+                case 1: MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32, 1>), grid, block, stream, mp); break;
+                case 2: MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32, 2>), grid, block, stream, mp); break;
+                case 3: MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32, 3>), grid, block, stream, mp); break;
+                case 4: MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32, 4>), grid, block, stream, mp); break;
+                default: MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32, 0>), grid, block, stream, mp);
+            }
+            kind = GK_MULTI32_DUAL;
+        } else {
+            switch (kl) {
+                case 1: MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 1>), grid, block, stream, mp); break;
+                case 2: MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 2>), grid, block, stream, mp); break;
+                case 3: MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 3>), grid, block, stream, mp); break;
+                case 4: MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 4>), grid, block, stream, mp); break;
+                default: MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 0>), grid, block, stream, mp);
+            }
+            kind = GK_MULTI32;
+        }
     } else if (any_dual) { MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 16>), grid, block, stream, mp); kind = GK_MULTI16_DUAL; }
     else { MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 16>), grid, block, stream, mp); }
     cx.last_kind = kind;

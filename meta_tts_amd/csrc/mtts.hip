@@ -348,11 +348,31 @@ int mtts_comm_init(mtts_handle* h, const void* id128, int rank, int world_size) 
     NcclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     if (h->comm.init(id, rank, world_size)) { h->eng.set_error(h->comm.err); return -1; }
+    // the overlapped, bucketed exchange (mtts_arm_allreduce_overlap): the engine issues its collectives through this hook
+    Engine& e = h->eng;
+    e.ar.ctx = &h->comm;
+    e.ar.sum = [](void* c, float* buf, size_t n, hipStream_t st) { return ((Comm*)c)->sum(buf, n, st); };
+    e.ar.rank = rank; e.ar.world = world_size;
+    if (e.ar_setup() < 0) return -1;   // (> 0: no bucket table for this architecture — the one-shot exchange stays available)
     return 0;
 }
+int mtts_arm_allreduce_overlap(mtts_handle* h) {
+    if (!h) return -1;
+    Engine& e = h->eng;
+    static const int on = [] { const char* v = getenv("MTTS_AR_OVERLAP"); return v ? atoi(v) : 1; }();
+    if (!on || !h->comm.comm || e.ar.sum == nullptr || e.comm_stream == nullptr || e.ar_buckets.empty()) return 1;
+    e.ar_armed = true;
+    return 0;
+}
+int mtts_allreduce_launches(mtts_handle* h) { return h ? h->eng.ar_launches : -1; }
 int mtts_allreduce_outer(mtts_handle* h) {
     Engine& e = h->eng;
     if (!h->comm.comm) { e.set_error("communicator not initialised (mtts_comm_init)"); return -1; }
+    e.ar_armed = false;
+    if (e.ar_issued) {   // the gradient call already sent every bucket and the tail (overlapped exchange): wait for them, install the buffers
+        e.ar_join();
+        return launched(e, e.sync_unpack());
+    }
     const float w = e.bn_sync_mode == 1 ? 1.f / (float)h->comm.world : (h->comm.rank == 0 ? 1.f : 0.f);
     if (e.sync_pack(w)) return -1;
     if (h->comm.sum(e.outer, (size_t)(e.n_total + e.sync_tail), e.stream)) { e.set_error(h->comm.err); return -1; }

@@ -433,6 +433,18 @@ class Engine:
         assert len(unique_id) == 128
         self._ck(self.lib.mtts_comm_init(self.h, C.create_string_buffer(unique_id, 128), rank, world_size))
 
+    def arm_allreduce_overlap(self) -> bool:
+        """Arm the overlapped, bucketed exchange for the NEXT gradient call (include/mtts.h); False: not available, allreduce_outer will
+        reduce the whole buffer in one collective as before."""
+        rc = self.lib.mtts_arm_allreduce_overlap(self.h)
+        if rc < 0:
+            self._ck(rc)
+        return rc == 0
+
+    @property
+    def allreduce_launches(self) -> int:
+        return int(self.lib.mtts_allreduce_launches(self.h))
+
     def allreduce_outer(self):
         """ncclAllReduce(SUM) of the outer-gradient buffer on the engine's stream (asynchronous)."""
         self._ck(self.lib.mtts_allreduce_outer(self.h))

@@ -412,6 +412,10 @@ class Trainer:
         (result, hold): hold = the optimizer must NOT step yet."""
         eng = self.system.engine
         eng.set_grad_accumulation(self._acc_i > 0)
+        if self.library_comm and self._acc_i == self.grad_acc - 1:
+            # the window's last gradient call fills the buffer the ranks exchange: its buckets leave on the communication stream as the
+            # backward completes them (DDP's bucketed all-reduce overlapping the backward, main.py:30-38); _allreduce then only joins them
+            eng.arm_allreduce_overlap()
         try:
             out = grad_call()
         finally:

@@ -393,6 +393,53 @@ def test_in_library_rccl_allreduce_world_size_one():
     eng.close()
 
 
+@pytest.mark.parametrize("kind", ["fo", "so", "plain"])
+def test_overlapped_bucketed_allreduce_world_size_one(kind):
+    """mtts_arm_allreduce_overlap (include/mtts.h; main.py:30-38: DDP's bucketed all-reduce overlapping the backward) with real RCCL
+    collectives on the real (asynchronous) streams, one rank: the gradient call sends one bucket per module in backward-completion
+    order on the communication stream; outer gradient, reduced losses and the clip + Adam after it must equal the one-shot exchange
+    bit for bit (a missing event wait would let a bucket leave before its gradients — or its task sum — were written).  Full-size
+    model, C3 task 0 (the single-task rank of the 8-GPU job: deferred weight gradients on the side stream)."""
+    sup, qry = synth.make_task(0)
+    dims = ModelDims()
+    mods = default_algorithm_config()["adapt"]["modules"]
+    eng = Engine(dims, adapt_modules=mods, max_tasks=1, max_B=5, max_S=80, max_T=max(int(sup[8]), int(qry[8])))
+    eng.comm_init(eng.comm_unique_id(), 0, 1)
+    params = synth.make_params(dims, 0, weight_scale=0.5)
+    names = list(eng.params)
+
+    def run(overlap):
+        eng.load_params(params)
+        eng.reset_optimizer()
+        eng.set_dropout(True, 5)
+        eng.set_batches(0, [sup])
+        eng.set_batches(1, [qry], spk_from=[sup], average_spk=True)
+        armed = eng.arm_allreduce_overlap() if overlap else None
+        if kind == "plain":
+            eng.plain_grad(0, 0.125, fetch_losses=False)
+        else:
+            eng.meta_grad(5, 1e-3, 0.125, second_order=(kind == "so"), fetch_losses=False)
+        eng.allreduce_outer()
+        eng.synchronize()
+        g = {n: eng.export(n, 1).copy() for n in names}
+        losses = np.array(eng.synced_losses())
+        eng.outer_update(lr=1e-3)
+        eng.synchronize()
+        return g, losses, {n: eng.export(n, 0).copy() for n in ("mel_linear.weight", "encoder.layer_stack.0.pos_ffn.w_1.weight", "postnet.convolutions.4.1.bias")}, armed
+
+    g0, l0, w0, _ = run(False)
+    for rep in range(2):               # twice: the second overlapped call re-uses events / ring slots of the first
+        g1, l1, w1, armed = run(True)
+        assert armed is True and eng.allreduce_launches == 3 + dims.dec_layers + dims.enc_layers + 1
+        np.testing.assert_array_equal(l1, l0)
+        for n in names:
+            np.testing.assert_array_equal(g1[n], g0[n], err_msg=n)
+        for n in w0:
+            np.testing.assert_array_equal(w1[n], w0[n], err_msg=n)
+    assert float(np.abs(l0).sum()) > 0
+    eng.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # f4: frame-level pitch / energy (preprocess `feature: frame_level`) and the shared speaker embedding on hardware
 # ---------------------------------------------------------------------------------------------------------------------
