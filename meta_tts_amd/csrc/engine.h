@@ -1769,6 +1769,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         ar_issued = false;
     }
 
+    // kernel-family choice of the pass's main-stream GEMM launches: plans of <= 2 tasks (a single-task rank of the 8-GPU job, C2, few-shot
+    // adaptation) keep the register-staged kernels also for launches of <= 768 workgroups — see gemm.h: gemm_glds_mode
+    void set_regime(const Plan& p) { gx.no_glds = gemm_glds_mode() == 0 || (gemm_glds_mode() < 0 && p.tasks <= 2); }
+
     // everything enqueued on the main stream so far happens before what is enqueued on the side stream next
     void fork_side() {
         hipEvent_t ev = ev_side[ev_next];
@@ -1966,6 +1970,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     }
     int forward(const Pass& ps) {
         const Plan& p = *ps.pl;
+        set_regime(p);
         const int d = cfg.d_model, nt = p.tasks;
         TS none{nullptr, 0};
         if (ps.train) ps.pl->drop_seed = ps.seed_override ? ps.seed_override : next_drop_seed();
@@ -2221,6 +2226,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     }
     int backward_impl(const Pass& ps, float scale, bool need_encoder) {
         const Plan& p = *ps.pl;
+        set_regime(p);
         const int d = cfg.d_model, nt = p.tasks, nm = cfg.n_mel;
         if (!ps.train) { set_error("backward needs a train-mode forward (batch statistics)"); return -1; }
         if (!p.has_targets) { set_error("backward needs a teacher-forced batch (targets)"); return -1; }

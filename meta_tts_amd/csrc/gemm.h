@@ -323,17 +323,17 @@ __device__ __forceinline__ void mma_half(const Frags<TM, TN, BK>& f, int hf, f32
 // Half fragments: the operands of ONE half (16 k-values) of a slice.  The rotating loop of gemm_f32_kloop keeps two of them (32 VGPRs for a
 // 32x32 wave tile) instead of two whole-slice fragment sets (64): the dominant kernels drop from 124 + 16 to under 112 + 16 registers,
 // i.e. from 3 to 4 resident waves per SIMD (the unified VGPR file holds 512 per lane).
-template <int TM, int TN>
-struct HalfFrags { float a[2][TM][4], b[2][TN][4]; };
+template <int TM, int TN, int NQ>   // NQ = BK / 16 groups of 8 k-values per half
+struct HalfFrags { float a[NQ][TM][4], b[NQ][TN][4]; };
 template <int V> struct KlTag { static constexpr int value = V; };   // 3: store + load (steady state), 2: store only, 1: last slice, 0: generic (tested per slice)
 
 #if !defined(MTTS_EMU)
-template <int TM, int TN, bool A_KC, bool B_KC, int LDA, int LDB>
-__device__ __forceinline__ void read_half(const float* As, const float* Bs, int wm0, int wn0, int lane, int hf, HalfFrags<TM, TN>& f) {
+template <int TM, int TN, int NQ, bool A_KC, bool B_KC, int LDA, int LDB>
+__device__ __forceinline__ void read_half(const float* As, const float* Bs, int wm0, int wn0, int lane, int hf, HalfFrags<TM, TN, NQ>& f) {
     const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int kb = 8 * (2 * hf + q) + 4 * h;
+    for (int q = 0; q < NQ; ++q) {
+        const int kb = 8 * (NQ * hf + q) + 4 * h;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if (A_KC) {
@@ -357,10 +357,10 @@ __device__ __forceinline__ void read_half(const float* As, const float* Bs, int 
     }
 }
 // the 8 x TM x TN MFMAs of a half, in the k order of mma_half (results are bit-identical to the KL = 0 loop)
-template <int TM, int TN>
-__device__ __forceinline__ void mma_hfrags(const HalfFrags<TM, TN>& f, f32x16 (&acc)[TM][TN]) {
+template <int TM, int TN, int NQ>
+__device__ __forceinline__ void mma_hfrags(const HalfFrags<TM, TN, NQ>& f, f32x16 (&acc)[TM][TN]) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -524,18 +524,14 @@ __device__ __forceinline__ GemmProb gemm_resolve2(const GemmArgs& g, int z, cons
 template <int FORM>
 __device__ __forceinline__ bool gemm_has_colsum(const GemmArgs& g) { return (FORM == GEMM_TN) && g.colsum != nullptr && !g.table; }
 
-#if defined(MTTS_EMU)
-#define MTTS_KL_PRIO(p) ((void)0)
-#else
-#define MTTS_KL_PRIO(p) do { if (KL == 3) __builtin_amdgcn_s_setprio(p); } while (0)
-#endif
 // K-loop of one output tile (origin m0, n0) of a resolved problem over the K-chunks [c_lo, c_hi): the products are added into acc.
 // cs_tile: the tile is the column-sum tile (its B operand is GemmArgs::colsum_w).
 // ABL (diagnostic builds only, results are wrong): bit 0 drops the in-loop global loads, bit 1 the LDS stores, bit 2 the
 // in-loop fragment reads, bit 3 the barrier — timing the kernel with one stage removed shows what that stage costs.
-// KL (K-loop variant, BK = 32 pipelined kernels; profiles/r05_kloop_ab.md): 0 = two whole-slice fragment sets, clustered phases (rounds 2-4);
-// 1 = rotating half fragments + loop-invariant pointer steps; 2 = 1 with s_setprio around the MFMA clusters; 3 = 0 with s_setprio;
-// 4 = 1 with the slice's LDS / global instructions interleaved into the MFMA chain (sched_group_barrier).
+// KL (K-loop variant of the pipelined 64x64 kernels; measured in profiles/r05_kloop_ab.md): 0 = two whole-slice fragment sets, clustered
+// phases (rounds 2-4); 1 = rotating half fragments + loop-invariant pointer steps; 4 = 1 with the slice's LDS / global instructions
+// interleaved into the MFMA chain (sched_group_barrier) — the default.  (Arms 2 / 3 of the A/B, s_setprio around the MFMA clusters of
+// 1 / 0, measured 3 % SLOWER on this lock-step structure and are gone.)
 template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0, int KL = 0>
 __device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb& pr, int z, int m0, int n0, bool cs_tile, int c_lo, int c_hi,
                                                float* smem, f32x16 (&acc)[(BM / WGM) / 32][(BN / WGN) / 32]) {
@@ -671,7 +667,8 @@ __device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb
     store_ab(0);
     __syncthreads();
 #if !defined(MTTS_EMU)
-    if constexpr (PIPE && BK == 32 && (KL == 1 || KL == 2 || KL == 4)) {
+    if constexpr (PIPE && (BK == 32 || BK == 16) && (KL == 1 || KL == 4)) {
+        constexpr int NQ = BK / 16, NMF = 4 * NQ;   // groups of 8 k-values / MFMA steps per half
         // Rotating half fragments.  Per slice c:  [read half 1 of c | store c+1 to LDS | issue the loads of c+2]  MFMA(half 0)  barrier
         // [read half 0 of c+1]  MFMA(half 1) — every LDS read is issued one MFMA cluster (8 x 64 cycles) before its first use.
         // Pointer steps: the K-slices of a workgroup are consecutive, so an operand's pointer advances by one of two loop-invariant
@@ -719,8 +716,8 @@ __device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb
                 }
             }
         };
-        HalfFrags<TM, TN> h0, h1;
-        constexpr int NDR = ((A_KC ? 2 : 8) * TM + (B_KC ? 2 : 8) * TN);   // LDS read instructions of a half (ds_read_b128 / ds_read_b32)
+        HalfFrags<TM, TN, NQ> h0, h1;
+        constexpr int NDR = NQ * ((A_KC ? 1 : 4) * TM + (B_KC ? 1 : 4) * TN);   // LDS read instructions of a half (ds_read_b128 / ds_read_b32)
         auto body = [&](int c, auto mode_tag) {
             // MODE 3: slices c + 1 and c + 2 exist and c + 2 is a whole one (steady state); 2: c + 1 exists, nothing left to load; 1: the last
             // slice; 0: decided per slice (the iteration that loads a zero-filled tail).  Modes 1-3 are straight-line code — which is what
@@ -728,44 +725,41 @@ __device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb
             constexpr int MODE = decltype(mode_tag)::value;
             const int nb = (c & 1) ^ 1;
             const float* Ac = smem + (c & 1) * (A_TILE + B_TILE);
-            read_half<TM, TN, A_KC, B_KC, LDA_S, LDB_S>(Ac, Ac + A_TILE, wm0, wn0, lane, 1, h1);
+            read_half<TM, TN, NQ, A_KC, B_KC, LDA_S, LDB_S>(Ac, Ac + A_TILE, wm0, wn0, lane, 1, h1);
             if (MODE >= 2 || (MODE == 0 && c + 1 < nchunks)) store_ab(nb);
             if (MODE == 3) load_next(mode_tag);
             else if (MODE == 0 && c + 2 < nchunks) load_next(mode_tag);
             if (KL != 4) __builtin_amdgcn_sched_barrier(0);
-            if (KL == 2) __builtin_amdgcn_s_setprio(2);
-            mma_hfrags<TM, TN>(h0, acc);
-            if (KL == 2) __builtin_amdgcn_s_setprio(0);
+            mma_hfrags<TM, TN, NQ>(h0, acc);
             if (KL == 4 && MODE != 0) {
                 // one group of memory instructions behind each MFMA of the cluster: the chain is dependent (an MFMA issues when its
                 // predecessor retires, 64 cycles later), so the LDS reads / writes and the global loads ride in its shadow instead of in front of it
+                constexpr int RD = NMF / 2, WR = NMF / 4;   // MFMA steps that carry reads / writes (the rest: loads)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                                                    // MFMA
-                    if (q < 4) __builtin_amdgcn_sched_group_barrier(0x100, (NDR + 3) / 4, 0);                                   // DS read (half 1 of this slice)
-                    else if (q < 6) { if (MODE >= 2) __builtin_amdgcn_sched_group_barrier(0x200, (A_LD4 + B_LD4 + 1) / 2, 0); }  // DS write (slice c + 1)
-                    else if (MODE == 3) __builtin_amdgcn_sched_group_barrier(0x020, (A_LD4 + B_LD4 + 1) / 2, 0);                // global loads (slice c + 2)
+                for (int q = 0; q < NMF; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                                                            // MFMA
+                    if (q < RD) __builtin_amdgcn_sched_group_barrier(0x100, (NDR + RD - 1) / RD, 0);                                    // DS read (half 1 of this slice)
+                    else if (q < RD + WR) { if (MODE >= 2) __builtin_amdgcn_sched_group_barrier(0x200, (A_LD4 + B_LD4 + WR - 1) / WR, 0); }   // DS write (slice c + 1)
+                    else if (MODE == 3) __builtin_amdgcn_sched_group_barrier(0x020, (A_LD4 + B_LD4 + WR - 1) / WR, 0);                  // global loads (slice c + 2)
                 }
             }
             __syncthreads();
             if (MODE >= 2 || (MODE == 0 && c + 1 < nchunks)) {
                 const float* An = smem + nb * (A_TILE + B_TILE);
-                read_half<TM, TN, A_KC, B_KC, LDA_S, LDB_S>(An, An + A_TILE, wm0, wn0, lane, 0, h0);
+                read_half<TM, TN, NQ, A_KC, B_KC, LDA_S, LDB_S>(An, An + A_TILE, wm0, wn0, lane, 0, h0);
             }
             if (KL != 4) __builtin_amdgcn_sched_barrier(0);
-            if (KL == 2) __builtin_amdgcn_s_setprio(2);
-            mma_hfrags<TM, TN>(h1, acc);
-            if (KL == 2) __builtin_amdgcn_s_setprio(0);
+            mma_hfrags<TM, TN, NQ>(h1, acc);
             if (KL == 4 && MODE >= 2) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < NMF; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-                    if (q < 4) __builtin_amdgcn_sched_group_barrier(0x100, (NDR + 3) / 4, 0);   // half 0 of slice c + 1
+                    if (q < NMF / 2) __builtin_amdgcn_sched_group_barrier(0x100, (NDR + NMF / 2 - 1) / (NMF / 2), 0);   // half 0 of slice c + 1
                 }
             }
         };
         if (nchunks > 1) load_next(KlTag<0>{});
-        read_half<TM, TN, A_KC, B_KC, LDA_S, LDB_S>(smem, smem + A_TILE, wm0, wn0, lane, 0, h0);
+        read_half<TM, TN, NQ, A_KC, B_KC, LDA_S, LDB_S>(smem, smem + A_TILE, wm0, wn0, lane, 0, h0);
         const int full = (K - kb0) / BK;                                        // whole slices from kb0 on
         const int n_fast = nchunks - 2 < full - 2 ? nchunks - 2 : full - 2;     // iterations whose slice c + 2 exists and is whole
         int c = 0;
@@ -800,17 +794,13 @@ __device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb
             const int nb = (c & 1) ^ 1;
             if (!(ABL & 2) && c + 1 < nchunks) store_ab(nb);
             if (!(ABL & 1) && c + 2 < nchunks) { load_a(kb0 + (c + 2) * BK); load_b(kb0 + (c + 2) * BK); }
-            MTTS_KL_PRIO(2);
             mma_half<TM, TN, BK>(fc, 0, acc);
-            MTTS_KL_PRIO(0);
             if (!(ABL & 8)) __syncthreads();
             if (!(ABL & 4) && c + 1 < nchunks) {
                 const float* As = smem + nb * (A_TILE + B_TILE);
                 read_frags<TM, TN, BK, A_KC, B_KC, LDA_S, LDB_S>(As, As + A_TILE, wm0, wn0, lane, fn);
             }
-            MTTS_KL_PRIO(2);
             mma_half<TM, TN, BK>(fc, 1, acc);
-            MTTS_KL_PRIO(0);
         };
         for (int c = 0; c < nchunks; c += 2) {
             step(c, f0, f1);
@@ -1019,12 +1009,18 @@ struct GemmProfiler {
 constexpr int kGemmXcdSwizzle = 1;     // XCD-grouped tile order of the plain grids (xcd_group_remap)
 constexpr int kGemmDefaultBk = 16;     // K-slice of the register-staged kernels (32 for long K-contiguous panels, see gemm_launch)
 constexpr bool kGemmDefaultPipe = true;  // software-pipelined K-loop
-// K-loop variant of the 64x64 BK = 32 pipelined kernels (gemm_f32_kloop: KL).  MTTS_KLOOP=0..4 picks another one for A/B runs
+// K-loop variant of the pipelined 64x64 kernels (gemm_f32_kloop: KL).  MTTS_KLOOP=0 / 1 / 4 picks one for A/B runs
 // (profiles/r05_kloop_ab.md); results are bit-identical across variants (same k order in every accumulator chain).
 constexpr int kGemmDefaultKloop = 4;
 inline int gemm_kloop_variant() {
-    static const int v = [] { const char* e = getenv("MTTS_KLOOP"); const int x = e ? atoi(e) : kGemmDefaultKloop; return (x >= 0 && x <= 4) ? x : kGemmDefaultKloop; }();
+    static const int v = [] { const char* e = getenv("MTTS_KLOOP"); const int x = e ? atoi(e) : kGemmDefaultKloop; return (x == 0 || x == 1 || x == 4) ? x : kGemmDefaultKloop; }();
     return v;
+}
+// The KL >= 1 loops step their operand pointers by loop-invariant distances, which needs conv taps that are whole multiples of the K-slice
+// (every channel count of the model is a multiple of 16; anything else keeps the generic KL = 0 loop)
+inline int gemm_kloop_for(const GemmArgs& g, int bk) {
+    const bool ok = (g.taps <= 1 || g.tap_k % bk == 0) && (g.a_tap_k >= 0x40000000 || g.a_tap_k % bk == 0);
+    return ok ? gemm_kloop_variant() : 0;
 }
 inline int gemm_xcd_swizzle() { return kGemmXcdSwizzle; }
 inline int gemm_default_bk() { return kGemmDefaultBk; }
@@ -1074,10 +1070,14 @@ inline void gemm_batch_begin(GemmCtx& cx) { cx.batch.open = true; }
 inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream);
 
 // LDS-DMA kernel family (gemm_glds.h, device builds only)
-inline bool gemm_use_glds() {   // MTTS_GLDS=0: the register-staged kernels also in the latency regime (A/B runs)
-    static const bool on = [] { const char* e = getenv("MTTS_GLDS"); return e ? atoi(e) != 0 : true; }();
-    return on;
+// LDS-DMA family: MTTS_GLDS=0 never / =1 wherever the launch rule allows / unset: the owner decides per pass through GemmCtx::no_glds
+// (engine.h: set_regime — round 5: with the interleaved K-loop the register-staged kernels beat the LDS-DMA family on plans of <= 2 tasks:
+// single-task rank 33.5 -> 32.0 ms first order, 83.9 -> 79.3 ms second order, profiles/r05_kloop_ab.md; the 8-task step is indifferent).
+inline int gemm_glds_mode() {
+    static const int m = [] { const char* e = getenv("MTTS_GLDS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    return m;
 }
+inline bool gemm_use_glds() { return gemm_glds_mode() != 0; }
 inline bool gemm_glds_ok(const GemmArgs& g) { return !(g.taps > 1 && g.tap_k % 32 != 0); }
 // n-tiles of a problem's grid: the tiles of C plus the column-sum tile (GemmArgs::colsum)
 inline int gemm_tiles_n(const GemmArgs& g, int max_N, int t) { return (max_N + t - 1) / t + (g.colsum ? 1 : 0); }
@@ -1215,15 +1215,18 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     int kind = GK_OTHER;
 #define MTTS_GEMM_CASE(F, T)                                                                              \
     if (form == F && tile == T) {                                                                         \
-        if (bk == 32 && pipe && T == 64) {                                                                \
-            switch (gemm_kloop_variant()) {                                                               \
-                case 1: MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 1>), grid, block, stream, g); break;   \
-                case 2: MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 2>), grid, block, stream, g); break;   \
-                case 3: MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 3>), grid, block, stream, g); break;   \
-                case 4: MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 4>), grid, block, stream, g); break;   \
-                default: MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 0>), grid, block, stream, g);         \
+        if (pipe && T == 64) {                                                                            \
+            const int kl = gemm_kloop_for(g, bk);                                                         \
+            if (bk == 32) {                                                                               \
+                if (kl == 4) MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 4>), grid, block, stream, g);        \
+                else if (kl == 1) MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 1>), grid, block, stream, g);   \
+                else MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 0>), grid, block, stream, g);                \
+                kind = GK_F32_64_BK32 + F;                                                                \
+            } else {                                                                                      \
+                if (kl == 4) MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 16, true, 2, 2, 0, 4>), grid, block, stream, g);        \
+                else MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 16, true, 2, 2, 0, 0>), grid, block, stream, g);                \
+                kind = GK_F32_64_BK16 + F;                                                                \
             }                                                                                             \
-            kind = GK_F32_64_BK32 + F;                                                                    \
         }                                                                                                 \
         else if (bk == 32 && pipe) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 32, true>), grid, block, stream, g); kind = (T == 64 ? GK_F32_64_BK32 : GK_F32_128) + F; }   \
         else if (bk == 32) { MTTS_LAUNCH((gemm_f32_kernel<F, T, T, 32, false>), grid, block, stream, g); kind = T == 64 ? GK_OTHER : GK_F32_128 + F; }     \
@@ -1390,28 +1393,31 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     else
 #endif
     if (bk32 && maxK >= 1024) {
-        const int kl = gemm_kloop_variant();
+        int kl = gemm_kloop_variant();
+        for (int i = 0; i < mp.n; ++i) kl = std::min(kl, gemm_kloop_for(mp.g[i], 32));
         if (any_dual) {
-            switch (kl) {
-                case 1: MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32, 1>), grid, block, stream, mp); break;
-                case 2: MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32, 2>), grid, block, stream, mp); break;
-                case 3: MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32, 3>), grid, block, stream, mp); break;
-                case 4: MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32, 4>), grid, block, stream, mp); break;
-                default: MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32, 0>), grid, block, stream, mp);
-            }
+            if (kl == 4) MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32, 4>), grid, block, stream, mp);
+            else if (kl == 1) MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32, 1>), grid, block, stream, mp);
+            else MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32, 0>), grid, block, stream, mp);
             kind = GK_MULTI32_DUAL;
         } else {
-            switch (kl) {
-                case 1: MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 1>), grid, block, stream, mp); break;
-                case 2: MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 2>), grid, block, stream, mp); break;
-                case 3: MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 3>), grid, block, stream, mp); break;
-                case 4: MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 4>), grid, block, stream, mp); break;
-                default: MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 0>), grid, block, stream, mp);
-            }
+            if (kl == 4) MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 4>), grid, block, stream, mp);
+            else if (kl == 1) MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 1>), grid, block, stream, mp);
+            else MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 0>), grid, block, stream, mp);
             kind = GK_MULTI32;
         }
-    } else if (any_dual) { MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 16>), grid, block, stream, mp); kind = GK_MULTI16_DUAL; }
-    else { MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 16>), grid, block, stream, mp); }
+    } else {
+        int kl = gemm_kloop_variant() == 4 ? 4 : 0;
+        for (int i = 0; i < mp.n; ++i) kl = std::min(kl, gemm_kloop_for(mp.g[i], 16) == 4 ? 4 : 0);
+        if (any_dual) {
+            if (kl == 4) MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 16, 4>), grid, block, stream, mp);
+            else MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 16, 0>), grid, block, stream, mp);
+            kind = GK_MULTI16_DUAL;
+        } else {
+            if (kl == 4) MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 16, 4>), grid, block, stream, mp);
+            else MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 16, 0>), grid, block, stream, mp);
+        }
+    }
     cx.last_kind = kind;
     if (prof.enabled) {
         hipEventRecord(e1, stream);

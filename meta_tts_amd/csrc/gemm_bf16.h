@@ -449,7 +449,7 @@ inline int gemm_bf16_launch(int form, const GemmArgs& g, int T, dim3 grid, hipSt
     if (pf_req) pf = pf_req;
 #endif
     if (form == GEMM_NT && g.Ah != nullptr) {   // both planes exist (gemm_bf16_planes_ok): the plane-staged K-loop
-        static const int plane_bk = [] { const char* e = getenv("MTTS_PLANE_BK"); return e ? atoi(e) : 64; }();
+        constexpr int plane_bk = 64;   // (BK = 32 measured slower on the long convolutions: profiles/r04_c2_bf16_planes.md)
         if (T == 128) { MTTS_LAUNCH((gemm_bf16_kernel<GEMM_NT_H, 128, 128, kBf16BK, 1>), grid, block, stream, g); return GK_BF16_128_H; }
         if (plane_bk == 64 && g.K >= 512) { MTTS_LAUNCH((gemm_bf16_kernel<GEMM_NT_H, 64, 64, 64, 1>), grid, block, stream, g); return GK_BF16_64_H64; }   // whole 128-byte lines per row and slice
         MTTS_LAUNCH((gemm_bf16_kernel<GEMM_NT_H, 64, 64, kBf16BK, 1>), grid, block, stream, g);
@@ -474,7 +474,7 @@ inline int gemm_bf16_multi_launch(const GemmMulti& mp, int T, bool dual, dim3 gr
     }
     bool planes = false;
     for (int i = 0; i < mp.n; ++i) planes = planes || mp.g[i].Ah != nullptr;
-    static const int plane_bk = [] { const char* e = getenv("MTTS_PLANE_BK"); return e ? atoi(e) : 64; }();
+    constexpr int plane_bk = 64;
     if (planes && !dual && plane_bk == 64) {
         MTTS_LAUNCH((gemm_bf16_multi_planes_kernel<64, 64, kBf16BK, 64, kBf16PF64>), grid, block, stream, mp);
         return GK_BF16_MULTI64_PLANES;

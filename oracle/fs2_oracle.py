@@ -37,6 +37,79 @@ KINK_LOG: Optional[list] = None
 KINK_EPS = 1e-6
 
 
+# bf16-operand mode (the engine's numerics mode 1 / 2, BASELINE config C2 "bf16"): BOTH operands of every contraction — Linear, Conv1d,
+# the two attention products — are rounded to bf16 (round-to-nearest-even) on the way into the product, forward AND backward (the
+# input gradient multiplies round(dY) by round(W), the weight gradient round(dY) by round(X)); accumulation, bias, normalisations,
+# softmax, losses and every stored tensor stay fp32.  With BF16_OPERANDS set the three product helpers below do exactly that through
+# custom autograd Functions, which gives the bf16 mode a MODEL-level reference that rounds what the mode rounds —
+# the fp32 oracle stays the distance that is reported, not the gate.
+BF16_OPERANDS = False
+
+
+def _r16(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _LinearBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        y = F.linear(_r16(x), _r16(w))
+        return y + b if b is not None else y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gr = _r16(g)
+        gx = gr @ _r16(w)
+        gw = gr.reshape(-1, gr.shape[-1]).t() @ _r16(x).reshape(-1, x.shape[-1])
+        gb = g.reshape(-1, g.shape[-1]).sum(0) if ctx.has_b else None      # (the bias gradient is a column sum of the fp32 dY, not a product)
+        return gx, gw, gb
+
+
+class _Conv1dBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, padding):
+        ctx.save_for_backward(x, w)
+        ctx.padding, ctx.has_b = padding, b is not None
+        return F.conv1d(_r16(x), _r16(w), b, padding=padding)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gr = _r16(g)
+        gx = torch.nn.grad.conv1d_input(x.shape, _r16(w), gr, padding=ctx.padding)
+        gw = torch.nn.grad.conv1d_weight(_r16(x), w.shape, gr, padding=ctx.padding)
+        gb = g.sum((0, 2)) if ctx.has_b else None
+        return gx, gw, gb, None
+
+
+class _BmmBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return torch.bmm(_r16(a), _r16(b))
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        gr = _r16(g)
+        return torch.bmm(gr, _r16(b).transpose(1, 2)), torch.bmm(_r16(a).transpose(1, 2), gr)
+
+
+def _linear(x, w, b=None):
+    return _LinearBF16.apply(x, w, b) if BF16_OPERANDS else F.linear(x, w, b)
+
+
+def _conv1d(x, w, b=None, padding=0):
+    return _Conv1dBF16.apply(x, w, b, padding) if BF16_OPERANDS else F.conv1d(x, w, b, padding=padding)
+
+
+def _bmm(a, b):
+    return _BmmBF16.apply(a, b) if BF16_OPERANDS else torch.bmm(a, b)
+
+
 def _relu(x):
     if KINK_LOG is not None:
         a = x.detach().abs()
@@ -70,10 +143,10 @@ def sinusoid_table(n_position: int, d_hid: int) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 def scaled_dot_product_attention(q, k, v, mask, temperature):
     """transformer/Modules.py:14-25 — softmax(masked_fill(q k^T / temperature, mask, -inf), dim=2) v."""
-    attn = torch.bmm(q, k.transpose(1, 2)) / temperature
+    attn = _bmm(q, k.transpose(1, 2)) / temperature
     attn = attn.masked_fill(mask, float("-inf"))
     attn = torch.softmax(attn, dim=2)
-    return torch.bmm(attn, v), attn
+    return _bmm(attn, v), attn
 
 
 def _drop(x, dropout, site: int, space: str, which: str):
@@ -86,16 +159,16 @@ def multi_head_attention(x, p: Params, pre: str, slf_attn_mask, n_head: int, dro
     head, fc, dropout (:54), post-LayerNorm over (out + residual), eps 1e-5."""
     B, L, d = x.shape
     d_k = d // n_head
-    q = F.linear(x, p[f"{pre}.w_qs.weight"], p[f"{pre}.w_qs.bias"]).view(B, L, n_head, d_k)
-    k = F.linear(x, p[f"{pre}.w_ks.weight"], p[f"{pre}.w_ks.bias"]).view(B, L, n_head, d_k)
-    v = F.linear(x, p[f"{pre}.w_vs.weight"], p[f"{pre}.w_vs.bias"]).view(B, L, n_head, d_k)
+    q = _linear(x, p[f"{pre}.w_qs.weight"], p[f"{pre}.w_qs.bias"]).view(B, L, n_head, d_k)
+    k = _linear(x, p[f"{pre}.w_ks.weight"], p[f"{pre}.w_ks.bias"]).view(B, L, n_head, d_k)
+    v = _linear(x, p[f"{pre}.w_vs.weight"], p[f"{pre}.w_vs.bias"]).view(B, L, n_head, d_k)
     q = q.permute(2, 0, 1, 3).contiguous().view(-1, L, d_k)
     k = k.permute(2, 0, 1, 3).contiguous().view(-1, L, d_k)
     v = v.permute(2, 0, 1, 3).contiguous().view(-1, L, d_k)
     mask = slf_attn_mask.repeat(n_head, 1, 1)
     out, attn = scaled_dot_product_attention(q, k, v, mask, math.sqrt(d_k))
     out = out.view(n_head, B, L, d_k).permute(1, 2, 0, 3).contiguous().view(B, L, -1)
-    out = F.linear(out, p[f"{pre}.fc.weight"], p[f"{pre}.fc.bias"])
+    out = _linear(out, p[f"{pre}.fc.weight"], p[f"{pre}.fc.bias"])
     out = _drop(out, dropout, site, space, "enc" if space == "P" else "dec")
     out = F.layer_norm(out + x, (d,), p[f"{pre}.layer_norm.weight"], p[f"{pre}.layer_norm.bias"], 1e-5)
     return out, attn
@@ -104,8 +177,8 @@ def multi_head_attention(x, p: Params, pre: str, slf_attn_mask, n_head: int, dro
 def positionwise_ffn(x, p: Params, pre: str, dropout=None, site: int = 0, space: str = "P"):
     """transformer/SubLayers.py:85-93 — LN(dropout(W2 * relu(W1 * x)) + x) with Conv1d W1 (k=9,pad=4), W2 (k=1)."""
     w1, w2 = p[f"{pre}.w_1.weight"], p[f"{pre}.w_2.weight"]
-    h = F.conv1d(x.transpose(1, 2), w1, p[f"{pre}.w_1.bias"], padding=(w1.shape[2] - 1) // 2)
-    h = F.conv1d(_relu(h), w2, p[f"{pre}.w_2.bias"], padding=(w2.shape[2] - 1) // 2)
+    h = _conv1d(x.transpose(1, 2), w1, p[f"{pre}.w_1.bias"], padding=(w1.shape[2] - 1) // 2)
+    h = _conv1d(_relu(h), w2, p[f"{pre}.w_2.bias"], padding=(w2.shape[2] - 1) // 2)
     h = _drop(h.transpose(1, 2), dropout, site, space, "enc" if space == "P" else "dec")
     d = x.shape[-1]
     return F.layer_norm(h + x, (d,), p[f"{pre}.layer_norm.weight"], p[f"{pre}.layer_norm.bias"], 1e-5)
@@ -169,12 +242,12 @@ def variance_predictor(x, mask, p: Params, pre: str, dropout=None, site: int = 1
     for i in (1, 2):
         w = p[f"{pre}.conv_layer.conv1d_{i}.conv.weight"]
         pad = (w.shape[2] - 1) // 2 if i == 1 else 1
-        x = F.conv1d(x.transpose(1, 2), w, p[f"{pre}.conv_layer.conv1d_{i}.conv.bias"], padding=pad).transpose(1, 2)
+        x = _conv1d(x.transpose(1, 2), w, p[f"{pre}.conv_layer.conv1d_{i}.conv.bias"], padding=pad).transpose(1, 2)
         x = _relu(x)
         x = F.layer_norm(x, (x.shape[-1],), p[f"{pre}.conv_layer.layer_norm_{i}.weight"],
                          p[f"{pre}.conv_layer.layer_norm_{i}.bias"], 1e-5)
         x = _drop(x, dropout, site + i - 1, space, "vp")
-    out = F.linear(x, p[f"{pre}.linear_layer.weight"], p[f"{pre}.linear_layer.bias"]).squeeze(-1)
+    out = F.linear(x, p[f"{pre}.linear_layer.weight"], p[f"{pre}.linear_layer.bias"]).squeeze(-1)   # (a 256 -> 1 row dot product: fp32 in every numerics mode of the engine)
     if mask is not None:
         out = out.masked_fill(mask, 0.0)
     return out
@@ -250,7 +323,7 @@ def postnet(x, p: Params, buffers: Optional[Dict[str, torch.Tensor]], training: 
     for i in range(n):
         pre = f"postnet.convolutions.{i}"
         w = p[f"{pre}.0.conv.weight"]
-        h = F.conv1d(h, w, p[f"{pre}.0.conv.bias"], padding=(w.shape[2] - 1) // 2)
+        h = _conv1d(h, w, p[f"{pre}.0.conv.bias"], padding=(w.shape[2] - 1) // 2)
         rm = rv = None
         if buffers is not None:
             rm, rv = buffers[f"{pre}.1.running_mean"], buffers[f"{pre}.1.running_var"]
@@ -292,7 +365,7 @@ def fs2_forward(p: Params, buffers, speakers, texts, src_lens, max_src_len, mels
         p_control, e_control, d_control, pitch_level, energy_level, dropout)
     out = out + spk.unsqueeze(1).expand(-1, out.shape[1], -1)
     out, mel_masks = decoder(out, mel_masks, p, n_head[1], training, max_seq_len, dropout)
-    mel = F.linear(out, p["mel_linear.weight"], p["mel_linear.bias"])
+    mel = _linear(out, p["mel_linear.weight"], p["mel_linear.bias"])
     mel_post = postnet(mel, p, buffers, training, dropout) + mel
     return (mel, mel_post, pp, ep, logd, d_rounded, src_masks, mel_masks, src_lens, mel_lens)
 
