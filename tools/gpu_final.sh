@@ -2,14 +2,14 @@
 # Final evidence of a round: shader clock beside the GEMM kernels, GPU tests, smoke, the default bench line, the single-task emulation,
 # kernel traces (8-task and single-task rank, first + second order) and the PMC passes (HBM bytes + MFMA busy per GEMM kernel, first- and
 # second-order) of the same bench command.   usage: tools/gpu_final.sh [tag]   ->  gpurun_out/<tag>/
-TAG=${1:-r04z}
+TAG=${1:-r05z}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 R=$PWD
 python -c "import __graft_entry__ as g; g.build_device()" > $OUT/build.log 2>&1
 [ -x tools/mfma_peak ] || hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o tools/mfma_peak > /dev/null 2>&1
 [ -x tools/clock_probe ] || hipcc --offload-arch=gfx950 -O3 tools/clock_probe.hip -Iinclude -Lmeta_tts_amd -lmtts -Wl,-rpath,'$ORIGIN/../meta_tts_amd' -o tools/clock_probe > /dev/null 2>&1
-for cfg in "17047 1024 2304 3064" "17047 1024 2304 1064" "4096 4096 4096 3064" "4096 4096 4096 3128" "22132 512 2560 3064" "2100 256 2304 4064"; do ./tools/clock_probe $cfg; done 2>&1 | tee $OUT/clock_probe.txt
+for cfg in "17047 1024 2304 3064" "17047 1024 2304 1064" "4096 4096 4096 3064" "4096 4096 4096 3128" "22132 512 2560 3064" "2100 256 2304 3064" "2100 256 2304 4064"; do ./tools/clock_probe $cfg; done 2>&1 | tee $OUT/clock_probe.txt
 ./tools/mfma_peak 100000 2>&1 | tail -3 >> $OUT/clock_probe.txt
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; tail -4 $OUT/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
