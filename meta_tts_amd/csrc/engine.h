@@ -938,6 +938,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (char* a : gs_mem) if (a) hipFree(a);
         if (arena_so) hipFree(arena_so);
         if (arena_so_defer) hipFree(arena_so_defer);
+        if (arena_so_defer_post) hipFree(arena_so_defer_post);
         if (hv) hipFree(hv);
         if (fast_hist) hipFree(fast_hist);
     }
@@ -1422,9 +1423,17 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         a.C = C; a.mode = 0; a.mfield = mfield(s);
         colreduce(p, a, out.p, nullptr, out.ts, maxM(p, s), on_side);
     }
+    // MEASUREMENT ONLY (results are wrong): MTTS_ABLATE_LN=1 drops every LayerNorm forward / backward launch of the FFT blocks and predictors, which
+    // bounds from above what folding bias + dropout + residual + LayerNorm into the producing GEMM's epilogue (and the LayerNorm backward into
+    // the consuming GEMM's prologue) could save — a timing run, never a result (profiles/r05_ab_log.md; bench.py refuses to gate parity on it)
+    static bool ablate_ln() {
+        static const bool on = [] { const char* e = getenv("MTTS_ABLATE_LN"); return e && atoi(e) != 0; }();
+        return on;
+    }
     void ln_fwd(const Pass& ps, Space s, TS a, TS res, long long g_off, long long b_off, const unsigned char* mask,
                 TS zout, TS y, TS st, int C, DropSpec din = DropSpec(), DropSpec dout = DropSpec(), bool y_twin = false) {
         // y_twin: bf16 mode — also write y's operand plane (H(y)): the next conv reads it instead of a conversion pass
+        if (ablate_ln()) return;
         const Plan& p = *ps.pl;
         TS gm = W(ps, g_off), bt = W(ps, b_off);
         MTTS_LAUNCH_LN(layernorm_fwd_kernel, C, row2_grid(maxM(p, s), p.tasks), dim3(256), stream, (const int*)p.meta, mfield(s),
@@ -1441,6 +1450,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                 TS dz, int C, int relu_on_z, TS dz_drop = TS{nullptr, 0}, DropSpec dd = DropSpec(), bool copy_always = false,
                 float* part = nullptr, DropSpec din = DropSpec(), int twin_sel = 0) {
         // twin_sel: bf16 mode — also write the operand plane of dz (1) or of dz_drop (2)
+        if (ablate_ln()) return;
         const Plan& p = *ps.pl;
         TS gm = W(ps, g_off);
         const int chunks = ln_chunks(maxM(p, s));
@@ -1769,9 +1779,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         ar_issued = false;
     }
 
-    // kernel-family choice of the pass's main-stream GEMM launches: plans of <= 2 tasks (a single-task rank of the 8-GPU job, C2, few-shot
-    // adaptation) keep the register-staged kernels also for launches of <= 768 workgroups — see gemm.h: gemm_glds_mode
-    void set_regime(const Plan& p) { gx.no_glds = gemm_glds_mode() == 0 || (gemm_glds_mode() < 0 && p.tasks <= 2); }
+    // kernel-family choice of the pass's main-stream GEMM launches (gemm.h: gemm_glds_mode): the LDS-DMA family only when MTTS_GLDS=1 asks for it
+    void set_regime(const Plan& p) { (void)p; gx.no_glds = gemm_glds_mode() == 0; }
 
     // everything enqueued on the main stream so far happens before what is enqueued on the side stream next
     void fork_side() {

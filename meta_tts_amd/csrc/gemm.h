@@ -1070,11 +1070,13 @@ inline void gemm_batch_begin(GemmCtx& cx) { cx.batch.open = true; }
 inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream);
 
 // LDS-DMA kernel family (gemm_glds.h, device builds only)
-// LDS-DMA family: MTTS_GLDS=0 never / =1 wherever the launch rule allows / unset: the owner decides per pass through GemmCtx::no_glds
-// (engine.h: set_regime — round 5: with the interleaved K-loop the register-staged kernels beat the LDS-DMA family on plans of <= 2 tasks:
-// single-task rank 33.5 -> 32.0 ms first order, 83.9 -> 79.3 ms second order, profiles/r05_kloop_ab.md; the 8-task step is indifferent).
+// LDS-DMA family (gemm_glds.h).  Round 5: with the interleaved K-loop (KL = 4) the register-staged kernels beat it in the latency regime it
+// was built for (single-task rank 33.5 -> 32.0 ms first order, 83.9 -> 79.3 ms second order; the 8-task step is indifferent: 158.0 vs
+// 157.4 ms, profiles/r05_kloop_ab.md), so the automatic tile choice no longer takes it.  MTTS_GLDS=1 restores the round 3-4 rule (launches
+// of <= 768 workgroups) for A/B runs — GemmCtx::no_glds (engine.h: set_regime) can then still veto it per pass; tile code 4064 selects
+// the family explicitly (kernel tests, micro-benchmarks).
 inline int gemm_glds_mode() {
-    static const int m = [] { const char* e = getenv("MTTS_GLDS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    static const int m = [] { const char* e = getenv("MTTS_GLDS"); return e ? (atoi(e) != 0 ? 1 : 0) : 0; }();
     return m;
 }
 inline bool gemm_use_glds() { return gemm_glds_mode() != 0; }

@@ -33,8 +33,14 @@ Params = Dict[str, torch.Tensor]
 # implementations may land on different sides, and their GRADIENTS then differ by that unit's whole contribution (a few rows of a
 # few tensors) although every forward value agrees to 1e-7.  A caller that compares gradients can ask which passes had such units:
 # with KINK_LOG a list, every ReLU of the model appends (min |pre-activation|, number of units with |pre-activation| < KINK_EPS).
+# The two L1 mel terms of the loss have the same property at |prediction - target| ~ 0: d|x|/dx = sign(x).  A weight gradient behind
+# them is a sum of n random-sign terms (n = valid frames x n_mel ~ 1.7e5 per task), so ONE flipped sign moves it by ~2 / sqrt(n) = 0.5 %
+# of its norm; mel_post agrees between two fp32 implementations to ~2e-5 after five inner steps, which puts about one element per task
+# and pass inside that band (measured: tools/dropout_grad_probe.py).  fs2_loss appends ("l1", elements of mel / mel_post with
+# |prediction - target| < L1_KINK_EPS) when asked.
 KINK_LOG: Optional[list] = None
 KINK_EPS = 1e-6
+L1_KINK_EPS = 1e-4
 
 
 # bf16-operand mode (the engine's numerics mode 1 / 2, BASELINE config C2 "bf16"): BOTH operands of every contraction — Linear, Conv1d,
@@ -370,7 +376,7 @@ def fs2_forward(p: Params, buffers, speakers, texts, src_lens, max_src_len, mels
     return (mel, mel_post, pp, ep, logd, d_rounded, src_masks, mel_masks, src_lens, mel_lens)
 
 
-def fs2_loss(batch, preds, pitch_level="phoneme_level", energy_level="phoneme_level"):
+def fs2_loss(batch, preds, pitch_level="phoneme_level", energy_level="phoneme_level", kink_log: Optional[list] = None):
     """lightning/model/loss.py:19-92 — L1 over valid frames x n_mel for mel / postnet mel, MSE over
     valid phonemes (or valid frames for a frame-level feature, :54-63) for pitch and energy, over valid
     phonemes for log-duration (target log(d + 1)); total = plain sum."""
@@ -381,6 +387,11 @@ def fs2_loss(batch, preds, pitch_level="phoneme_level", energy_level="phoneme_le
     mel_t = mel_t[:, : mm.shape[1], :]
     mel_l = F.l1_loss(mel.masked_select(mm.unsqueeze(-1)), mel_t.masked_select(mm.unsqueeze(-1)))
     post_l = F.l1_loss(mel_post.masked_select(mm.unsqueeze(-1)), mel_t.masked_select(mm.unsqueeze(-1)))
+    if kink_log is not None:
+        with torch.no_grad():
+            tsel = mel_t.masked_select(mm.unsqueeze(-1))
+            kink_log.append(("l1", int(((mel.masked_select(mm.unsqueeze(-1)) - tsel).abs() < L1_KINK_EPS).sum()),
+                             int(((mel_post.masked_select(mm.unsqueeze(-1)) - tsel).abs() < L1_KINK_EPS).sum())))
     pm = sm if pitch_level == "phoneme_level" else mm
     em = sm if energy_level == "phoneme_level" else mm
     p_l = F.mse_loss(pp.masked_select(pm), p_t.masked_select(pm))
@@ -416,7 +427,8 @@ def maml_task(p: Params, buffers, sup, qry, *, steps: int, lr: float, second_ord
               modules: Sequence[str], n_head=(2, 2), max_seq_len=1000, training=True, dropout=None, kink_log: Optional[list] = None):
     """``dropout``: None, or a list of steps + 1 DropoutMasks (one per inner step, then the query pass — the order in which the
     engine draws its plan seeds, engine.h: meta_grad / run_encoder_ahead).  ``kink_log``: a list that receives one
-    (min |pre-activation|, units below KINK_EPS) pair per ReLU of the QUERY pass.
+    (min |pre-activation|, units below KINK_EPS) pair per ReLU of the QUERY pass and one ("l1", mel elements, mel_post elements within
+    L1_KINK_EPS of the target) entry for its loss.
 
     One task of a meta-step: ``steps`` inner SGD updates on the support batch
     (base_adaptor.py:100-112, ``first_order = not train``), then the query pass with the support
@@ -449,7 +461,7 @@ def maml_task(p: Params, buffers, sup, qry, *, steps: int, lr: float, second_ord
                             training=training, average_spk_emb=True, dropout=dropout[steps] if dropout else None)
     finally:
         KINK_LOG = None
-    qloss = fs2_loss(qry, preds)
+    qloss = fs2_loss(qry, preds, kink_log=kink_log)
     return qloss, sup_losses, fast, preds
 
 
