@@ -1663,7 +1663,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     struct ArHook { void* ctx = nullptr; int (*sum)(void*, float*, size_t, hipStream_t) = nullptr; int rank = 0, world = 1; };
     ArHook ar;
     hipStream_t comm_stream = nullptr;
-    static constexpr int kArEvents = 8;
+    static constexpr int kArEvents = 64;   // more than one exchange records (2 per bucket + the tail: 27 at base.yaml): no event is re-recorded while a wait on it can be pending
     hipEvent_t ev_ar[kArEvents] = {};
     hipEvent_t ev_ar_done = nullptr;
     int ev_ar_next = 0;

@@ -961,12 +961,12 @@ enum GemmKind {
 };
 inline const char* gemm_kind_name(int k) {
     static const char* names[GK_COUNT] = {
-        "gemm_f32_kernel<0, 64, 64, 16, true, 2, 2, 0>", "gemm_f32_kernel<1, 64, 64, 16, true, 2, 2, 0>", "gemm_f32_kernel<2, 64, 64, 16, true, 2, 2, 0>",
-        "gemm_f32_kernel<0, 64, 64, 32, true, 2, 2, 0>", "gemm_f32_kernel<1, 64, 64, 32, true, 2, 2, 0>", "gemm_f32_kernel<2, 64, 64, 32, true, 2, 2, 0>",
+        "gemm_f32_kernel<0, 64, 64, 16, true, 2, 2, 0, 4>", "gemm_f32_kernel<1, 64, 64, 16, true, 2, 2, 0, 4>", "gemm_f32_kernel<2, 64, 64, 16, true, 2, 2, 0, 4>",
+        "gemm_f32_kernel<0, 64, 64, 32, true, 2, 2, 0, 4>", "gemm_f32_kernel<1, 64, 64, 32, true, 2, 2, 0, 4>", "gemm_f32_kernel<2, 64, 64, 32, true, 2, 2, 0, 4>",
         "gemm_f32_kernel<0, 128, 128, ...>", "gemm_f32_kernel<1, 128, 128, ...>", "gemm_f32_kernel<2, 128, 128, ...>",
         "gemm_glds_kernel<0>", "gemm_glds_kernel<1>", "gemm_glds_kernel<2>",
-        "gemm_f32_multi_kernel<64, 64, 16>", "gemm_f32_multi_kernel<64, 64, 32>", "gemm_glds_multi_kernel",
-        "gemm_f32_kernel<other>", "gemm_f32_multi_dual_kernel<64, 64, 16>", "gemm_f32_multi_dual_kernel<64, 64, 32>", "gemm_glds_multi_dual_kernel",
+        "gemm_f32_multi_kernel<64, 64, 16, 4>", "gemm_f32_multi_kernel<64, 64, 32, 4>", "gemm_glds_multi_kernel",   // (the trailing 4 = the default K-loop variant, MTTS_KLOOP)
+        "gemm_f32_kernel<other>", "gemm_f32_multi_dual_kernel<64, 64, 16, 4>", "gemm_f32_multi_dual_kernel<64, 64, 32, 4>", "gemm_glds_multi_dual_kernel",
         "gemm_bf16_kernel<0, 64, 64, 32, 1>", "gemm_bf16_kernel<1, 64, 64, 32, 1>", "gemm_bf16_kernel<2, 64, 64, 32, 1>",
         "gemm_bf16_kernel<0, 128, 128, 32, 1>", "gemm_bf16_kernel<1, 128, 128, 32, 1>", "gemm_bf16_kernel<2, 128, 128, 32, 1>",
         "gemm_bf16_multi_kernel<64, 64, 32, 1, false>", "gemm_bf16_multi_kernel<128, 128, 32, 1, false>",

@@ -12,5 +12,5 @@ hdr() { echo "<!-- $1 (1x MI355X, tools/gpu_final.sh $T; summarised by profiles/
 { hdr "... --steps 5 --emulate-world 8: single-task rank, first order"; cat $S/kernel_trace_1.md; } > $D/r05_kernel_trace_single_task.md
 { hdr "... --steps 3 --emulate-world 8 --order 2: single-task rank, second order"; cat $S/kernel_trace_1so.md; } > $D/r05_kernel_trace_single_task_second_order.md
 for t in 8 8so 1 1so; do cp $S/timeline_$t.txt $D/r05_timeline_$t.txt; done
-{ echo "# python -m pytest tests -m gpu -q on the MI355X box (tools/gpu_final.sh $T)"; tail -n 30 $S/pytest.log; echo; cat $S/smoke.log | tail -n 2; } > $D/r05_gpu_pytest_final.txt
+{ echo "# python -m pytest tests -m gpu -q on the MI355X box (tools/gpu_final.sh $T)"; grep -vE "^(HIP version|ROCm version|Hostname|Librccl path|RCCL version|.*NCCL_DEBUG)" $S/pytest.log | tail -n 30; echo; cat $S/smoke.log | tail -n 2; } > $D/r05_gpu_pytest_final.txt
 ls -la $D | grep r05_

@@ -11,7 +11,7 @@ python -c "import __graft_entry__ as g; g.build_device()" > $OUT/build.log 2>&1
 [ -x tools/clock_probe ] || hipcc --offload-arch=gfx950 -O3 tools/clock_probe.hip -Iinclude -Lmeta_tts_amd -lmtts -Wl,-rpath,'$ORIGIN/../meta_tts_amd' -o tools/clock_probe > /dev/null 2>&1
 for cfg in "17047 1024 2304 3064" "17047 1024 2304 1064" "4096 4096 4096 3064" "4096 4096 4096 3128" "22132 512 2560 3064" "2100 256 2304 3064" "2100 256 2304 4064"; do ./tools/clock_probe $cfg; done 2>&1 | tee $OUT/clock_probe.txt
 ./tools/mfma_peak 100000 2>&1 | tail -3 >> $OUT/clock_probe.txt
-timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; tail -4 $OUT/pytest.log
+timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; grep -E "passed|failed|^FAILED|pytest rc" $OUT/pytest.log | tail -6
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 timeout 900 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 X="--no-cpu-baseline --no-inference --no-frontend --no-baseline-c2"
