@@ -1718,6 +1718,9 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (auto& r : rng) if (r.first >= 0 && r.second > r.first && ((r.second - r.first) % 4) == 0 && (r.first % 4) == 0) ar_buckets.push_back(r); else if (r.first >= 0) { ar_buckets.clear(); return 1; }
         // (a module without parameters has no bucket: the completion-order indices above then no longer match, so require them all)
         if ((int)ar_buckets.size() != nb) { ar_buckets.clear(); return 1; }
+        long long covered = 0;
+        for (const auto& r : ar_buckets) covered += r.second - r.first;
+        if (covered != n_total) { ar_buckets.clear(); return 1; }   // (the buckets must tile the whole outer gradient)
         return 0;
     }
     void ar_destroy() {

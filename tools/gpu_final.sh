@@ -13,7 +13,7 @@ for cfg in "17047 1024 2304 3064" "17047 1024 2304 1064" "4096 4096 4096 3064" "
 ./tools/mfma_peak 100000 2>&1 | tail -3 >> $OUT/clock_probe.txt
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; grep -E "passed|failed|^FAILED|pytest rc" $OUT/pytest.log | tail -6
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
-timeout 900 python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 X="--no-cpu-baseline --no-inference --no-frontend --no-baseline-c2"
 timeout 400 python bench.py --steps 10 --warmup 3 --emulate-world 8 $X > $OUT/bench_w8.json 2> $OUT/bench_w8.err
 cd /tmp
