@@ -77,6 +77,23 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// counter-based dropout mask shared by dropout_kernel and the LayerNorm kernels that apply it in passing: keep bits of
+// the four elements (row, c .. c+3) of task z = 16-bit fields of splitmix64(seed, z, element id / 4)
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+struct DropSpec { unsigned seed = 0, thr16 = 0; float scale = 1.f; };  // thr16 == 0: off
+__device__ __forceinline__ float4 drop4(const DropSpec& d, int z, int row, int C, int c, float4 v) {
+    const unsigned long long base = ((unsigned long long)d.seed << 32) ^ ((unsigned long long)z << 24);
+    const unsigned long long h = splitmix64(base + ((unsigned long long)row * (unsigned)C + (unsigned)c) / 4ull);
+    return make_float4(((h) & 0xFFFFu) >= d.thr16 ? v.x * d.scale : 0.f, ((h >> 16) & 0xFFFFu) >= d.thr16 ? v.y * d.scale : 0.f,
+                       ((h >> 32) & 0xFFFFu) >= d.thr16 ? v.z * d.scale : 0.f, ((h >> 48) & 0xFFFFu) >= d.thr16 ? v.w * d.scale : 0.f);
+}
+
+
 }  // namespace mtts
 
 // cross-workgroup hand-off primitives (split-K rendezvous in gemm.h)

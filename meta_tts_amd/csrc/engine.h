@@ -1298,9 +1298,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // Y[M,N] = conv_k(X)[M, k*Cin] * W[N][k*Cin]^T + b   (k = 1: Linear)
     // (x2, w2): second source of a dual-source launch, y = conv(x; w) + conv(x2; w2) (GemmArgs::A2 — the tangent pairs of engine_so.inc)
     // x_plane: x's operand plane is current (its producer wrote it); y_twin: write y's plane in the epilogue (bf16 mode, see H())
+    // ln (optional): row-complete epilogue — bias + dropout + residual + LayerNorm behind the GEMM (gemm.h: LnFuse; ln_fused_fwd below)
     void conv_fwd(const Pass& ps, Space s, TS x, int cin, int k, TS w, TS b, int cout, TS y, int flags,
                   const unsigned char* rowmask, TS relu_ref = TS{nullptr, 0}, TS x2 = TS{nullptr, 0}, TS w2 = TS{nullptr, 0},
-                  bool x_plane = false, bool y_twin = false) {
+                  bool x_plane = false, bool y_twin = false, const LnFuse* ln = nullptr) {
         const Plan& p = *ps.pl;
         GemmArgs g = rowgemm(p, s, GEMM_NT);
         const int pad = k / 2;
@@ -1322,8 +1323,36 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             }
         }
         if (y_twin) g.Ch = H(y.p);
+        if (ln) g.ln = *ln;
         gemm_launch(gx, GEMM_NT, g, maxM(p, s), cout, p.tasks, stream, 0, nsrc * 2.0 * alg_rows(p, s) * cout * k * cin, sumM(p, s),
                     4.0 * (alg_rows(p, s) * (nsrc * cin + cout) + nsrc * (double)p.tasks * cout * k * cin));
+    }
+    // sublayer GEMM + `LayerNorm(dropout(.) + residual)` (SubLayers.py:54-55,90-91): the GEMM followed by layernorm_fwd_kernel — or, with
+    // MTTS_LN_FUSE=1, ONE launch when the GEMM can carry the row-complete epilogue (fp32 mode, C <= 256, a launcher context with counters).
+    // Built and measured in round 5, bit-identical results, but SLOWER: 8-task step 157.3 -> 158.8 ms, single-task rank
+    // 32.5 -> 34.2 ms, second order 81.4 -> 83.1 ms (profiles/r05_ab_log.md) — the write-through stores, the drain + counter rendezvous and the
+    // one-workgroup-per-m-tile tail cost more than the 5-17 us launch they replace — so it stays opt-in.
+    // z receives the sublayer output a, then (in place) a' = dropout(a) + res — what the backward keeps; y the normalised rows.
+    void ln_fused_fwd(const Pass& ps, Space s, TS x, int cin, int k, TS w, TS b, TS z, TS res, long long g_off, long long b_off,
+                      const unsigned char* mask, TS y, TS st, int C, DropSpec din, bool x_plane, bool y_twin) {
+        static const bool fuse_on = [] { const char* e = getenv("MTTS_LN_FUSE"); return e ? atoi(e) != 0 : false; }();
+        const Plan& p = *ps.pl;
+        GemmArgs probe;
+        probe.N = C;
+        if (fuse_on && !ablate_ln() && !gx.batch.open && gemm_ln_fusable(gx, GEMM_NT, probe, maxM(p, s), p.tasks)) {
+            LnFuse f;
+            TS gm = W(ps, g_off), bt = W(ps, b_off);
+            f.res = res.p; f.res_gs = res.ts;
+            f.gamma = gm.p; f.beta = bt.p; f.par_gs = gm.ts;
+            f.mask = mask; f.mask_gs = row_ts(s);
+            f.y = y.p; f.y_gs = y.ts;
+            f.stats = st.p; f.st_gs = st.ts;
+            f.drop_seed = din.seed; f.drop_thr16 = din.thr16; f.drop_scale = din.scale;
+            conv_fwd(ps, s, x, cin, k, w, b, C, z, 0, nullptr, TS{nullptr, 0}, TS{nullptr, 0}, TS{nullptr, 0}, x_plane, false, &f);
+            return;
+        }
+        conv_fwd(ps, s, x, cin, k, w, b, C, z, 0, nullptr, TS{nullptr, 0}, TS{nullptr, 0}, TS{nullptr, 0}, x_plane, false);
+        ln_fwd(ps, s, z, res, g_off, b_off, mask, z, y, st, C, din, DropSpec(), y_twin);
     }
     // dX[M,Cin] (+)= sum_taps dY[M +- tap, Cout] * W  (conv dgrad over the same [Cout][k][Cin] image)
     void conv_dgrad(const Pass& ps, Space s, TS dy, int cout, int k, TS w, int cin, TS dx, int flags,
@@ -1539,14 +1568,15 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
                 MTTS_LAUNCH(softmax_fwd_kernel, dim3((L + 3) / 4, 1, groups), dim3(256), stream, seqs, b.P.p);
             attn_gemm(ps, s, TAB_PV, GEMM_NN, b.P.p, 0, b.qkv.p, 3 * d, b.O.p, d, 1.f, heads);
         }
-        conv_fwd(ps, s, b.O, d, 1, W(ps, P.wfc), W(ps, P.bfc), d, b.z1, 0, nullptr);
-        // self.dropout(self.fc(output)) + residual -> LayerNorm (SubLayers.py:54-55): the dropout rides in the LayerNorm kernel
-        // (bf16 mode: y1's and h's operand planes are written by their producers — the LayerNorm kernel, conv1's epilogue)
-        ln_fwd(ps, s, b.z1, xin, P.ln1g, P.ln1b, vm, b.z1, b.y1, b.st1, d, drop_spec(ps, block_dropout(s), site_base), DropSpec(), true);
+        // self.dropout(self.fc(output)) + residual -> LayerNorm (SubLayers.py:54-55): in the fc GEMM's launch (row-complete epilogue), or
+        // the dropout riding in the LayerNorm kernel (bf16 mode: y1's and h's operand planes are written by their producers — the LayerNorm
+        // kernel, conv1's epilogue)
+        ln_fused_fwd(ps, s, b.O, d, 1, W(ps, P.wfc), W(ps, P.bfc), b.z1, xin, P.ln1g, P.ln1b, vm, b.y1, b.st1, d,
+                     drop_spec(ps, block_dropout(s), site_base), false, true);
         conv_fwd(ps, s, b.y1, d, cfg.k1, W(ps, P.w1), W(ps, P.b1), cfg.d_ff, b.h, GEMM_RELU, im, TS{nullptr, 0}, TS{nullptr, 0}, TS{nullptr, 0}, true, true);
-        conv_fwd(ps, s, b.h, cfg.d_ff, cfg.k2, W(ps, P.w2), W(ps, P.b2), d, b.z2, 0, nullptr, TS{nullptr, 0}, TS{nullptr, 0}, TS{nullptr, 0}, true, false);
         // self.dropout(output) + residual -> LayerNorm (SubLayers.py:90-91)
-        ln_fwd(ps, s, b.z2, b.y1, P.ln2g, P.ln2b, vm, b.z2, b.y2, b.st2, d, drop_spec(ps, block_dropout(s), site_base + 1));
+        ln_fused_fwd(ps, s, b.h, cfg.d_ff, cfg.k2, W(ps, P.w2), W(ps, P.b2), b.z2, b.y1, P.ln2g, P.ln2b, vm, b.y2, b.st2, d,
+                     drop_spec(ps, block_dropout(s), site_base + 1), true, false);
     }
 
     // g0_in holds dL/dy2; K.g0 receives dL/dx, K.gh / K.dy1 / K.dO / K.gqkv the gradients in between (LayerKeep: by default aliases of

@@ -127,6 +127,25 @@ inline void xcd_sched_build(XcdSched& s, const int* dims, int cls, int tn, int u
     s.ps[8] = idx;
 }
 
+// Row-complete epilogue of an NT problem whose N is the whole row (N = C <= 256 columns = up to four 64-column tiles): bias + dropout +
+// residual + LayerNorm behind the GEMM without a tile that spans the row.  Every tile writes its 64 x 64 piece of a = A B^T + bias THROUGH
+// the L2 (sc1), the workgroups of an m-tile count themselves on one agent-scope counter, and the LAST to arrive — one acquire — reads the
+// 64 complete rows back (L2-hot), applies the dropout mask, adds the residual, normalises (one wavefront per row, DPP reductions) and writes
+// z (in place of a: the activation the backward keeps), y and the row statistics: exactly layernorm_fwd_kernel's arithmetic, in the GEMM's
+// launch (SubLayers.py:54-55,90-91: self.layer_norm(self.dropout(sublayer(x)) + residual)).  ctr == nullptr: off.
+struct LnFuse {
+    const float* res = nullptr;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    const unsigned char* mask = nullptr;
+    float* y = nullptr;
+    float* stats = nullptr;
+    int* ctr = nullptr;          // [groups][m-tiles] arrival counters, zero between launches (the last arriver re-arms its own)
+    long long res_gs = 0, par_gs = 0, mask_gs = 0, y_gs = 0, st_gs = 0;
+    unsigned drop_seed = 0, drop_thr16 = 0;
+    float drop_scale = 1.f, eps = 1e-5f;
+};
+
 struct GemmArgs {
     const float* A = nullptr;
     const float* B = nullptr;
@@ -191,6 +210,7 @@ struct GemmArgs {
     long long bh_gs = 0;
     bf16_t* Ch = nullptr;
     bool plane_only = false;
+    LnFuse ln;   // row-complete LayerNorm epilogue (NT, N <= 256; the launcher never splits K of such a problem)
     // task-per-XCD schedule (launches of 8 — opt-in 4 / 2 — groups).  host_dims: HOST array of the groups' dimptr values, read by the
     // launcher to build `xs`; never dereferenced on the device.
     const int* host_dims = nullptr;
@@ -371,6 +391,15 @@ __device__ __forceinline__ void mma_hfrags(const HalfFrags<TM, TN, NQ>& f, f32x1
 }
 #endif
 
+// one float written through the XCD's L2 (see st4_through below)
+__device__ __forceinline__ void st1_through(float* p, float v) {
+#if defined(MTTS_EMU)
+    *p = v;
+#else
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+
 // Fused epilogue shared by the fp32 and the split-bf16 kernels: alpha, bias, accumulate, ReLU, ReLU-mask of a
 // saved activation, row mask, output row remap.  (mb, nb) = origin of this wave's tile.
 template <int TM, int TN>
@@ -401,7 +430,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int z, f32x16 (
                 if (g.flags & GEMM_LRELU) v = v > 0.f ? v : g.act_slope * v;
                 if (relu_ref && !(relu_ref[(long long)m * g.ld_relu + n] > 0.f)) v = 0.f;
                 if (rowmask && !rowmask[m]) v = 0.f;
-                *p = v;
+                if (g.ln.ctr) st1_through(p, v);   // (read back by the m-tile's last workgroup: LnFuse)
+                else *p = v;
                 if (Ch) Ch[(long long)mo * ldc + n] = f32_to_bf16(v);
             }
         }
@@ -810,6 +840,63 @@ __device__ __forceinline__ void gemm_f32_kloop(const GemmArgs& g, const GemmProb
 
 }
 
+// LnFuse: the m-tile's last workgroup normalises its BM rows (see the struct).  Same publication protocol as slab_combine: write-through
+// payload (gemm_epilogue), every storing wave drains, one relaxed agent-scope increment, ONE acquire on the last arriver, plain loads.
+template <int BM, int NTH>
+__device__ __forceinline__ void gemm_ln_tail(const GemmArgs& g, const GemmProb& pr, int z, int m0) {
+    const LnFuse& f = g.ln;
+    const int C = pr.N, tiles_n = (C + 63) / 64, tiles_m = (pr.M + BM - 1) / BM;
+    // (counter slot: groups are laid out with the launch's common m-tile bound, which the engine passes through tiles_pg)
+    int* ctr = f.ctr + (long long)z * g.tiles_pg + m0 / BM;
+    (void)tiles_m;
+    __shared__ int s_ln_last;
+    MTTS_WAIT_VMEM();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_ln_last = (MTTS_ATOMIC_INC_AGENT(ctr) == tiles_n - 1) ? 1 : 0;
+        if (s_ln_last) MTTS_FENCE_ACQUIRE_AGENT();
+    }
+    __syncthreads();
+    if (!s_ln_last) return;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NTH / 64, RPW = BM / NW;   // rows per wavefront
+    const int c = lane * 4;
+    const float* gm = f.gamma + (long long)z * f.par_gs;
+    const float* bt = f.beta + (long long)z * f.par_gs;
+    DropSpec din;
+    din.seed = f.drop_seed; din.thr16 = f.drop_thr16; din.scale = f.drop_scale;
+    for (int i = 0; i < RPW; ++i) {
+        const int row = m0 + wave * RPW + i;
+        if (row >= pr.M) break;
+        float* pz = pr.C + (long long)row * pr.ldc;
+        float4 x = zero4();
+        if (c < C) {
+            x = ld4(pz + c);
+            if (din.thr16) x = drop4(din, z, row, C, c, x);
+            if (f.res) { const float4 r4 = ld4(f.res + (long long)z * f.res_gs + (long long)row * C + c); x = make_float4(x.x + r4.x, x.y + r4.y, x.z + r4.z, x.w + r4.w); }
+        }
+        const float mean = wave_sum(c < C ? (x.x + x.y) + (x.z + x.w) : 0.f) / (float)C;
+        const float dx = x.x - mean, dy = x.y - mean, dz = x.z - mean, dw = x.w - mean;
+        const float rstd = rsqrtf(wave_sum(c < C ? (dx * dx + dy * dy) + (dz * dz + dw * dw) : 0.f) / (float)C + f.eps);
+        const bool keep = f.mask ? f.mask[(long long)z * f.mask_gs + row] != 0 : true;
+        if (c < C) {
+            st4(pz + c, x);
+            float4 o = zero4();
+            if (keep) {
+                const float4 g4 = ld4(gm + c), b4 = ld4(bt + c);
+                o = make_float4(dx * rstd * g4.x + b4.x, dy * rstd * g4.y + b4.y, dz * rstd * g4.z + b4.z, dw * rstd * g4.w + b4.w);
+            }
+            st4(f.y + (long long)z * f.y_gs + (long long)row * C + c, o);
+        }
+        if (lane == 0) {
+            float* st = f.stats + (long long)z * f.st_gs + (long long)row * 2;
+            st[0] = mean;
+            st[1] = rstd;
+        }
+    }
+    if (tid == 0) *ctr = 0;
+}
+
 // What follows the K-loop: the column sums of the extra n-tile, or the fused epilogue.
 template <int TM, int TN, int WGM, int WGN>
 __device__ __forceinline__ void gemm_finish(const GemmArgs& g, const GemmProb& pr, int z, int m0, int n0, bool cs_tile, f32x16 (&acc)[TM][TN]) {
@@ -828,6 +915,7 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& g, const GemmProb& p
         return;
     }
     gemm_epilogue<TM, TN>(g, z, acc, pr.C, pr.ldc, pr.M, pr.N, m0 + wm0, n0 + wn0, lane);
+    if (g.ln.ctr) gemm_ln_tail<32 * TM * WGM, 64 * WGM * WGN>(g, pr, z, m0);
 }
 
 // One workgroup's share of one problem: output tile `bxs` (times split) of group `z`.
@@ -1030,6 +1118,7 @@ inline bool gemm_default_pipe() { return kGemmDefaultPipe; }
 struct GemmWorkspace { float* ws = nullptr; int* ctr = nullptr; };
 constexpr long long kSplitWsFloats = 16ll << 20;  // 64 MB of partial tiles
 constexpr int kSplitCtrs = 1 << 16;
+constexpr int kLnCtrs = 4096;                     // the last kLnCtrs counters: arrival counters of row-complete LayerNorm epilogues (LnFuse)
 
 // Launch batching: between gemm_batch_begin() and gemm_batch_end() every eligible gemm_launch (automatic tile choice) is queued
 // instead of launched; gemm_batch_end() issues the queue as ONE launch (gemm_f32_multi_kernel / gemm_glds_multi_kernel).
@@ -1066,6 +1155,25 @@ struct GemmCtx {
         prof.destroy();
     }
 };
+// LnFuse (requested by the caller through g.ln.y): can this launch carry it, and its counter slice.  `used` = counters already handed out
+// inside the same launch.  Returns false (and sets cx.error) when the request cannot be honoured — the engine asks gemm_ln_fusable first.
+inline bool gemm_ln_fusable(const GemmCtx& cx, int form, const GemmArgs& g, int max_M, int groups) {
+    return form == GEMM_NT && !cx.bf16 && cx.wsp.ctr != nullptr && g.N <= 256 && g.N % 4 == 0 && !g.table && !g.c_rowmap && !g.A2 &&
+           !(g.flags & GEMM_ACCUM) && !g.colsum && (long long)groups * ((max_M + 63) / 64) <= kLnCtrs;
+}
+inline bool gemm_ln_bind(GemmCtx& cx, int form, GemmArgs& g, int max_M, int groups, int tile, int& used) {
+    if (!g.ln.y) { g.ln.ctr = nullptr; return true; }
+    const int tiles_m = (max_M + 63) / 64;
+    if (tile != 64 || !gemm_ln_fusable(cx, form, g, max_M, groups) || used + groups * tiles_m > kLnCtrs) {
+        cx.error = "row-complete LayerNorm epilogue requested for a launch that cannot carry it";
+        return false;
+    }
+    g.ln.ctr = cx.wsp.ctr + (kSplitCtrs - kLnCtrs) + used;
+    g.tiles_pg = tiles_m;   // (counter stride between groups; the problem is never split, so the split-K meaning of the field is free)
+    g.splitk = 1;
+    used += groups * tiles_m;
+    return true;
+}
 inline void gemm_batch_begin(GemmCtx& cx) { cx.batch.open = true; }
 inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream);
 
@@ -1203,6 +1311,7 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     // split-K for under-filled grids (single-task ranks, the phoneme-side GEMMs, small wgrads): enough workgroups for
     // ~4 per CU, each still reducing >= 4 K-chunks
     const int S = 1;   // (stand-alone launches never split K: the long chains of under-filled batches are cut in gemm_batch_end)
+    { int used = 0; if (!gemm_ln_bind(cx, form, g, max_M, groups, bf16 ? 0 : tile, used)) return; }
     const int nth = 256;
     const long grid_tiles = ntiles(tile);
     dim3 block(nth), grid((unsigned)(grid_tiles * S), 1, (unsigned)groups);
@@ -1335,6 +1444,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     const int T = !bf16 ? 64 : (b.force_tile ? b.force_tile : (batch_wgs128 >= 512.0 ? 128 : 64));
     GemmWorkspace* wsp = nullptr;
     long long ws_off = 0, ctr_off = 0;
+    int ln_used = 0;
     for (int i = 0; i < mp.n; ++i) {
         const GemmPending& p = b.q[i];
         mp.form[i] = p.form; mp.groups[i] = p.groups; mp.g[i] = p.g;
@@ -1343,10 +1453,10 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
         int S = 1;
         const int nch = (gemm_keff(p.g) + 15) / 16;
         constexpr double ratio = 1.5;
-        if (small_batch && T == 64 && !p.g.table && !p.g.colsum && nch > per_cu / ratio) {
+        if (small_batch && T == 64 && !p.g.table && !p.g.colsum && !p.g.ln.y && nch > per_cu / ratio) {
             S = (int)std::min<double>(std::min<double>(std::ceil(nch / std::max(per_cu / ratio, 1.0)), nch / 16), 8);
             const long long slots = (long long)tiles * p.groups;
-            if (S >= 2 && ((ws_off + slots * S * 4096) > kSplitWsFloats || ctr_off + slots > kSplitCtrs)) S = 1;
+            if (S >= 2 && ((ws_off + slots * S * 4096) > kSplitWsFloats || ctr_off + slots > kSplitCtrs - kLnCtrs)) S = 1;
             if (S >= 2) {
                 if (!wsp) wsp = &cx.wsp;
                 if (wsp->ws) {
@@ -1355,6 +1465,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
                 } else S = 1;
             } else S = 1;
         }
+        if (!gemm_ln_bind(cx, p.form, mp.g[i], p.max_M, p.groups, bf16 ? 0 : T, ln_used)) { b.q.clear(); return; }
         mp.xcd_group[i] = gemm_xcd_swizzle() ? std::min(gemm_tiles_n(p.g, p.max_N, T) * S, 64) : 0;
         mp.tiles_pg[i] = tiles * S;
         long slots = (long)tiles * S * p.groups;

@@ -66,7 +66,10 @@ OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "M
 # MTTS_PANEL_ORDER=0: the B-panel-major XCD tile order of under-filled launches off (csrc/gemm.h: xcd_panel_locate) — placement only
 # MTTS_PRED_EARLY=0: the phoneme-level predictors' backward at its textual place on the main stream instead of early on the side stream
 # MTTS_SO_DEFER_POST=0: second order — the PostNet layers' hv(W) products inside the tangent launches instead of on the side stream (round 5)
-KERNEL_ARMS = [{"MTTS_FUSED_ATTN": "0"}, {"MTTS_ENC_AHEAD_QUERY": "0"}, {"MTTS_PANEL_ORDER": "0"}, {"MTTS_PRED_EARLY": "0"}, {"MTTS_SO_DEFER_POST": "0"}]
+# MTTS_LN_FUSE=1: `LayerNorm(dropout(sublayer) + residual)` as the fc / w_2 GEMM's row-complete epilogue (gemm.h: LnFuse, round 5; opt-in: measured
+# slower) instead of a launch of its own — the same arithmetic in the same order: bit-identical
+KERNEL_ARMS = [{"MTTS_FUSED_ATTN": "0"}, {"MTTS_ENC_AHEAD_QUERY": "0"}, {"MTTS_PANEL_ORDER": "0"}, {"MTTS_PRED_EARLY": "0"}, {"MTTS_SO_DEFER_POST": "0"},
+               {"MTTS_LN_FUSE": "1"}]
 
 
 def _compare(tmp_path, gpu):
@@ -96,7 +99,9 @@ def _compare(tmp_path, gpu):
     for i, arm in enumerate(KERNEL_ARMS):
         d = _run(tmp_path, f"kernel{i}", dict(common, **arm), gpu)
         for k in a:
-            if ("MTTS_ENC_AHEAD_QUERY" in arm or "MTTS_PANEL_ORDER" in arm or "MTTS_PRED_EARLY" in arm or "MTTS_SO_DEFER_POST" in arm) and not gpu:
+            if "MTTS_LN_FUSE" in arm:
+                np.testing.assert_array_equal(a[k], d[k], err_msg=f"{arm} {k}")     # (emulator AND hardware: nothing is summed in another order)
+            elif ("MTTS_ENC_AHEAD_QUERY" in arm or "MTTS_PANEL_ORDER" in arm or "MTTS_PRED_EARLY" in arm or "MTTS_SO_DEFER_POST" in arm) and not gpu:
                 np.testing.assert_array_equal(a[k], d[k], err_msg=f"{arm} {k}")     # (pure re-plumbing: bit-identical)
             else:
                 np.testing.assert_allclose(a[k], d[k], rtol=5e-4, atol=2e-6 * max(1.0, float(np.abs(a[k]).max())), err_msg=f"{arm} {k}")
