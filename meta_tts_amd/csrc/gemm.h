@@ -402,7 +402,8 @@ __device__ __forceinline__ void st1_through(float* p, float v) {
 
 // Fused epilogue shared by the fp32 and the split-bf16 kernels: alpha, bias, accumulate, ReLU, ReLU-mask of a
 // saved activation, row mask, output row remap.  (mb, nb) = origin of this wave's tile.
-template <int TM, int TN>
+// LNF: the kernel instantiation carries the row-complete LayerNorm epilogue (LnFuse) — only those pay for its stores, barrier and tail code
+template <int TM, int TN, bool LNF = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int z, f32x16 (&acc)[TM][TN], float* C, int ldc, int M, int N,
                                               int mb, int nb, int lane) {
     const float* bias = g.bias ? g.bias + (long long)z * g.bias_gs : nullptr;
@@ -430,7 +431,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int z, f32x16 (
                 if (g.flags & GEMM_LRELU) v = v > 0.f ? v : g.act_slope * v;
                 if (relu_ref && !(relu_ref[(long long)m * g.ld_relu + n] > 0.f)) v = 0.f;
                 if (rowmask && !rowmask[m]) v = 0.f;
-                if (g.ln.ctr) st1_through(p, v);   // (read back by the m-tile's last workgroup: LnFuse)
+                if (LNF && g.ln.ctr) st1_through(p, v);   // (read back by the m-tile's last workgroup: LnFuse)
                 else *p = v;
                 if (Ch) Ch[(long long)mo * ldc + n] = f32_to_bf16(v);
             }
@@ -898,7 +899,7 @@ __device__ __forceinline__ void gemm_ln_tail(const GemmArgs& g, const GemmProb& 
 }
 
 // What follows the K-loop: the column sums of the extra n-tile, or the fused epilogue.
-template <int TM, int TN, int WGM, int WGN>
+template <int TM, int TN, int WGM, int WGN, bool LNF = false>
 __device__ __forceinline__ void gemm_finish(const GemmArgs& g, const GemmProb& pr, int z, int m0, int n0, bool cs_tile, f32x16 (&acc)[TM][TN]) {
     const int tid = MTTS_OPAQUE_TID(), lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / WGN) * (32 * TM), wn0 = (wave % WGN) * (32 * TN);
@@ -914,15 +915,15 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& g, const GemmProb& p
         }
         return;
     }
-    gemm_epilogue<TM, TN>(g, z, acc, pr.C, pr.ldc, pr.M, pr.N, m0 + wm0, n0 + wn0, lane);
-    if (g.ln.ctr) gemm_ln_tail<32 * TM * WGM, 64 * WGM * WGN>(g, pr, z, m0);
+    gemm_epilogue<TM, TN, LNF>(g, z, acc, pr.C, pr.ldc, pr.M, pr.N, m0 + wm0, n0 + wn0, lane);
+    if constexpr (LNF) { if (g.ln.ctr) gemm_ln_tail<32 * TM * WGM, 64 * WGM * WGN>(g, pr, z, m0); }
 }
 
 // One workgroup's share of one problem: output tile `bxs` (times split) of group `z`.
 // DUAL: the kernel also runs the second source of dual-source problems (GemmArgs::A2) — a second, separately inlined K-loop into the
 // same accumulators.  (A runtime loop over the sources around ONE inlined K-loop costs every kernel ~10 VGPRs of spilled SGPR state
 // — the multi-problem BK = 32 kernel drops from 4 to 3 workgroups per CU — so only the kernels that may be handed such problems pay for it.)
-template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0, bool DUAL = false, int KL = 0>
+template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0, bool DUAL = false, int KL = 0, bool LNF = false>
 __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs, float* smem) {
     constexpr int NTH = 64 * WGM * WGN;
     constexpr int TM = (BM / WGM) / 32, TN = (BN / WGN) / 32;
@@ -952,10 +953,10 @@ __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs,
         }
     }
     if (S > 1 && !splitk_combine<TM, TN, NTH>(g, z, tile_lin, split, S, acc)) return;
-    gemm_finish<TM, TN, WGM, WGN>(g, pr, z, m0, n0, cs_tile, acc);
+    gemm_finish<TM, TN, WGM, WGN, LNF>(g, pr, z, m0, n0, cs_tile, acc);
 }
 
-template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0, int KL = 0>
+template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2, int ABL = 0, int KL = 0, bool LNF = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[GemmSmem<FORM, BM, BN, BK>::FLOATS];
     int z = blockIdx.z;
@@ -963,7 +964,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_f32_kernel(GemmArgs g) {
     if (g.xs.on) { if (!xcd_sched_locate(g.xs, bxs, z, bxs)) return; }   // 1-D grid, task-per-XCD order
     else if (g.swizzle == 2) { if (!xcd_panel_locate(bxs, g.po_tiles_m, (g.N + BN - 1) / BN + (gemm_has_colsum<FORM>(g) ? 1 : 0), g.splitk > 1 ? g.splitk : 1, bxs)) return; }
     else if (g.swizzle) bxs = xcd_group_remap(bxs, (int)gridDim.x, xcd_group_size((g.N + BN - 1) / BN, g.splitk));
-    gemm_f32_body<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL, false, KL>(g, z, bxs, smem);
+    gemm_f32_body<FORM, BM, BN, BK, PIPE, WGM, WGN, ABL, false, KL, LNF>(g, z, bxs, smem);
 }
 
 // Several independent problems (any mix of forms, e.g. the dgrad and the wgrad of one layer) in ONE launch: workgroups
@@ -1004,7 +1005,7 @@ __device__ __forceinline__ bool gemm_multi_locate(const GemmMulti& mp, int& p, i
     bx = lin - z * tiles;
     return true;
 }
-template <int BM, int BN, int BK, int KL = 0>
+template <int BM, int BN, int BK, int KL = 0, bool LNF = false>
 __global__ __launch_bounds__(256) void gemm_f32_multi_kernel(GemmMulti mp) {
     constexpr int F0 = GemmSmem<GEMM_NT, BM, BN, BK>::FLOATS, F1 = GemmSmem<GEMM_NN, BM, BN, BK>::FLOATS, F2 = GemmSmem<GEMM_TN, BM, BN, BK>::FLOATS;
     constexpr int FL = F0 > F1 ? (F0 > F2 ? F0 : F2) : (F1 > F2 ? F1 : F2);
@@ -1012,7 +1013,7 @@ __global__ __launch_bounds__(256) void gemm_f32_multi_kernel(GemmMulti mp) {
     int p, z, bx;
     if (!gemm_multi_locate(mp, p, z, bx)) return;
     const int form = mp.form[p];
-    if (form == GEMM_NT) gemm_f32_body<GEMM_NT, BM, BN, BK, true, 2, 2, 0, false, KL>(mp.g[p], z, bx, smem);
+    if (form == GEMM_NT) gemm_f32_body<GEMM_NT, BM, BN, BK, true, 2, 2, 0, false, KL, LNF>(mp.g[p], z, bx, smem);
     else if (form == GEMM_NN) gemm_f32_body<GEMM_NN, BM, BN, BK, true, 2, 2, 0, false, KL>(mp.g[p], z, bx, smem);
     else gemm_f32_body<GEMM_TN, BM, BN, BK, true, 2, 2, 0, false, KL>(mp.g[p], z, bx, smem);
 }
@@ -1158,7 +1159,7 @@ struct GemmCtx {
 // LnFuse (requested by the caller through g.ln.y): can this launch carry it, and its counter slice.  `used` = counters already handed out
 // inside the same launch.  Returns false (and sets cx.error) when the request cannot be honoured — the engine asks gemm_ln_fusable first.
 inline bool gemm_ln_fusable(const GemmCtx& cx, int form, const GemmArgs& g, int max_M, int groups) {
-    return form == GEMM_NT && !cx.bf16 && cx.wsp.ctr != nullptr && g.N <= 256 && g.N % 4 == 0 && !g.table && !g.c_rowmap && !g.A2 &&
+    return form == GEMM_NT && !cx.bf16 && cx.wsp.ctr != nullptr && gemm_kloop_variant() == 4 && g.N <= 256 && g.N % 4 == 0 && !g.table && !g.c_rowmap && !g.A2 &&
            !(g.flags & GEMM_ACCUM) && !g.colsum && (long long)groups * ((max_M + 63) / 64) <= kLnCtrs;
 }
 inline bool gemm_ln_bind(GemmCtx& cx, int form, GemmArgs& g, int max_M, int groups, int tile, int& used) {
@@ -1297,7 +1298,7 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     else if (tile == 4064) { glds = gemm_glds_ok(g); tile = 64; }            // explicit request (kernel tests, microbenchmarks)
     else if (user_tile == 0 && tile == 64) {
         const long wgs = (long)std::ceil(rows / 64.0) * gemm_tiles_n(g, max_N, 64);
-        glds = gemm_use_glds() && gemm_glds_ok(g) && wgs <= gemm_glds_max_wgs() && !cx.no_glds;
+        glds = gemm_use_glds() && gemm_glds_ok(g) && wgs <= gemm_glds_max_wgs() && !cx.no_glds && !g.ln.y;
     }
 #else
     if (tile == 4064) tile = 64;
@@ -1328,7 +1329,11 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     if (form == F && tile == T) {                                                                         \
         if (pipe && T == 64) {                                                                            \
             const int kl = gemm_kloop_for(g, bk);                                                         \
-            if (bk == 32) {                                                                               \
+            if (F == GEMM_NT && g.ln.ctr) {   /* row-complete LayerNorm epilogue (LnFuse): instantiations of their own */    \
+                if (bk == 32) MTTS_LAUNCH((gemm_f32_kernel<GEMM_NT, 64, 64, 32, true, 2, 2, 0, 4, true>), grid, block, stream, g);   \
+                else MTTS_LAUNCH((gemm_f32_kernel<GEMM_NT, 64, 64, 16, true, 2, 2, 0, 4, true>), grid, block, stream, g);            \
+                kind = (bk == 32 ? GK_F32_64_BK32 : GK_F32_64_BK16) + F;                                  \
+            } else if (bk == 32) {                                                                        \
                 if (kl == 4) MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 4>), grid, block, stream, g);        \
                 else if (kl == 1) MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 1>), grid, block, stream, g);   \
                 else MTTS_LAUNCH((gemm_f32_kernel<F, 64, 64, 32, true, 2, 2, 0, 0>), grid, block, stream, g);                \
@@ -1492,7 +1497,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
         if (mp.g[i].taps > 1 && mp.g[i].tap_k % 32 != 0) bk32 = false;
         maxK = std::max(maxK, gemm_keff(mp.g[i]));
     }
-    bool glds = gemm_use_glds() && small_batch && !cx.no_glds;
+    bool glds = gemm_use_glds() && small_batch && !cx.no_glds && ln_used == 0;
     if (b.force_family) { glds = b.force_family == 4064; bk32 = bk32 && b.force_family == 32; if (bk32) maxK = std::max(maxK, 1024); }
     for (int i = 0; i < mp.n; ++i) glds = glds && gemm_glds_ok(mp.g[i]);
     int kind = GK_MULTI16;
@@ -1514,7 +1519,8 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
             else MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 32, 0>), grid, block, stream, mp);
             kind = GK_MULTI32_DUAL;
         } else {
-            if (kl == 4) MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 4>), grid, block, stream, mp);
+            if (ln_used > 0) MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 4, true>), grid, block, stream, mp);
+            else if (kl == 4) MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 4>), grid, block, stream, mp);
             else if (kl == 1) MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 1>), grid, block, stream, mp);
             else MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 32, 0>), grid, block, stream, mp);
             kind = GK_MULTI32;
@@ -1527,7 +1533,8 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
             else MTTS_LAUNCH((gemm_f32_multi_dual_kernel<64, 64, 16, 0>), grid, block, stream, mp);
             kind = GK_MULTI16_DUAL;
         } else {
-            if (kl == 4) MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 16, 4>), grid, block, stream, mp);
+            if (ln_used > 0) MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 16, 4, true>), grid, block, stream, mp);
+            else if (kl == 4) MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 16, 4>), grid, block, stream, mp);
             else MTTS_LAUNCH((gemm_f32_multi_kernel<64, 64, 16, 0>), grid, block, stream, mp);
         }
     }
