@@ -402,8 +402,11 @@ class Trainer:
         eng.sync_unpack()
 
     def synced_losses(self):
-        """Mean over ALL tasks of the meta-batch of the six losses of the last step (what the reference logs with sync_dist=True)."""
-        return self.system.engine.synced_losses()
+        """Mean over ALL tasks (all ranks) of the six losses of the last gradient call — what the reference logs with `sync_dist=True` at that
+        `training_step` (meta.py:78-79).  With gradient accumulation (grad_acc_step = N) that is the window's LAST micro-batch, as in the
+        reference, where every micro-batch logs its own losses; the exchange tail carries the sums scaled by grad_scale = 1 / (tasks x N) — the
+        accumulation divisor is undone here."""
+        return self.system.engine.synced_losses() * float(self.grad_acc)
 
     def _with_accumulation(self, grad_call):
         """Runs one gradient call of an accumulation window.  The engine's accumulate flag is armed for THIS call only (cleared in a

@@ -125,3 +125,22 @@ def test_conv1d_fwd_dgrad_wgrad(lib, tile, L, Cin, Cout, k):
     assert (dx - dxr).abs().max().item() < tol(dxr)
     dwr = wt.grad.permute(0, 2, 1)
     assert (dw - dwr).abs().max().item() < tol(dwr) * 4
+
+
+@pytest.mark.gpu
+def test_kloop_variants_are_bit_identical():
+    """MTTS_KLOOP = 0 / 1 / 4 (csrc/gemm.h: gemm_f32_kloop KL — the round 2-4 loop, rotating half fragments, the interleaved default) compute
+    every accumulator chain in the same k order: NT / NN / TN products with partial last slices and ragged M / N, BK = 32 and the k = 9
+    convolution's three forms must give the same bits (tools/kloop_forms.py hash; the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for kl in ("0", "1", "4"):
+        env = dict(os.environ, MTTS_KLOOP=kl)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "kloop_forms.py"), "hash"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("KLOOP")][-1]
+        digests[kl] = line.split()[-1]
+    assert len(set(digests.values())) == 1, digests

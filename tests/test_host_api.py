@@ -671,8 +671,10 @@ def test_gradient_accumulation_matches_one_step_on_the_joint_batch(cfgs, emu_lib
     _, _, lr = tr.meta_step([t1], total_tasks=1)
     assert lr is None and acc.global_step == 0
     np.testing.assert_array_equal(acc.state_dict()["model.mel_linear.weight"], before)   # nothing stepped yet
-    _, _, lr = tr.meta_step([t2], total_tasks=1)
+    q2, _, lr = tr.meta_step([t2], total_tasks=1)
     assert lr is not None and acc.global_step == 1
+    # the reduced losses are those of the window's LAST micro-batch (each training_step logs its own, meta.py:78-79), not divided by N
+    np.testing.assert_allclose(tr.synced_losses(), np.asarray(q2)[0], rtol=1e-6)
     ref = get_system("meta")(pre, mc, tc, ac, max_tasks=2, max_batch=3, max_src_len=16, max_mel_len=96, lib_path=emu_lib)
     Trainer(ref).meta_step([t1, t2], total_tasks=2)
     for k in ("model.mel_linear.weight", "model.decoder.layer_stack.1.pos_ffn.w_1.weight", "model.encoder.layer_stack.0.slf_attn.fc.weight",
