@@ -2587,6 +2587,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     int outer_update(const float* g, float lr, float b1, float b2, float eps, float weight_decay, float max_norm,
                      float* norm_out_host) {
         const int nb = 512;
+        if (ar_issued) ar_join();  // (an overlapped exchange nobody joined with mtts_allreduce_outer: the clip must still see the reduced buffer)
         shadows_current = false;   // theta is about to move
         MTTS_LAUNCH(sumsq_partial_kernel, dim3(nb), dim3(256), stream, g, n_total / 4, norm_partial);
         MTTS_LAUNCH(sumsq_final_kernel, dim3(1), dim3(64), stream, (const float*)norm_partial, nb, norm_out, extra_sumsq);
