@@ -650,6 +650,22 @@ def test_dvec_few_shot_test_step_averages_support_embeddings(cfgs, emu_lib):
     assert abs(got - float(lo[0])) < 2e-4 * max(1.0, abs(float(lo[0])))
 
 
+def test_trainer_refuses_an_exchange_view_without_the_tail(cfgs, emu_lib):
+    """the collective covers the outer gradient AND the exchange tail (loss scalars + BatchNorm buffers); a view of the gradient alone
+    would make every non-zero rank unpack its own zeroed tail into its BatchNorm running buffers.  Trainer must refuse it."""
+    import torch
+    pre, mc, tc, ac = cfgs
+    sysm = get_system("meta")(pre, mc, tc, ac, max_tasks=1, max_batch=3, max_src_len=16, max_mel_len=96, lib_path=emu_lib)
+    eng = sysm.engine
+    assert eng.sync_floats > eng.n_total
+    with pytest.raises(ValueError):
+        Trainer(sysm, outer_grad_tensor=torch.zeros(eng.n_total))
+    Trainer(sysm, outer_grad_tensor=torch.zeros(eng.sync_floats))      # the full exchange buffer is accepted
+    assert eng.bn_pack_weight(0, 4) == 1.0 and eng.bn_pack_weight(2, 4) == 0.0
+    eng.set_bn_sync("mean")
+    assert eng.bn_pack_weight(2, 4) == 0.25
+
+
 def test_gradient_accumulation_matches_one_step_on_the_joint_batch(cfgs, emu_lib):
     """optimizer.grad_acc_step = 2 (main.py:62 accumulate_grad_batches): two meta-batches of one task each, ONE optimizer step on the sum
     of their halved gradients — the same parameters as one step on a meta-batch holding both tasks; the optimizer must not move between
