@@ -552,6 +552,9 @@ def gemm_profile(eng, run, sites=False):
         with open(dump) as f:
             for r in csv.DictReader(f):
                 recs.append((eng.lib.mtts_profile_kernel_name(int(r["kind"])).decode(), int(r["K"]), float(r["us"]), float(r["gflop"]), int(r.get("site", 0))))
+        if os.environ.get("MTTS_BENCH_KEEP_SITES"):   # (tools/gemm_sites.py reads the per-launch records of the roofline leg from here)
+            import shutil
+            shutil.copy(dump, os.environ["MTTS_BENCH_KEEP_SITES"])
         os.unlink(dump)
     except Exception:  # noqa: BLE001
         recs = []

@@ -191,6 +191,11 @@ int mtts_imaml_finish(mtts_handle* h, float inner_lr, float reg_param, float gra
 /* BaseAdaptorSystem.adapt alone (few-shot test loop, base_adaptor.py:155-189): `steps` first-order inner steps
  * on slot 0; reset != 0 starts from a fresh clone of theta, else continues on the current fast weights. */
 int mtts_adapt(mtts_handle* h, int steps, float inner_lr, int reset, float* sup_losses_host /* [steps][n_tasks][6] */);
+/* The inner SGD step (learn2learn maml_update through systems/utils.py:39-47: p <- p - lr * g per adapted parameter) runs module by module on
+ * a stream of the handle behind the backward that produces the gradients, instead of as one pass between that backward and the next
+ * forward (MTTS_UPD_OVERLAP=0, iMAML's proximal step and architectures without the module table keep the single pass; results are
+ * bit-identical).  Returns the launches the LAST inner step's update took: > 1 module by module, 0 the single pass. */
+int mtts_inner_update_launches(mtts_handle* h);
 /* BaselineSystem.training_step (lightning/systems/baseline.py:25-36): plain gradient of slot's batches */
 int mtts_plain_grad(mtts_handle* h, int slot, float grad_scale, float* losses_host);
 /* device pointer of the outer gradient (mtts_param_total floats) — the buffer the host all-reduces

@@ -77,6 +77,7 @@ EXPORTS = {
     "mtts_allreduce_outer": (C.c_int, [C.c_void_p]),
     "mtts_arm_allreduce_overlap": (C.c_int, [C.c_void_p]),
     "mtts_allreduce_launches": (C.c_int, [C.c_void_p]),
+    "mtts_inner_update_launches": (C.c_int, [C.c_void_p]),
     "mtts_outer_sync_floats": (C.c_int64, [C.c_void_p]),
     "mtts_sync_pack": (C.c_int, [C.c_void_p, C.c_float]),
     "mtts_sync_unpack": (C.c_int, [C.c_void_p]),

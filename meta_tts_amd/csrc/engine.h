@@ -614,6 +614,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         fast_cur = fast; grad_dst = grad;
         if (gx.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace)"); return -1; }
         if (init_defer() != 0) return -1;
+        if (upd_setup() < 0) return -1;
         HIP_CHECK(hipMalloc((void**)&norm_partial, 1024 * sizeof(float)));
         HIP_CHECK(hipMalloc((void**)&norm_out, 4 * sizeof(float)));
         // frozen tables: sinusoid positions (Models.py:10-30, float64 math), linear bins
@@ -914,6 +915,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     }
     void destroy() {
         ar_destroy();
+        upd_destroy();
         if (side) { hipStreamSynchronize(side); hipStreamDestroy(side); }
         for (auto& e : ev_side) if (e) hipEventDestroy(e);
         if (ev_join) hipEventDestroy(ev_join);
@@ -1715,7 +1717,11 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             for (auto& e : ev_ar) HIP_CHECK(hipEventCreate(&e));
             HIP_CHECK(hipEventCreate(&ev_ar_done));
         }
-        ar_buckets.clear();
+        return build_buckets(ar_buckets);
+    }
+    // the module buckets of the flat parameter buffer, in backward-completion order; 0 when the architecture has them all
+    int build_buckets(std::vector<std::pair<long long, long long>>& out) const {
+        out.clear();
         if (cfg.enc_layers < 1) return 1;
         std::vector<const ParamEntry*> order;
         for (const ParamEntry& e : entries) order.push_back(&e);
@@ -1745,12 +1751,12 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             }
         }
         if (prev >= 0) rng[(size_t)prev].second = n_total;
-        for (auto& r : rng) if (r.first >= 0 && r.second > r.first && ((r.second - r.first) % 4) == 0 && (r.first % 4) == 0) ar_buckets.push_back(r); else if (r.first >= 0) { ar_buckets.clear(); return 1; }
+        for (auto& r : rng) if (r.first >= 0 && r.second > r.first && ((r.second - r.first) % 4) == 0 && (r.first % 4) == 0) out.push_back(r); else if (r.first >= 0) { out.clear(); return 1; }
         // (a module without parameters has no bucket: the completion-order indices above then no longer match, so require them all)
-        if ((int)ar_buckets.size() != nb) { ar_buckets.clear(); return 1; }
+        if ((int)out.size() != nb) { out.clear(); return 1; }
         long long covered = 0;
-        for (const auto& r : ar_buckets) covered += r.second - r.first;
-        if (covered != n_total) { ar_buckets.clear(); return 1; }   // (the buckets must tile the whole outer gradient)
+        for (const auto& r : out) covered += r.second - r.first;
+        if (covered != n_total) { out.clear(); return 1; }   // (the buckets must tile the whole outer gradient)
         return 0;
     }
     void ar_destroy() {
@@ -1811,6 +1817,78 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         hipStreamWaitEvent(stream, ev_ar_done, 0);
         ar_issued = false;
     }
+
+    // ---- inner SGD step, module by module behind the backward that produces its gradients (systems/utils.py:39-47 through learn2learn's
+    // maml_update: p <- p - lr * g per parameter; no step of the reference orders the parameters against each other) --------------------
+    // The monolithic update is an HBM-bound pass over every task's fast weights and gradients (3.4 GB at 8 tasks) that nothing overlaps
+    // with when it sits between the backward and the next forward.  Cut at the same module boundaries as the exchange buckets, each piece
+    // runs on `upd_stream` the moment its module's parameter gradients are complete (and its weights have been read for the last time in
+    // this backward: a module's input-gradient GEMMs come before its hook), under the matrix-core-bound backward of the modules below it.
+    // Same kernel, same floats: bit-identical to the monolithic update (tests/test_deferred_paths.py).  MTTS_UPD_OVERLAP=0: one launch.
+    hipStream_t upd_stream = nullptr;
+    static constexpr int kUpdEvents = 64;
+    hipEvent_t ev_upd[kUpdEvents] = {};
+    hipEvent_t ev_upd_done = nullptr;
+    int ev_upd_next = 0;
+    std::vector<std::pair<long long, long long>> upd_buckets;
+    bool upd_active = false;
+    int upd_next = 0, upd_nt = 0, upd_launches = 0;
+    float upd_lr = 0.f;
+    int upd_setup() {
+        static const int on = [] { const char* e = getenv("MTTS_UPD_OVERLAP"); return e ? atoi(e) : 1; }();
+        upd_buckets.clear();
+        if (!on || n_adapt <= 0 || (adapt_start % 4) != 0 || (n_adapt % 4) != 0) return 1;
+        if (build_buckets(upd_buckets)) return 1;
+        if (!upd_stream) {
+            HIP_CHECK(hipStreamCreateWithFlags(&upd_stream, hipStreamNonBlocking));
+            for (auto& e : ev_upd) HIP_CHECK(hipEventCreate(&e));
+            HIP_CHECK(hipEventCreate(&ev_upd_done));
+        }
+        return 0;
+    }
+    void upd_destroy() {
+        if (upd_stream) { hipStreamSynchronize(upd_stream); hipStreamDestroy(upd_stream); upd_stream = nullptr; }
+        for (auto& e : ev_upd) if (e) { hipEventDestroy(e); e = nullptr; }
+        if (ev_upd_done) { hipEventDestroy(ev_upd_done); ev_upd_done = nullptr; }
+    }
+    bool upd_begin(int nt, float lr) {
+        if (upd_stream == nullptr || upd_buckets.empty() || n_adapt <= 0 || inner_prox > 0.f) return false;
+        upd_active = true; upd_next = 0; upd_nt = nt; upd_lr = lr; upd_launches = 0;
+        return true;
+    }
+    void upd_wait_for(hipStream_t producer) {
+        hipEvent_t ev = ev_upd[ev_upd_next];
+        ev_upd_next = (ev_upd_next + 1) % kUpdEvents;
+        hipEventRecord(ev, producer);
+        hipStreamWaitEvent(upd_stream, ev, 0);
+    }
+    // modules 0 .. upto are done: their slices of the fast weights take the step
+    void upd_ready(int upto) {
+        if (!upd_active) return;
+        if (upto >= (int)upd_buckets.size()) upto = (int)upd_buckets.size() - 1;
+        bool waited = false;
+        for (; upd_next <= upto; ++upd_next) {
+            const long long lo = std::max(upd_buckets[(size_t)upd_next].first, adapt_start);
+            const long long hi = std::min(upd_buckets[(size_t)upd_next].second, adapt_start + n_adapt);
+            if (hi <= lo) continue;
+            if (!waited) {
+                upd_wait_for(stream);
+                if (defer_live && side) upd_wait_for(side);
+                waited = true;
+            }
+            MTTS_LAUNCH(sgd_update_kernel, dim3(blocks_for((hi - lo) / 4), 1, upd_nt), dim3(256), upd_stream, fast + (lo - adapt_start),
+                        (const float*)(grad + lo), (hi - lo) / 4, upd_lr, n_adapt, n_total);
+            ++upd_launches;
+        }
+    }
+    // after the backward: the modules it did not reach (an encoder that is not adapted has no slice), then the main stream waits
+    void upd_end() {
+        upd_ready((int)upd_buckets.size() - 1);
+        upd_active = false;
+        hipEventRecord(ev_upd_done, upd_stream);
+        hipStreamWaitEvent(stream, ev_upd_done, 0);
+    }
+    void module_done(int idx) { ar_ready(idx); upd_ready(idx); }
 
     // kernel-family choice of the pass's main-stream GEMM launches (gemm.h: gemm_glds_mode): the LDS-DMA family only when MTTS_GLDS=1 asks for it
     void set_regime(const Plan& p) { (void)p; gx.no_glds = gemm_glds_mode() == 0; }
@@ -2328,7 +2406,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         // ---- mel_linear -------------------------------------------------------------------
         set_tag(0);
         TS none{nullptr, 0};
-        ar_ready(ar_idx_postnet());
+        module_done(ar_idx_postnet());
         const bool dfm = defer_ok(p);   // gRm / gMelF are final from here on: their parameter gradients can run on the side stream
         if (!dfm) colsum(ps, SP_R, gRm, nm, nullptr, none, Gd(mel_b));
         MTTS_LAUNCH(gather_rows_kernel, row_grid(p.maxMf, nt), dim3(256), stream, (const int*)p.meta, (int)META_MF,
@@ -2354,7 +2432,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             site_base = 64 + 2 * l;
             fft_bwd(ps, SP_F, cfg.dec_heads, decP[l], decB[l], xin, l == cfg.dec_layers - 1 ? K.dec_top : K.dec[l + 1].g0, K.dec[l], dSf,
                     defer_ok(p) ? &decG[l] : nullptr);
-            ar_ready(ar_idx_dec(l));   // (overlapped exchange: PostNet, mel_linear and the decoder layers down to l are complete)
+            module_done(ar_idx_dec(l));   // (overlapped exchange: PostNet, mel_linear and the decoder layers down to l are complete)
         }
         const TS gF0 = cfg.dec_layers ? K.dec[0].g0 : K.dec_top;   // gradient of the decoder input
         // speaker vector gradient, part 1: every valid frame
@@ -2426,14 +2504,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         MTTS_LAUNCH(speaker_table_grad_kernel, dim3(cfg.n_speaker, 1, nt), dim3(64), sst, (const int*)p.meta,
                     (const float*)dspk.p, dspk.ts, (const int*)p.spk_ids, (long long)cap_B + 1, cap_B, p.average_spk,
                     Gd(spk_table).p, n_total, d);
-        ar_ready(ar_idx_spk());        // variance adaptor + speaker table
+        module_done(ar_idx_spk());        // variance adaptor + speaker table
         if (!need_encoder) return 0;
         // ---- encoder ------------------------------------------------------------------------
         for (int l = cfg.enc_layers - 1; l >= 0; --l) {
             TS xin = l == 0 ? emb_out : encB[l - 1].y2;
             site_base = 2 * l;
             fft_bwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], xin, gP0, LayerKeep{gP0, gPh, gP1, gP1, gPqkv}, dSp, defer_ok(p) ? &encG[l] : nullptr);
-            if (l > 0) ar_ready(ar_idx_enc(l));   // (layer 0's bucket also holds the word embedding, below)
+            if (l > 0) module_done(ar_idx_enc(l));   // (layer 0's bucket also holds the word embedding, below)
         }
         // word embedding (padding row 0 keeps a zero gradient); p_tok is 0 on invalid rows, and
         // gP0 is only meaningful on valid rows -> scan with the token ids masked by validity
@@ -2454,6 +2532,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         else
             MTTS_LAUNCH(sgd_update_kernel, dim3(blocks_for(n_adapt / 4), 1, nt), dim3(256), stream, fast, (const float*)(grad + adapt_start),
                         n_adapt / 4, inner_lr, n_adapt, n_total);
+    }
+    // backward of an inner step + its SGD step (the step overlapped module by module when upd_setup made that possible)
+    int inner_backward_update(const Pass& ps, int nt, float inner_lr) {
+        const bool overlapped = upd_begin(nt, inner_lr);
+        const int rc = backward(ps, 1.f, encoder_adapted());
+        if (overlapped) upd_end();
+        else if (!rc) { inner_update(nt, inner_lr); upd_launches = 0; }
+        return rc;
     }
     // the inner-loop backward must reach the encoder when adapt.modules lists it (config/algorithm/dev.yaml does)
     bool encoder_adapted() const { return (cfg.adapt_mask >> MOD_ENCODER) & 1; }
@@ -2479,8 +2565,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             if (ahead) { hipStreamWaitEvent(stream, ev_enc[s], 0); ps.seed_override = seeds[s]; ps.enc_out = enc_ahead[s]; }
             if (forward(ps)) return -1;
             if (sup_losses_out && loss(ps, sup_losses_out + (long long)s * nt * 6)) return -1;
-            if (backward(ps, 1.f, encoder_adapted())) return -1;
-            inner_update(nt, inner_lr);
+            if (inner_backward_update(ps, nt, inner_lr)) return -1;
         }
         Pass pq{&qp, true, true};
         if (ahead && qseed) {   // the query pass's encoder ran ahead on the second side stream
@@ -2517,8 +2602,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             if (ahead) { hipStreamWaitEvent(stream, ev_enc[s2], 0); ps.seed_override = seeds[s2]; ps.enc_out = enc_ahead[s2]; }
             if (forward(ps)) return -1;
             if (sup_losses_out && loss(ps, sup_losses_out + (long long)s2 * nt * 6)) return -1;
-            if (backward(ps, 1.f, encoder_adapted())) return -1;
-            inner_update(nt, inner_lr);
+            if (inner_backward_update(ps, nt, inner_lr)) return -1;
         }
         return 0;
     }

@@ -365,6 +365,7 @@ int mtts_arm_allreduce_overlap(mtts_handle* h) {
     return 0;
 }
 int mtts_allreduce_launches(mtts_handle* h) { return h ? h->eng.ar_launches : -1; }
+int mtts_inner_update_launches(mtts_handle* h) { return h ? h->eng.upd_launches : -1; }
 int mtts_allreduce_outer(mtts_handle* h) {
     Engine& e = h->eng;
     if (!h->comm.comm) { e.set_error("communicator not initialised (mtts_comm_init)"); return -1; }

@@ -445,6 +445,11 @@ class Engine:
     def allreduce_launches(self) -> int:
         return int(self.lib.mtts_allreduce_launches(self.h))
 
+    @property
+    def inner_update_launches(self) -> int:
+        """Launches of the last inner SGD step: > 1 when it ran module by module behind its backward, 0 for the single pass."""
+        return int(self.lib.mtts_inner_update_launches(self.h))
+
     def allreduce_outer(self):
         """ncclAllReduce(SUM) of the outer-gradient buffer on the engine's stream (asynchronous)."""
         self._ck(self.lib.mtts_allreduce_outer(self.h))

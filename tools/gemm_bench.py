@@ -49,7 +49,7 @@ if os.environ.get("BENCH_CUSTOM"):   # "name,M,N,K;name,M,N,K": extra shapes (e.
 elif os.environ.get("BENCH_SHAPES"):
     shapes = [s for s in shapes if any(k in s[0] for k in os.environ["BENCH_SHAPES"].split(","))]
 for name, M, N, K in shapes:
-    for form in (0, 1, 2):
+    for form in tuple(int(f) for f in os.environ.get('BENCH_FORMS', '0,1,2').split(',')):
         for tile in TILES:
             if form == 2:  # TN: output [M', N'] small, reduction long — use wgrad-like shapes
                 m2, n2, k2 = N, K, M // 8 if M > 8192 else M
