@@ -551,7 +551,8 @@ def gemm_profile(eng, run, sites=False):
         import csv
         with open(dump) as f:
             for r in csv.DictReader(f):
-                recs.append((eng.lib.mtts_profile_kernel_name(int(r["kind"])).decode(), int(r["K"]), float(r["us"]), float(r["gflop"]), int(r.get("site", 0))))
+                recs.append((eng.lib.mtts_profile_kernel_name(int(r["kind"])).decode(), int(r["K"]), float(r["us"]), float(r["gflop"]), int(r.get("site", 0)),
+                             int(r.get("ctx", 0))))
         if os.environ.get("MTTS_BENCH_KEEP_SITES"):   # (tools/gemm_sites.py reads the per-launch records of the roofline leg from here)
             import shutil
             shutil.copy(dump, os.environ["MTTS_BENCH_KEEP_SITES"])
@@ -571,7 +572,7 @@ def launch_classes(recs, kernel, dims):
     hide behind one average."""
     k9 = (dims.k1 * dims.d_model, dims.k1 * dims.d_ff)
     agg = {}
-    for name, K, us, gf, site in recs:
+    for name, K, us, gf, site, _ctx in recs:
         if name != kernel:
             continue
         label = SITE_CLASSES.get(site, "site %d" % site)
@@ -583,6 +584,24 @@ def launch_classes(recs, kernel, dims):
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         tf = a[2] / a[1] * 1e3 if a[1] > 0 else 0.0   # GFLOP / us = 1e15 flop/s = 1000 TFLOP/s
         out[k] = {"launches": a[0], "ms": round(a[1] * 1e-3, 2), "achieved": round(tf, 2), "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4)}
+    return out
+
+
+def stream_split(recs):
+    """The GEMM launches of the meta-step by the stream that carried them.  A launch is timed by HIP events on its OWN stream: what runs on a side
+    stream (the encoder run-ahead of the inner steps, deferred weight gradients) runs UNDER the main stream's launches, so its event time is
+    stretched by the sharing and overlaps theirs — `all_gemm.ms_per_meta_step` is the plain sum over all three streams (it can exceed the
+    step), the main stream's share is the part of it that sits on the step's critical path."""
+    names = {0: "main stream", 1: "weight-gradient side stream", 2: "run-ahead side stream"}
+    agg = {}
+    for _name, _K, us, gf, _site, ctx in recs:
+        a = agg.setdefault(names.get(ctx, "stream %d" % ctx), [0, 0.0, 0.0])
+        a[0] += 1; a[1] += us; a[2] += gf
+    out = {}
+    for k, a in agg.items():
+        tf = a[2] / a[1] * 1e3 if a[1] > 0 else 0.0
+        out[k] = {"launches": a[0], "ms": round(a[1] * 1e-3, 2), "alg_tflop": round(a[2] * 1e-3, 3), "achieved": round(tf, 2),
+                  "frac": round(tf / FP32_MATRIX_PEAK_TFLOPS, 4)}
     return out
 
 
@@ -804,6 +823,7 @@ def main():
         rows, recs = gemm_profile(eng, lambda: eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=(args.order == 2), fetch_losses=False), sites=True)
         roof = roofline_of(rows, "kernels")
         roof["by_site_class"] = launch_classes(recs, roof["kernel"], dims)
+        roof["all_gemm"]["by_stream"] = stream_split(recs)
         if so is not None:
             rows2 = gemm_profile(eng, lambda: eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=True, fetch_losses=False))
             r2 = roofline_of(rows2, "kernels_second_order")

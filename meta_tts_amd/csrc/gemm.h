@@ -1069,6 +1069,7 @@ inline const char* gemm_kind_name(int k) {
 // one record per launch, aggregated per kernel kind.
 struct GemmProfiler {
     struct Rec { int kernel; double flops; hipEvent_t e0, e1; int form = 0, tile = 0, N = 0, K = 0, groups = 0, splitk = 1; double rows = 0, bytes = 0; int tag = 0; };
+    int ctx = 0;   // which of the handle's launch contexts this is: 0 the main stream, 1 the weight-gradient side stream, 2 the run-ahead side stream (CSV column)
     int tag = 0;   // call-site class of the launches being recorded (set by the owner: 0 other, 1 encoder blocks, 2 decoder blocks, 3 PostNet, 4 variance predictors)
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -1084,13 +1085,13 @@ struct GemmProfiler {
     void report(double out[GK_COUNT][4]) {
         for (int k = 0; k < GK_COUNT; ++k) out[k][0] = out[k][1] = out[k][2] = out[k][3] = 0.0;
         FILE* dump = (getenv("MTTS_GEMM_DUMP") && !recs.empty()) ? fopen(getenv("MTTS_GEMM_DUMP"), "a") : nullptr;  // per-launch CSV (tools/gemm_sites.py); appended: a handle reports its three launch contexts one after the other
-        if (dump && ftell(dump) == 0) fprintf(dump, "kind,form,tile,N,K,rows,groups,splitk,us,gflop,site\n");
+        if (dump && ftell(dump) == 0) fprintf(dump, "kind,form,tile,N,K,rows,groups,splitk,us,gflop,site,ctx\n");
         for (auto& r : recs) {
             hipEventSynchronize(r.e1);
             float ms = 0.f;
             hipEventElapsedTime(&ms, r.e0, r.e1);
             out[r.kernel][0] += 1.0; out[r.kernel][1] += ms; out[r.kernel][2] += r.flops; out[r.kernel][3] += r.bytes;
-            if (dump) fprintf(dump, "%d,%d,%d,%d,%d,%.0f,%d,%d,%.2f,%.4f,%d\n", r.kernel, r.form, r.tile, r.N, r.K, r.rows, r.groups, r.splitk, 1e3 * ms, r.flops * 1e-9, r.tag);
+            if (dump) fprintf(dump, "%d,%d,%d,%d,%d,%.0f,%d,%d,%.2f,%.4f,%d,%d\n", r.kernel, r.form, r.tile, r.N, r.K, r.rows, r.groups, r.splitk, 1e3 * ms, r.flops * 1e-9, r.tag, ctx);
         }
         if (dump) fclose(dump);
     }

@@ -411,9 +411,11 @@ int mtts_reset_optimizer(mtts_handle* h) {
 
 int mtts_profile_gemm(mtts_handle* h, int enable) {
     if (!h) return -1;
+    int id = 0;
     for (GemmCtx* cx : {&h->eng.gx, &h->eng.gx_side, &h->eng.gx_side2}) {   // the side streams' launches (deferred parameter gradients) count too
         cx->prof.reset();
         cx->prof.enabled = enable != 0;
+        cx->prof.ctx = id++;
     }
     return 0;
 }
