@@ -796,6 +796,7 @@ def main():
     for _ in range(args.warmup):
         meta_step()
     dt = timed(args.steps, timed_ar=True)
+    inner_upd = eng.inner_update_launches   # launches of the last timed inner step's SGD update (> 0: module by module behind its backward)
     ar_ms = None
     ar_launches = eng.allreduce_launches if (n > 1 and ar_overlapped[0]) else (1 if n > 1 else None)
     if ar_events:
@@ -950,8 +951,8 @@ def main():
                            "tasks_per_gpu": META_BATCH // n, "inner_steps": INNER_STEPS, "order": "first" if args.order == 1 else "second", "parallelism": f"task-dp{n}",
                            "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "dropout": "identity (parity config)" if args.no_dropout else "on (0.2 / 0.5 / 0.5, counter-based masks)",
                            "batch_ingestion": "resident (uploaded once before the timed region)" if args.resident_batches else "inside every timed step (host 12-tuples -> HBM + plans)",
-                           "inner_update": ("module by module behind the backward, %d launches per inner step on a stream of its own" % eng.inner_update_launches)
-                                           if eng.inner_update_launches > 0 else "one launch between the backward and the next forward"},
+                           "inner_update": ("module by module behind the backward, %d launches per inner step on a stream of its own" % inner_upd)
+                                           if inner_upd > 0 else "one launch between the backward and the next forward"},
                 **({"emulated_world": part, "note": "diagnostic: rank-0 share of an emulated multi-rank run, no collective"} if part != n else {}),
                 "batch_ingest_ms_per_step": round(ingest_ms, 3),
                 "rccl_ranks": n if n > 1 else None, "allreduce_impl": ar_impl, "allreduce_ms_per_step": round(ar_ms, 3) if ar_ms is not None else None,
