@@ -1193,6 +1193,24 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             p.sumMp += Mp; p.sumMf += Mf; p.sumMr += Mr;
         }
         p.n_enc_groups = nseq[0]; p.n_dec_groups = nseq[1];
+        // Attention groups longest first.  A (sequence, head) pair is ~L / 32 workgroups of cost ~L each and a grid is dispatched group by group, so in
+        // batch order the last dispatch round of the fused forward (1.1 k workgroups on 512 slots at 8 tasks) and of the backward's grouped GEMMs is
+        // whatever pairs happen to come last; sorted, the long pairs start first and the short ones fill the tail.  Every table entry carries its own
+        // offsets, so the order is free; the sort is stable (the heads of a sequence stay neighbours).  MTTS_ATTN_SORT=0: batch order.
+        static const bool attn_sort = [] { const char* e = getenv("MTTS_ATTN_SORT"); return e ? atoi(e) != 0 : true; }();
+        for (int which = 0; attn_sort && which < 2; ++which) {
+            const int n = nseq[which];
+            if (n < 2) continue;
+            std::vector<int> idx((size_t)n);
+            for (int i = 0; i < n; ++i) idx[(size_t)i] = i;
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return seqs[which][a].L > seqs[which][b].L; });
+            std::vector<AttnSeq> sq(seqs[which], seqs[which] + n);
+            for (int i = 0; i < n; ++i) seqs[which][i] = sq[(size_t)idx[(size_t)i]];
+            for (int k = 0; k < 6; ++k) {
+                std::vector<GemmGroupDesc> tb(tabs[which][k], tabs[which][k] + n);
+                for (int i = 0; i < n; ++i) tabs[which][k][i] = tb[(size_t)idx[(size_t)i]];
+            }
+        }
         // ONE transfer: everything up to the mel area, plus the used part of the mel area
         const size_t bytes = any_mels ? img.mels + (size_t)mel_used * sizeof(float) : img.mels;
         HIP_CHECK(hipMemcpyAsync(p.img_dev, H, bytes, hipMemcpyHostToDevice, stream));

@@ -69,10 +69,12 @@ OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "M
 # MTTS_SO_DEFER_POST=0: second order — the PostNet layers' hv(W) products inside the tangent launches instead of on the side stream (round 5)
 # MTTS_LN_FUSE=1: `LayerNorm(dropout(sublayer) + residual)` as the fc / w_2 GEMM's row-complete epilogue (gemm.h: LnFuse, round 5; opt-in: measured
 # slower) instead of a launch of its own — the same arithmetic in the same order: bit-identical
+# MTTS_ATTN_SORT=0: the attention (sequence, head) groups in batch order instead of longest first (engine.h: build_plan) — independent groups in another
+# dispatch order: bit-identical
 # MTTS_UPD_OVERLAP=0: the inner SGD step as ONE launch between the backward and the next forward instead of module by module on a stream of
 # its own behind the backward (engine.h: upd_ready, round 5) — the same kernel on the same floats: bit-identical
 KERNEL_ARMS = [{"MTTS_FUSED_ATTN": "0"}, {"MTTS_ENC_AHEAD_QUERY": "0"}, {"MTTS_PANEL_ORDER": "0"}, {"MTTS_PRED_EARLY": "0"}, {"MTTS_SO_DEFER_POST": "0"},
-               {"MTTS_LN_FUSE": "1"}, {"MTTS_UPD_OVERLAP": "0"}]
+               {"MTTS_LN_FUSE": "1"}, {"MTTS_UPD_OVERLAP": "0"}, {"MTTS_ATTN_SORT": "0"}]
 
 
 def _compare(tmp_path, gpu):
@@ -105,7 +107,7 @@ def _compare(tmp_path, gpu):
             if k == "upd_launches":
                 # the default ran the inner SGD step module by module (speaker table + variance adaptor, 2 decoder layers, PostNet); the arm, in one pass
                 assert int(a[k]) >= 3 and int(d[k]) == (0 if "MTTS_UPD_OVERLAP" in arm else int(a[k])), (arm, a[k], d[k])
-            elif "MTTS_LN_FUSE" in arm or "MTTS_UPD_OVERLAP" in arm:
+            elif "MTTS_LN_FUSE" in arm or "MTTS_UPD_OVERLAP" in arm or "MTTS_ATTN_SORT" in arm:
                 np.testing.assert_array_equal(a[k], d[k], err_msg=f"{arm} {k}")     # (emulator AND hardware: nothing is summed in another order)
             elif ("MTTS_ENC_AHEAD_QUERY" in arm or "MTTS_PANEL_ORDER" in arm or "MTTS_PRED_EARLY" in arm or "MTTS_SO_DEFER_POST" in arm) and not gpu:
                 np.testing.assert_array_equal(a[k], d[k], err_msg=f"{arm} {k}")     # (pure re-plumbing: bit-identical)
