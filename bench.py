@@ -32,14 +32,16 @@ INNER_STEPS = 5
 INNER_LR = 0.001
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PARITY_RTOL = 2e-3  # per-task query losses of the timed configuration (dropout off) vs the oracle; the line is refused above it
-PARITY_GRAD_RTOL = 1e-2  # sampled per-task query-gradient tensors, max-abs error relative to the tensor's max-abs
-PARITY_GRAD_KINK_L2 = 3e-2  # ... of a task with ReLU / L1 kinks inside fp32 noise (see parity_check below): relative L2 error instead
+# Sampled per-task query-gradient tensors are judged by the float64 arbiter (oracle/arbiter.py): err(engine, fp64) <= 3 * err(oracle32, fp64) + 1e-3
+# per tensor (max-norm relative to the tensor's largest fp64 entry), L1 signs of the elements inside fp32 noise of their target taken from each
+# party's own forward output, single ReLU units inside fp32 noise of zero priced one by one where a tensor still fails.  No L2 escape.
 # Random-init weights of the timed meta-step: every Linear / Conv1d weight matrix x 0.5 (synth.make_params), the initialisation on which five
 # inner SGD steps at the reference's lr 1e-3 are contractive (the support loss falls), as in tests/golden/maml_small_lr1e-3_scaled.npz and
 # tests/test_gpu_timed_config.py.  On unscaled random weights the inner loop is expansive: summation-order differences between any two
 # correct fp32 implementations are amplified to several per cent of the query gradient after 5 steps (measured 3.6-5.5 %), which makes a
 # gradient comparison meaningless.  Timing does not depend on the weight values.
 WEIGHT_SCALE = 0.5
+EXCHANGE_RTOL = 5e-3   # N > 1: all-reduced outer gradient vs the single-handle 8-task gradient (grouped-vs-alone bound of tests/test_gpu_timed_config.py)
 
 
 def noam_lr(step, d_model=256, warm=4000, anneal=(300000, 400000, 500000), rate=0.3):
@@ -71,6 +73,8 @@ def maybe_self_launch(args):
         return None
     import subprocess
     env = dict(os.environ)
+    if getattr(args, "selftest_emu", False):
+        env.setdefault("OMP_NUM_THREADS", "2")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL between the ranks
     return subprocess.call(spawn_command(args.gpus, sys.argv[1:]), env=env)
 
@@ -104,14 +108,15 @@ GRAD_SAMPLES = ("mel_linear.weight", "decoder.layer_stack.5.pos_ffn.w_2.weight",
 DROPOUT_SEED = 1234      # mtts_set_dropout(h, 1, DROPOUT_SEED + rank) for the timed steps AND for the parity run
 
 
-def _oracle_masks(dims, sup, qry, task, seed=DROPOUT_SEED):
+def _oracle_masks(dims, sup, qry, task, seed=DROPOUT_SEED, steps=None):
     """The engine's dropout masks of one task's 5 inner steps + query pass (plan seeds in draw order), generated BEFORE any clock
     starts: the timed oracle then pays one multiply per dropout site, as the reference does."""
     from oracle.dropout_masks import DropoutMasks, plan_seed
     probs = dict(enc=dims.enc_dropout, dec=dims.dec_dropout, vp=dims.vp_dropout, postnet=0.5)
     out = []
-    for k in range(INNER_STEPS + 1):
-        b = sup if k < INNER_STEPS else qry
+    steps = INNER_STEPS if steps is None else steps
+    for k in range(steps + 1):
+        b = sup if k < steps else qry
         out.append(DropoutMasks(plan_seed(seed, k + 1), task, probs).precompute(
             len(b[4]), int(b[5]), [int(x) for x in b[7]], int(b[8]), enc_layers=dims.enc_layers, dec_layers=dims.dec_layers, d_model=dims.d_model,
             vp_filter=dims.vp_filter, postnet_dim=dims.postnet_dim, postnet_layers=dims.postnet_layers, n_mel=dims.n_mel, max_seq_len=dims.max_seq_len))
@@ -239,7 +244,7 @@ def cpu_baseline_concurrent(thread_legs, pin=True, timeout_s=240.0, dropout=True
     return out
 
 
-def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True, dropout=True):
+def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True, dropout=True, make_task=None, inner_steps=None, grad_samples=None):
     """Oracle (oracle/fs2_oracle.py) on the host cores.  Sequential leg: whole first-order tasks of the same workload, one after the
     other at the best swept intra-op thread count, until ~budget_s of CPU time is spent; meta-steps/s = 1 / (8 * mean task time).
     Concurrent leg (cpu_baseline_concurrent): the 8 tasks as 8 processes at once — the harder same-box baseline; `value` is the
@@ -248,10 +253,13 @@ def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True, dropout=True):
     from meta_tts_amd import synth
     from oracle import fs2_oracle as O
     host_cores = os.cpu_count() or torch.get_num_threads()
+    make_task = make_task or synth.make_task
+    inner_steps = inner_steps or INNER_STEPS
+    grad_samples = grad_samples or GRAD_SAMPLES
     params, buffers, names = _oracle_state(dims)
     # intra-op thread sweep on ONE inner step (support forward + backward of task 0): torch's default (= every hardware thread)
     # is not the fastest setting for these GEMM sizes; the whole-task timing below runs at the best count found
-    sup0, qry0 = synth.make_task(0)
+    sup0, qry0 = make_task(0)
     tb0 = O.to_torch_batch(sup0)
     sweep = {}
     for nthr in sorted({t for t in (8, 16, 32, 64, 128) if t <= host_cores}):
@@ -261,37 +269,39 @@ def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True, dropout=True):
         best = None
         for rep in range(2):
             t0 = time.perf_counter()
-            lo = O.fs2_loss(tb0, O.fs2_forward(params, buffers, *tb0[2:], n_head=(dims.enc_heads, dims.dec_heads), training=True))
+            lo = O.fs2_loss(tb0, O.fs2_forward(params, buffers, *tb0[2:], n_head=(dims.enc_heads, dims.dec_heads), max_seq_len=dims.max_seq_len, training=True))
             torch.autograd.grad(lo[0], [params[n] for n in names], allow_unused=True)
             dt1 = time.perf_counter() - t0
             best = dt1 if best is None else min(best, dt1)
         sweep[nthr] = round(best, 3)
     cores = min(sweep, key=sweep.get)
     torch.set_num_threads(cores)
-    times, q_ref, g_ref, kinks = [], [], [], []
+    times, q_ref, g_ref, kinks, mels_ref = [], [], [], [], []
     t_all = time.perf_counter()
     j = 0
     while j < META_BATCH and (time.perf_counter() - t_all) < budget_s:
-        sup, qry = synth.make_task(j)
+        sup, qry = make_task(j)
         klog = []
-        masks = _oracle_masks(dims, sup, qry, j) if dropout else None   # (untimed: the engine's counter-based masks, so that the oracle runs the TIMED configuration)
+        masks = _oracle_masks(dims, sup, qry, j, steps=inner_steps) if dropout else None   # (untimed: the engine's counter-based masks, so that the oracle runs the TIMED configuration)
         t0 = time.perf_counter()
-        ql, _, _, _ = O.maml_task(params, buffers, O.to_torch_batch(sup), O.to_torch_batch(qry), steps=INNER_STEPS, lr=INNER_LR,
-                                  second_order=False, modules=mods, n_head=(dims.enc_heads, dims.dec_heads), dropout=masks, kink_log=klog)
+        ql, _, _, qpreds = O.maml_task(params, buffers, O.to_torch_batch(sup), O.to_torch_batch(qry), steps=inner_steps, lr=INNER_LR,
+                                       second_order=False, modules=mods, n_head=(dims.enc_heads, dims.dec_heads), max_seq_len=dims.max_seq_len, dropout=masks,
+                                       kink_log=klog)
         del masks
         gr = torch.autograd.grad(ql[0], [params[n] for n in names], allow_unused=True)
         times.append(time.perf_counter() - t0)
+        mels_ref.append((qpreds[0].detach().numpy().copy(), qpreds[1].detach().numpy().copy()))   # the fp64 arbiter reads this party's L1 signs off its own output
         q_ref.append([float(x) for x in ql])
         relu_log = [e for e in klog if e[0] != "l1"]
         l1_log = [e for e in klog if e[0] == "l1"]
         kinks.append({"relu_units_below_1e-6": int(sum(c for _, c in relu_log)), "min_abs_preactivation": float(min(m for m, _ in relu_log)),
                       "l1_elements_within_1e-4_of_target": int(sum(a + b for _, a, b in l1_log))})
         by_name = dict(zip(names, gr))
-        g_ref.append({n: (by_name[n].detach().numpy().copy() if by_name[n] is not None else None) for n in GRAD_SAMPLES})
+        g_ref.append({n: (by_name[n].detach().numpy().copy() if by_name[n] is not None else None) for n in grad_samples})
         j += 1
     mean_t = float(np.mean(times))
     seq = {"value": 1.0 / (META_BATCH * mean_t), "unit": "meta-steps/s", "cores": int(cores),
-           "sample": f"{len(times)} of {META_BATCH} tasks (5 inner steps + query fwd/bwd each, first-order, dropout {'on' if dropout else 'off'}, fp32 torch-CPU oracle) one after the other at the "
+           "sample": f"{len(times)} of {META_BATCH} tasks ({inner_steps} inner steps + query fwd/bwd each, first-order, dropout {'on' if dropout else 'off'}, fp32 torch-CPU oracle) one after the other at the "
                      f"best of the swept intra-op thread counts ({cores}); {mean_t:.2f} s/task, clip+Adam excluded (<1%)"}
     conc, conc_err, sweep_c = None, None, {}
     if concurrent:
@@ -325,7 +335,7 @@ def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True, dropout=True):
     best_leg = "concurrent" if (conc is not None and conc["value"] > seq["value"]) else "sequential"
     top = conc if best_leg == "concurrent" else seq
     return {"value": top["value"], "unit": "meta-steps/s", "cores": int(top["cores"]), "kind": "port", "sample": top["sample"], "leg": best_leg,
-            "query_losses": q_ref, "grad_samples": g_ref, "query_pass_kinks": kinks,
+            "query_losses": q_ref, "grad_samples": g_ref, "query_mels": mels_ref, "query_pass_kinks": kinks,
             "host_cores": int(host_cores), "thread_sweep_s_per_inner_step": {str(k): v for k, v in sweep.items()},
             "sequential": seq, "concurrent": conc if conc is not None else {"error": conc_err},
             "note": "value = the FASTER of the two CPU legs (speedup_vs_cpu_baseline is quoted against it); north-star target >= 10x"}
@@ -537,7 +547,10 @@ def gemm_profile(eng, run, sites=False):
         os.environ["MTTS_GEMM_DUMP"] = dump
     eng.profile_gemm(True)
     run()
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    else:
+        eng.synchronize()          # (--selftest-emu: the SIMT emulator on CPU)
     rep = eng.profile_report()   # {kernel name as rocprofv3 prints it: [launches, ms, flops, bytes]}
     eng.profile_gemm(False)
     rows = [(name, r[0], r[1], r[2], r[3]) for name, r in rep.items()]
@@ -637,6 +650,33 @@ def roofline_of(rows, pmc_key=None):
                                                "alg_gbytes": round(r[4] / 1e9, 3)} for r in rows}}}
 
 
+def replica_digest(eng, dims):
+    """CRC32 of everything a replica carries from one meta-step to the next: parameters, Adam m / v, PostNet BatchNorm running buffers."""
+    import zlib
+    crc = {"theta": 0, "adam_m": 0, "adam_v": 0, "bn_buffers": 0}
+    for name in eng.params:
+        for key, which in (("theta", 0), ("adam_m", 4), ("adam_v", 5)):
+            crc[key] = zlib.crc32(np.ascontiguousarray(eng.export(name, which)).tobytes(), crc[key])
+    for i in range(dims.postnet_layers):
+        for a in eng.get_bn_buffers(i)[:2]:
+            crc["bn_buffers"] = zlib.crc32(np.ascontiguousarray(a).tobytes(), crc["bn_buffers"])
+    return crc
+
+
+def _tiny_dims():
+    """--selftest-emu: a small architecture (same code paths, tiny GEMMs) — the model of the CPU test-suite's emulator tests."""
+    from meta_tts_amd.config import ModelDims, default_model_config, default_preprocess_config
+    mc = default_model_config()
+    mc["transformer"].update(dict(encoder_layer=1, decoder_layer=2, encoder_hidden=32, decoder_hidden=32, conv_filter_size=64, encoder_head=2, decoder_head=2))
+    mc["variance_predictor"].update(dict(filter_size=32))
+    mc["variance_embedding"]["n_bins"] = 16
+    mc["max_seq_len"] = 64
+    mc["_postnet_dim"] = 48
+    pc = default_preprocess_config()
+    pc["preprocessing"]["mel"]["n_mel_channels"] = 32
+    return ModelDims(mc, pc, n_speaker=12, vocab=40)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -660,6 +700,7 @@ def main():
                     help="diagnostic: run ONE process with the task share of rank 0 of this many ranks (no collective) to see the per-rank "
                          "step time of an N-GPU run on a 1-GPU box; the JSON line is marked emulated and is not a bench result")
     ap.add_argument("--selftest-spawn", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--selftest-emu", action="store_true", help=argparse.SUPPRESS)   # tests/test_bench_spawn.py: this file's N-rank flow on CPU (gloo + SIMT emulator, tiny model)
     args = ap.parse_args()
 
     rc = maybe_self_launch(args)
@@ -682,30 +723,56 @@ def main():
         raise SystemExit(f"bench.py: {world} rank(s) running but --gpus {args.gpus} requested")
     n = world
     assert META_BATCH % n == 0, "the 8-task meta-batch must split evenly over the ranks"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    if torch.cuda.device_count() < n:
-        raise SystemExit(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPU(s) visible")
-    torch.cuda.set_device(local_rank)
-    if n > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=n)
-        assert dist.get_world_size() == n
-    if rank == 0:
-        ge.build_device()
-    if n > 1:
-        dist.barrier()
+    emu = bool(args.selftest_emu)       # CPU self-test of THIS flow (not a bench result): gloo ranks, the kernels behind the SIMT emulator, a tiny model
+    import datetime
+    if emu:
+        lib_path, dev = ge.build_emulator(), "cpu"
+        if n > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=n)
+    else:
+        lib_path, dev = None, f"cuda:{local_rank}"
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        if torch.cuda.device_count() < n:
+            raise SystemExit(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPU(s) visible")
+        torch.cuda.set_device(local_rank)
+        if n > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            # (rank 0 runs its roofline / CPU-baseline / parity legs while the other ranks wait in a barrier: minutes, not the default 10 of the watchdog)
+            dist.init_process_group("nccl", rank=rank, world_size=n, timeout=datetime.timedelta(minutes=40))
+            assert dist.get_world_size() == n
+        if rank == 0:
+            ge.build_device()
+        if n > 1:
+            dist.barrier()
 
-    dims = ModelDims()
+    def dev_sync():
+        if emu:
+            eng.synchronize()
+        else:
+            torch.cuda.synchronize()
+
     alg = default_algorithm_config()
     trn = default_train_config()["optimizer"]
     mods = alg["adapt"]["modules"]
     part = args.emulate_world if (args.emulate_world and n == 1) else n
     local = list(range(rank * META_BATCH // part, (rank + 1) * META_BATCH // part))
-    tasks = [synth.make_task(j) for j in local]
+    if emu:
+        dims = _tiny_dims()
+        small = dict(n_mel=dims.n_mel, vocab=dims.vocab, s_range=(5, 13), d_range=(1, 6), first_len=12)
+        make_task = lambda j: (synth.make_batch(100 + 2 * j, 3, speaker=2 + j, **small), synth.make_batch(101 + 2 * j, 2, speaker=2 + j, **small))  # noqa: E731
+        max_B, max_S, inner_steps = 3, 16, 2
+        grad_samples = ("mel_linear.weight", "decoder.layer_stack.1.pos_ffn.w_2.weight", "encoder.layer_stack.0.pos_ffn.w_1.weight",
+                        "variance_adaptor.pitch_embedding.weight", "speaker_emb.model.weight")
+    else:
+        dims = ModelDims()
+        make_task, max_B, max_S, inner_steps, grad_samples = synth.make_task, 5, 80, INNER_STEPS, GRAD_SAMPLES
+    tasks = [make_task(j) for j in local]
     max_T = max(max(s[8], q[8]) for s, q in tasks)
-    eng = Engine(dims, adapt_modules=mods, max_tasks=len(local), max_B=5, max_S=80, max_T=max_T, device=local_rank)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng = Engine(dims, adapt_modules=mods, max_tasks=len(local), max_B=max_B, max_S=max_S, max_T=max_T, device=local_rank if not emu else 0, lib_path=lib_path)
+    if not emu:
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.load_params(synth.make_params(dims, 0, weight_scale=WEIGHT_SCALE))
     eng.set_dropout(not args.no_dropout, DROPOUT_SEED + rank)  # train-mode dropout as in the reference's inner/outer loop (per-rank stream)
     sup_b, qry_b = [t[0] for t in tasks], [t[1] for t in tasks]
@@ -725,10 +792,12 @@ def main():
         # and ncclCommInitRank entered, (4) its outcome is MIN-reduced again
         why = ""
         try:
+            if emu:
+                raise RuntimeError("emulator build: the library's communicator is a loop-back, gloo carries the exchange")
             uid = eng.comm_unique_id()
         except Exception as ex:  # noqa: BLE001
             uid, why = None, str(ex)
-        flag = torch.tensor([1 if uid is not None else 0], device=f"cuda:{local_rank}")
+        flag = torch.tensor([1 if uid is not None else 0], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
         if ok:
@@ -738,11 +807,16 @@ def main():
                 eng.comm_init(ids[0], rank, n)
             except Exception as ex:  # noqa: BLE001
                 ok, why = False, str(ex)
-            flag = torch.tensor([1 if ok else 0], device=f"cuda:{local_rank}")
+            flag = torch.tensor([1 if ok else 0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = bool(flag.item())
         if ok:
             ar_impl = "libmtts: ncclAllReduce via dlopen(librccl.so) on the engine stream"
+        elif emu:
+            import ctypes
+            buf = (ctypes.c_float * eng.sync_floats).from_address(eng.outer_grad_ptr())      # emulator: the "device" buffer is host memory
+            outer = torch.from_numpy(np.ctypeslib.as_array(buf))
+            ar_impl = "torch.distributed (gloo) all_reduce on the emulator's host buffer — CPU self-test"
         else:
             outer = torch.as_tensor(eng.outer_grad_view(), device=f"cuda:{local_rank}")
             ar_impl = f"torch.distributed all_reduce (library communicator unavailable on some rank: {why or 'see other ranks'})"
@@ -751,16 +825,32 @@ def main():
     ar_events = []
     ar_overlapped = [False]
 
-    def meta_step(order=None, timed_ar=False):
-        if not args.resident_batches:
-            ingest()  # host 12-tuples -> HBM + row-space plans, every step (what PL's batch transfer + collate hand-off cost)
-        if n > 1 and outer is None and not args.no_ar_overlap:
+    class _Clock:
+        """Elapsed ms between two points of the stream the exchange is enqueued on (HIP events; wall clock on the emulator)."""
+        def __init__(self):
+            self.a = self.b = None
+        def start(self):
+            if emu:
+                self.a = time.perf_counter()
+            else:
+                self.a = torch.cuda.Event(enable_timing=True); self.a.record()
+        def stop(self):
+            if emu:
+                self.b = time.perf_counter()
+            else:
+                self.b = torch.cuda.Event(enable_timing=True); self.b.record()
+        def ms(self):
+            return 1e3 * (self.b - self.a) if emu else self.a.elapsed_time(self.b)
+
+    def grad_and_exchange(order=None, timed_ar=False, overlap=True):
+        """The gradient call of this rank's tasks + the exchange step (nothing for one rank)."""
+        if n > 1 and outer is None and overlap and not args.no_ar_overlap:
             ar_overlapped[0] = eng.arm_allreduce_overlap()   # the buckets leave on the comm stream as the backward completes them
-        eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=((order or args.order) == 2), fetch_losses=False)
+        eng.meta_grad(inner_steps, INNER_LR, 1.0 / META_BATCH, second_order=((order or args.order) == 2), fetch_losses=False)
         if n > 1:
-            if timed_ar:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+            ck = _Clock() if timed_ar else None
+            if ck:
+                ck.start()
             if outer is None:
                 eng.allreduce_outer()          # overlapped: joins the bucket collectives already in flight (what is timed here is the EXPOSED part);
                                                # otherwise gradient + exchange tail (loss scalars, BatchNorm buffers) in one ncclAllReduce
@@ -768,27 +858,32 @@ def main():
                 eng.sync_pack(eng.bn_pack_weight(rank, n))
                 dist.all_reduce(outer, op=dist.ReduceOp.SUM)
                 eng.sync_unpack()
-            if timed_ar:
-                e1.record()
-                ar_events.append((e0, e1))
+            if ck:
+                ck.stop()
+                ar_events.append(ck)
+
+    def meta_step(order=None, timed_ar=False):
+        if not args.resident_batches:
+            ingest()  # host 12-tuples -> HBM + row-space plans, every step (what PL's batch transfer + collate hand-off cost)
+        grad_and_exchange(order, timed_ar)
         eng.outer_update(lr=noam_lr(step_no[0], dims.d_model, trn["warm_up_step"], trn["anneal_steps"], trn["anneal_rate"]),
                          betas=tuple(trn["betas"]), eps=trn["eps"], weight_decay=trn["weight_decay"],
                          max_norm=trn["grad_clip_thresh"])
         step_no[0] += 1
 
     def timed(k, order=None, timed_ar=False):
-        torch.cuda.synchronize()
+        dev_sync()
         if n > 1:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(k):
             meta_step(order, timed_ar)
-        torch.cuda.synchronize()
+        dev_sync()
         if n > 1:
             dist.barrier()
         d = time.perf_counter() - t0
         if n > 1:
-            tt = torch.tensor([d], device=f"cuda:{local_rank}", dtype=torch.float64)
+            tt = torch.tensor([d], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             d = float(tt.item())
         return d
@@ -800,13 +895,14 @@ def main():
     ar_ms = None
     ar_launches = eng.allreduce_launches if (n > 1 and ar_overlapped[0]) else (1 if n > 1 else None)
     if ar_events:
-        ar_ms = float(np.mean([a.elapsed_time(b) for a, b in ar_events]))  # events on the stream RCCL was enqueued on (torch's current stream)
+        dev_sync()
+        ar_ms = float(np.mean([c.ms() for c in ar_events]))  # events on the stream RCCL was enqueued on (torch's current stream)
     # cost of the per-step ingestion alone (host -> HBM + plans), for the record
-    torch.cuda.synchronize()
+    dev_sync()
     t_in = time.perf_counter()
     for _ in range(3):
         ingest()
-    torch.cuda.synchronize()
+    dev_sync()
     ingest_ms = 1e3 * (time.perf_counter() - t_in) / 3
     so = None
     if args.order == 1 and not args.no_second_order:
@@ -816,30 +912,80 @@ def main():
         dso = timed(so_steps, 2)
         so = {"value": round(so_steps / dso, 4), "unit": "meta-steps/s", "ms_per_step": round(1e3 * dso / so_steps, 2), "steps": so_steps,
               "workload": "same 8-task meta-step, second-order MAML (Hessian-vector recursion through the 5 inner steps)"}
+    # ---- N > 1: the run verifies itself ---------------------------------------------------------------------------------
+    replicas, exchange = None, None
+    if n > 1:
+        # (1) every rank ends the timed steps with bit-identical weights, Adam moments and BatchNorm buffers: CRC32 of each, all-gathered
+        dig = replica_digest(eng, dims)
+        allg = [None] * n
+        dist.all_gather_object(allg, dig)
+        same = all(d == allg[0] for d in allg)
+        replicas = {"bit_identical": bool(same), "crc32": {k: "%08x" % v for k, v in allg[0].items()}, "ranks_compared": n,
+                    "what": "CRC32 over every parameter tensor, Adam m, Adam v and the PostNet BatchNorm running buffers after the timed steps, one digest per rank"}
+        if not same:
+            raise SystemExit(f"bench.py: replicas diverged after the timed steps: {allg}")
+        # (2) the all-reduced outer gradient equals the one a single handle computes for the whole 8-task meta-batch.  Dropout off for this step only
+        # (a rank's masks are keyed by its own seed and the task's position in ITS launch group, a lone handle's by position 0..7), initial weights
+        init = synth.make_params(dims, 0, weight_scale=WEIGHT_SCALE)
+        eng.load_params(init)
+        eng.set_dropout(False, 0)
+        ingest()
+        grad_and_exchange(1)
+        dev_sync()
+        reduced = {name: eng.export(name, 1).astype(np.float64) for name in grad_samples}
+        synced = np.asarray(eng.synced_losses(), np.float64)
+        if rank == 0:
+            all_tasks = [make_task(j) for j in range(META_BATCH)]
+            e8 = Engine(dims, adapt_modules=mods, max_tasks=META_BATCH, max_B=max_B, max_S=max_S, max_T=max(max(s_[8], q_[8]) for s_, q_ in all_tasks),
+                        device=local_rank if not emu else 0, lib_path=lib_path)
+            e8.load_params(init)
+            e8.set_batches(0, [t[0] for t in all_tasks])
+            e8.set_batches(1, [t[1] for t in all_tasks], spk_from=[t[0] for t in all_tasks], average_spk=True)
+            q8, _ = e8.meta_grad(inner_steps, INNER_LR, 1.0 / META_BATCH, fetch_losses=True)
+            errs = {}
+            for name in grad_samples:
+                ref8 = e8.export(name, 1).astype(np.float64)
+                errs[name] = float(np.abs(reduced[name] - ref8).max() / max(float(np.abs(ref8).max()), 1e-30))
+            e8.close()
+            loss_err = float(np.abs(synced - np.asarray(q8, np.float64).mean(axis=0)).max() / max(float(np.abs(np.asarray(q8)).max()), 1e-30))
+            exchange = {"max_rel": max(errs.values()), "per_tensor": errs, "rtol": EXCHANGE_RTOL, "synced_losses_rel": loss_err,
+                        "what": "sampled tensors of the ALL-REDUCED outer gradient of the N-rank run against the outer gradient one handle computes for the whole "
+                                "8-task meta-batch (grouped launches) from the same weights, dropout off for this step; max |a - b| / max |b|.  Bound: the grouped-vs-alone "
+                                "difference of tests/test_gpu_timed_config.py (other split-K factors / K-groups, amplified by five SGD steps), not bit equality",
+                        "ok": bool(max(errs.values()) <= EXCHANGE_RTOL and loss_err <= 1e-4)}
+        ok_t = torch.tensor([1 if (exchange is None or exchange["ok"]) else 0], device=dev)
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        if not bool(ok_t.item()):
+            raise SystemExit(f"bench.py: the all-reduced outer gradient disagrees with the single-handle 8-task gradient: {exchange}")
+        eng.load_params(init)
+        eng.set_dropout(not args.no_dropout, DROPOUT_SEED + rank)
+        ingest()
     q_losses = None
     roof = None
     if rank == 0:
-        q_losses, _ = eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, fetch_losses=True)
-    if rank == 0 and n == 1 and not args.no_roofline:
-        rows, recs = gemm_profile(eng, lambda: eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=(args.order == 2), fetch_losses=False), sites=True)
-        roof = roofline_of(rows, "kernels")
+        q_losses, _ = eng.meta_grad(inner_steps, INNER_LR, 1.0 / META_BATCH, fetch_losses=True)
+    if rank == 0 and not args.no_roofline:
+        # (N > 1: rank 0's own launches — its share of the tasks; no collective is armed here, the other ranks wait in the closing barrier)
+        rows, recs = gemm_profile(eng, lambda: eng.meta_grad(inner_steps, INNER_LR, 1.0 / META_BATCH, second_order=(args.order == 2), fetch_losses=False), sites=True)
+        roof = roofline_of(rows, "kernels" if len(local) == META_BATCH else None)     # (the committed PMC traffic figures are per launch of the 8-task step)
         roof["by_site_class"] = launch_classes(recs, roof["kernel"], dims)
         roof["all_gemm"]["by_stream"] = stream_split(recs)
+        roof["tasks_in_the_launches"] = len(local)
         if so is not None:
-            rows2 = gemm_profile(eng, lambda: eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, second_order=True, fetch_losses=False))
-            r2 = roofline_of(rows2, "kernels_second_order")
+            rows2 = gemm_profile(eng, lambda: eng.meta_grad(inner_steps, INNER_LR, 1.0 / META_BATCH, second_order=True, fetch_losses=False))
+            r2 = roofline_of(rows2, "kernels_second_order" if len(local) == META_BATCH else None)
             so["roofline"] = {k: r2[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launches", "avg_launch_us", "alg_gflop_per_launch",
                                                  "alg_bytes_per_launch", "traffic", "traffic_source", "traffic_over_alg_bytes", "mfma_pipe_busy_frac_pmc")}
             so["roofline"]["all_gemm"] = {k: r2["all_gemm"][k] for k in ("ms_per_meta_step", "alg_tflop_per_meta_step", "achieved", "frac")}
-            so["whole_step_tflops"] = round(r2["all_gemm"]["alg_tflop_per_meta_step"] / (so["ms_per_step"] * 1e-3), 2)
+            so["whole_step_tflops"] = round(r2["all_gemm"]["alg_tflop_per_meta_step"] * (META_BATCH // len(local)) / (so["ms_per_step"] * 1e-3), 2)
             # SURVEY.md section 8(d) prices a second-order meta-step at 35.5 TFLOP (reverse sweep = 2 x (fwd + bwd) per inner step); the
             # forward-over-reverse HVP executes more (every tangent GEMM is a pair): quote the whole step against the SURVEY figure too
             so["survey_tflop_per_meta_step"] = 35.5
             so["whole_step_tflops_survey_convention"] = round(35.5 / (so["ms_per_step"] * 1e-3), 2)
-            so["whole_step_frac_survey_convention"] = round(35.5 / (so["ms_per_step"] * 1e-3) / FP32_MATRIX_PEAK_TFLOPS, 4)
+            so["whole_step_frac_survey_convention"] = round(35.5 / (so["ms_per_step"] * 1e-3) / (FP32_MATRIX_PEAK_TFLOPS * n), 4)
             so["roofline"]["note"] = "achieved = EXECUTED contraction flops of the launches (tangent pairs included) / launch time"
     hbm = None
-    if rank == 0 and n == 1 and not args.no_roofline:
+    if rank == 0 and n == 1 and not emu and not args.no_roofline:
         # the HBM-bound tail of the step, reported as achieved GB/s against the 8 TB/s HBM3E peak: fused clip + Adam
         # (grad-norm reduction + update: 32 B per parameter) timed on its own with events on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -858,9 +1004,11 @@ def main():
     cpu_error = None
     if os.environ.get("MTTS_ABLATE_LN", "0") not in ("", "0") and not args.no_cpu_baseline:
         raise SystemExit("bench.py: MTTS_ABLATE_LN is a timing-only ablation (wrong results): run it with --no-cpu-baseline (no parity gate, no headline line)")
-    if rank == 0 and n == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
+        # (N > 1: still rank 0, on the box's host cores, while the other ranks wait in the closing barrier)
         try:
-            cpu = cpu_baseline(dims, mods, concurrent=not args.no_cpu_concurrent, dropout=not args.no_dropout)
+            cpu = cpu_baseline(dims, mods, concurrent=(not args.no_cpu_concurrent) and not emu, dropout=not args.no_dropout, make_task=make_task,
+                               inner_steps=inner_steps, grad_samples=grad_samples, budget_s=25.0 if not emu else 120.0)
         except Exception as ex:  # noqa: BLE001
             cpu_error = f"{type(ex).__name__}: {ex}"
     # parity of the TIMED configuration (this rank's grouped tasks, the kernels and launch paths the clock just ran) against the
@@ -873,48 +1021,54 @@ def main():
         eng.load_params(synth.make_params(dims, 0, weight_scale=WEIGHT_SCALE))
         eng.set_dropout(not args.no_dropout, DROPOUT_SEED)
         ingest()
-        q_parity, _ = eng.meta_grad(INNER_STEPS, INNER_LR, 1.0 / META_BATCH, fetch_losses=True)
+        q_parity, _ = eng.meta_grad(inner_steps, INNER_LR, 1.0 / META_BATCH, fetch_losses=True)
         # oracle row j = task j = local[j] on rank 0; an emulated rank holds fewer tasks than the oracle may have run (and the oracle's
         # budget may have stopped short of this rank's share): compare the common prefix
         m = min(len(cpu["query_losses"]), len(local))
         ref = np.asarray(cpu["query_losses"], np.float64)[:m]
         got = np.asarray(q_parity, np.float64)[:m]
         rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-6)
-        # ... and sampled tensors of the per-task query gradient (what the outer gradient is the mean of) against the oracle's autograd,
-        # at the bench's own weights: |got - ref|_max / |ref|_max per tensor
-        # A tensor passes when max |got - ref| <= PARITY_GRAD_RTOL * max |ref|.  Kinks: the loss is piecewise smooth (ReLU in every FFN / predictor,
-        # |x| in the two mel terms); where the oracle's query pass of a task has a ReLU pre-activation within 1e-6 of zero, or a mel / mel_post
-        # element within 1e-4 of its target (oracle/fs2_oracle.py KINK_LOG), two correct fp32 implementations may sit on different sides, and their
-        # gradients then differ by that unit's WHOLE contribution although every forward value agrees to 1e-5: a flipped ReLU moves a few rows of a
-        # few tensors by per cents (measured: task 3, energy predictor conv1, pre-activation 3.7e-8 -> 3 rows of pitch_embedding off by 2.7 % of the
-        # tensor's largest entry), ONE flipped L1 sign moves every tensor upstream of it by ~2 / sqrt(valid frames x n_mel) = 0.5 % of its norm
-        # (measured: task 3, 1 of 167 360 mel_post signs -> all PostNet tensors 0.7-2.2 %; tools/dropout_grad_probe.py, profiles/r05_dropout_parity.md).
-        # For such a task a tensor may instead pass on its relative L2 error <= PARITY_GRAD_KINK_L2, and the line says which did.
-        g_rel, g_worst, g_l2, kink_passes = 0.0, None, 0.0, []
+        # ... and sampled tensors of the per-task query gradient (what the outer gradient is the mean of).  The loss is piecewise smooth (ReLU in
+        # every FFN / predictor, |x| in the two mel terms): where a unit sits inside fp32 noise of its kink two correct fp32 implementations decide
+        # differently and their gradients differ by that unit's WHOLE contribution (profiles/r05_dropout_parity.md), so engine-vs-oracle32 alone cannot
+        # tell a flip from a bug.  The arbiter (oracle/arbiter.py) evaluates every task in float64 with the same masks and gates
+        # err(engine, fp64) <= 3 * err(oracle32, fp64) + 1e-3 per tensor, after taking the L1 signs of the ambiguous elements from each party's OWN
+        # mel / mel_post output (exact) and, for a tensor that still fails, switching identified single ReLU units (|pre-activation| < 1e-6 in fp64)
+        # whose exactly priced contribution shrinks the residual.  Both errors are reported per task.
+        from oracle import arbiter as ARB
+        jobs = []
         for jt in range(m):
-            kinky = cpu["query_pass_kinks"][jt]["relu_units_below_1e-6"] > 0 or cpu["query_pass_kinks"][jt]["l1_elements_within_1e-4_of_target"] > 0
-            for name, gref in cpu["grad_samples"][jt].items():
-                if gref is None:
-                    continue
-                gg = eng.export(name, 2, jt).astype(np.float64) * META_BATCH    # backward ran with grad_scale = 1 / META_BATCH
-                r = float(np.abs(gg - gref).max() / max(float(np.abs(gref).max()), 1e-30))
-                l2 = float(np.sqrt(((gg - gref) ** 2).sum()) / max(float(np.sqrt((gref.astype(np.float64) ** 2).sum())), 1e-30))
-                g_l2 = max(g_l2, l2)
-                if r > PARITY_GRAD_RTOL and kinky and l2 <= PARITY_GRAD_KINK_L2:
-                    kink_passes.append({"task": jt, "tensor": name, "max_rel": r, "rel_l2": l2, **cpu["query_pass_kinks"][jt]})
-                    continue
-                if r > g_rel:
-                    g_rel, g_worst = r, f"task {jt}: {name}"
+            eo = eng.outputs(1, jt)
+            e_grads = {name: eng.export(name, 2, jt).astype(np.float64) * META_BATCH for name in grad_samples}   # backward ran with grad_scale = 1 / META_BATCH
+            o_grads = {name: (g if g is not None else np.zeros_like(e_grads[name])) for name, g in cpu["grad_samples"][jt].items()}
+            jobs.append(dict(task=local[jt], group_index=jt, threads=16, dropout_seed=None if args.no_dropout else DROPOUT_SEED, steps=inner_steps, lr=INNER_LR,
+                             weight_scale=WEIGHT_SCALE, modules=list(mods), names=list(grad_samples),
+                             parties={"engine": {"grads": e_grads, "mel": eo["mel"], "mel_post": eo["mel_post"]},
+                                      "oracle32": {"grads": o_grads, "mel": cpu["query_mels"][jt][0], "mel_post": cpu["query_mels"][jt][1]}}))
+            if emu:   # the tiny model of the self-test is not what the worker rebuilds from seeds: hand it over
+                jobs[-1].update(model=(dims.model_config, dims.preprocess_config, dims.n_speaker, dims.vocab), sup=make_task(local[jt])[0], qry=make_task(local[jt])[1])
+        t_arb = time.perf_counter()
+        reports = [ARB.synth_task_worker(jb) for jb in jobs] if emu else ARB.run_pool(jobs, processes=min(len(jobs), max(1, (os.cpu_count() or 8) // 16)))
+        arb_s = time.perf_counter() - t_arb
+        digests = [dict(task=r["task"], **ARB.summarize(r)) for r in reports]
+        def worst(key):
+            c = [(d[key]["err"], f"task {d['task']}: {d[key]['tensor']}") for d in digests if key in d]
+            return max(c) if c else (None, None)
+        g_rel, g_worst = worst("engine_l1_max")
+        o_rel, o_worst = worst("oracle32_l1_max")
+        arb_ok = all(d["pass"] for d in digests)
         parity = {"tasks_checked": int(m), "tasks_grouped_in_the_launches": len(local), "max_rel": float(rel.max()), "rtol": PARITY_RTOL,
                   "what": "per-task query (total, mel, postnet mel, pitch, energy, duration) losses after 5 inner steps, " + ("dropout off" if args.no_dropout else
                           "dropout on (the timed configuration and seed; the oracle applies the engine's counter-based masks, oracle/dropout_masks.py)") + ", vs oracle/fs2_oracle.py",
-                  "grad_max_rel": g_rel, "grad_rtol": PARITY_GRAD_RTOL, "grad_worst": g_worst, "grad_tensors": list(GRAD_SAMPLES), "grad_max_rel_l2": g_l2,
-                  "grad_what": "max |got - ref| / max |ref| over the sampled per-task query-gradient tensors (first-order outer gradient before the mean), same run",
-                  "kink_tensors": kink_passes, "kink_l2_bound": PARITY_GRAD_KINK_L2,
-                  "kink_rule": "a tensor of a task whose oracle query pass had a ReLU pre-activation below 1e-6 in magnitude or a mel / mel_post element within 1e-4 of "
-                               "its target may pass on relative L2 error instead of the max norm: the gradient is discontinuous there (one flipped L1 sign = 0.5 % "
-                               "of every upstream tensor's norm)"}
-        if not (rel.max() <= PARITY_RTOL) or not (g_rel <= PARITY_GRAD_RTOL):
+                  "grad_tensors": list(grad_samples),
+                  "grad_gate": reports[0]["gate"], "grad_pass": bool(arb_ok),
+                  "grad_err_engine_vs_fp64": g_rel, "grad_err_engine_worst": g_worst, "grad_err_oracle32_vs_fp64": o_rel, "grad_err_oracle32_worst": o_worst,
+                  "grad_err_engine_vs_fp64_raw": worst("engine_raw_max")[0], "grad_err_oracle32_vs_fp64_raw": worst("oracle32_raw_max")[0],
+                  "grad_what": "sampled per-task query-gradient tensors (first-order outer gradient before the mean) of the engine AND of the fp32 oracle against a float64 "
+                               "evaluation of the same task with the same masks; max |g - g64| / max |g64| per tensor; `raw` = plain, the gated figure has the L1 signs of "
+                               "elements within 1e-4 of their target taken from the party's own mel / mel_post output",
+                  "arbiter_s": round(arb_s, 1), "per_task": digests}
+        if not (rel.max() <= PARITY_RTOL) or not arb_ok:
             raise SystemExit(f"bench.py: parity check of the timed configuration failed: {parity}")
     eng.close()
     # auxiliary legs (other BASELINE configs, components beside the hot path): a failure there is reported in the line, it must not
@@ -928,14 +1082,14 @@ def main():
             aux_errors[name] = f"{type(ex).__name__}: {ex}"
             return None
     infer = None
-    if rank == 0 and n == 1 and not args.no_inference:
+    if rank == 0 and n == 1 and not emu and not args.no_inference:
         infer = guarded("inference_c5", inference_leg, dims, mods, local_rank)
-    mel_l1 = guarded("mel_l1_vs_reference", mel_l1_leg, dims, local_rank) if (rank == 0 and n == 1) else None
+    mel_l1 = guarded("mel_l1_vs_reference", mel_l1_leg, dims, local_rank) if (rank == 0 and n == 1 and not emu) else None
     c2 = None
-    if rank == 0 and n == 1 and not args.no_baseline_c2:
+    if rank == 0 and n == 1 and not emu and not args.no_baseline_c2:
         c2 = guarded("baseline_c2", baseline_c2_leg, dims, local_rank, noam_lr, trn)
     front = None
-    if rank == 0 and n == 1 and not args.no_frontend and part == n:
+    if rank == 0 and n == 1 and not emu and not args.no_frontend and part == n:
         front = guarded("frontend", frontend_leg, local_rank)
     if n > 1:
         dist.barrier()
@@ -948,7 +1102,7 @@ def main():
                 "config": {"workload": ("C3: Meta-TTS MAML first-order" if args.order == 1 else "C4-style: Meta-TTS MAML second-order") + " (algorithm=meta_emb_vad, inner=5, meta-batch=8 tasks x (5 support + 5 query utts)), "
                                        "FastSpeech2 base.yaml, outer mean + clip(1.0) + Adam/Noam", "meta_batch": META_BATCH,
                            "weights": "random init, Linear / Conv1d weight matrices x %g (5 inner steps at lr 1e-3 contractive; see WEIGHT_SCALE)" % WEIGHT_SCALE,
-                           "tasks_per_gpu": META_BATCH // n, "inner_steps": INNER_STEPS, "order": "first" if args.order == 1 else "second", "parallelism": f"task-dp{n}",
+                           "tasks_per_gpu": META_BATCH // part, "inner_steps": inner_steps, "order": "first" if args.order == 1 else "second", "parallelism": f"task-dp{n}",
                            "numerics": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "dropout": "identity (parity config)" if args.no_dropout else "on (0.2 / 0.5 / 0.5, counter-based masks)",
                            "batch_ingestion": "resident (uploaded once before the timed region)" if args.resident_batches else "inside every timed step (host 12-tuples -> HBM + plans)",
                            "inner_update": ("module by module behind the backward, %d launches per inner step on a stream of its own" % inner_upd)
@@ -962,7 +1116,10 @@ def main():
                                                "encoder 3 .. 0 + word embedding) + the exchange tail, on a communication stream behind events of the main / weight-gradient streams; "
                                                "allreduce_ms_per_step = what mtts_allreduce_outer still waits for (exposed)"} if n > 1 else None),
                 "allreduce_carries": "flat outer gradient + 6 loss scalars (sync_dist mean) + PostNet BatchNorm running buffers (rank 0's, as DDP broadcast_buffers)" if n > 1 else None,
+                "replicas": replicas, "outer_gradient_vs_single_handle": exchange,
                 "query_total_loss_mean": round(float(q_losses[:, 0].mean()), 5) if q_losses is not None else None}
+        if emu:
+            line["selftest"] = "emu: CPU self-test of the N-rank flow (gloo + SIMT emulator, tiny model) - NOT a bench result"
         if so is not None:
             line["second_order"] = so
         line["parity_check"] = parity
@@ -983,9 +1140,11 @@ def main():
         if hbm is not None:
             line["hbm_bound_kernels"] = hbm
         if cpu is not None:
-            cpu = {k: v for k, v in cpu.items() if k not in ("query_losses", "grad_samples")}
+            cpu = {k: v for k, v in cpu.items() if k not in ("query_losses", "grad_samples", "query_mels")}
             line["cpu_baseline"] = cpu
             line["speedup_vs_cpu_baseline"] = round((args.steps / dt) / cpu["value"], 1)
+            if n > 1:
+                cpu["note_n_gpus"] = "timed on rank 0's host cores while the other ranks wait in the closing barrier"
         print(json.dumps(line))
 
 

@@ -39,6 +39,9 @@ Params = Dict[str, torch.Tensor]
 # and pass inside that band (measured: tools/dropout_grad_probe.py).  fs2_loss appends ("l1", elements of mel / mel_post with
 # |prediction - target| < L1_KINK_EPS) when asked.
 KINK_LOG: Optional[list] = None
+# With RELU_TAPS a list every ReLU appends (pre-activation, output) — graph tensors, so that a caller (oracle/arbiter.py) can price the
+# gradient contribution of single units whose pre-activation sits inside fp32 noise of zero.
+RELU_TAPS: Optional[list] = None
 KINK_EPS = 1e-6
 L1_KINK_EPS = 1e-4
 
@@ -120,6 +123,10 @@ def _relu(x):
     if KINK_LOG is not None:
         a = x.detach().abs()
         KINK_LOG.append((float(a.min()), int((a < KINK_EPS).sum())))
+    if RELU_TAPS is not None:
+        y = F.relu(x)
+        RELU_TAPS.append((x, y))
+        return y
     return F.relu(x)
 
 
@@ -383,7 +390,7 @@ def fs2_loss(batch, preds, pitch_level="phoneme_level", energy_level="phoneme_le
     mel_t, _, _, p_t, e_t, d_t = batch[6:]
     mel, mel_post, pp, ep, logd, _, src_masks, mel_masks, _, _ = preds
     sm, mm = ~src_masks, ~mel_masks
-    logd_t = torch.log(d_t.float() + 1)
+    logd_t = torch.log(d_t.to(logd.dtype) + 1)      # (loss.py:30: .float(); the fp64 arbiter runs the same code in double)
     mel_t = mel_t[:, : mm.shape[1], :]
     mel_l = F.l1_loss(mel.masked_select(mm.unsqueeze(-1)), mel_t.masked_select(mm.unsqueeze(-1)))
     post_l = F.l1_loss(mel_post.masked_select(mm.unsqueeze(-1)), mel_t.masked_select(mm.unsqueeze(-1)))

@@ -62,17 +62,16 @@ def tiny_dims(**over):
     return ModelDims(mc, pc, n_speaker=over.pop("n_speaker", 12), vocab=over.pop("vocab", 40))
 
 
-def kink_count(klog):
-    """ReLU units within 1e-6 of zero + L1 elements within 1e-4 of the target that a KINK_LOG of the oracle recorded."""
-    return sum(e[1] for e in klog if e[0] != "l1") + sum(e[1] + e[2] for e in klog if e[0] == "l1")
-
-
-def assert_grad_close(got, ref, rtol, kinks, name="", kink_l2=3e-2, atol=0.0):
-    """Gradient parity with kinks (oracle/fs2_oracle.py KINK_LOG): max |got - ref| <= rtol * max |ref| — or, when the oracle's pass had a ReLU
-    pre-activation / an L1 residual inside fp32 noise of zero (`kinks` > 0: the gradient is discontinuous there, one flipped L1 sign moves
-    every upstream tensor by ~2 / sqrt(valid frames x n_mel) of its norm), a relative L2 error <= kink_l2."""
-    err = float(np.abs(got - ref).max())
-    if err <= rtol * float(np.abs(ref).max()) + atol:
-        return
-    l2 = float(np.linalg.norm(got - ref) / max(float(np.linalg.norm(ref)), 1e-30))
-    assert kinks > 0 and l2 <= kink_l2, (name, err / max(float(np.abs(ref).max()), 1e-30), l2, kinks)
+def check_grads(pairs, rtol, arbitrate, atol=0.0, label=""):
+    """Gradient parity on a piecewise-smooth loss without an escape hatch.  `pairs`: {tensor name: (engine gradient, fp32-oracle gradient)}.
+    A tensor passes when max |got - ref| <= rtol * max |ref| + atol (it agrees tightly with an independent fp32 implementation).  Every tensor
+    that does not is handed to the float64 arbiter (`arbitrate(names)` -> oracle/arbiter.py report with both parties): it must pass
+    err(engine, fp64) <= 3 * err(oracle32, fp64) + 1e-3 there, where L1 sign flips are read off each party's own forward output and ReLU flips are
+    identified unit by unit — a ReLU / L1 kink inside fp32 noise is explained exactly, anything else fails.  Returns the arbiter's report (or None)."""
+    failing = [n for n, (got, ref) in pairs.items() if float(np.abs(got - ref).max()) > rtol * float(np.abs(ref).max()) + atol]
+    if not failing:
+        return None
+    rep = arbitrate(failing)
+    bad = {n: rep["tensors"][n] for n in failing if not rep["tensors"][n]["ok"]}
+    assert not bad, (label, bad, rep["parties"])
+    return rep

@@ -125,12 +125,15 @@ def test_few_shot_test_step_full_size_vs_oracle():
     same = out["d_rounded"] == ref_d
     assert same.mean() > 0.99, same.mean()  # a rounding flip needs exp(logd) within ~1e-5 of a half-integer after 5 SGD steps
     assert int(fr[9].max()) > 200
-    if same.all():
-        np.testing.assert_array_equal(out["mel_lens"], fr[9].numpy())
-        for b in range(5):
-            n = int(out["mel_lens"][b])
-            d = np.abs(out["mel_post"][b, :n] - fr[1].numpy()[b, :n])
-            assert d.mean() <= 2e-4, (b, d.mean())
+    # mel of every utterance whose predicted durations all agree (a flipped duration shifts that utterance's frames; its neighbours in the batch
+    # still see it through the PostNet's BatchNorm statistics, which one frame in ~2 000 moves far below the tolerance)
+    ok_utts = [b for b in range(5) if bool(same[b].all())]
+    assert len(ok_utts) >= 4, same.all(axis=1)
+    for b in ok_utts:
+        assert int(out["mel_lens"][b]) == int(fr[9][b])
+        n = int(out["mel_lens"][b])
+        d = np.abs(out["mel_post"][b, :n] - fr[1].numpy()[b, :n])
+        assert d.mean() <= 2e-4, (b, d.mean())
     eng.close()
 
 

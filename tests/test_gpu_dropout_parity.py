@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-from oracle_util import O, assert_grad_close, heads, kink_count, synth, torch_buffers, torch_params
+from oracle_util import O, check_grads, heads, synth, torch_buffers, torch_params
+from oracle import arbiter as ARB
 from oracle.dropout_masks import DropoutMasks, plan_seed
 from meta_tts_amd.config import ModelDims, default_algorithm_config
 from meta_tts_amd.engine import Engine
@@ -62,13 +63,8 @@ def test_plain_step_full_size_dropout_on(tasks):
     p = torch_params(DIMS, requires_grad=True, weight_scale=SCALE)
     tb = O.to_torch_batch(sup)
     dm = DropoutMasks(plan_seed(SEED, 1), 0)
-    klog = []
-    O.KINK_LOG = klog
-    try:
-        o = O.fs2_forward(p, torch_buffers(DIMS), *tb[2:], n_head=heads(DIMS), training=True, dropout=dm)
-    finally:
-        O.KINK_LOG = None
-    lo = O.fs2_loss(tb, o, kink_log=klog)
+    o = O.fs2_forward(p, torch_buffers(DIMS), *tb[2:], n_head=heads(DIMS), training=True, dropout=dm)
+    lo = O.fs2_loss(tb, o)
     l1 = float(np.abs(out["mel_post"] - o[1].detach().numpy()).mean())
     assert l1 < 1e-4, f"mel L1 vs oracle with dropout on: {l1}"           # the north-star gate, in the timed configuration
     for k, ref in (("mel", o[0]), ("p", o[2]), ("e", o[3]), ("logd", o[4])):
@@ -76,8 +72,15 @@ def test_plain_step_full_size_dropout_on(tasks):
     np.testing.assert_allclose(q[0], [float(x) for x in lo], rtol=2e-5)
     names = SAMPLED + ["encoder.layer_stack.0.slf_attn.w_qs.weight", "encoder.layer_stack.3.pos_ffn.w_1.weight", "encoder.src_word_emb.weight"]
     gs = torch.autograd.grad(lo[0], [p[n] for n in names])
-    for n, g in zip(names, gs):
-        assert_grad_close(eng.export(n, 1), g.numpy(), 1e-3, kink_count(klog), n, atol=1e-7)
+    got = {n: eng.export(n, 1) for n in names}
+    ref = {n: g.numpy() for n, g in zip(names, gs)}
+
+    def arbitrate(failing):   # a plain step = a "task" with no inner steps whose query batch is the support batch (mean of 5 identical speaker rows)
+        return ARB.arbitrate_task(synth.make_params(DIMS, 0, weight_scale=SCALE), synth.make_buffers(DIMS), sup, sup, modules=MODS, n_head=heads(DIMS),
+                                  max_seq_len=DIMS.max_seq_len, steps=0, lr=0.0, masks=[DropoutMasks(plan_seed(SEED, 1), 0)], names=failing,
+                                  parties={"engine": {"grads": got, "mel": out["mel"], "mel_post": out["mel_post"]},
+                                           "oracle32": {"grads": ref, "mel": o[0].detach().numpy(), "mel_post": o[1].detach().numpy()}})
+    check_grads({n: (got[n], ref[n]) for n in names}, 1e-3, arbitrate, atol=1e-7, label="plain step")
     # and the masks matter at these tolerances: the dropout-off oracle is far away
     with torch.no_grad():
         o0 = O.fs2_forward(p, torch_buffers(DIMS), *tb[2:], n_head=heads(DIMS), training=True)
@@ -96,21 +99,27 @@ def test_eight_grouped_tasks_first_order_dropout_on(tasks):
     q, s = eng.meta_grad(5, LR, 1.0 / 8)
     p = torch_params(DIMS, requires_grad=True, weight_scale=SCALE)
     buf = torch_buffers(DIMS)
-    ref_g = {n: np.zeros_like(p[n].detach().numpy()) for n in SAMPLED}
-    kinks = 0
+    mean_g = {n: np.zeros(p[n].shape, np.float64) for n in SAMPLED}
     for j, (sup, qry) in enumerate(tasks):
         dms = [DropoutMasks(plan_seed(SEED, k + 1), j) for k in range(6)]
-        klog = []
-        ql, sl, _, _ = O.maml_task(p, buf, O.to_torch_batch(sup), O.to_torch_batch(qry), steps=5, lr=LR, second_order=False, modules=MODS,
-                                   n_head=heads(DIMS), dropout=dms, kink_log=klog)
-        kinks += kink_count(klog)
+        ql, sl, _, qp = O.maml_task(p, buf, O.to_torch_batch(sup), O.to_torch_batch(qry), steps=5, lr=LR, second_order=False, modules=MODS,
+                                    n_head=heads(DIMS), dropout=dms)
         np.testing.assert_allclose(q[j], [float(x) for x in ql], rtol=2e-3, err_msg=f"query losses of task {j}")
         np.testing.assert_allclose(s[:, j, :], np.array([[float(x) for x in l] for l in sl]), rtol=2e-3, err_msg=f"support losses of task {j}")
         gs = torch.autograd.grad(ql[0], [p[n] for n in SAMPLED])
-        for n, g in zip(SAMPLED, gs):
-            ref_g[n] += g.numpy() / 8.0
-    for n in SAMPLED:                                        # which = 1: the outer gradient (mean over the 8 tasks)
-        assert_grad_close(eng.export(n, 1), ref_g[n], 3e-3, kinks, n)
+        ref = {n: g.numpy() for n, g in zip(SAMPLED, gs)}
+        got = {n: eng.export(n, 2, j).astype(np.float64) * 8.0 for n in SAMPLED}          # which = 2: task j's own gradient (grad_scale 1/8)
+        out = eng.outputs(1, j)
+
+        def arbitrate(failing, j=j, got=got, ref=ref, out=out, qp=qp):
+            return ARB.synth_task_worker(dict(task=j, threads=16, dropout_seed=SEED, steps=5, lr=LR, weight_scale=SCALE, modules=MODS, names=failing,
+                                              parties={"engine": {"grads": got, "mel": out["mel"], "mel_post": out["mel_post"]},
+                                                       "oracle32": {"grads": ref, "mel": qp[0].detach().numpy(), "mel_post": qp[1].detach().numpy()}}))
+        check_grads({n: (got[n], ref[n]) for n in SAMPLED}, 3e-3, arbitrate, label=f"task {j}")
+        for n in SAMPLED:
+            mean_g[n] += got[n] / 8.0
+    for n in SAMPLED:                                        # which = 1: the outer gradient IS the mean of the per-task gradients just checked
+        np.testing.assert_allclose(eng.export(n, 1), mean_g[n], rtol=0, atol=2e-6 * np.abs(mean_g[n]).max(), err_msg=n)
     eng.close()
 
 
@@ -127,13 +136,54 @@ def test_second_order_task_dropout_on(tasks):
     for j in (1, 6):
         sup, qry = tasks[j]
         dms = [DropoutMasks(plan_seed(SEED + 1, k + 1), j) for k in range(6)]
-        klog = []
-        ql, _, _, _ = O.maml_task(p, buf, O.to_torch_batch(sup), O.to_torch_batch(qry), steps=5, lr=LR, second_order=True, modules=MODS,
-                                  n_head=heads(DIMS), dropout=dms, kink_log=klog)
+        ql, _, _, qp = O.maml_task(p, buf, O.to_torch_batch(sup), O.to_torch_batch(qry), steps=5, lr=LR, second_order=True, modules=MODS,
+                                   n_head=heads(DIMS), dropout=dms)
         np.testing.assert_allclose(q[j], [float(x) for x in ql], rtol=2e-3)
         gs = torch.autograd.grad(ql[0], [p[n] for n in names])
-        for n, g in zip(names, gs):
-            # (second order also differentiates through the inner steps' kinks, which the query-pass log does not see: the L2 fallback applies
-            # whenever the query pass itself had one)
-            assert_grad_close(eng.export(n, 2, j), g.numpy(), 1.5e-2 if n.startswith("encoder.") else 5e-3, kink_count(klog), f"task {j}: {n}")
+        ref = {n: g.numpy() for n, g in zip(names, gs)}
+        got = {n: eng.export(n, 2, j) for n in names}
+        out = eng.outputs(1, j)
+        T = out["mel_post"].shape[1]       # the query pass's outputs survive the reverse sweep (the arbiter reads the engine's L1 signs off them)
+        assert float(np.abs(out["mel_post"] - qp[1].detach().numpy()[:, :T]).mean()) < 1e-4
+
+        def arbitrate(failing, j=j, got=got, ref=ref, out=out, qp=qp):
+            # second order in float64 (create_graph through the five inner steps).  A kink of an INNER pass moves the outer gradient only by
+            # lr x that unit's contribution (it changes the fast weights, not the query graph), so the query pass's kinks are the ones priced.
+            return ARB.synth_task_worker(dict(task=j, threads=16, dropout_seed=SEED + 1, steps=5, lr=LR, weight_scale=SCALE, modules=MODS, names=failing,
+                                              second_order=True,
+                                              parties={"engine": {"grads": got, "mel": out["mel"], "mel_post": out["mel_post"]},
+                                                       "oracle32": {"grads": ref, "mel": qp[0].detach().numpy(), "mel_post": qp[1].detach().numpy()}}))
+        tight = {n: (got[n], ref[n]) for n in names if not n.startswith("encoder.")}
+        check_grads(tight, 5e-3, arbitrate, label=f"task {j}")
+        # (the encoder's q projection only sees the second-order terms — the smallest signal of the set — and five reverse steps amplify
+        # summation-order differences most there: tests/test_gpu_timed_config.py)
+        check_grads({n: (got[n], ref[n]) for n in names if n.startswith("encoder.")}, 1.5e-2, arbitrate, label=f"task {j}")
     eng.close()
+
+
+@pytest.mark.slow
+def test_eight_tasks_every_sampled_tensor_through_the_fp64_arbiter(tasks):
+    """The timed configuration judged the way bench.py's parity_check judges it, for ALL 8 tasks and every sampled tensor whether or not it agrees
+    tightly with the fp32 oracle: float64 evaluation per task (8 worker processes), err(engine, fp64) <= 3 * err(oracle32, fp64) + 1e-3."""
+    eng = _engine(8, tasks)
+    _set(eng, tasks)
+    eng.set_dropout(True, SEED)
+    eng.meta_grad(5, LR, 1.0 / 8)
+    p = torch_params(DIMS, requires_grad=True, weight_scale=SCALE)
+    buf = torch_buffers(DIMS)
+    jobs = []
+    for j, (sup, qry) in enumerate(tasks):
+        dms = [DropoutMasks(plan_seed(SEED, k + 1), j) for k in range(6)]
+        ql, _, _, qp = O.maml_task(p, buf, O.to_torch_batch(sup), O.to_torch_batch(qry), steps=5, lr=LR, second_order=False, modules=MODS,
+                                   n_head=heads(DIMS), dropout=dms)
+        gs = torch.autograd.grad(ql[0], [p[n] for n in SAMPLED])
+        out = eng.outputs(1, j)
+        jobs.append(dict(task=j, threads=16, dropout_seed=SEED, steps=5, lr=LR, weight_scale=SCALE, modules=MODS, names=SAMPLED,
+                         parties={"engine": {"grads": {n: eng.export(n, 2, j).astype(np.float64) * 8.0 for n in SAMPLED}, "mel": out["mel"], "mel_post": out["mel_post"]},
+                                  "oracle32": {"grads": {n: g.numpy() for n, g in zip(SAMPLED, gs)}, "mel": qp[0].detach().numpy(), "mel_post": qp[1].detach().numpy()}}))
+    eng.close()
+    reports = ARB.run_pool(jobs, processes=8)
+    digests = [ARB.summarize(r) for r in reports]
+    assert all(d["pass"] for d in digests), digests
+    for d in digests:      # the engine is as close to float64 as the fp32 oracle is (the gate's floor is 1e-3)
+        assert d["engine_l1_max"]["err"] <= 3 * d["oracle32_l1_max"]["err"] + 1e-3 or d["parties"]["engine"].get("relu_flips_used", 0) > 0, d
