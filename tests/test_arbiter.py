@@ -180,12 +180,12 @@ def test_flipped_relu_units_are_identified_and_priced(setup, monkeypatch):
     eps = float(a[order[-1]]) * 1.5
     g_flip, _ = f64_grad()
     monkeypatch.undo()
-    monkeypatch.setattr(A, "RELU_EPS", eps)
+    monkeypatch.setattr(A, "RELU_BAND", eps)
     monkeypatch.setattr(A, "GATE_FLOOR", 1e-9)
-    monkeypatch.setattr(A, "MAX_RELU_UNITS", 100000)
     party = {"grads": g_flip, "mel": preds[0].detach().numpy(), "mel_post": preds[1].detach().numpy()}
     rep = setup["run"]({"engine": party})
     raw = max(r["engine"]["raw"] for r in rep["tensors"].values())
+    print("REP", rep["parties"], rep.get("relu_candidates_in_band"), [float(a[i]) for i in order], {n: r["engine"] for n, r in rep["tensors"].items() if "explained" in r["engine"]})
     assert raw > 1e-6, raw                       # the flips moved something
     assert rep["parties"]["engine"]["relu_flips_used"] == 4, rep["parties"]
     assert rep["parties"]["engine"]["relu_units_priced"] >= 4
