@@ -223,6 +223,13 @@ int mtts_allreduce_outer(mtts_handle* h);
  * Results equal the one-shot exchange's (the same floats, the same collective, in pieces).  mtts_allreduce_launches: collectives the
  * last overlapped exchange issued (buckets + tail). */
 int mtts_arm_allreduce_overlap(mtts_handle* h);
+/* Take the arming back (a caller whose gradient call will not happen after all: an exception between arming and the call, an aborted
+ * accumulation window).  The gradient calls also disarm on EVERY exit path, failures included, so a stale flag can never make a later,
+ * unrelated gradient call of this rank issue collectives its peers do not.  mtts_comm_init makes the ranks agree on the bucket table
+ * (a SUM of (n, n^2) over the ranks): if any rank has no table, the overlap is off on all of them — mtts_allreduce_bucket_agreement: 1 agreed,
+ * 0 disagreed (overlap off everywhere), -1 no communicator. */
+int mtts_disarm_allreduce_overlap(mtts_handle* h);
+int mtts_allreduce_bucket_agreement(mtts_handle* h);
 int mtts_allreduce_launches(mtts_handle* h);
 /* What DDP moves between ranks BESIDES the gradient rides behind the flat outer gradient in the same buffer and the same collective:
  * [n_total .. n_total+6) the six losses of the last mtts_meta_grad / mtts_plain_grad call, summed over this rank's tasks and scaled by its

@@ -76,6 +76,8 @@ EXPORTS = {
     "mtts_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "mtts_allreduce_outer": (C.c_int, [C.c_void_p]),
     "mtts_arm_allreduce_overlap": (C.c_int, [C.c_void_p]),
+    "mtts_disarm_allreduce_overlap": (C.c_int, [C.c_void_p]),
+    "mtts_allreduce_bucket_agreement": (C.c_int, [C.c_void_p]),
     "mtts_allreduce_launches": (C.c_int, [C.c_void_p]),
     "mtts_inner_update_launches": (C.c_int, [C.c_void_p]),
     "mtts_outer_sync_floats": (C.c_int64, [C.c_void_p]),

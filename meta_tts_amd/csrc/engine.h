@@ -1475,10 +1475,16 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // MEASUREMENT ONLY (results are wrong): MTTS_ABLATE_LN=1 drops every LayerNorm forward / backward launch of the FFT blocks and predictors, which
     // bounds from above what folding bias + dropout + residual + LayerNorm into the producing GEMM's epilogue (and the LayerNorm backward into
     // the consuming GEMM's prologue) could save — a timing run, never a result (profiles/r05_ab_log.md; bench.py refuses to gate parity on it)
+    // The switch only exists in a library built with -DMTTS_ABLATE (a diagnostic build: `hipcc ... -DMTTS_ABLATE`); the shipped libmtts.so has no
+    // way to skip a LayerNorm, whatever its environment holds.
+#if defined(MTTS_ABLATE)
     static bool ablate_ln() {
         static const bool on = [] { const char* e = getenv("MTTS_ABLATE_LN"); return e && atoi(e) != 0; }();
         return on;
     }
+#else
+    static constexpr bool ablate_ln() { return false; }
+#endif
     void ln_fwd(const Pass& ps, Space s, TS a, TS res, long long g_off, long long b_off, const unsigned char* mask,
                 TS zout, TS y, TS st, int C, DropSpec din = DropSpec(), DropSpec dout = DropSpec(), bool y_twin = false) {
         // y_twin: bf16 mode — also write y's operand plane (H(y)): the next conv reads it instead of a conversion pass
@@ -1722,6 +1728,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     int ar_next = 0, ar_nt = 0;
     float ar_axpy = 0.f;            // second order: grad[range] += ar_axpy * hv[range] in front of the task sum (the last reverse step's update)
     int ar_launches = 0;            // collectives issued by the last overlapped exchange (tests, bench line)
+    int ar_bucket_agreement = -1;   // mtts_comm_init: 1 = every rank holds the same bucket table, 0 = they disagreed (overlap off everywhere), -1 = no communicator yet
     int ar_idx_postnet() const { return 0; }
     int ar_idx_dec(int l) const { return 1 + (cfg.dec_layers - 1 - l); }
     int ar_idx_va() const { return 1 + cfg.dec_layers; }
@@ -2594,6 +2601,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (forward(pq)) return -1;
         if (loss(pq, losses_out ? losses_out : losses)) return -1;
         if (!losses_out || losses_out == losses) { sync_nt = nt; sync_scale = grad_scale; }
+        else ar_armed = false;               // (the exchange tail is packed from `losses`: a caller-supplied buffer takes the one-shot exchange)
         const bool overlap = ar_begin(nt);   // (mtts_arm_allreduce_overlap: the buckets leave as the query backward completes them)
         if (overlap) ar_tail();
         const int rc = backward(pq, grad_scale, true);
@@ -2633,6 +2641,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         if (forward(ps)) return -1;
         if (loss(ps, losses_out ? losses_out : losses)) return -1;
         if (!losses_out || losses_out == losses) { sync_nt = p.tasks; sync_scale = grad_scale; }
+        else ar_armed = false;
         const bool overlap = ar_begin(p.tasks);
         if (overlap) ar_tail();
         const int rc = backward(ps, grad_scale, true);

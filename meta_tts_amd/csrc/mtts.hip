@@ -283,9 +283,18 @@ int mtts_backward(mtts_handle* h, int slot, int use_fast, float scale, int need_
     return launched(e, e.backward(ps, scale, need_encoder != 0));
 }
 
+// mtts_arm_allreduce_overlap is one-shot: the flag must not outlive the gradient call it was set for.  A call that fails before it reaches
+// ar_begin (forward / loss error, a failing reverse step) would otherwise leave it set, and the NEXT unrelated gradient call of this rank — a
+// validation pass, a retry — would issue collectives its peers do not.
+struct ArmGuard {
+    Engine& e;
+    ~ArmGuard() { e.ar_armed = false; }
+};
+
 int mtts_meta_grad(mtts_handle* h, int steps, float inner_lr, float grad_scale, int second_order, float* qry_losses_host,
                    float* sup_losses_host) {
     Engine& e = h->eng;
+    ArmGuard disarm{e};   // an armed overlapped exchange is for THIS call only, however it ends
     if (steps < 0 || steps > h->sup_losses_cap) { e.set_error("too many inner steps"); return -1; }
     for (int sl = 0; sl < 2; ++sl) if (e.plans[sl].tasks > 0 && e.retarget(sl, true)) return -1;
     if (launched(e, second_order ? e.meta_grad_so(steps, inner_lr, grad_scale, e.losses, h->sup_losses_dev)
@@ -325,6 +334,7 @@ int mtts_imaml_finish(mtts_handle* h, float inner_lr, float reg_param, float gra
 
 int mtts_plain_grad(mtts_handle* h, int slot, float grad_scale, float* losses_host) {
     Engine& e = h->eng;
+    ArmGuard disarm{e};
     if (slot < 0 || slot > 1) { e.set_error("bad slot"); return -1; }
     if (e.plans[slot].tasks > 0 && e.retarget(slot, true)) return -1;
     if (launched(e, e.plain_grad(slot, grad_scale, e.losses))) return -1;
@@ -353,7 +363,33 @@ int mtts_comm_init(mtts_handle* h, const void* id128, int rank, int world_size) 
     e.ar.ctx = &h->comm;
     e.ar.sum = [](void* c, float* buf, size_t n, hipStream_t st) { return ((Comm*)c)->sum(buf, n, st); };
     e.ar.rank = rank; e.ar.world = world_size;
-    if (e.ar_setup() < 0) return -1;   // (> 0: no bucket table for this architecture — the one-shot exchange stays available)
+    auto rollback = [&](const std::string& why) {   // no half-initialised communicator: the caller may fall back to its own all-reduce
+        h->comm.release();
+        e.ar.ctx = nullptr; e.ar.sum = nullptr; e.ar.rank = 0; e.ar.world = 1;
+        e.ar_buckets.clear();
+        e.set_error(why);
+        return -1;
+    };
+    if (e.ar_setup() < 0) return rollback("overlapped exchange: stream / event creation failed");   // (> 0: no bucket table for this architecture — the one-shot exchange stays available)
+    // every rank decides LOCALLY whether it has a bucket table; a rank that does not would issue 1 collective against its peers' N + 1.  Agree on
+    // it here, collectively: SUM of (n, n^2) over the ranks — all n equal  <=>  world * sum(n^2) == (sum n)^2.  Any disagreement switches the
+    // overlap off on EVERY rank (the one-shot exchange needs no table).
+    {
+        float probe[4] = {(float)e.ar_buckets.size(), (float)(e.ar_buckets.size() * e.ar_buckets.size()), 0.f, 0.f};
+        float* dev = e.outer + e.n_total;            // the exchange tail: scratch until the first sync_pack
+        if (hipMemcpyAsync(dev, probe, sizeof(probe), hipMemcpyHostToDevice, e.stream) != hipSuccess) return rollback("bucket agreement: copy failed");
+        if (h->comm.sum(dev, 4, e.stream)) return rollback(h->comm.err);
+        if (hipMemcpyAsync(probe, dev, sizeof(probe), hipMemcpyDeviceToHost, e.stream) != hipSuccess || hipStreamSynchronize(e.stream) != hipSuccess)
+            return rollback("bucket agreement: copy back failed");
+        const double sn = probe[0], sq = probe[1];
+        e.ar_bucket_agreement = (fabs((double)world_size * sq - sn * sn) < 0.5) ? 1 : 0;
+        if (!e.ar_bucket_agreement) e.ar_buckets.clear();
+    }
+    return 0;
+}
+int mtts_disarm_allreduce_overlap(mtts_handle* h) {
+    if (!h) return -1;
+    h->eng.ar_armed = false;
     return 0;
 }
 int mtts_arm_allreduce_overlap(mtts_handle* h) {
@@ -365,6 +401,7 @@ int mtts_arm_allreduce_overlap(mtts_handle* h) {
     return 0;
 }
 int mtts_allreduce_launches(mtts_handle* h) { return h ? h->eng.ar_launches : -1; }
+int mtts_allreduce_bucket_agreement(mtts_handle* h) { return h ? h->eng.ar_bucket_agreement : -1; }
 int mtts_inner_update_launches(mtts_handle* h) { return h ? h->eng.upd_launches : -1; }
 int mtts_allreduce_outer(mtts_handle* h) {
     Engine& e = h->eng;

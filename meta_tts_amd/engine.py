@@ -441,6 +441,16 @@ class Engine:
             self._ck(rc)
         return rc == 0
 
+    def disarm_allreduce_overlap(self):
+        """Take the arming back (the gradient call it was meant for will not happen); the gradient calls disarm on every exit path themselves."""
+        self._ck(self.lib.mtts_disarm_allreduce_overlap(self.h))
+
+    @property
+    def allreduce_bucket_agreement(self) -> int:
+        """1: every rank holds the same bucket table (agreed collectively in comm_init); 0: they disagreed, the overlap is off on all ranks;
+        -1: no communicator."""
+        return int(self.lib.mtts_allreduce_bucket_agreement(self.h))
+
     @property
     def allreduce_launches(self) -> int:
         return int(self.lib.mtts_allreduce_launches(self.h))

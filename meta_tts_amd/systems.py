@@ -423,6 +423,7 @@ class Trainer:
             out = grad_call()
         finally:
             eng.set_grad_accumulation(False)
+            eng.disarm_allreduce_overlap()      # (a Python exception in front of the engine call: the arming must not reach a later, unrelated gradient call)
         self._acc_i += 1
         if self._acc_i < self.grad_acc:
             return out, True

@@ -101,3 +101,34 @@ def test_exchange_really_sums_and_unarmed_calls_are_unchanged(emu_lib):
     for n in eng.params:
         np.testing.assert_array_equal(eng.export(n, 1), 2.0 * local[n], err_msg=n)
     eng.close()
+
+
+def test_arming_does_not_outlive_a_failed_or_abandoned_gradient_call(emu_lib):
+    """the arming is one-shot.  (a) A gradient call that fails BEFORE it reaches the exchange (here: too many inner steps — refused in
+    the C ABI) must leave the handle disarmed; (b) mtts_disarm_allreduce_overlap takes an arming back (systems.Trainer calls it in its finally).
+    In both cases the next, un-armed gradient call issues NO collectives: its outer gradient is the local one (the loop-back communicator would
+    have doubled it)."""
+    from meta_tts_amd.engine import MttsError
+    dims, eng, sup, qry = _engine(emu_lib, 1)
+    assert eng.allreduce_bucket_agreement == 1          # agreed collectively in comm_init
+    eng.set_dropout(False)
+    eng.set_batches(0, sup)
+    eng.set_batches(1, qry, spk_from=sup, average_spk=True)
+    eng.meta_grad(2, 1e-3, 1.0, fetch_losses=False)
+    local = {n: eng.export(n, 1).copy() for n in eng.params}
+    # (a)
+    assert eng.arm_allreduce_overlap()
+    with pytest.raises(MttsError):
+        eng.meta_grad(10 ** 6, 1e-3, 1.0, fetch_losses=False)
+    eng.meta_grad(2, 1e-3, 1.0, fetch_losses=False)
+    eng.synchronize()
+    for n in eng.params:
+        np.testing.assert_array_equal(eng.export(n, 1), local[n], err_msg=n)
+    # (b)
+    assert eng.arm_allreduce_overlap()
+    eng.disarm_allreduce_overlap()
+    eng.meta_grad(2, 1e-3, 1.0, fetch_losses=False)
+    eng.synchronize()
+    for n in eng.params:
+        np.testing.assert_array_equal(eng.export(n, 1), local[n], err_msg=n)
+    eng.close()
