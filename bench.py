@@ -105,6 +105,9 @@ GRAD_SAMPLES = ("mel_linear.weight", "decoder.layer_stack.5.pos_ffn.w_2.weight",
                 "variance_adaptor.pitch_embedding.weight", "speaker_emb.model.weight")
 
 
+# allocator / OpenMP-runtime settings of the concurrent CPU-baseline workers (set in the worker before torch loads; see cpu_baseline)
+CPU_RUNTIME_ENV = {"OMP_WAIT_POLICY": "PASSIVE", "GOMP_SPINCOUNT": "0", "MALLOC_ARENA_MAX": "1", "MALLOC_MMAP_THRESHOLD_": "33554432",
+                   "MALLOC_TRIM_THRESHOLD_": "4294967295", "MALLOC_TOP_PAD_": "268435456"}
 DROPOUT_SEED = 1234      # mtts_set_dropout(h, 1, DROPOUT_SEED + rank) for the timed steps AND for the parity run
 
 
@@ -161,12 +164,14 @@ def _cpu_partition(nproc):
     return groups, len(phys)
 
 
-def _cpu_task_worker(j, cpus, thread_legs, barrier, out_q, dropout=True):
+def _cpu_task_worker(j, cpus, thread_legs, barrier, out_q, dropout=True, env=None, interop=0):
     """One task process of the concurrent CPU baseline: task j of the meta-batch (5 inner steps + query forward / backward, first
     order, the oracle, dropout as timed), pinned to its own run of physical cores (`cpus`, _cpu_partition) BEFORE torch / OpenMP start
     (OMP_PLACES=cores, OMP_PROC_BIND=close: intra-op thread i sits on core i of the run).  One leg per entry of `thread_legs` (intra-op
     threads); all processes leave the barrier together, the parent clocks the slowest."""
     pinned = False
+    for k, v in (env or {}).items():      # allocator / OpenMP runtime settings: in place before torch (and its OpenMP runtime) load
+        os.environ[k] = str(v)
     if cpus:
         try:
             os.sched_setaffinity(0, set(cpus))
@@ -177,6 +182,8 @@ def _cpu_task_worker(j, cpus, thread_legs, barrier, out_q, dropout=True):
             pass
     import torch
     torch.set_num_threads(max(thread_legs))
+    if interop:
+        torch.set_num_interop_threads(int(interop))
     from meta_tts_amd import synth
     from meta_tts_amd.config import ModelDims, default_algorithm_config
     from oracle import fs2_oracle as O
@@ -202,7 +209,7 @@ def _cpu_task_worker(j, cpus, thread_legs, barrier, out_q, dropout=True):
     out_q.put((j, times, pinned))
 
 
-def cpu_baseline_concurrent(thread_legs, pin=True, timeout_s=240.0, dropout=True):
+def cpu_baseline_concurrent(thread_legs, pin=True, timeout_s=240.0, dropout=True, env=None, interop=0):
     """BASELINE.md section 3 "all host cores": the 8 tasks of a meta-batch as 8 processes started together, each pinned to 1/8 of the
     box's physical cores (pin=True) and run once per entry of `thread_legs` intra-op threads; one meta-step = the wall time from the
     common start to the LAST process finishing its task (mean + clip + Adam excluded: < 1 %).  Returns one record per leg."""
@@ -214,7 +221,7 @@ def cpu_baseline_concurrent(thread_legs, pin=True, timeout_s=240.0, dropout=True
     ctx = mp.get_context("spawn")
     barrier = ctx.Barrier(META_BATCH + 1)
     q = ctx.Queue()
-    procs = [ctx.Process(target=_cpu_task_worker, args=(j, groups[j], list(thread_legs), barrier, q, dropout), daemon=True) for j in range(META_BATCH)]
+    procs = [ctx.Process(target=_cpu_task_worker, args=(j, groups[j], list(thread_legs), barrier, q, dropout, env, interop), daemon=True) for j in range(META_BATCH)]
     for pr in procs:
         pr.start()
     walls = []
@@ -303,33 +310,29 @@ def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True, dropout=True, make_
     seq = {"value": 1.0 / (META_BATCH * mean_t), "unit": "meta-steps/s", "cores": int(cores),
            "sample": f"{len(times)} of {META_BATCH} tasks ({inner_steps} inner steps + query fwd/bwd each, first-order, dropout {'on' if dropout else 'off'}, fp32 torch-CPU oracle) one after the other at the "
                      f"best of the swept intra-op thread counts ({cores}); {mean_t:.2f} s/task, clip+Adam excluded (<1%)"}
-    conc, conc_err, sweep_c = None, None, {}
+    conc, conc_err, sweep_c, full_box = None, None, {}, None
     if concurrent:
         # 8 task processes at once, each pinned to its own eighth of the box's physical cores (sched_setaffinity + OMP_PLACES=cores +
-        # OMP_PROC_BIND=close).  One spawn, one leg per intra-op thread count: one thread per physical core of the share,
-        # half, a quarter; then the round-4 harness (unpinned, 2 threads per process).  Measured on the 128-core / 256-thread box of round 5
-        # (profiles/r05_cpu_baseline_scaling.md): pinned x16 16.8 s per meta-step, x8 9.6 s, x32 (SMT) 74.9 s, unpinned x2 7.0 s; one process
-        # alone: 0.23 s per inner step at 16 threads, 0.35 at 8, 0.32 at 32, 0.99 at 64.  The torch-CPU oracle is a chain of small ops
-        # whose allocator / page-fault traffic and OpenMP fork-join dominate beyond ~16 busy threads on the box, pinned or not; the fastest leg is
-        # the concurrent figure and `cores` says how many threads it really used.
+        # OMP_PROC_BIND=close), ONE spawn, one leg per intra-op thread count: one thread per physical core of the share (= the whole box without
+        # SMT: the `full_box` figure), half, a quarter.  Runtime settings measured on the 128-core / 256-thread box (profiles/r06_cpu_baseline.md):
+        # OMP_WAIT_POLICY=PASSIVE + GOMP_SPINCOUNT=0 is the one that matters (idle OpenMP workers of 128 busy threads otherwise spin against each
+        # other: pinned x16 16.8 -> 10.7 s per meta-step); glibc malloc with one arena and no trimming (MALLOC_*) is worth 3-7 %; a single inter-op
+        # thread changes nothing; OMP_WAIT_POLICY=ACTIVE 26 s.  Even so the torch-CPU oracle does not scale with threads on this workload — pinned x4
+        # 6.3 s, x8 7.5 s, x16 10.9 s, x32 (SMT) 24.5 s, unpinned x2 6.7 s — a chain of small ops bound by memory traffic and fork-join, not by
+        # FLOPs: `value` is the FASTEST leg (the strongest CPU competitor), `full_box` the leg that occupies every physical core.
         groups, n_phys = _cpu_partition(META_BATCH)
         share = max(1, n_phys // META_BATCH)             # physical cores per task process
-        # (both SMT threads of every core measured 75 s per meta-step on the 128-core box — 4.5x slower than one thread per core — and is not run)
         legs = sorted({share, max(1, share // 2), max(1, share // 4)}, reverse=True)
         try:
-            for r in cpu_baseline_concurrent(legs, pin=True, dropout=dropout):
+            for r in cpu_baseline_concurrent(legs, pin=True, dropout=dropout, env=CPU_RUNTIME_ENV):
                 sweep_c[f"pinned x{r['threads_per_process']}"] = r["s_per_meta_step"]
+                r["runtime_env"] = dict(CPU_RUNTIME_ENV)
+                if r["threads_per_process"] == share:
+                    full_box = r
                 if conc is None or r["value"] > conc["value"]:
                     conc = r
         except Exception as ex:  # noqa: BLE001
             conc_err = f"{type(ex).__name__}: {ex}"
-        try:
-            for r in cpu_baseline_concurrent([2], pin=False, dropout=dropout):
-                sweep_c[f"unpinned x{r['threads_per_process']}"] = r["s_per_meta_step"]
-                if conc is None or r["value"] > conc["value"]:
-                    conc = r
-        except Exception as ex:  # noqa: BLE001
-            conc_err = conc_err or f"{type(ex).__name__}: {ex}"
         if conc is not None:
             conc["s_per_meta_step_by_leg"] = sweep_c
     best_leg = "concurrent" if (conc is not None and conc["value"] > seq["value"]) else "sequential"
@@ -338,6 +341,8 @@ def cpu_baseline(dims, mods, budget_s=25.0, concurrent=True, dropout=True, make_
             "query_losses": q_ref, "grad_samples": g_ref, "query_mels": mels_ref, "query_pass_kinks": kinks,
             "host_cores": int(host_cores), "thread_sweep_s_per_inner_step": {str(k): v for k, v in sweep.items()},
             "sequential": seq, "concurrent": conc if conc is not None else {"error": conc_err},
+            "full_box": ({"value": full_box["value"], "unit": "meta-steps/s", "cores": full_box["cores"], "physical_cores": full_box["physical_cores"],
+                          "s_per_meta_step": full_box["s_per_meta_step"], "sample": full_box["sample"]} if full_box is not None else None),
             "note": "value = the FASTER of the two CPU legs (speedup_vs_cpu_baseline is quoted against it); north-star target >= 10x"}
 
 
@@ -1148,6 +1153,8 @@ def main():
             cpu = {k: v for k, v in cpu.items() if k not in ("query_losses", "grad_samples", "query_mels")}
             line["cpu_baseline"] = cpu
             line["speedup_vs_cpu_baseline"] = round((args.steps / dt) / cpu["value"], 1)
+            if cpu.get("full_box"):
+                line["speedup_vs_cpu_baseline_full_box"] = round((args.steps / dt) / cpu["full_box"]["value"], 1)
             if n > 1:
                 cpu["note_n_gpus"] = "timed on rank 0's host cores while the other ranks wait in the closing barrier"
         print(json.dumps(line))
