@@ -1052,32 +1052,50 @@ def main():
                                       "oracle32": {"grads": o_grads, "mel": cpu["query_mels"][jt][0], "mel_post": cpu["query_mels"][jt][1]}}))
             if emu:   # the tiny model of the self-test is not what the worker rebuilds from seeds: hand it over
                 jobs[-1].update(model=(dims.model_config, dims.preprocess_config, dims.n_speaker, dims.vocab), sup=make_task(local[jt])[0], qry=make_task(local[jt])[1])
-        t_arb = time.perf_counter()
-        reports = [ARB.synth_task_worker(jb) for jb in jobs] if emu else ARB.run_pool(jobs, processes=min(len(jobs), max(1, (os.cpu_count() or 8) // 16)))
-        arb_s = time.perf_counter() - t_arb
-        digests = [dict(task=r["task"], **ARB.summarize(r)) for r in reports]
-        def worst(key):
-            c = [(d[key]["err"], f"task {d['task']}: {d[key]['tensor']}") for d in digests if key in d]
-            return max(c) if c else (None, None)
-        g_rel, g_worst = worst("engine_gated_max")
-        o_rel, o_worst = worst("oracle32_gated_max")
-        arb_ok = all(d["pass"] for d in digests)
-        parity = {"tasks_checked": int(m), "tasks_grouped_in_the_launches": len(local), "max_rel": float(rel.max()), "rtol": PARITY_RTOL,
-                  "what": "per-task query (total, mel, postnet mel, pitch, energy, duration) losses after 5 inner steps, " + ("dropout off" if args.no_dropout else
-                          "dropout on (the timed configuration and seed; the oracle applies the engine's counter-based masks, oracle/dropout_masks.py)") + ", vs oracle/fs2_oracle.py",
-                  "grad_tensors": list(grad_samples),
-                  "grad_gate": reports[0]["gate"], "grad_pass": bool(arb_ok),
-                  "grad_err_engine_vs_fp64": g_rel, "grad_err_engine_worst": g_worst, "grad_err_oracle32_vs_fp64": o_rel, "grad_err_oracle32_worst": o_worst,
-                  "grad_err_engine_vs_fp64_raw": worst("engine_raw_max")[0], "grad_err_oracle32_vs_fp64_raw": worst("oracle32_raw_max")[0],
-                  "grad_err_engine_vs_fp64_l1_signs_only": worst("engine_l1_max")[0], "grad_err_oracle32_vs_fp64_l1_signs_only": worst("oracle32_l1_max")[0],
-                  "relu_flips_granted": {"engine": int(sum(d["parties"]["engine"].get("relu_flips_used", 0) for d in digests)),
-                                         "oracle32": int(sum(d["parties"]["oracle32"].get("relu_flips_used", 0) for d in digests))},
-                  "l1_flips": {"engine": int(sum(d["parties"]["engine"]["l1_flips"] for d in digests)), "oracle32": int(sum(d["parties"]["oracle32"]["l1_flips"] for d in digests))},
-                  "grad_what": "sampled per-task query-gradient tensors (first-order outer gradient before the mean) of the engine AND of the fp32 oracle against a float64 "
-                               "evaluation of the same task with the same masks; max |g - g64| / max |g64| per tensor; `raw` = plain; `l1_signs_only` = the L1 signs of "
-                               "elements within 1e-4 of their target taken from the party's own mel / mel_post output; the headline (gated) figure additionally has identified single "
-                               "ReLU units (float64 pre-activation inside 5e-5 of zero) switched for tensors that would otherwise fail, each priced exactly",
-                  "arbiter_s": round(arb_s, 1), "per_task": digests}
+        arb_error = None
+        try:
+            t_arb = time.perf_counter()
+            reports = [ARB.synth_task_worker(jb) for jb in jobs] if emu else ARB.run_pool(jobs, processes=min(len(jobs), max(1, (os.cpu_count() or 8) // 16)))
+            arb_s = time.perf_counter() - t_arb
+            digests = [dict(task=r["task"], **ARB.summarize(r)) for r in reports]
+            def worst(key):
+                c = [(d[key]["err"], f"task {d['task']}: {d[key]['tensor']}") for d in digests if key in d]
+                return max(c) if c else (None, None)
+            g_rel, g_worst = worst("engine_gated_max")
+            o_rel, o_worst = worst("oracle32_gated_max")
+            arb_ok = all(d["pass"] for d in digests)
+            parity = {"tasks_checked": int(m), "tasks_grouped_in_the_launches": len(local), "max_rel": float(rel.max()), "rtol": PARITY_RTOL,
+                      "what": "per-task query (total, mel, postnet mel, pitch, energy, duration) losses after 5 inner steps, " + ("dropout off" if args.no_dropout else
+                              "dropout on (the timed configuration and seed; the oracle applies the engine's counter-based masks, oracle/dropout_masks.py)") + ", vs oracle/fs2_oracle.py",
+                      "grad_tensors": list(grad_samples),
+                      "grad_gate": reports[0]["gate"], "grad_pass": bool(arb_ok),
+                      "grad_err_engine_vs_fp64": g_rel, "grad_err_engine_worst": g_worst, "grad_err_oracle32_vs_fp64": o_rel, "grad_err_oracle32_worst": o_worst,
+                      "grad_err_engine_vs_fp64_raw": worst("engine_raw_max")[0], "grad_err_oracle32_vs_fp64_raw": worst("oracle32_raw_max")[0],
+                      "grad_err_engine_vs_fp64_l1_signs_only": worst("engine_l1_max")[0], "grad_err_oracle32_vs_fp64_l1_signs_only": worst("oracle32_l1_max")[0],
+                      "relu_flips_granted": {"engine": int(sum(d["parties"]["engine"].get("relu_flips_used", 0) for d in digests)),
+                                             "oracle32": int(sum(d["parties"]["oracle32"].get("relu_flips_used", 0) for d in digests))},
+                      "l1_flips": {"engine": int(sum(d["parties"]["engine"]["l1_flips"] for d in digests)), "oracle32": int(sum(d["parties"]["oracle32"]["l1_flips"] for d in digests))},
+                      "grad_what": "sampled per-task query-gradient tensors (first-order outer gradient before the mean) of the engine AND of the fp32 oracle against a float64 "
+                                   "evaluation of the same task with the same masks; max |g - g64| / max |g64| per tensor; `raw` = plain; `l1_signs_only` = the L1 signs of "
+                                   "elements within 1e-4 of their target taken from the party's own mel / mel_post output; the headline (gated) figure additionally has identified single "
+                                   "ReLU units (float64 pre-activation inside 5e-5 of zero) switched for tensors that would otherwise fail, each priced exactly",
+                      "arbiter_s": round(arb_s, 1), "per_task": digests}
+        except Exception as ex:  # noqa: BLE001
+            # the arbiter is infrastructure (8 worker processes, float64 autograd): if IT fails, the gate falls back to the plain comparison with the
+            # fp32 oracle at 1e-2 of each tensor's largest entry — no kink allowance of any kind — and the line says so
+            arb_error = f"{type(ex).__name__}: {ex}"
+            worst_t, worst_e = None, 0.0
+            for jb in jobs:
+                for name in grad_samples:
+                    ge_, go_ = jb["parties"]["engine"]["grads"][name], np.asarray(jb["parties"]["oracle32"]["grads"][name], np.float64)
+                    e_ = float(np.abs(ge_ - go_).max() / max(float(np.abs(go_).max()), 1e-30))
+                    if e_ > worst_e:
+                        worst_e, worst_t = e_, f"task {jb['task']}: {name}"
+            arb_ok = worst_e <= 1e-2
+            parity = {"tasks_checked": int(m), "tasks_grouped_in_the_launches": len(local), "max_rel": float(rel.max()), "rtol": PARITY_RTOL,
+                      "grad_tensors": list(grad_samples), "grad_pass": bool(arb_ok), "arbiter_error": arb_error,
+                      "grad_gate": "FALLBACK (the float64 arbiter could not run): max |engine - oracle32| <= 1e-2 * max |oracle32| per sampled tensor, no kink allowance",
+                      "grad_max_rel_vs_oracle32": worst_e, "grad_worst": worst_t}
         if not (rel.max() <= PARITY_RTOL) or not arb_ok:
             raise SystemExit(f"bench.py: parity check of the timed configuration failed: {parity}")
     eng.close()

@@ -33,9 +33,9 @@ GATE_FACTOR = 3.0
 GATE_FLOOR = 1e-3
 L1_EPS = 1e-4
 RELU_EPS = 1e-6          # reported: units this close to zero in float64 (the count the fp32 oracle's KINK_LOG uses)
-RELU_BAND = 5e-5         # candidates for a flip: an fp32 forward after five inner steps agrees with float64 to ~2e-5 (mel), so a unit whose float64
-                         # pre-activation is inside this band can sit on the other side of zero in a correct fp32 implementation
-MAX_PRICED = 48          # candidates priced exactly per party (the best by the screening score <residual, contribution>)
+RELU_BAND = 1e-4         # candidates for a flip: an fp32 forward after five inner steps agrees with float64 to ~2e-5 (mel), so a unit whose float64
+                         # pre-activation is inside this band (5x that) can sit on the other side of zero in a correct fp32 implementation
+MAX_PRICED = 64          # candidates priced exactly per party (the best by the screening score <residual, contribution>)
 MAX_FLIPS = 32           # flips a party may be granted per task: "a handful" of ~1e7 units
 
 
