@@ -632,7 +632,7 @@ def roofline_of(rows, pmc_key=None):
     # committed separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (profiles/).
     traffic, traffic_src, mfma_busy = None, None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r05_pmc_hbm.json", "r04_pmc_hbm.json", "r03_pmc_hbm.json"):
+    for name in ("r06_pmc_hbm.json", "r05_pmc_hbm.json", "r04_pmc_hbm.json", "r03_pmc_hbm.json"):
         pmc_path = os.path.join(here, "profiles", name)
         if pmc_key is not None and os.path.exists(pmc_path):
             with open(pmc_path) as f:

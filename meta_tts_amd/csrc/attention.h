@@ -35,6 +35,10 @@ struct AttnFwdArgs {
     float* O; int ld_o;
     float scale;
     int dk;                          // head width: multiple of 8, <= 128
+#if defined(MTTS_ATTN_DIAG)
+    int diag;                        // diagnostic builds only (tools/attn_phases.sh; WRONG results, timing of the phases): bit 0 / 1 / 2 = skip phase A / B / C,
+                                     // bit 3 = every lane of phase A reads its chunk's FIRST key row (one cache line per load instruction), bit 4 = no score stores
+#endif
 };
 
 constexpr int kAttnQ = 32;           // query rows per workgroup
@@ -62,6 +66,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     const int nkc = (L + 31) / 32;                 // 32-key chunks
 
     // ---- phase A: S = scale * Q K^T
+#if defined(MTTS_ATTN_DIAG)
+    if (!(a.diag & 1))
+#endif
     {
         // the Q tile as A fragments: lane (row l31, half h) holds channels 8j + 4h .. + 3 of every step j (rows beyond the sequence repeat
         // its last row: their results are never stored)
@@ -69,7 +76,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
         float4 qf[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) qf[j] = ld4(qp + 8 * j);
+#if defined(MTTS_ATTN_DIAG)
+        const int kdiag = (a.diag & 8) ? 0 : 1;
+        auto kptr = [&](int c) { return Kg + (long long)(c * 32 + kdiag * l31 < L ? c * 32 + kdiag * l31 : L - 1) * a.ld_k + 4 * h; };
+#else
         auto kptr = [&](int c) { return Kg + (long long)(c * 32 + l31 < L ? c * 32 + l31 : L - 1) * a.ld_k + 4 * h; };
+#endif
 #if defined(MTTS_EMU)
         for (int c = wave; c < nkc; c += 4) {
             const float* kp = kptr(c) - 4 * h;
@@ -107,6 +119,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j].w, kc[j].w, acc, 0, 0, 0);
             }
             const int col = c * 32 + l31;
+#if defined(MTTS_ATTN_DIAG)
+            if (a.diag & 16) { if (acc[0] == 12345.678f) Ss[col] = acc[0]; return; }
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) Ss[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + col] = acc[r] * a.scale;
         };
@@ -120,6 +135,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
 
     // ---- phase B: row softmax over the L valid keys; P -> HBM once, and kept in LDS (columns L .. 32 * nkc zeroed for phase C).
     // A wavefront owns 8 rows and walks them 4 at a time (four independent reduction chains per pass over the LDS row).
+#if defined(MTTS_ATTN_DIAG)
+    if (!(a.diag & 2))
+#endif
     for (int rg = 0; rg < kAttnQ / 4; rg += 4) {
         const int row0 = wave * (kAttnQ / 4) + rg;
         if (q0 + row0 >= L) break;   // (wave-uniform)
@@ -151,6 +169,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     __syncthreads();
 
     // ---- phase C: O = P V; this wavefront's 32 output columns
+#if defined(MTTS_ATTN_DIAG)
+    if (a.diag & 4) return;
+#endif
     if (32 * wave >= dk) return;
     const int ocol = 32 * wave + l31 < dk ? 32 * wave + l31 : dk - 1;
     f32x16 acc;

@@ -1575,6 +1575,9 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             fa.Q = fa.K = fa.V = b.qkv.p; fa.ld_q = fa.ld_k = fa.ld_v = 3 * d;
             fa.P = b.P.p; fa.O = b.O.p; fa.ld_o = d;
             fa.scale = 1.f / sqrtf((float)dk); fa.dk = dk;
+#if defined(MTTS_ATTN_DIAG)
+            fa.diag = 0;
+#endif
             GemmProfiler& prof = gx.prof;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (prof.enabled) { e0 = prof.get(); e1 = prof.get(); hipEventRecord(e0, stream); }

@@ -265,7 +265,7 @@ def synth_task_worker(job: dict) -> dict:
         masks = [DropoutMasks(plan_seed(int(job["dropout_seed"]), k + 1), int(job.get("group_index", j)), probs) for k in range(int(job["steps"]) + 1)]
     rep = arbitrate_task(synth.make_params(dims, 0, weight_scale=float(job["weight_scale"])), synth.make_buffers(dims), sup, qry, modules=job["modules"],
                          n_head=(dims.enc_heads, dims.dec_heads), max_seq_len=dims.max_seq_len, steps=int(job["steps"]), lr=float(job["lr"]), masks=masks,
-                         names=list(job["names"]), parties=job["parties"], second_order=bool(job.get("second_order", False)))
+                         names=list(job["names"]), parties=job["parties"], second_order=bool(job.get("second_order", False)), explain=bool(job.get("explain", True)))
     rep["task"] = j
     return rep
 

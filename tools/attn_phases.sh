@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"; OUT=gpurun_out/${1:-r06attn}; mkdir -p $OUT
 export MTTS_PROBE_LIB=$R/tools/libmtts_diag.so
 cd /tmp
 for shape in "421 80" "589 10" "128 80"; do
-  for mask in 0 1 2 4 3 5 6 7; do
+  for mask in 0 1 2 4 3 5 6 7 14 22 30; do
     rm -rf /tmp/attn_prof; MTTS_ATTN_DIAG_MASK=$mask rocprofv3 --kernel-trace --stats -d /tmp/attn_prof -o t -- python $R/tools/attn_probe.py $shape 20 > /tmp/attn_prof.log 2>&1
     DB=$(find /tmp/attn_prof -name "*.db" | head -1)
     python - "$DB" "$shape" $mask <<'PY'

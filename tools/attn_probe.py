@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from meta_tts_amd import _lib  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.load(os.environ.get("MTTS_PROBE_LIB"))   # (a diagnostic build: tools/attn_phases.sh)
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 421
 n_mat = int(sys.argv[2]) if len(sys.argv) > 2 else 80
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20

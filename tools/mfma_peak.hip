@@ -51,6 +51,9 @@ static void run(int wgs_per_cu, int iters) {
 
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 200000;
+    run<1>(1, iters);      // ONE dependent chain per wave (what a 32 x 32 output tile per wave is: attention.h phases A / C), 1 / 2 / 4 waves per SIMD
+    run<1>(2, iters / 2);
+    run<1>(4, iters / 4);
     run<2>(1, iters);      // one wave per SIMD, two dependent chains: 2 x 64-cycle MFMAs back to back (issue-bound check)
     run<4>(1, iters);
     run<4>(2, iters / 2);  // two waves per SIMD

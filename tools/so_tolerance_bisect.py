@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""the second-order gradient of the encoder's q projection (the smallest signal of the sampled set) was 9.4e-3 off the fp32 oracle on task 5
+after round 5's kernel / placement changes (<= 5e-3 before).  Is that a precision regression of one arm, or summation-order noise?  Per arm (child process:
+the switches are read once) the 8-task grouped second-order meta-gradient, error of task 5's sampled tensors against (a) the fp32 oracle's double backward
+and (b) a FLOAT64 evaluation of the same task (oracle/arbiter.py) — which also says how far the fp32 ORACLE is from float64.
+usage: so_tolerance_bisect.py            (parent)      |      so_tolerance_bisect.py --child OUT.npz"""
+import json, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+TASK, LR, SCALE = 5, 0.001, 0.5
+NAMES = ["encoder.layer_stack.0.slf_attn.w_qs.weight", "decoder.layer_stack.0.slf_attn.w_qs.weight", "mel_linear.weight", "postnet.convolutions.2.0.conv.weight",
+         "decoder.layer_stack.3.pos_ffn.w_1.weight"]
+ARMS = ["BASE", "MTTS_KLOOP=0", "MTTS_GLDS=1", "MTTS_UPD_OVERLAP=0", "MTTS_ATTN_SORT=0", "MTTS_FUSED_ATTN=0", "MTTS_XCD_SCHED=0", "MTTS_SO_KEEP_ACT=0 MTTS_SO_KEEP_GRAD=0"]
+
+
+def child(out):
+    from meta_tts_amd import synth
+    from meta_tts_amd.config import ModelDims, default_algorithm_config
+    from meta_tts_amd.engine import Engine
+    dims, mods = ModelDims(), default_algorithm_config()["adapt"]["modules"]
+    tasks = [synth.make_task(j) for j in range(8)]
+    eng = Engine(dims, adapt_modules=mods, max_tasks=8, max_B=5, max_S=80, max_T=max(max(s[8], q[8]) for s, q in tasks))
+    eng.load_params(synth.make_params(dims, 0, weight_scale=SCALE))
+    eng.set_batches(0, [t[0] for t in tasks]); eng.set_batches(1, [t[1] for t in tasks], spk_from=[t[0] for t in tasks], average_spk=True)
+    eng.meta_grad(5, LR, 1.0, second_order=True)
+    o = eng.outputs(1, TASK)
+    np.savez(out, mel=o["mel"], mel_post=o["mel_post"], **{n: eng.export(n, 2, TASK) for n in NAMES})
+    eng.close()
+
+
+def main():
+    import torch
+    torch.set_num_threads(16)
+    from oracle_util import O, heads, synth, torch_buffers, torch_params
+    from oracle import arbiter as ARB
+    from meta_tts_amd.config import ModelDims, default_algorithm_config
+    dims, mods = ModelDims(), default_algorithm_config()["adapt"]["modules"]
+    sup, qry = synth.make_task(TASK)
+    p = torch_params(dims, requires_grad=True, weight_scale=SCALE)
+    ql, _, _, qp = O.maml_task(p, torch_buffers(dims), O.to_torch_batch(sup), O.to_torch_batch(qry), steps=5, lr=LR, second_order=True, modules=mods, n_head=heads(dims))
+    gs = torch.autograd.grad(ql[0], [p[n] for n in NAMES])
+    o32 = {"grads": {n: g.numpy() for n, g in zip(NAMES, gs)}, "mel": qp[0].detach().numpy(), "mel_post": qp[1].detach().numpy()}
+    rows = []
+    for arm in ARMS:
+        env = dict(os.environ)
+        for kv in arm.split():
+            if "=" in kv:
+                k, v = kv.split("=", 1); env[k] = v
+        out = f"/tmp/so_bisect_{len(rows)}.npz"
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", out], env=env, capture_output=True, text=True)
+        if r.returncode != 0:
+            rows.append({"arm": arm, "error": r.stderr[-300:]}); continue
+        z = np.load(out)
+        eng = {"grads": {n: z[n] for n in NAMES}, "mel": z["mel"], "mel_post": z["mel_post"]}
+        vs32 = {n: float(np.abs(z[n] - o32["grads"][n]).max() / np.abs(o32["grads"][n]).max()) for n in NAMES}
+        rows.append({"arm": arm, "vs_oracle32": vs32, "engine": eng})
+    # float64 second-order evaluation of the task once; every arm and the fp32 oracle against it
+    rep = ARB.synth_task_worker(dict(task=TASK, threads=16, dropout_seed=None, steps=5, lr=LR, weight_scale=SCALE, modules=mods, names=NAMES, second_order=True, explain=False,   # (raw / L1-sign errors only: pricing ReLU units through the second-order graph for nine parties takes tens of minutes)
+                                     parties={**{f"arm{i}": r["engine"] for i, r in enumerate(rows) if "engine" in r}, "engine": rows[0]["engine"], "oracle32": o32}))
+    print("| arm | " + " | ".join(n.split(".")[0][:3] + "." + n.split(".")[-2][:6] + " vs o32 / vs f64" for n in NAMES) + " |")
+    print("|---|" + "---|" * len(NAMES))
+    for i, r in enumerate(rows):
+        if "engine" not in r:
+            print(f"| {r['arm']} | ERROR {r['error'][:80]} |"); continue
+        print(f"| {r['arm']} | " + " | ".join(f"{r['vs_oracle32'][n]:.2e} / {rep['tensors'][n][f'arm{i}']['raw']:.2e}" for n in NAMES) + " |")
+    print("| fp32 oracle vs float64 | " + " | ".join(f"{rep['tensors'][n]['oracle32']['raw']:.2e}" for n in NAMES) + " |")
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--child":
+        child(sys.argv[2])
+    else:
+        main()
