@@ -78,3 +78,13 @@ def test_emulate_world_reports_the_emulated_share():
     d = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")][0]
     assert d["n_gpus"] == 1 and d["emulated_world"] == 8 and d["config"]["tasks_per_gpu"] == 1 and d["roofline"]["tasks_in_the_launches"] == 1
     assert d["replicas"] is None and d["outer_gradient_vs_single_handle"] is None
+
+
+def test_replica_check_bites():
+    """The self-verification is not decorative: one float of one rank's weights off by 1e-6 after the timed steps and the run refuses to print a line."""
+    env = _env()
+    env["MTTS_SELFTEST_BREAK_REPLICA"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-emu", "--steps", "1", "--warmup", "0", "--no-second-order",
+                          "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode != 0
+    assert "replicas diverged" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
