@@ -1459,7 +1459,8 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
         int S = 1;
         const int nch = (gemm_keff(p.g) + 15) / 16;
         constexpr double ratio = 1.5;
-        if (small_batch && T == 64 && !p.g.table && !p.g.colsum && !p.g.ln.y && nch > per_cu / ratio) {
+        static const int split_on = [] { const char* e = getenv("MTTS_BATCH_SPLITK"); return e ? atoi(e) : 1; }();   // 0: never cut K (an arm of tools/so_tolerance_bisect.py)
+        if (split_on && small_batch && T == 64 && !p.g.table && !p.g.colsum && !p.g.ln.y && nch > per_cu / ratio) {
             S = (int)std::min<double>(std::min<double>(std::ceil(nch / std::max(per_cu / ratio, 1.0)), nch / 16), 8);
             const long long slots = (long long)tiles * p.groups;
             if (S >= 2 && ((ws_off + slots * S * 4096) > kSplitWsFloats || ctr_off + slots > kSplitCtrs - kLnCtrs)) S = 1;

@@ -114,18 +114,33 @@ def test_second_order_grouped_vs_oracle(tasks, which):
     p = torch_params(DIMS, requires_grad=True, weight_scale=SCALE)
     buf = torch_buffers(DIMS)
     names = SAMPLED + ["encoder.layer_stack.0.slf_attn.w_qs.weight"]   # second order reaches the (non-adapted) encoder through the fast weights
+    from oracle_util import check_grads
+    from oracle import arbiter as ARB
     for j in which:
         sup, qry = tasks[j]
-        ql, _, _, _ = O.maml_task(p, buf, O.to_torch_batch(sup), O.to_torch_batch(qry), steps=5, lr=LR, second_order=True, modules=MODS,
-                                  n_head=heads(DIMS))
+        ql, _, _, qp = O.maml_task(p, buf, O.to_torch_batch(sup), O.to_torch_batch(qry), steps=5, lr=LR, second_order=True, modules=MODS,
+                                   n_head=heads(DIMS))
         np.testing.assert_allclose(q[j], [float(x) for x in ql], rtol=2e-3)
         gs = torch.autograd.grad(ql[0], [p[n] for n in names])
-        for n, g in zip(names, gs):
-            got = eng.export(n, 2, j)
-            # (the encoder's q projection only sees the second-order terms — the smallest signal of the set, largest entry 3.5e-4 — and five
-            # reverse steps amplify summation-order differences most there: measured 9.4e-3 on task 5 in round 5, 5e-3 elsewhere)
-            tol = 1.5e-2 if n.startswith("encoder.") else 5e-3
-            assert np.abs(got - g.numpy()).max() <= tol * np.abs(g.numpy()).max(), (j, n)
+        ref = {n: g.numpy() for n, g in zip(names, gs)}
+        got = {n: eng.export(n, 2, j) for n in names}
+        out = eng.outputs(1, j)
+
+        def arbitrate(failing, j=j, got=got, ref=ref, out=out, qp=qp):
+            # float64 second-order evaluation of the task, L1 signs of the ambiguous mel / mel_post elements from each party's own query-pass output
+            # (explain=False: pricing single ReLU units through the five-step double backward costs minutes per unit)
+            return ARB.synth_task_worker(dict(task=j, threads=16, dropout_seed=None, steps=5, lr=LR, weight_scale=SCALE, modules=MODS, names=failing,
+                                              second_order=True, explain=False,
+                                              parties={"engine": {"grads": got, "mel": out["mel"], "mel_post": out["mel_post"]},
+                                                       "oracle32": {"grads": ref, "mel": qp[0].detach().numpy(), "mel_post": qp[1].detach().numpy()}}))
+        # profiles/r06_so_bisect.md: the 5e-4 ... 1.2e-3 round 5 measured on these tensors (task 5) is ONE flipped L1 sign of the query pass — with the
+        # engine's own signs it is 3e-6 ... 4e-5 of float64, the fp32 oracle's own distance.  So: tight against the fp32 oracle, or through the arbiter.
+        check_grads({n: (got[n], ref[n]) for n in names if not n.startswith("encoder.")}, 2e-3, arbitrate, label=f"task {j}")
+        for n in names:
+            if n.startswith("encoder."):
+                # the encoder's q projection only sees the second-order terms (the whole signal is scaled by the inner lr: largest entry 3.5e-4), so a
+                # kink unit of an INNER pass moves it at full relative size: 9.3e-3 on task 5 with one such unit, 8.7e-5 in an arm without it (same table)
+                assert np.abs(got[n] - ref[n]).max() <= 1.5e-2 * np.abs(ref[n]).max(), (j, n)
     eng.close()
 
 

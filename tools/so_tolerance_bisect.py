@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 TASK, LR, SCALE = 5, 0.001, 0.5
 NAMES = ["encoder.layer_stack.0.slf_attn.w_qs.weight", "decoder.layer_stack.0.slf_attn.w_qs.weight", "mel_linear.weight", "postnet.convolutions.2.0.conv.weight",
          "decoder.layer_stack.3.pos_ffn.w_1.weight"]
-ARMS = ["BASE", "MTTS_KLOOP=0", "MTTS_GLDS=1", "MTTS_UPD_OVERLAP=0", "MTTS_ATTN_SORT=0", "MTTS_FUSED_ATTN=0", "MTTS_XCD_SCHED=0", "MTTS_SO_KEEP_ACT=0 MTTS_SO_KEEP_GRAD=0"]
+ARMS = os.environ.get("BISECT_ARMS", "").split(";") if os.environ.get("BISECT_ARMS") else ["BASE", "MTTS_KLOOP=0", "MTTS_GLDS=1", "MTTS_UPD_OVERLAP=0", "MTTS_ATTN_SORT=0", "MTTS_FUSED_ATTN=0", "MTTS_XCD_SCHED=0", "MTTS_SO_KEEP_ACT=0 MTTS_SO_KEEP_GRAD=0", "MTTS_BATCH_SPLITK=0", "MTTS_SINGLE_MULTI=0"]
 
 
 def child(out):
@@ -58,13 +58,16 @@ def main():
     # float64 second-order evaluation of the task once; every arm and the fp32 oracle against it
     rep = ARB.synth_task_worker(dict(task=TASK, threads=16, dropout_seed=None, steps=5, lr=LR, weight_scale=SCALE, modules=mods, names=NAMES, second_order=True, explain=False,   # (raw / L1-sign errors only: pricing ReLU units through the second-order graph for nine parties takes tens of minutes)
                                      parties={**{f"arm{i}": r["engine"] for i, r in enumerate(rows) if "engine" in r}, "engine": rows[0]["engine"], "oracle32": o32}))
-    print("| arm | " + " | ".join(n.split(".")[0][:3] + "." + n.split(".")[-2][:6] + " vs o32 / vs f64" for n in NAMES) + " |")
-    print("|---|" + "---|" * len(NAMES))
+    print("| arm | " + " | ".join(n.split(".")[0][:3] + "." + n.split(".")[-2][:6] + " vs o32 / vs f64 raw / vs f64 with the party's own L1 signs" for n in NAMES) + " | L1 flips |")
+    print("|---|" + "---|" * (len(NAMES) + 1))
     for i, r in enumerate(rows):
         if "engine" not in r:
             print(f"| {r['arm']} | ERROR {r['error'][:80]} |"); continue
-        print(f"| {r['arm']} | " + " | ".join(f"{r['vs_oracle32'][n]:.2e} / {rep['tensors'][n][f'arm{i}']['raw']:.2e}" for n in NAMES) + " |")
-    print("| fp32 oracle vs float64 | " + " | ".join(f"{rep['tensors'][n]['oracle32']['raw']:.2e}" for n in NAMES) + " |")
+        print(f"| {r['arm']} | " + " | ".join(f"{r['vs_oracle32'][n]:.2e} / {rep['tensors'][n][f'arm{i}']['raw']:.2e} / {rep['tensors'][n][f'arm{i}']['l1']:.2e}" for n in NAMES)
+              + f" | {rep['parties'][f'arm{i}']['l1_flips']} |")
+    print("| fp32 oracle vs float64 | " + " | ".join(f"{rep['tensors'][n]['oracle32']['raw']:.2e} / {rep['tensors'][n]['oracle32']['l1']:.2e}" for n in NAMES)
+          + f" | {rep['parties']['oracle32']['l1_flips']} |")
+    print(f"(query pass of task {TASK}: {rep['l1_ambiguous_elements']} mel / mel_post elements within 1e-4 of their target, {rep['relu_ambiguous_units']} ReLU units within 1e-6 of zero in float64)")
 
 
 if __name__ == "__main__":
