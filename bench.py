@@ -897,6 +897,7 @@ def main():
         meta_step()
     dt = timed(args.steps, timed_ar=True)
     inner_upd = eng.inner_update_launches   # launches of the last timed inner step's SGD update (> 0: module by module behind its backward)
+    bucket_agreement = eng.allreduce_bucket_agreement if (n > 1 and outer is None) else None   # 1: the ranks agreed on the bucket table in mtts_comm_init
     ar_ms = None
     ar_launches = eng.allreduce_launches if (n > 1 and ar_overlapped[0]) else (1 if n > 1 else None)
     if ar_events:
@@ -1142,7 +1143,7 @@ def main():
                 "batch_ingest_ms_per_step": round(ingest_ms, 3),
                 "rccl_ranks": n if n > 1 else None, "allreduce_impl": ar_impl, "allreduce_ms_per_step": round(ar_ms, 3) if ar_ms is not None else None,
                 "allreduce_payload_mbytes": round(4e-6 * eng.n_total, 1) if n > 1 else None,
-                "allreduce_overlap": ({"on": bool(ar_overlapped[0]), "collectives_per_step": ar_launches,
+                "allreduce_overlap": ({"on": bool(ar_overlapped[0]), "collectives_per_step": ar_launches, "bucket_table_agreed_across_ranks": (bucket_agreement == 1) if bucket_agreement is not None else None,
                                        "what": "one ncclAllReduce per module bucket in backward-completion order (PostNet, decoder 5 + mel_linear .. decoder 0, variance adaptor, speaker table, "
                                                "encoder 3 .. 0 + word embedding) + the exchange tail, on a communication stream behind events of the main / weight-gradient streams; "
                                                "allreduce_ms_per_step = what mtts_allreduce_outer still waits for (exposed)"} if n > 1 else None),
