@@ -1413,6 +1413,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     mp.n = (int)b.q.size();
     int max_groups = 0;
     double flops = 0.0, rows = 0.0, bytes = 0.0;
+    int max_split = 1;   // (profiler record: the largest split factor among the launch's problems)
     // split-K for the long chains of an under-filled batch: a tile whose K-loop is longer than two thirds (swept: 1 / 1.25 .. 1 / 1.5)
     // of the whole batch's per-CU work would finish last on its own (single-task ranks: the k=9 dgrad tile, 576 slices, beside a
     // batch that is worth ~590 slices per CU), so it is cut into S workgroups (rendezvous in splitk_combine)
@@ -1468,6 +1469,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
                 if (!wsp) wsp = &cx.wsp;
                 if (wsp->ws) {
                     mp.g[i].splitk = S; mp.g[i].tiles_pg = tiles; mp.g[i].ws = wsp->ws + ws_off; mp.g[i].tile_ctr = wsp->ctr + ctr_off;
+                    max_split = std::max(max_split, S);
                     ws_off += slots * S * 4096; ctr_off += slots;
                 } else S = 1;
             } else S = 1;
@@ -1544,7 +1546,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     if (prof.enabled) {
         hipEventRecord(e1, stream);
         GemmProfiler::Rec rec{kind, flops, e0, e1};
-        rec.form = 3; rec.tile = bf16 ? 16000 + T : (glds ? 4064 : 64); rec.N = mp.n; rec.K = maxK; rec.groups = mp.start[mp.n]; rec.splitk = 1; rec.rows = rows; rec.bytes = bytes; rec.tag = prof.tag;  // multi: N = problems, K = longest K, groups = workgroups
+        rec.form = 3; rec.tile = bf16 ? 16000 + T : (glds ? 4064 : 64); rec.N = mp.n; rec.K = maxK; rec.groups = mp.start[mp.n]; rec.splitk = max_split; rec.rows = rows; rec.bytes = bytes; rec.tag = prof.tag;  // multi: N = problems, K = longest K, groups = workgroups
         prof.recs.push_back(rec);
     }
     b.q.clear();
