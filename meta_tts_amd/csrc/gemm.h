@@ -1143,6 +1143,7 @@ struct GemmCtx {
     bool bf16 = false;         // numerics mode of the owner: bf16 operand family (gemm_bf16.h) for every problem it can take
     const char* error = nullptr;   // sticky: a launch the launcher refused (the C ABI entry points turn it into an error return)
     bool flushing = false;     // gemm_batch_end is issuing the queue
+    bool prefer_bk16 = false;   // multi-problem launches of this context take the BK = 16 kernels (20 KB of LDS per workgroup instead of 37) whatever their K
     bool no_glds = false;   // never pick the LDS-DMA kernels (48 KB of LDS per workgroup: a side-stream launch would leave no LDS for the main stream's)
     int alloc_workspace() {
         if (wsp.ws) return 0;
@@ -1514,7 +1515,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     if (glds) { gemm_glds_multi_launch(mp, grid, stream, any_dual); kind = any_dual ? GK_GLDS_MULTI_DUAL : GK_GLDS_MULTI; }
     else
 #endif
-    if (bk32 && maxK >= 1024) {
+    if (bk32 && maxK >= 1024 && !cx.prefer_bk16) {
         int kl = gemm_kloop_variant();
         for (int i = 0; i < mp.n; ++i) kl = std::min(kl, gemm_kloop_for(mp.g[i], 32));
         if (any_dual) {

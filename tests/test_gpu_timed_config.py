@@ -158,3 +158,41 @@ def test_reference_fixtures_on_the_other_launch_paths(knobs):
                         os.path.join(ROOT, "tests", "test_gpu_c5_training.py")], env=env, capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and " failed" not in r.stdout and " error" not in r.stdout, r.stdout[-500:]
+
+
+def test_side_stream_bk16_kernels_are_bit_identical(tmp_path):
+    """Round 6: the weight-gradient side stream's launches take the BK = 16 kernels (smaller LDS footprint beside the critical stream's launches).  Another
+    K-slice length is the same k-ordered MFMA chain: a full-size single-task meta-gradient (the deferred regime, where the side stream carries every weight
+    gradient), first and second order, must come out bit for bit the same with MTTS_SIDE_BK16=0."""
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from meta_tts_amd import synth
+from meta_tts_amd.config import ModelDims, default_algorithm_config
+from meta_tts_amd.engine import Engine
+dims, mods = ModelDims(), default_algorithm_config()["adapt"]["modules"]
+sup, qry = synth.make_task(3)
+eng = Engine(dims, adapt_modules=mods, max_tasks=1, max_B=5, max_S=80, max_T=max(sup[8], qry[8]))
+eng.load_params(synth.make_params(dims, 0, weight_scale=0.5))
+eng.set_dropout(True, 9)
+out = {}
+for order in (1, 2):
+    eng.set_batches(0, [sup]); eng.set_batches(1, [qry], spk_from=[sup], average_spk=True)
+    q, s = eng.meta_grad(5, 1e-3, 1.0, second_order=(order == 2))
+    out["q%%d" %% order] = q
+    for n in ("decoder.layer_stack.0.pos_ffn.w_1.weight", "decoder.layer_stack.5.slf_attn.w_qs.weight", "postnet.convolutions.1.0.conv.weight",
+              "postnet.convolutions.3.0.conv.bias", "mel_linear.weight", "variance_adaptor.pitch_predictor.conv_layer.conv1d_2.conv.weight"):
+        out["g%%d_%%s" %% (order, n)] = eng.export(n, 1)
+np.savez(sys.argv[1], **out)
+""" % ROOT
+    res = []
+    for v in ("1", "0"):
+        env = dict(os.environ); env["MTTS_SIDE_BK16"] = v
+        path = str(tmp_path / f"bk16_{v}.npz")
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(dict(np.load(path)))
+    assert set(res[0]) == set(res[1]) and len(res[0]) == 14
+    for k in res[0]:
+        np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=k)
+    assert float(np.abs(res[0]["g1_postnet.convolutions.1.0.conv.weight"]).max()) > 0
