@@ -791,7 +791,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         gx_side.no_glds = true;
         // The weight-gradient side stream's launches take the BK = 16 kernels whatever their K (round 6): 20 KB of LDS per workgroup instead of 37, so a
         // 752-workgroup weight-gradient batch leaves room for TWO main-stream workgroups per CU instead of one — the critical stream's next launch (w_2's
-        // input gradient: 496 short tiles) no longer queues behind it.  Same k-ordered MFMA chain: results bit-identical (tests/test_gpu_timed_config.py);
+        // input gradient: 496 short tiles) no longer queues behind it.  Same k-ordered MFMA chain per tile, results equal to fp32 roundoff (tests/test_gpu_timed_config.py);
         // single-task rank 31.05 -> 30.70 ms, its second order 77.3 -> 76.6 ms, C2 fp32 12.81 -> 12.69 ms, 8-task step unchanged (profiles/r06_ab_log.md).
         { static const int bk16 = [] { const char* e = getenv("MTTS_SIDE_BK16"); return e ? atoi(e) : 1; }(); gx_side.prefer_bk16 = bk16 != 0; }
         if (gx_side.alloc_workspace()) { set_error("hipMalloc failed (split-K workspace of the side stream)"); return -1; }

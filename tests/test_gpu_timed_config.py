@@ -160,10 +160,11 @@ def test_reference_fixtures_on_the_other_launch_paths(knobs):
     assert " passed" in r.stdout and " failed" not in r.stdout and " error" not in r.stdout, r.stdout[-500:]
 
 
-def test_side_stream_bk16_kernels_are_bit_identical(tmp_path):
+def test_side_stream_bk16_kernels_change_results_by_roundoff_only(tmp_path):
     """Round 6: the weight-gradient side stream's launches take the BK = 16 kernels (smaller LDS footprint beside the critical stream's launches).  Another
-    K-slice length is the same k-ordered MFMA chain: a full-size single-task meta-gradient (the deferred regime, where the side stream carries every weight
-    gradient), first and second order, must come out bit for bit the same with MTTS_SIDE_BK16=0."""
+    K-slice length is the same k-ordered MFMA chain per tile; only the K-split boundaries of split problems move (chunks of 16 instead of 32): a full-size
+    single-task meta-gradient (the deferred regime, where the side stream carries every weight gradient), first and second order, agrees with
+    MTTS_SIDE_BK16=0 to fp32 roundoff on the losses (measured 1e-7) and to a kink unit's contribution on the gradients."""
     code = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
@@ -193,6 +194,13 @@ np.savez(sys.argv[1], **out)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(dict(np.load(path)))
     assert set(res[0]) == set(res[1]) and len(res[0]) == 14
+    scale = max(float(np.abs(v).max()) for k, v in res[1].items() if k.startswith("g"))
     for k in res[0]:
-        np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=k)
+        if k.startswith("q"):
+            np.testing.assert_allclose(res[0][k], res[1][k], rtol=2e-6, err_msg=k)
+        else:
+            # a roundoff-level change of an inner step's weight gradient (1e-7 on the fast weights) may put a ReLU / L1 unit of a later pass on the other
+            # side of its kink (profiles/r06_so_bisect.md, r06_unscaled_maml.md): bounded by such a unit's whole contribution, measured 1.1e-5 absolute
+            # on a tensor whose largest entry is 1e-3
+            assert float(np.abs(res[0][k] - res[1][k]).max()) <= 2e-2 * float(np.abs(res[1][k]).max()) + 1e-6 * scale, k   # (a conv bias in front of a BatchNorm: pure rounding noise)
     assert float(np.abs(res[0]["g1_postnet.convolutions.1.0.conv.weight"]).max()) > 0
