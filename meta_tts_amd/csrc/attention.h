@@ -35,6 +35,8 @@ struct AttnFwdArgs {
     float* O; int ld_o;
     float scale;
     int dk;                          // head width: multiple of 8, <= 128
+    int rot;                         // 1: the key chunks of phase A start at wavefront (blockIdx.x + blockIdx.z) & 3 instead of 0 — with nkc % 4 != 0 the first
+                                     // wavefronts carry one chunk more, and wavefront w of every workgroup sits on SIMD w: unrotated, SIMDs 0-1 of every CU carry the kernel
 #if defined(MTTS_ATTN_DIAG)
     int diag;                        // diagnostic builds only (tools/attn_phases.sh; WRONG results, timing of the phases): bit 0 / 1 / 2 = skip phase A / B / C,
                                      // bit 3 = every lane of phase A reads its chunk's FIRST key row (one cache line per load instruction), bit 4 = no score stores
@@ -42,6 +44,7 @@ struct AttnFwdArgs {
 };
 
 constexpr int kAttnQ = 32;           // query rows per workgroup
+inline int attn_rot_default() { static const int r = [] { const char* e = getenv("MTTS_ATTN_ROT"); return e ? atoi(e) : 0; }(); return r; }
 
 // NJ = dk / 8: a compile-time head width keeps every fragment load unconditional (a load behind a run-time "j < dk / 8" test, or a prefetch
 // behind "is there a next chunk", makes hipcc drain vmcnt(0) in front of the MFMAs that follow: the whole L2 latency exposed per chunk —
@@ -64,6 +67,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     float* Pg = a.P + sq.s_off;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int nkc = (L + 31) / 32;                 // 32-key chunks
+    const int wva = a.rot ? ((wave + (int)blockIdx.x + (int)blockIdx.z) & 3) : wave;   // this wavefront's first chunk of phase A
 
     // ---- phase A: S = scale * Q K^T
 #if defined(MTTS_ATTN_DIAG)
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
 #else
         float4 kf[2][NJ];
         {
-            const float* kp = kptr(wave);   // (clamped rows when this wavefront has no chunk at all)
+            const float* kp = kptr(wva);   // (clamped rows when this wavefront has no chunk at all)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) kf[0][j] = ld4(kp + 8 * j);
         }
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) Ss[((r & 3) + 8 * (r >> 2) + 4 * h) * LD + col] = acc[r] * a.scale;
         };
-        for (int c = wave; c < nkc; c += 8) {
+        for (int c = wva; c < nkc; c += 8) {
             chunk(c, kf[0], kf[1]);
             if (c + 4 < nkc) chunk(c + 4, kf[1], kf[0]);
         }

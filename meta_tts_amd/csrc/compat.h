@@ -101,6 +101,7 @@ __device__ __forceinline__ float4 drop4(const DropSpec& d, int z, int row, int C
 #define MTTS_UNIFORM(x) (x)
 #define MTTS_OPAQUE_TID() ((int)threadIdx.x)
 #define MTTS_WAIT_VMEM() ((void)0)
+#define MTTS_SETPRIO_HIGH() ((void)0)
 #define MTTS_FENCE_RELEASE_AGENT() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define MTTS_FENCE_ACQUIRE_AGENT() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define MTTS_ATOMIC_INC_AGENT(p) atomicAdd((p), 1)
@@ -112,6 +113,7 @@ __device__ __forceinline__ float4 drop4(const DropSpec& d, int z, int row, int C
 __device__ __forceinline__ int mtts_opaque_tid() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
 #define MTTS_OPAQUE_TID() mtts_opaque_tid()
 #define MTTS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define MTTS_SETPRIO_HIGH() __builtin_amdgcn_s_setprio(3)   // wavefront issue priority 3 (of 0..3) until the wavefront ends
 #define MTTS_FENCE_RELEASE_AGENT() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
 #define MTTS_FENCE_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define MTTS_ATOMIC_INC_AGENT(p) __hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)

@@ -173,6 +173,11 @@ public:
     // concurrently with the backward chain of the layers below, and are joined before anything reads the parameter gradients.
     struct LayerGrad { TS dc, gh, da, gqkv; float *part2, *part1; };   // part2 / part1: the 8-row gamma / beta partials LN2's / LN1's backward kernel leaves (folded on the side stream)
     std::vector<LayerGrad> encG, decG;
+    // Beyond the deferred regime (more tasks per launch than defer_tasks): the LayerNorm gamma / beta folds of the FFT blocks still leave the critical
+    // stream — every site keeps its backward kernel's partials in a buffer of its own ([cap_tasks][ln_chunks][3][d_model], 2 per layer) and the two
+    // colfinal launches of a layer go out on the side stream behind the layer's backward (fft_bwd: fold_part).  MTTS_LN_FOLD_SIDE=0: on the main stream.
+    float* arena_lnpart = nullptr;
+    std::vector<float*> encLnPart, decLnPart;   // [2 * layer + 0] = LN2's partials, [2 * layer + 1] = LN1's
     struct PredGrad { TS g2a, g2b; float *part2, *part1; };   // variance predictor: d(conv2 out), d(conv1 out), the gamma / beta partials of its two LayerNorms
     PredGrad predG[3];
     std::vector<TS> postG;               // per PostNet layer: gradient of the conv output (what its weight-gradient GEMM reads)
@@ -725,6 +730,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
     }
 
+    static bool ln_fold_side_on() { static const int on = [] { const char* e = getenv("MTTS_LN_FOLD_SIDE"); return e ? atoi(e) : 1; }(); return on != 0; }
     // buffers, stream and events of the deferred weight-gradient path (see LayerGrad)
     int init_defer() {
         constexpr int max_defer_tasks = 2;
@@ -763,6 +769,15 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         };
         mk(encG, cfg.enc_layers, capMp);
         mk(decG, cfg.dec_layers, capMf);
+        if (cap_tasks > defer_tasks && ln_fold_side_on()) {
+            const size_t pe = (((size_t)cap_tasks * ln_chunks(capMp) * 3 * d * sizeof(float)) + 255) & ~(size_t)255;
+            const size_t pd = (((size_t)cap_tasks * ln_chunks(capMf) * 3 * d * sizeof(float)) + 255) & ~(size_t)255;
+            HIP_CHECK(hipMalloc((void**)&arena_lnpart, 2 * (cfg.enc_layers * pe + cfg.dec_layers * pd) + 256));
+            char* c2 = (char*)arena_lnpart;
+            encLnPart.resize(2 * (size_t)cfg.enc_layers); decLnPart.resize(2 * (size_t)cfg.dec_layers);
+            for (auto& q : encLnPart) { q = (float*)c2; c2 += pe; }
+            for (auto& q : decLnPart) { q = (float*)c2; c2 += pd; }
+        }
         {   // the early predictor backward's buffers: every task of a launch (not only the deferred regime's)
             const long long ts = (long long)(capMp + 2 * G) * d;
             HIP_CHECK(hipMalloc((void**)&arena_pred, (size_t)(4 + kAhead) * cap_tasks * ts * sizeof(float)));
@@ -930,6 +945,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         gx_side2.release();
         gx_side.release();
         if (arena_defer) hipFree(arena_defer);
+        if (arena_lnpart) hipFree(arena_lnpart);
         if (arena_pred) hipFree(arena_pred);
         destroy_planes();
         if (col_partial_side) hipFree(col_partial_side);
@@ -1579,7 +1595,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             fa.tab_pv = (s == SP_P) ? p.enc_tab[TAB_PV] : p.dec_tab[TAB_PV];
             fa.Q = fa.K = fa.V = b.qkv.p; fa.ld_q = fa.ld_k = fa.ld_v = 3 * d;
             fa.P = b.P.p; fa.O = b.O.p; fa.ld_o = d;
-            fa.scale = 1.f / sqrtf((float)dk); fa.dk = dk;
+            fa.scale = 1.f / sqrtf((float)dk); fa.dk = dk; fa.rot = attn_rot_default();
 #if defined(MTTS_ATTN_DIAG)
             fa.diag = 0;
 #endif
@@ -1617,8 +1633,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // the shared scratch, with g0_in == K.g0 and K.dy1 == K.dO); dS is scratch
     // lg != null: deferred weight gradients (see LayerGrad) — the four gradients the layer's weight-gradient GEMMs read go to
     // lg's buffers, the GEMMs themselves to the side stream
+    // fold_part != null (and lg == null): the two LayerNorms' gamma / beta partials stay in fold_part[0] (LN2) / fold_part[1] (LN1) and are
+    // folded on the side stream behind this layer's backward instead of by two launches inside the critical chain
     void fft_bwd(const Pass& ps, Space s, int heads, const FFTP& P, LayerBuf& b, TS xin, TS g0_in, const LayerKeep& K,
-                 TS dS, LayerGrad* lg = nullptr) {
+                 TS dS, LayerGrad* lg = nullptr, float* const* fold_part = nullptr) {
         TagScope tag_scope(*this, s == SP_P ? 1 : 2);
         const Plan& p = *ps.pl;
         const int d = cfg.d_model, dk = d / heads, ff = cfg.d_ff;
@@ -1631,7 +1649,9 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         TS gm = (s == SP_P) ? gPm : gFm;                                   // masked copy feeds the conv branch, g1 the residual
         const DropSpec dd2 = drop_spec(ps, block_dropout(s), site_base + 1);
         // (bf16 mode: the plane of dc — whichever of the kernel's two outputs that is — and, below, gh's by conv2's epilogue)
-        ln_bwd(ps, s, g0_in, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0, df ? lg->dc : gm, dd2, df, df ? lg->part2 : nullptr, DropSpec(),
+        float* const fp2 = (!df && fold_part && side) ? fold_part[0] : nullptr;
+        float* const fp1 = (!df && fold_part && side) ? fold_part[1] : nullptr;
+        ln_bwd(ps, s, g0_in, b.z2, b.st2, P.ln2g, P.ln2b, vm, g1, d, 0, df ? lg->dc : gm, dd2, df, df ? lg->part2 : fp2, DropSpec(),
                (df || dd2.thr16) ? 2 : 1);
         TS dc = df ? lg->dc : (dd2.thr16 ? gm : g1);
         // conv2
@@ -1648,7 +1668,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         }
         // LN1 backward -> g0 = dz1
         const DropSpec dd1 = drop_spec(ps, block_dropout(s), site_base);
-        ln_bwd(ps, s, g1, b.z1, b.st1, P.ln1g, P.ln1b, vm, g0, d, 0, df ? lg->da : gm, dd1, df, df ? lg->part1 : nullptr);
+        ln_bwd(ps, s, g1, b.z1, b.st1, P.ln1g, P.ln1b, vm, g0, d, 0, df ? lg->da : gm, dd1, df, df ? lg->part1 : fp1);
         TS da = df ? lg->da : (dd1.thr16 ? gm : g0);
         // fc
         {
@@ -1693,6 +1713,10 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             ln_param_grads_side(ps, s, lg->part2, P.ln2g, P.ln2b, d);
             ln_param_grads_side(ps, s, lg->part1, P.ln1g, P.ln1b, d);
             defer_live = true;
+        } else if (fp2) {
+            fork_side();
+            ln_param_grads_side(ps, s, fp2, P.ln2g, P.ln2b, d);
+            ln_param_grads_side(ps, s, fp1, P.ln1g, P.ln1b, d);
         }
     }
     // weight gradients may be deferred to the side stream for this plan (under-filled launches; the bias
@@ -1924,7 +1948,15 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     void module_done(int idx) { ar_ready(idx); upd_ready(idx); }
 
     // kernel-family choice of the pass's main-stream GEMM launches (gemm.h: gemm_glds_mode): the LDS-DMA family only when MTTS_GLDS=1 asks for it
-    void set_regime(const Plan& p) { (void)p; gx.no_glds = gemm_glds_mode() == 0; }
+    // per pass: the LDS-DMA family switch, and the critical stream's wavefront priority — in the deferred regime (weight gradients, run-ahead and
+    // predictors on side streams beside an under-filled critical chain) the main stream's GEMM wavefronts issue at priority 3 (s_setprio), the
+    // side streams' at the default 0: single-task rank 30.89 -> 30.39 ms, 8-task step unchanged with or without (profiles/r06_ab_log.md).
+    // MTTS_MAIN_PRIO=0: never; 2: every regime.
+    void set_regime(const Plan& p) {
+        gx.no_glds = gemm_glds_mode() == 0;
+        static const int mp = [] { const char* e = getenv("MTTS_MAIN_PRIO"); return e ? atoi(e) : 1; }();
+        gx.wave_prio = (mp == 2 || (mp == 1 && defer_ok(p))) ? 1 : 0;
+    }
 
     // everything enqueued on the main stream so far happens before what is enqueued on the side stream next
     void fork_side() {
@@ -2464,7 +2496,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             TS xin = l == 0 ? dec_in : decB[l - 1].y2;
             site_base = 64 + 2 * l;
             fft_bwd(ps, SP_F, cfg.dec_heads, decP[l], decB[l], xin, l == cfg.dec_layers - 1 ? K.dec_top : K.dec[l + 1].g0, K.dec[l], dSf,
-                    defer_ok(p) ? &decG[l] : nullptr);
+                    defer_ok(p) ? &decG[l] : nullptr, decLnPart.empty() ? nullptr : &decLnPart[2 * (size_t)l]);
             module_done(ar_idx_dec(l));   // (overlapped exchange: PostNet, mel_linear and the decoder layers down to l are complete)
         }
         const TS gF0 = cfg.dec_layers ? K.dec[0].g0 : K.dec_top;   // gradient of the decoder input
@@ -2543,7 +2575,8 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
         for (int l = cfg.enc_layers - 1; l >= 0; --l) {
             TS xin = l == 0 ? emb_out : encB[l - 1].y2;
             site_base = 2 * l;
-            fft_bwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], xin, gP0, LayerKeep{gP0, gPh, gP1, gP1, gPqkv}, dSp, defer_ok(p) ? &encG[l] : nullptr);
+            fft_bwd(ps, SP_P, cfg.enc_heads, encP[l], encB[l], xin, gP0, LayerKeep{gP0, gPh, gP1, gP1, gPqkv}, dSp, defer_ok(p) ? &encG[l] : nullptr,
+                    encLnPart.empty() ? nullptr : &encLnPart[2 * (size_t)l]);
             if (l > 0) module_done(ar_idx_enc(l));   // (layer 0's bucket also holds the word embedding, below)
         }
         // word embedding (padding row 0 keeps a zero gradient); p_tok is 0 on invalid rows, and

@@ -215,6 +215,10 @@ struct GemmArgs {
     // launcher to build `xs`; never dereferenced on the device.
     const int* host_dims = nullptr;
     XcdSched xs;
+    // > 0: the launch's wavefronts raise their issue priority (s_setprio 3) — set by the launcher from GemmCtx::wave_prio for the launches of
+    // the CRITICAL stream of a multi-stream step, so that on a SIMD they share with a side stream's wavefronts (priority 0) the critical
+    // chain's MFMAs / LDS reads issue first and the side work takes the slots the chain leaves (speed only: never changes a result)
+    int wave_prio = 0;
 };
 // K-loop length of a problem for the launch heuristics (both sources of a dual-source problem)
 inline int gemm_keff(const GemmArgs& g) { return g.A2 ? 2 * g.K : g.K; }
@@ -927,6 +931,7 @@ template <int FORM, int BM, int BN, int BK, bool PIPE, int WGM = 2, int WGN = 2,
 __device__ __forceinline__ void gemm_f32_body(const GemmArgs& g, int z, int bxs, float* smem) {
     constexpr int NTH = 64 * WGM * WGN;
     constexpr int TM = (BM / WGM) / 32, TN = (BN / WGN) / 32;
+    if (g.wave_prio > 0) MTTS_SETPRIO_HIGH();
     const GemmProb pr = gemm_resolve(g, z);
     const bool has_cs = gemm_has_colsum<FORM>(g);
     const int tiles_nc = (pr.N + BN - 1) / BN, tiles_n = tiles_nc + (has_cs ? 1 : 0), tiles_m = (pr.M + BM - 1) / BM;
@@ -1144,6 +1149,7 @@ struct GemmCtx {
     const char* error = nullptr;   // sticky: a launch the launcher refused (the C ABI entry points turn it into an error return)
     bool flushing = false;     // gemm_batch_end is issuing the queue
     bool prefer_bk16 = false;   // multi-problem launches of this context take the BK = 16 kernels (20 KB of LDS per workgroup instead of 37) whatever their K
+    int wave_prio = 0;      // GemmArgs::wave_prio of every launch of this context (the engine sets it on the critical stream's context while side streams carry work)
     bool no_glds = false;   // never pick the LDS-DMA kernels (48 KB of LDS per workgroup: a side-stream launch would leave no LDS for the main stream's)
     int alloc_workspace() {
         if (wsp.ws) return 0;
@@ -1255,6 +1261,7 @@ inline void gemm_launch(GemmCtx& cx, int form, const GemmArgs& g_in, int max_M, 
     if (max_M <= 0 || max_N <= 0 || groups <= 0) return;
     GemmArgs g = g_in;
     g.swizzle = gemm_xcd_swizzle();
+    g.wave_prio = cx.wave_prio;
     // bf16 planes: kept only where the plane-staged K-loop will run (bf16 mode, an NT problem it can take); the twin of C in bf16 mode only
     if (!(cx.bf16 && gemm_bf16_ok(g) && gemm_bf16_planes_ok(form, g))) {
         if (g.plane_only) { cx.error = "plane-only GEMM problem outside the bf16 plane path"; return; }
@@ -1456,7 +1463,7 @@ inline void gemm_batch_end(GemmCtx& cx, hipStream_t stream) {
     for (int i = 0; i < mp.n; ++i) {
         const GemmPending& p = b.q[i];
         mp.form[i] = p.form; mp.groups[i] = p.groups; mp.g[i] = p.g;
-        mp.g[i].swizzle = 0; mp.g[i].splitk = 1;
+        mp.g[i].swizzle = 0; mp.g[i].splitk = 1; mp.g[i].wave_prio = cx.wave_prio;
         const int tiles = ((p.max_M + T - 1) / T) * gemm_tiles_n(p.g, p.max_N, T);
         int S = 1;
         const int nch = (gemm_keff(p.g) + 15) / 16;

@@ -131,6 +131,14 @@ def _compare_beyond_deferred_regime(tmp_path, gpu):
             np.testing.assert_allclose(a[k], b[k], rtol=2e-4, atol=1e-6 * max(1.0, float(np.abs(b[k]).max())), err_msg=k)
         else:
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    # round 6: the FFT blocks' LayerNorm gamma / beta folds on the side stream (per-site partial buffers; MTTS_LN_FOLD_SIDE=0: two colfinal launches
+    # per layer inside the critical chain, the shared scratch) and the critical stream's wavefront priority (MTTS_MAIN_PRIO=2: s_setprio 3 in every
+    # regime, 0: never) — the same kernels on the same floats in the same order: bit for bit, emulator AND hardware
+    c = _run(tmp_path, "fold_main", {"MTTS_LN_FOLD_SIDE": "0", "MTTS_MAIN_PRIO": "0"}, gpu, tasks=3)
+    d = _run(tmp_path, "prio_all", {"MTTS_MAIN_PRIO": "2"}, gpu, tasks=3)
+    for k in a:
+        np.testing.assert_array_equal(a[k], c[k], err_msg=f"MTTS_LN_FOLD_SIDE=0 {k}")
+        np.testing.assert_array_equal(a[k], d[k], err_msg=f"MTTS_MAIN_PRIO=2 {k}")
 
 
 def test_side_stream_paths_beyond_the_deferred_regime_emulator(tmp_path):
@@ -141,3 +149,8 @@ def test_side_stream_paths_beyond_the_deferred_regime_emulator(tmp_path):
 @pytest.mark.gpu
 def test_side_stream_paths_change_nothing_gpu(tmp_path):
     _compare(tmp_path, True)
+
+
+@pytest.mark.gpu
+def test_side_stream_paths_beyond_the_deferred_regime_gpu(tmp_path):
+    _compare_beyond_deferred_regime(tmp_path, True)
