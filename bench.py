@@ -637,7 +637,14 @@ def roofline_of(rows, pmc_key=None):
         if pmc_key is not None and os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 table = json.load(f).get(pmc_key, {})
-            k = table.get(dom[0]) or table.get(dom[0].split("<")[0])
+            # the profiler's name may carry trailing template arguments the launcher's kind name leaves out ("..., 4>" vs "..., 4, false>"): the
+            # exact symbol first, then the one symbol it prefixes, and only then the family aggregate (which averages over OTHER instantiations
+            # too — rounds 5's line quoted that aggregate for the dominant kernel: 288 MB instead of its own 437 MB per launch)
+            k = table.get(dom[0])
+            if not k and dom[0].endswith(">"):
+                pre = [v for kk, v in table.items() if kk.startswith(dom[0][:-1] + ",")]
+                k = pre[0] if len(pre) == 1 else None
+            k = k or table.get(dom[0].split("<")[0])
             if k:
                 traffic, traffic_src, mfma_busy = k.get("hbm_bytes_per_launch"), "profiles/" + name, k.get("mfma_busy_frac")
                 break
@@ -742,6 +749,8 @@ def main():
         if torch.cuda.device_count() < n:
             raise SystemExit(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPU(s) visible")
         torch.cuda.set_device(local_rank)
+        if os.environ.get("BENCH_STREAM_PRIO"):   # A/B runs: the step's critical stream as a torch stream of this priority (-1 = high)
+            torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["BENCH_STREAM_PRIO"])))
         if n > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             # (rank 0 runs its roofline / CPU-baseline / parity legs while the other ranks wait in a barrier: minutes, not the default 10 of the watchdog)
@@ -876,6 +885,8 @@ def main():
                          max_norm=trn["grad_clip_thresh"])
         step_no[0] += 1
 
+    enqueue_s = [0.0]
+
     def timed(k, order=None, timed_ar=False):
         dev_sync()
         if n > 1:
@@ -883,6 +894,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(k):
             meta_step(order, timed_ar)
+        enqueue_s[0] = time.perf_counter() - t0   # host time to ENQUEUE the k steps (the device may still be running them)
         dev_sync()
         if n > 1:
             dist.barrier()
@@ -896,6 +908,7 @@ def main():
     for _ in range(args.warmup):
         meta_step()
     dt = timed(args.steps, timed_ar=True)
+    host_enqueue_ms = 1e3 * enqueue_s[0] / args.steps   # when this approaches ms_per_step the step is bound by the host's launch rate, not by the device
     inner_upd = eng.inner_update_launches   # launches of the last timed inner step's SGD update (> 0: module by module behind its backward)
     bucket_agreement = eng.allreduce_bucket_agreement if (n > 1 and outer is None) else None   # 1: the ranks agreed on the bucket table in mtts_comm_init
     ar_ms = None
@@ -1141,6 +1154,7 @@ def main():
                                            if inner_upd > 0 else "one launch between the backward and the next forward"},
                 **({"emulated_world": part, "note": "diagnostic: rank-0 share of an emulated multi-rank run, no collective"} if part != n else {}),
                 "batch_ingest_ms_per_step": round(ingest_ms, 3),
+                "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
                 "rccl_ranks": n if n > 1 else None, "allreduce_impl": ar_impl, "allreduce_ms_per_step": round(ar_ms, 3) if ar_ms is not None else None,
                 "allreduce_payload_mbytes": round(4e-6 * eng.n_total, 1) if n > 1 else None,
                 "allreduce_overlap": ({"on": bool(ar_overlapped[0]), "collectives_per_step": ar_launches, "bucket_table_agreed_across_ranks": (bucket_agreement == 1) if bucket_agreement is not None else None,

@@ -35,6 +35,7 @@ struct AttnFwdArgs {
     float* O; int ld_o;
     float scale;
     int dk;                          // head width: multiple of 8, <= 128
+    int prio;                        // > 0: the wavefronts raise their issue priority (the critical stream's launches beside side-stream work; gemm.h: GemmArgs::wave_prio)
     int rot;                         // 1: the key chunks of phase A start at wavefront (blockIdx.x + blockIdx.z) & 3 instead of 0 — with nkc % 4 != 0 the first
                                      // wavefronts carry one chunk more, and wavefront w of every workgroup sits on SIMD w: unrotated, SIMDs 0-1 of every CU carry the kernel
 #if defined(MTTS_ATTN_DIAG)
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs a) {
     constexpr int dk = 8 * NJ;
     const int q0 = blockIdx.x * kAttnQ;
     if (q0 >= L) return;
+    if (a.prio > 0) MTTS_SETPRIO_HIGH();
     const GemmGroupDesc dq = a.tab_qk[z], dv = a.tab_pv[z];
     const float* Qg = a.Q + dq.a_off;
     const float* Kg = a.K + dq.b_off;

@@ -733,7 +733,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     static bool ln_fold_side_on() { static const int on = [] { const char* e = getenv("MTTS_LN_FOLD_SIDE"); return e ? atoi(e) : 1; }(); return on != 0; }
     // buffers, stream and events of the deferred weight-gradient path (see LayerGrad)
     int init_defer() {
-        constexpr int max_defer_tasks = 2;
+        static const int max_defer_tasks = [] { const char* e = getenv("MTTS_DEFER_TASKS"); return e ? atoi(e) : 2; }();   // (A/B runs: 4 / 8)
         defer_tasks = std::min(cap_tasks, max_defer_tasks);
         if (defer_tasks < 1) { defer_tasks = 0; return 0; }
         const int d = cfg.d_model;
@@ -1595,7 +1595,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
             fa.tab_pv = (s == SP_P) ? p.enc_tab[TAB_PV] : p.dec_tab[TAB_PV];
             fa.Q = fa.K = fa.V = b.qkv.p; fa.ld_q = fa.ld_k = fa.ld_v = 3 * d;
             fa.P = b.P.p; fa.O = b.O.p; fa.ld_o = d;
-            fa.scale = 1.f / sqrtf((float)dk); fa.dk = dk; fa.rot = attn_rot_default();
+            fa.scale = 1.f / sqrtf((float)dk); fa.dk = dk; fa.rot = attn_rot_default(); fa.prio = gx.wave_prio;
 #if defined(MTTS_ATTN_DIAG)
             fa.diag = 0;
 #endif
@@ -1723,7 +1723,7 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // gradient rides on the GEMM — the separate column reduction would run on the main stream)
     bool defer_ok(const Plan& p) const {
         static const int on = [] { const char* e = getenv("MTTS_DEFER_WGRAD"); return e ? atoi(e) : 1; }();
-        constexpr long long max_rows = 16000LL;   // beyond this the launches fill the chip and the wgrad + dgrad pairing wins (measured: 4 / 8 tasks per rank neutral / -1 %)
+        static const long long max_rows = [] { const char* e = getenv("MTTS_DEFER_MAX_ROWS"); return e ? atoll(e) : 16000LL; }();   // beyond this the launches fill the chip and the wgrad + dgrad pairing wins (measured: 4 / 8 tasks per rank neutral / -1 %)
         return on && defer_tasks > 0 && p.tasks <= defer_tasks && p.sumMf <= max_rows && side != nullptr;
     }
     // call-site class of the GEMM launches issued from here on (the profiler's per-launch records carry it: GemmProfiler::tag)

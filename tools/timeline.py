@@ -52,6 +52,24 @@ def main():
     print("|---|---:|---:|---:|")
     for n, (k, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
         print(f"| `{n}` | {k} | {ms:.2f} | {1e3 * ms / k:.1f} |")
+    # gaps INSIDE the busiest queue (the critical stream): idle time in front of each dispatch (end of the previous dispatch of the same queue ->
+    # its start), gaps above 200 us (step boundaries, host work) left out; attributed to the kernel that starts after the gap
+    mq = sorted(main_q, key=lambda r: r[1])
+    gap_by = collections.defaultdict(lambda: [0, 0.0])
+    gtot, gn, ghist = 0.0, 0, collections.Counter()
+    for a, b in zip(mq, mq[1:]):
+        g = (b[1] - a[2]) / 1e3
+        if 0 < g < 200:
+            n = b[0].replace("mtts::", "").replace("void ", "")[:50]
+            gap_by[n][0] += 1; gap_by[n][1] += g
+            gtot += g; gn += 1
+            ghist[min(int(g // 2) * 2, 20)] += 1
+    print(f"\nbusiest queue: {gn} gaps below 200 us between consecutive dispatches, total {gtot / 1e3:.2f} ms, mean {gtot / max(gn, 1):.2f} us; "
+          "histogram (us bucket: count) " + ", ".join(f"{k}{'+' if k == 20 else ''}: {v}" for k, v in sorted(ghist.items())))
+    print("| kernel that starts after the gap | gaps | total ms | mean us |")
+    print("|---|---:|---:|---:|")
+    for n, (k, us) in sorted(gap_by.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"| `{n}` | {k} | {us / 1e3:.2f} | {us / k:.1f} |")
     # duration histogram of the busiest queue's kernels
     edges = [5, 10, 20, 40, 80, 160, 320, 1e9]
     hist = [[0, 0.0] for _ in edges]
