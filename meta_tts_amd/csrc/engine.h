@@ -1950,12 +1950,14 @@ struct GemmBatchScope {  // RAII around gemm_batch_begin / gemm_batch_end (gemm.
     // kernel-family choice of the pass's main-stream GEMM launches (gemm.h: gemm_glds_mode): the LDS-DMA family only when MTTS_GLDS=1 asks for it
     // per pass: the LDS-DMA family switch, and the critical stream's wavefront priority — in the deferred regime (weight gradients, run-ahead and
     // predictors on side streams beside an under-filled critical chain) the main stream's GEMM wavefronts issue at priority 3 (s_setprio), the
-    // side streams' at the default 0: single-task rank 30.89 -> 30.39 ms, 8-task step unchanged with or without (profiles/r06_ab_log.md).
-    // MTTS_MAIN_PRIO=0: never; 2: every regime.
+    // side streams' at the default 0: single-task rank 30.89 -> 30.39 ms, two tasks per rank 47.2 -> 46.8 ms; the 8-task step is unchanged with or without,
+    // and a deferred launch of 6 750 frame rows (C2, batch 16) LOSES 1.1 % (fp32) / 2.4 % (bf16) — there the side stream's weight gradients are the
+    // tail the step waits for — so the priority is raised up to kPrioMaxRows frame rows only (profiles/r06_ab_log.md).  MTTS_MAIN_PRIO=0: never; 2: every regime.
+    static constexpr long long kPrioMaxRows = 5200;
     void set_regime(const Plan& p) {
         gx.no_glds = gemm_glds_mode() == 0;
         static const int mp = [] { const char* e = getenv("MTTS_MAIN_PRIO"); return e ? atoi(e) : 1; }();
-        gx.wave_prio = (mp == 2 || (mp == 1 && defer_ok(p))) ? 1 : 0;
+        gx.wave_prio = (mp == 2 || (mp == 1 && defer_ok(p) && p.sumMf <= kPrioMaxRows)) ? 1 : 0;
     }
 
     // everything enqueued on the main stream so far happens before what is enqueued on the side stream next

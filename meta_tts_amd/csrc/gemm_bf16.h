@@ -351,6 +351,7 @@ template <int FORM, int BM, int BN, int BK, int PF, bool DUAL = false>
 __device__ __forceinline__ void gemm_bf16_body(const GemmArgs& g, int z, int bxs, float* smem) {
     constexpr int WGM = 2, WGN = 2, NTH = 256;
     constexpr int TM = (BM / WGM) / 32, TN = (BN / WGN) / 32;
+    if (g.wave_prio > 0) MTTS_SETPRIO_HIGH();   // (the critical stream's launches beside side-stream work: GemmArgs::wave_prio)
     const GemmProb pr = gemm_resolve(g, z);
     const bool has_cs = gemm_has_colsum<FORM>(g);
     const int tiles_nc = (pr.N + BN - 1) / BN, tiles_n = tiles_nc + (has_cs ? 1 : 0), tiles_m = (pr.M + BM - 1) / BM;
