@@ -885,8 +885,6 @@ def main():
                          max_norm=trn["grad_clip_thresh"])
         step_no[0] += 1
 
-    enqueue_s = [0.0]
-
     def timed(k, order=None, timed_ar=False):
         dev_sync()
         if n > 1:
@@ -894,7 +892,6 @@ def main():
         t0 = time.perf_counter()
         for _ in range(k):
             meta_step(order, timed_ar)
-        enqueue_s[0] = time.perf_counter() - t0   # host time to ENQUEUE the k steps (the device may still be running them)
         dev_sync()
         if n > 1:
             dist.barrier()
@@ -908,7 +905,13 @@ def main():
     for _ in range(args.warmup):
         meta_step()
     dt = timed(args.steps, timed_ar=True)
-    host_enqueue_ms = 1e3 * enqueue_s[0] / args.steps   # when this approaches ms_per_step the step is bound by the host's launch rate, not by the device
+    # host time to ENQUEUE one meta-step from an idle stream (the device is still running it when the call returns): the host's own cost of the step's
+    # ~1 500-1 750 launches.  (Inside the timed loop the host runs ahead until the queue's ring is full, so its loop time there equals the device's.)
+    dev_sync()
+    t_h = time.perf_counter()
+    meta_step()
+    host_enqueue_ms = 1e3 * (time.perf_counter() - t_h)
+    dev_sync()
     inner_upd = eng.inner_update_launches   # launches of the last timed inner step's SGD update (> 0: module by module behind its backward)
     bucket_agreement = eng.allreduce_bucket_agreement if (n > 1 and outer is None) else None   # 1: the ranks agreed on the bucket table in mtts_comm_init
     ar_ms = None
@@ -1154,7 +1157,7 @@ def main():
                                            if inner_upd > 0 else "one launch between the backward and the next forward"},
                 **({"emulated_world": part, "note": "diagnostic: rank-0 share of an emulated multi-rank run, no collective"} if part != n else {}),
                 "batch_ingest_ms_per_step": round(ingest_ms, 3),
-                "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
+                "host_enqueue_ms_from_idle": round(host_enqueue_ms, 3),
                 "rccl_ranks": n if n > 1 else None, "allreduce_impl": ar_impl, "allreduce_ms_per_step": round(ar_ms, 3) if ar_ms is not None else None,
                 "allreduce_payload_mbytes": round(4e-6 * eng.n_total, 1) if n > 1 else None,
                 "allreduce_overlap": ({"on": bool(ar_overlapped[0]), "collectives_per_step": ar_launches, "bucket_table_agreed_across_ranks": (bucket_agreement == 1) if bucket_agreement is not None else None,

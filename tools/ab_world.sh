@@ -14,7 +14,7 @@ import json, sys
 try:
     d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
     so = d.get("second_order") or {}
-    print(f"  world {sys.argv[2]} ({8 // int(sys.argv[2])} tasks/rank): {d['ms_per_step']:.2f} ms (host enqueue {d.get('host_enqueue_ms_per_step')} ms)" + (f"  so {so['ms_per_step']:.2f} ms" if so else ""))
+    print(f"  world {sys.argv[2]} ({8 // int(sys.argv[2])} tasks/rank): {d['ms_per_step']:.2f} ms (host enqueue {d.get('host_enqueue_ms_from_idle')} ms)" + (f"  so {so['ms_per_step']:.2f} ms" if so else ""))
 except Exception as ex:
     print("  world", sys.argv[2], "ERROR", ex)
 P
