@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Timeline of a rocprofv3 --kernel-trace rocpd database: per-queue busy time, union busy time, idle gaps and the kernels that
 occupy the longest queue — what a latency-bound step (single-task rank) is waiting on.
+CAUTION for latency-bound steps: under rocprofv3 the host pays ~2x per launch — a single-task rank's step is 37 ms instead of 30 and the host, not the
+device, sets its pace (bench line: host_enqueue_ms_from_idle 34.9 ms under the profiler, 17.2 ms without) — so the waits this prints in front of the
+kernels that follow a burst of side-stream launches are the profiled host's, not the product's.
 Usage: timeline.py results.db [skip_fraction]   (the first skip_fraction of the trace — warm-up, engine creation — is ignored)"""
 import collections
 import sqlite3
@@ -66,6 +69,18 @@ def main():
             ghist[min(int(g // 2) * 2, 20)] += 1
     print(f"\nbusiest queue: {gn} gaps below 200 us between consecutive dispatches, total {gtot / 1e3:.2f} ms, mean {gtot / max(gn, 1):.2f} us; "
           "histogram (us bucket: count) " + ", ".join(f"{k}{'+' if k == 20 else ''}: {v}" for k, v in sorted(ghist.items())))
+    pair = collections.defaultdict(lambda: [0, 0.0])
+    for a, b in zip(mq, mq[1:]):
+        g = (b[1] - a[2]) / 1e3
+        if 15 <= g < 2000:
+            k = (a[0].replace("mtts::", "").replace("void ", "").split("(")[0][:40], b[0].replace("mtts::", "").replace("void ", "").split("(")[0][:40])
+            pair[k][0] += 1; pair[k][1] += g
+    print("\nbusiest queue: waits of 15 us .. 2 ms, by (kernel before -> kernel after):")
+    print("| before -> after | waits | total ms | mean us |")
+    print("|---|---:|---:|---:|")
+    for k, (n_, us) in sorted(pair.items(), key=lambda kv: -kv[1][1])[:16]:
+        print(f"| `{k[0]}` -> `{k[1]}` | {n_} | {us / 1e3:.2f} | {us / n_:.1f} |")
+    print()
     print("| kernel that starts after the gap | gaps | total ms | mean us |")
     print("|---|---:|---:|---:|")
     for n, (k, us) in sorted(gap_by.items(), key=lambda kv: -kv[1][1])[:14]:
