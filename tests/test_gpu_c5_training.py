@@ -396,17 +396,19 @@ def test_in_library_rccl_allreduce_world_size_one():
     eng.close()
 
 
-@pytest.mark.parametrize("kind", ["fo", "so", "plain"])
-def test_overlapped_bucketed_allreduce_world_size_one(kind):
+@pytest.mark.parametrize("kind,n_tasks", [("fo", 1), ("so", 1), ("plain", 1), ("fo", 4), ("so", 4)])
+def test_overlapped_bucketed_allreduce_world_size_one(kind, n_tasks):
     """mtts_arm_allreduce_overlap (include/mtts.h; main.py:30-38: DDP's bucketed all-reduce overlapping the backward) with real RCCL
     collectives on the real (asynchronous) streams, one rank: the gradient call sends one bucket per module in backward-completion
     order on the communication stream; outer gradient, reduced losses and the clip + Adam after it must equal the one-shot exchange
     bit for bit (a missing event wait would let a bucket leave before its gradients — or its task sum — were written).  Full-size
-    model, C3 task 0 (the single-task rank of the 8-GPU job: deferred weight gradients on the side stream)."""
-    sup, qry = synth.make_task(0)
+    model, C3 task 0 (the single-task rank of the 8-GPU job: deferred weight gradients on the side stream) — and C3 tasks 0-3 in one handle (the rank of
+    a 2-GPU job: beyond the deferred regime, where round 6 put the FFT blocks' LayerNorm parameter folds on the side stream — a bucket must wait for them too)."""
+    tasks = [synth.make_task(j) for j in range(n_tasks)]
+    sup, qry = [t[0] for t in tasks], [t[1] for t in tasks]
     dims = ModelDims()
     mods = default_algorithm_config()["adapt"]["modules"]
-    eng = Engine(dims, adapt_modules=mods, max_tasks=1, max_B=5, max_S=80, max_T=max(int(sup[8]), int(qry[8])))
+    eng = Engine(dims, adapt_modules=mods, max_tasks=n_tasks, max_B=5, max_S=80, max_T=max(max(int(s[8]), int(q[8])) for s, q in tasks))
     eng.comm_init(eng.comm_unique_id(), 0, 1)
     params = synth.make_params(dims, 0, weight_scale=0.5)
     names = list(eng.params)
@@ -415,8 +417,8 @@ def test_overlapped_bucketed_allreduce_world_size_one(kind):
         eng.load_params(params)
         eng.reset_optimizer()
         eng.set_dropout(True, 5)
-        eng.set_batches(0, [sup])
-        eng.set_batches(1, [qry], spk_from=[sup], average_spk=True)
+        eng.set_batches(0, sup)
+        eng.set_batches(1, qry, spk_from=sup, average_spk=True)
         armed = eng.arm_allreduce_overlap() if overlap else None
         if kind == "plain":
             eng.plain_grad(0, 0.125, fetch_losses=False)
