@@ -23,7 +23,9 @@ __global__ void ln_jvp_fwd_kernel(const int* meta, int mfield, const float* ta, 
                                   long long tres_ts, const float* zin, long long z_ts, const float* stats, long long st_ts,
                                   const float* gamma, long long par_ts, const float* tgamma, const float* tbeta,
                                   long long tpar_ts, const unsigned char* mask, long long mask_ts, float* tz_out,
-                                  long long tz_ts, float* ty, long long ty_ts, float* tstats, long long tst_ts, int C) {
+                                  long long tz_ts, float* ty, long long ty_ts, float* tstats, long long tst_ts, int C, DropSpec din) {
+    // din: dropout applied to ta on load (the tangent of `dropout(sublayer(x)) + residual`, SubLayers.py:54-55,90-91: the mask of the forward site —
+    // it used to be a dropout launch of its own in front of this kernel)
     ROW_PROLOGUE(mfield)
     const float* pa = ta + (long long)z * ta_ts + (long long)row * C;
     const float* pr = tres ? tres + (long long)z * tres_ts + (long long)row * C : nullptr;
@@ -38,6 +40,7 @@ __global__ void ln_jvp_fwd_kernel(const int* meta, int mfield, const float* ta, 
         tv[n] = zero4(); xh[n] = zero4();
         if (c >= C) continue;
         float4 t = ld4(pa + c);
+        if (din.thr16) t = drop4(din, z, row, C, c, t);
         if (pr) { const float4 r4 = ld4(pr + c); t = f4(t.x + r4.x, t.y + r4.y, t.z + r4.z, t.w + r4.w); }
         const float4 x = ld4(pz + c);
         tv[n] = t;
@@ -87,13 +90,20 @@ __global__ void ln_jvp_bwd_kernel(const int* meta, int mfield, const float* dy, 
                                   const float* tz, long long tz_ts, const float* tstats, long long tst_ts, const float* gamma,
                                   long long par_ts, const float* tgamma, long long tpar_ts, const unsigned char* mask,
                                   long long mask_ts, float* dz, long long dz_ts, float* tgz, long long tgz_ts, int C,
-                                  int relu_on_z) {
+                                  int relu_on_z, float* dz_drop, long long dzd_ts, float* tgz_drop, long long tgd_ts, DropSpec dd) {
+    // dz_drop / tgz_drop (optional, both or neither): dropout(dz) / dropout(tgz) with the mask of the forward site — the gradients entering the
+    // dropped branch, while dz / tgz continue along the residual path (two dropout launches behind this kernel until round 6)
     ROW_PROLOGUE(mfield)
     float* pdz = dz + (long long)z * dz_ts + (long long)row * C;
     float* ptg = tgz + (long long)z * tgz_ts + (long long)row * C;
+    float* pdd = dz_drop ? dz_drop + (long long)z * dzd_ts + (long long)row * C : nullptr;
+    float* ptd = dz_drop ? tgz_drop + (long long)z * tgd_ts + (long long)row * C : nullptr;
     const bool keep = mask ? (mask[(long long)z * mask_ts + row] != 0) : true;
     if (!keep) {
-        for (int c = lane * 4; c < C; c += 256) { st4(pdz + c, zero4()); st4(ptg + c, zero4()); }
+        for (int c = lane * 4; c < C; c += 256) {
+            st4(pdz + c, zero4()); st4(ptg + c, zero4());
+            if (pdd) { st4(pdd + c, zero4()); st4(ptd + c, zero4()); }
+        }
         return;
     }
     const float* pdy = dy + (long long)z * dy_ts + (long long)row * C;
@@ -145,6 +155,10 @@ __global__ void ln_jvp_bwd_kernel(const int* meta, int mfield, const float* dy, 
         }
         st4(pdz + c, f4(o1[0], o1[1], o1[2], o1[3]));
         st4(ptg + c, f4(o2[0], o2[1], o2[2], o2[3]));
+        if (pdd) {
+            st4(pdd + c, drop4(dd, z, row, C, c, f4(o1[0], o1[1], o1[2], o1[3])));
+            st4(ptd + c, drop4(dd, z, row, C, c, f4(o2[0], o2[1], o2[2], o2[3])));
+        }
     }
 }
 

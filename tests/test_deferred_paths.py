@@ -73,8 +73,10 @@ OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "M
 # dispatch order: bit-identical
 # MTTS_UPD_OVERLAP=0: the inner SGD step as ONE launch between the backward and the next forward instead of module by module on a stream of
 # its own behind the backward (engine.h: upd_ready, round 5) — the same kernel on the same floats: bit-identical
+# MTTS_SO_FUSE_DROP=0: second order — the tangent FFT blocks' dropout launches (two in front of the forward's LayerNorm tangents, four behind the backward's) as
+# launches of their own instead of riding in the LayerNorm tangent kernels (round 6) — the same masks on the same values: bit-identical
 KERNEL_ARMS = [{"MTTS_FUSED_ATTN": "0"}, {"MTTS_ENC_AHEAD_QUERY": "0"}, {"MTTS_PANEL_ORDER": "0"}, {"MTTS_PRED_EARLY": "0"}, {"MTTS_SO_DEFER_POST": "0"},
-               {"MTTS_LN_FUSE": "1"}, {"MTTS_UPD_OVERLAP": "0"}, {"MTTS_ATTN_SORT": "0"}]
+               {"MTTS_LN_FUSE": "1"}, {"MTTS_UPD_OVERLAP": "0"}, {"MTTS_ATTN_SORT": "0"}, {"MTTS_SO_FUSE_DROP": "0"}]
 
 
 def _compare(tmp_path, gpu):
@@ -107,7 +109,7 @@ def _compare(tmp_path, gpu):
             if k == "upd_launches":
                 # the default ran the inner SGD step module by module (speaker table + variance adaptor, 2 decoder layers, PostNet); the arm, in one pass
                 assert int(a[k]) >= 3 and int(d[k]) == (0 if "MTTS_UPD_OVERLAP" in arm else int(a[k])), (arm, a[k], d[k])
-            elif "MTTS_LN_FUSE" in arm or "MTTS_UPD_OVERLAP" in arm or "MTTS_ATTN_SORT" in arm:
+            elif "MTTS_LN_FUSE" in arm or "MTTS_UPD_OVERLAP" in arm or "MTTS_ATTN_SORT" in arm or "MTTS_SO_FUSE_DROP" in arm:
                 np.testing.assert_array_equal(a[k], d[k], err_msg=f"{arm} {k}")     # (emulator AND hardware: nothing is summed in another order)
             elif ("MTTS_ENC_AHEAD_QUERY" in arm or "MTTS_PANEL_ORDER" in arm or "MTTS_PRED_EARLY" in arm or "MTTS_SO_DEFER_POST" in arm) and not gpu:
                 np.testing.assert_array_equal(a[k], d[k], err_msg=f"{arm} {k}")     # (pure re-plumbing: bit-identical)
@@ -136,9 +138,11 @@ def _compare_beyond_deferred_regime(tmp_path, gpu):
     # regime, 0: never) — the same kernels on the same floats in the same order: bit for bit, emulator AND hardware
     c = _run(tmp_path, "fold_main", {"MTTS_LN_FOLD_SIDE": "0", "MTTS_MAIN_PRIO": "0"}, gpu, tasks=3)
     d = _run(tmp_path, "prio_all", {"MTTS_MAIN_PRIO": "2"}, gpu, tasks=3)
+    e = _run(tmp_path, "so_drop_launches", {"MTTS_SO_FUSE_DROP": "0"}, gpu, tasks=3)   # (the shared-scratch arm of the tangent blocks' masked copies)
     for k in a:
         np.testing.assert_array_equal(a[k], c[k], err_msg=f"MTTS_LN_FOLD_SIDE=0 {k}")
         np.testing.assert_array_equal(a[k], d[k], err_msg=f"MTTS_MAIN_PRIO=2 {k}")
+        np.testing.assert_array_equal(a[k], e[k], err_msg=f"MTTS_SO_FUSE_DROP=0 {k}")
 
 
 def test_side_stream_paths_beyond_the_deferred_regime_emulator(tmp_path):
