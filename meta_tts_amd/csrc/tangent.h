@@ -23,7 +23,8 @@ __global__ void ln_jvp_fwd_kernel(const int* meta, int mfield, const float* ta, 
                                   long long tres_ts, const float* zin, long long z_ts, const float* stats, long long st_ts,
                                   const float* gamma, long long par_ts, const float* tgamma, const float* tbeta,
                                   long long tpar_ts, const unsigned char* mask, long long mask_ts, float* tz_out,
-                                  long long tz_ts, float* ty, long long ty_ts, float* tstats, long long tst_ts, int C, DropSpec din) {
+                                  long long tz_ts, float* ty, long long ty_ts, float* tstats, long long tst_ts, int C, DropSpec din, DropSpec dout) {
+    // dout: dropout applied to ty before the store (the variance predictors' F.dropout sits BEHIND the LayerNorm, modules.py:222-235)
     // din: dropout applied to ta on load (the tangent of `dropout(sublayer(x)) + residual`, SubLayers.py:54-55,90-91: the mask of the forward site —
     // it used to be a dropout launch of its own in front of this kernel)
     ROW_PROLOGUE(mfield)
@@ -70,6 +71,7 @@ __global__ void ln_jvp_fwd_kernel(const int* meta, int mfield, const float* ta, 
             for (int k = 0; k < 4; ++k) r_[k] = tg_[k] * xh_[k] + g_[k] * rstd * (tv_[k] - m1 - xh_[k] * m2) + tb_[k];
             o = f4(r_[0], r_[1], r_[2], r_[3]);
         }
+        if (dout.thr16) o = drop4(dout, z, row, C, c, o);
         st4(po + c, o);
     }
     if (lane == 0) {
