@@ -92,7 +92,8 @@ __global__ void ln_jvp_bwd_kernel(const int* meta, int mfield, const float* dy, 
                                   const float* tz, long long tz_ts, const float* tstats, long long tst_ts, const float* gamma,
                                   long long par_ts, const float* tgamma, long long tpar_ts, const unsigned char* mask,
                                   long long mask_ts, float* dz, long long dz_ts, float* tgz, long long tgz_ts, int C,
-                                  int relu_on_z, float* dz_drop, long long dzd_ts, float* tgz_drop, long long tgd_ts, DropSpec dd) {
+                                  int relu_on_z, float* dz_drop, long long dzd_ts, float* tgz_drop, long long tgd_ts, DropSpec dd, DropSpec din) {
+    // din: dropout applied to dy and tgy on load (a dropout that sits BEHIND this LayerNorm in the forward: the variance predictors)
     // dz_drop / tgz_drop (optional, both or neither): dropout(dz) / dropout(tgz) with the mask of the forward site — the gradients entering the
     // dropped branch, while dz / tgz continue along the residual path (two dropout launches behind this kernel until round 6)
     ROW_PROLOGUE(mfield)
@@ -123,7 +124,9 @@ __global__ void ln_jvp_bwd_kernel(const int* meta, int mfield, const float* dy, 
     for (int n = 0; n < NV; ++n) {
         const int c = lane * 4 + 256 * n;
         if (c >= C) continue;
-        const float4 d4 = ld4(pdy + c), t4 = ld4(ptgy + c), x4 = ld4(pz + c), tz4 = ld4(ptz + c), g4 = ld4(g + c);
+        float4 d4 = ld4(pdy + c), t4 = ld4(ptgy + c);
+        const float4 x4 = ld4(pz + c), tz4 = ld4(ptz + c), g4 = ld4(g + c);
+        if (din.thr16) { d4 = drop4(din, z, row, C, c, d4); t4 = drop4(din, z, row, C, c, t4); }
         const float4 tg4 = tgm ? ld4(tgm + c) : zero4();
         const float d_[4] = {d4.x, d4.y, d4.z, d4.w}, t_[4] = {t4.x, t4.y, t4.z, t4.w}, x_[4] = {x4.x, x4.y, x4.z, x4.w};
         const float tz_[4] = {tz4.x, tz4.y, tz4.z, tz4.w}, g_[4] = {g4.x, g4.y, g4.z, g4.w}, tgm_[4] = {tg4.x, tg4.y, tg4.z, tg4.w};
