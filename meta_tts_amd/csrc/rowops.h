@@ -289,7 +289,7 @@ struct ColArgs {
     const float* Y2 = nullptr; long long y2_ts = 0;
     const float* stats2 = nullptr; long long st2_ts = 0;
     float yscale = 1.f;  // Y holds dropout(tanh(.)): y = Y * yscale with yscale = 1 - p (modes 3, 6)
-    DropSpec xdrop;      // mode 3: dropout applied to X (= dY) on load — the backward of the dropout behind the BatchNorm layer; mode 5: to X and X2 (both incoming gradients of a LayerNorm tangent backward)
+    DropSpec xdrop;      // mode 3: dropout applied to X (= dY) on load — the backward of the dropout behind the BatchNorm layer; modes 5 / 6: to X and X2 (both incoming gradients of a LayerNorm / BatchNorm tangent backward)
     int C = 0, mode = 0, do_tanh = 0, mfield = 0, accumulate = 0;
 };
 
@@ -368,6 +368,10 @@ __device__ __forceinline__ void col_body(const int* meta, const ColArgs& a, floa
                     }
                 } else {  // mode 6
                     float zz[4], dy[4], tc[4]; ldv(pz, m, zz); ldv(px2, m, dy); ldv(pz2, m, tc);
+                    if (a.xdrop.thr16) {   // the dropout behind the BatchNorm layer: its backward masks both incoming gradients on load (as mode 3 does for X)
+                        const float4 t0 = drop4(a.xdrop, z, m, C, c, make_float4(x[0], x[1], x[2], x[3])), t1 = drop4(a.xdrop, z, m, C, c, make_float4(dy[0], dy[1], dy[2], dy[3]));
+                        x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; dy[0] = t1.x; dy[1] = t1.y; dy[2] = t1.z; dy[3] = t1.w;
+                    }
                     float g[4], tg[4];
                     for (int k = 0; k < 4; ++k) { g[k] = dy[k]; tg[k] = x[k]; }
                     if (a.do_tanh) {

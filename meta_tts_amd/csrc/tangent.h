@@ -215,7 +215,8 @@ __global__ void bn_jvp_apply_kernel(const int* meta, const float* X, long long x
                                     long long tsum_ts, const float* gamma, long long par_ts, const float* tgamma,
                                     const float* tbeta, long long tpar_ts, const float* A, long long a_ts,
                                     const unsigned char* inrect, long long row_ts, int do_tanh, float* tA, long long ta_ts,
-                                    int C, float yscale) {
+                                    int C, float yscale, DropSpec dout) {
+    // dout: dropout applied to tA before the store (the mask of the layer's forward dropout; a dropout launch of its own until round 6)
     ROW_PROLOGUE(META_MR)
     float* po = tA + (long long)z * ta_ts + (long long)row * C;
     if (!inrect[(long long)z * row_ts + row]) { for (int c = lane * 4; c < C; c += 256) st4(po + c, zero4()); return; }
@@ -245,7 +246,9 @@ __global__ void bn_jvp_apply_kernel(const int* meta, const float* X, long long x
             if (do_tanh) { const float yy = a_[k] * yscale; ty *= (1.f - yy * yy); }
             o[k] = ty;
         }
-        st4(po + c, f4(o[0], o[1], o[2], o[3]));
+        float4 o4 = f4(o[0], o[1], o[2], o[3]);
+        if (dout.thr16) o4 = drop4(dout, z, row, C, c, o4);
+        st4(po + c, o4);
     }
 }
 
@@ -262,7 +265,8 @@ __global__ void bn_jvp_bwd_kernel(const int* meta, const float* dY, long long dy
                                   long long par_ts, const float* tgamma, long long tpar_ts, const float* dgamma,
                                   const float* dbeta, long long dg_ts, const float* tA0, const float* tA1, long long tA_ts,
                                   const unsigned char* inrect, long long row_ts, int do_tanh, float* dX, long long dx_ts,
-                                  float* tdX, long long tdx_ts, int C, float yscale) {
+                                  float* tdX, long long tdx_ts, int C, float yscale, DropSpec din) {
+    // din: the backward of the dropout behind the layer, applied to dY and tgY on load (two dropout launches in front of this kernel until round 6)
     ROW_PROLOGUE(META_MR)
     float* pdx = dX + (long long)z * dx_ts + (long long)row * C;
     float* ptd = tdX + (long long)z * tdx_ts + (long long)row * C;
@@ -283,7 +287,12 @@ __global__ void bn_jvp_bwd_kernel(const int* meta, const float* dY, long long dy
     for (int c = lane * 4; c < C; c += 256) {
         float dy_[4], tgy_[4], a_[4], ta_[4], x_[4], tx_[4], mu_[4], rs_[4], q1_[4], q0_[4], g_[4], tgm_[4], dg_[4], db_[4], a0_[4], a1_[4];
         auto L = [&](const float* p, float (&v)[4]) { const float4 t = ld4(p + c); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; };
-        L(pdy, dy_); L(ptgy, tgy_); L(pa, a_); L(pta, ta_); L(px, x_); L(ptx, tx_); L(st, mu_); L(st + C, rs_);
+        L(pdy, dy_); L(ptgy, tgy_);
+        if (din.thr16) {
+            const float4 t0 = drop4(din, z, row, C, c, f4(dy_[0], dy_[1], dy_[2], dy_[3])), t1 = drop4(din, z, row, C, c, f4(tgy_[0], tgy_[1], tgy_[2], tgy_[3]));
+            dy_[0] = t0.x; dy_[1] = t0.y; dy_[2] = t0.z; dy_[3] = t0.w; tgy_[0] = t1.x; tgy_[1] = t1.y; tgy_[2] = t1.z; tgy_[3] = t1.w;
+        }
+        L(pa, a_); L(pta, ta_); L(px, x_); L(ptx, tx_); L(st, mu_); L(st + C, rs_);
         L(s1, q1_); L(s0, q0_); L(g, g_); L(dg, dg_); L(db, db_); L(a0, a0_); L(a1, a1_);
         if (tgm) L(tgm, tgm_); else { tgm_[0] = tgm_[1] = tgm_[2] = tgm_[3] = 0.f; }
         float o0[4], o1[4];
