@@ -87,83 +87,115 @@ __global__ void ln_jvp_fwd_kernel(const int* meta, int mfield, const float* ta, 
 //   tg_z = -r m2 dz + r (tg - mean(tg) - t_xhat a2 - xhat (mean(tg xhat) + mean(g t_xhat)))
 // masked rows give 0 for both; relu_on_z multiplies both by [z > 0].
 template <int NV>
-__global__ void ln_jvp_bwd_kernel(const int* meta, int mfield, const float* dy, long long dy_ts, const float* tgy,
+__global__ __launch_bounds__(256) void ln_jvp_bwd_kernel(const int* meta, int mfield, const float* dy, long long dy_ts, const float* tgy,
                                   long long tgy_ts, const float* zin, long long z_ts, const float* stats, long long st_ts,
                                   const float* tz, long long tz_ts, const float* tstats, long long tst_ts, const float* gamma,
                                   long long par_ts, const float* tgamma, long long tpar_ts, const unsigned char* mask,
                                   long long mask_ts, float* dz, long long dz_ts, float* tgz, long long tgz_ts, int C,
-                                  int relu_on_z, float* dz_drop, long long dzd_ts, float* tgz_drop, long long tgd_ts, DropSpec dd, DropSpec din) {
+                                  int relu_on_z, float* dz_drop, long long dzd_ts, float* tgz_drop, long long tgd_ts, DropSpec dd, DropSpec din,
+                                  float* partial, int max_chunks) {
     // din: dropout applied to dy and tgy on load (a dropout that sits BEHIND this LayerNorm in the forward: the variance predictors)
     // dz_drop / tgz_drop (optional, both or neither): dropout(dz) / dropout(tgz) with the mask of the forward site — the gradients entering the
     // dropped branch, while dz / tgz continue along the residual path (two dropout launches behind this kernel until round 6)
-    ROW_PROLOGUE(mfield)
-    float* pdz = dz + (long long)z * dz_ts + (long long)row * C;
-    float* ptg = tgz + (long long)z * tgz_ts + (long long)row * C;
-    float* pdd = dz_drop ? dz_drop + (long long)z * dzd_ts + (long long)row * C : nullptr;
-    float* ptd = dz_drop ? tgz_drop + (long long)z * tgd_ts + (long long)row * C : nullptr;
-    const bool keep = mask ? (mask[(long long)z * mask_ts + row] != 0) : true;
-    if (!keep) {
-        for (int c = lane * 4; c < C; c += 256) {
-            st4(pdz + c, zero4()); st4(ptg + c, zero4());
-            if (pdd) { st4(pdd + c, zero4()); st4(ptd + c, zero4()); }
+    // partial (optional): stage 1 of hv(gamma) = sum_rows (tgy xhat + dy t_xhat) and hv(beta) = sum_rows tgy over the unmasked rows rides here —
+    // [task][chunk of kLnRows rows][3][C] (rows 0 / 1 used), folded by colfinal_kernel like the primal kernel's (layernorm_bwd_kernel) — instead of a
+    // reduction launch (ColArgs mode 5) that read the same five arrays again.  A workgroup = kLnRows rows, two per wavefront (launch: row2_grid).
+    __shared__ __attribute__((aligned(16))) float red[4][2][256 * NV];
+    const int z = blockIdx.z;
+    const int M_ = meta[z * META_STRIDE + mfield];
+    if ((int)blockIdx.x * kLnRows >= M_) return;                       // (whole workgroup)
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    float4 pg[NV], pb[NV];
+#pragma unroll
+    for (int n = 0; n < NV; ++n) { pg[n] = zero4(); pb[n] = zero4(); }
+    for (int q = 0; q < 2; ++q) {
+        const int row = (int)blockIdx.x * kLnRows + wave * 2 + q;
+        if (row >= M_) continue;                                         // (wave-uniform)
+        float* pdz = dz + (long long)z * dz_ts + (long long)row * C;
+        float* ptg = tgz + (long long)z * tgz_ts + (long long)row * C;
+        float* pdd = dz_drop ? dz_drop + (long long)z * dzd_ts + (long long)row * C : nullptr;
+        float* ptd = dz_drop ? tgz_drop + (long long)z * tgd_ts + (long long)row * C : nullptr;
+        const bool keep = mask ? (mask[(long long)z * mask_ts + row] != 0) : true;
+        if (!keep) {
+            for (int c = lane * 4; c < C; c += 256) {
+                st4(pdz + c, zero4()); st4(ptg + c, zero4());
+                if (pdd) { st4(pdd + c, zero4()); st4(ptd + c, zero4()); }
+            }
+            continue;
         }
-        return;
+        const float* pdy = dy + (long long)z * dy_ts + (long long)row * C;
+        const float* ptgy = tgy + (long long)z * tgy_ts + (long long)row * C;
+        const float* pz = zin + (long long)z * z_ts + (long long)row * C;
+        const float* ptz = tz + (long long)z * tz_ts + (long long)row * C;
+        const float* st = stats + (long long)z * st_ts + (long long)row * 2;
+        const float* ts = tstats + (long long)z * tst_ts + (long long)row * 2;
+        const float mean = st[0], rstd = st[1], m1 = ts[0], m2 = ts[1];
+        const float* g = gamma + (long long)z * par_ts;
+        const float* tgm = tgamma ? tgamma + (long long)z * tpar_ts : nullptr;
+        float gv[NV][4], tgv[NV][4], xh[NV][4], txh[NV][4], zz[NV][4];
+        float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int c = lane * 4 + 256 * n;
+            if (c >= C) continue;
+            float4 d4 = ld4(pdy + c), t4 = ld4(ptgy + c);
+            const float4 x4 = ld4(pz + c), tz4 = ld4(ptz + c), g4 = ld4(g + c);
+            if (din.thr16) { d4 = drop4(din, z, row, C, c, d4); t4 = drop4(din, z, row, C, c, t4); }
+            const float4 tg4 = tgm ? ld4(tgm + c) : zero4();
+            const float d_[4] = {d4.x, d4.y, d4.z, d4.w}, t_[4] = {t4.x, t4.y, t4.z, t4.w}, x_[4] = {x4.x, x4.y, x4.z, x4.w};
+            const float tz_[4] = {tz4.x, tz4.y, tz4.z, tz4.w}, g_[4] = {g4.x, g4.y, g4.z, g4.w}, tgm_[4] = {tg4.x, tg4.y, tg4.z, tg4.w};
+            float hg_[4], hb_[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                zz[n][k] = x_[k];
+                xh[n][k] = (x_[k] - mean) * rstd;
+                txh[n][k] = rstd * (tz_[k] - m1 - xh[n][k] * m2);
+                gv[n][k] = d_[k] * g_[k];
+                tgv[n][k] = t_[k] * g_[k] + d_[k] * tgm_[k];
+                a1 += gv[n][k];
+                a2 += gv[n][k] * xh[n][k];
+                b1 += tgv[n][k];
+                b2 += tgv[n][k] * xh[n][k] + gv[n][k] * txh[n][k];
+                hg_[k] = t_[k] * xh[n][k] + d_[k] * txh[n][k];
+                hb_[k] = t_[k];
+            }
+            pg[n].x += hg_[0]; pg[n].y += hg_[1]; pg[n].z += hg_[2]; pg[n].w += hg_[3];
+            pb[n].x += hb_[0]; pb[n].y += hb_[1]; pb[n].z += hb_[2]; pb[n].w += hb_[3];
+        }
+        const float invC = 1.f / (float)C;
+        a1 = wave_sum(a1) * invC; a2 = wave_sum(a2) * invC; b1 = wave_sum(b1) * invC; b2 = wave_sum(b2) * invC;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c >= C) continue;
+            float o1[4], o2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dzk = rstd * (gv[i][k] - a1 - xh[i][k] * a2);
+                float tk = -rstd * m2 * dzk + rstd * (tgv[i][k] - b1 - txh[i][k] * a2 - xh[i][k] * b2);
+                float pk = dzk;
+                if (relu_on_z && !(zz[i][k] > 0.f)) { pk = 0.f; tk = 0.f; }
+                o1[k] = pk; o2[k] = tk;
+            }
+            st4(pdz + c, f4(o1[0], o1[1], o1[2], o1[3]));
+            st4(ptg + c, f4(o2[0], o2[1], o2[2], o2[3]));
+            if (pdd) {
+                st4(pdd + c, drop4(dd, z, row, C, c, f4(o1[0], o1[1], o1[2], o1[3])));
+                st4(ptd + c, drop4(dd, z, row, C, c, f4(o2[0], o2[1], o2[2], o2[3])));
+            }
+        }
     }
-    const float* pdy = dy + (long long)z * dy_ts + (long long)row * C;
-    const float* ptgy = tgy + (long long)z * tgy_ts + (long long)row * C;
-    const float* pz = zin + (long long)z * z_ts + (long long)row * C;
-    const float* ptz = tz + (long long)z * tz_ts + (long long)row * C;
-    const float* st = stats + (long long)z * st_ts + (long long)row * 2;
-    const float* ts = tstats + (long long)z * tst_ts + (long long)row * 2;
-    const float mean = st[0], rstd = st[1], m1 = ts[0], m2 = ts[1];
-    const float* g = gamma + (long long)z * par_ts;
-    const float* tgm = tgamma ? tgamma + (long long)z * tpar_ts : nullptr;
-    float gv[NV][4], tgv[NV][4], xh[NV][4], txh[NV][4], zz[NV][4];
-    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+    if (!partial) return;
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
         const int c = lane * 4 + 256 * n;
-        if (c >= C) continue;
-        float4 d4 = ld4(pdy + c), t4 = ld4(ptgy + c);
-        const float4 x4 = ld4(pz + c), tz4 = ld4(ptz + c), g4 = ld4(g + c);
-        if (din.thr16) { d4 = drop4(din, z, row, C, c, d4); t4 = drop4(din, z, row, C, c, t4); }
-        const float4 tg4 = tgm ? ld4(tgm + c) : zero4();
-        const float d_[4] = {d4.x, d4.y, d4.z, d4.w}, t_[4] = {t4.x, t4.y, t4.z, t4.w}, x_[4] = {x4.x, x4.y, x4.z, x4.w};
-        const float tz_[4] = {tz4.x, tz4.y, tz4.z, tz4.w}, g_[4] = {g4.x, g4.y, g4.z, g4.w}, tgm_[4] = {tg4.x, tg4.y, tg4.z, tg4.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            zz[n][k] = x_[k];
-            xh[n][k] = (x_[k] - mean) * rstd;
-            txh[n][k] = rstd * (tz_[k] - m1 - xh[n][k] * m2);
-            gv[n][k] = d_[k] * g_[k];
-            tgv[n][k] = t_[k] * g_[k] + d_[k] * tgm_[k];
-            a1 += gv[n][k];
-            a2 += gv[n][k] * xh[n][k];
-            b1 += tgv[n][k];
-            b2 += tgv[n][k] * xh[n][k] + gv[n][k] * txh[n][k];
-        }
+        if (c < C) { st4(&red[wave][0][c], pg[n]); st4(&red[wave][1][c], pb[n]); }
     }
-    const float invC = 1.f / (float)C;
-    a1 = wave_sum(a1) * invC; a2 = wave_sum(a2) * invC; b1 = wave_sum(b1) * invC; b2 = wave_sum(b2) * invC;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = lane * 4 + 256 * i;
-        if (c >= C) continue;
-        float o1[4], o2[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float dzk = rstd * (gv[i][k] - a1 - xh[i][k] * a2);
-            float tk = -rstd * m2 * dzk + rstd * (tgv[i][k] - b1 - txh[i][k] * a2 - xh[i][k] * b2);
-            float pk = dzk;
-            if (relu_on_z && !(zz[i][k] > 0.f)) { pk = 0.f; tk = 0.f; }
-            o1[k] = pk; o2[k] = tk;
-        }
-        st4(pdz + c, f4(o1[0], o1[1], o1[2], o1[3]));
-        st4(ptg + c, f4(o2[0], o2[1], o2[2], o2[3]));
-        if (pdd) {
-            st4(pdd + c, drop4(dd, z, row, C, c, f4(o1[0], o1[1], o1[2], o1[3])));
-            st4(ptd + c, drop4(dd, z, row, C, c, f4(o2[0], o2[1], o2[2], o2[3])));
-        }
+    __syncthreads();
+    float* out = partial + ((long long)z * max_chunks + blockIdx.x) * 3 * C;   // (wave order: fixed => run-to-run identical)
+    for (int idx = (int)threadIdx.x; idx < 2 * C; idx += 256) {
+        const int k = idx >= C ? 1 : 0, c = idx - k * C;
+        out[(long long)k * C + c] = (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]);
     }
 }
 

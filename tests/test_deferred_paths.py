@@ -76,7 +76,9 @@ OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "M
 # MTTS_SO_FUSE_DROP=0: second order — the tangent FFT blocks' dropout launches (two in front of the forward's LayerNorm tangents, four behind the backward's) as
 # launches of their own instead of riding in the LayerNorm tangent kernels (round 6) — the same masks on the same values: bit-identical
 KERNEL_ARMS = [{"MTTS_FUSED_ATTN": "0"}, {"MTTS_ENC_AHEAD_QUERY": "0"}, {"MTTS_PANEL_ORDER": "0"}, {"MTTS_PRED_EARLY": "0"}, {"MTTS_SO_DEFER_POST": "0"},
-               {"MTTS_LN_FUSE": "1"}, {"MTTS_UPD_OVERLAP": "0"}, {"MTTS_ATTN_SORT": "0"}, {"MTTS_SO_FUSE_DROP": "0"}]
+               {"MTTS_LN_FUSE": "1"}, {"MTTS_UPD_OVERLAP": "0"}, {"MTTS_ATTN_SORT": "0"}, {"MTTS_SO_FUSE_DROP": "0"}, {"MTTS_SO_LN_PART": "0"}]
+# MTTS_SO_LN_PART=0: second order — hv(gamma) / hv(beta) of every LayerNorm by a two-launch reduction in front of the LayerNorm tangent backward
+# (ColArgs mode 5) instead of 8-row partials emitted by that kernel + one fold (round 6): another summation order of the same products — fp32 roundoff
 
 
 def _compare(tmp_path, gpu):
