@@ -76,7 +76,9 @@ OFF = {"MTTS_DEFER_WGRAD": "0", "MTTS_ENC_AHEAD": "0", "MTTS_PRED_SIDE": "0", "M
 # MTTS_SO_FUSE_DROP=0: second order — the tangent FFT blocks' dropout launches (two in front of the forward's LayerNorm tangents, four behind the backward's) as
 # launches of their own instead of riding in the LayerNorm tangent kernels (round 6) — the same masks on the same values: bit-identical
 KERNEL_ARMS = [{"MTTS_FUSED_ATTN": "0"}, {"MTTS_ENC_AHEAD_QUERY": "0"}, {"MTTS_PANEL_ORDER": "0"}, {"MTTS_PRED_EARLY": "0"}, {"MTTS_SO_DEFER_POST": "0"},
-               {"MTTS_LN_FUSE": "1"}, {"MTTS_UPD_OVERLAP": "0"}, {"MTTS_ATTN_SORT": "0"}, {"MTTS_SO_FUSE_DROP": "0"}, {"MTTS_SO_LN_PART": "0"}, {"MTTS_SO_PRED_SIDE": "0"}]
+               {"MTTS_LN_FUSE": "1"}, {"MTTS_UPD_OVERLAP": "0"}, {"MTTS_ATTN_SORT": "0"}, {"MTTS_SO_FUSE_DROP": "0"}, {"MTTS_SO_LN_PART": "0"}, {"MTTS_SO_PRED_SIDE": "0"}, {"MTTS_SO_TABLE_SIDE": "0"}]
+# MTTS_SO_TABLE_SIDE=0: second order — the embedding tables' hv (table_grad_kernel) on the critical stream instead of the side stream (from a snapshot where the
+# critical stream goes on accumulating into the gradient it reads; round 6): the same kernel on the same floats: bit-identical
 # MTTS_SO_PRED_SIDE=0: second order — the hv reductions of the predictors' 256 -> 1 projections on the critical stream instead of the side stream (round 6): the same
 # kernels on the same floats: bit-identical
 # MTTS_SO_LN_PART=0: second order — hv(gamma) / hv(beta) of every LayerNorm by a two-launch reduction in front of the LayerNorm tangent backward
@@ -113,7 +115,7 @@ def _compare(tmp_path, gpu):
             if k == "upd_launches":
                 # the default ran the inner SGD step module by module (speaker table + variance adaptor, 2 decoder layers, PostNet); the arm, in one pass
                 assert int(a[k]) >= 3 and int(d[k]) == (0 if "MTTS_UPD_OVERLAP" in arm else int(a[k])), (arm, a[k], d[k])
-            elif "MTTS_LN_FUSE" in arm or "MTTS_UPD_OVERLAP" in arm or "MTTS_ATTN_SORT" in arm or "MTTS_SO_FUSE_DROP" in arm or "MTTS_SO_PRED_SIDE" in arm:
+            elif "MTTS_LN_FUSE" in arm or "MTTS_UPD_OVERLAP" in arm or "MTTS_ATTN_SORT" in arm or "MTTS_SO_FUSE_DROP" in arm or "MTTS_SO_PRED_SIDE" in arm or "MTTS_SO_TABLE_SIDE" in arm:
                 np.testing.assert_array_equal(a[k], d[k], err_msg=f"{arm} {k}")     # (emulator AND hardware: nothing is summed in another order)
             elif ("MTTS_ENC_AHEAD_QUERY" in arm or "MTTS_PANEL_ORDER" in arm or "MTTS_PRED_EARLY" in arm or "MTTS_SO_DEFER_POST" in arm) and not gpu:
                 np.testing.assert_array_equal(a[k], d[k], err_msg=f"{arm} {k}")     # (pure re-plumbing: bit-identical)
